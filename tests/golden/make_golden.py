@@ -1,0 +1,289 @@
+"""Generate the golden fixtures in tests/golden/ by RUNNING the real reference.
+
+Run in the build container only (the reference is mounted read-only at
+/root/reference and cannot travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+Every array written is data (inputs, parameters, outputs of the reference);
+no reference source is stored.  The fixtures pin oracle/ (tests/test_oracle_golden.py)
+and, through it and directly, the HIP path (tests/test_gpu_*.py).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+
+from torchflows.flows import Flow  # noqa: E402  (reference)
+from torchflows.bijections.finite.autoregressive.architectures import (  # noqa: E402
+    RealNVP, CouplingRQNSF, NICE)
+from torchflows.bijections.finite.autoregressive.conditioning.coupling_masks import HalfSplit  # noqa: E402
+from torchflows.bijections.finite.autoregressive.layers import (  # noqa: E402
+    ActNorm, ElementwiseAffine, AffineCoupling, RQSCoupling)
+from torchflows.bijections.finite.autoregressive.transformers.linear.affine import Affine  # noqa: E402
+from torchflows.bijections.finite.autoregressive.transformers.spline.rational_quadratic import (  # noqa: E402
+    RationalQuadratic)
+from torchflows.bijections.finite.matrix.permutation import ReversePermutationMatrix  # noqa: E402
+from torchflows.base_distributions.gaussian import DiagonalGaussian  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ---------------------------------------------------------------- F1 affine
+def gen_affine():
+    out = {}
+    torch.manual_seed(0)
+    for T in (2, 32, 128):
+        tr = Affine((T,))
+        x = torch.randn(64, T) * 2
+        h = torch.randn(64, T, 2)
+        # stress rows: large |u| (alpha tiny / huge), zero params (identity)
+        h[0] = 0.0
+        h[1, :, 0] = 30.0
+        h[2, :, 0] = -30.0
+        z, ld = tr.forward(x, h)
+        xi, ldi = tr.inverse(x, h)
+        out.update({f"T{T}_x": np32(x), f"T{T}_h": np32(h), f"T{T}_z": np32(z),
+                    f"T{T}_ld": np32(ld), f"T{T}_xinv": np32(xi), f"T{T}_ldinv": np32(ldi)})
+    save("affine.npz", **out)
+
+
+# ---------------------------------------------------------------- F2 spline
+def rqs_case(T, boundary, n_bins, x, h):
+    tr = RationalQuadratic((T,), boundary=boundary, n_bins=n_bins)
+    z, ld = tr.forward(x, h)
+    xi, ldi = tr.inverse(x, h)
+    # per-element log-dets and bin indices through a 1-element event
+    tr1 = RationalQuadratic((1,), boundary=boundary, n_bins=n_bins)
+    P = 3 * n_bins - 1
+    _, ld_el = tr1.forward(x.reshape(-1, 1), h.reshape(-1, 1, P))
+    _, ldi_el = tr1.inverse(x.reshape(-1, 1), h.reshape(-1, 1, P))
+    hf = h.reshape(-1, P)
+    bin_x, _ = tr.compute_bins(hf[:, :n_bins], -boundary, boundary)
+    bin_y, _ = tr.compute_bins(hf[:, :n_bins] + hf[:, n_bins:2 * n_bins] / 1000, -boundary, boundary)
+    xf = x.reshape(-1, 1).contiguous()
+    inside = ((xf > -boundary) & (xf < boundary)).reshape(-1)
+    kf = torch.searchsorted(bin_x, xf).reshape(-1) - 1
+    ki = torch.searchsorted(bin_y, xf).reshape(-1) - 1
+    kf = torch.where(inside, kf, torch.full_like(kf, -1))
+    ki = torch.where(inside, ki, torch.full_like(ki, -1))
+    return dict(x=np32(x), h=np32(h), z=np32(z), ld=np32(ld), xinv=np32(xi), ldinv=np32(ldi),
+                ld_el=np32(ld_el).reshape(x.shape), ldinv_el=np32(ldi_el).reshape(x.shape),
+                k=np32(kf).astype(np.int32).reshape(x.shape),
+                kinv=np32(ki).astype(np.int32).reshape(x.shape),
+                bin_x=np32(bin_x).reshape(*x.shape, n_bins + 1),
+                bin_y=np32(bin_y).reshape(*x.shape, n_bins + 1))
+
+
+def gen_rqs():
+    out = {}
+    torch.manual_seed(0)
+    T = 8
+    cases = []
+    for boundary in (50.0, 5.0):
+        for n_bins in (8, 4):
+            P = 3 * n_bins - 1
+            rows_x, rows_h = [], []
+            for xs in (0.01, 1.0, 3.0, 30.0, 100.0):
+                for hs in (0.3, 1.0, 5.0):
+                    rows_x.append(torch.randn(6, T) * xs)
+                    rows_h.append(torch.randn(6, T, P) * hs)
+            x = torch.cat(rows_x)
+            h = torch.cat(rows_h)
+            # probes: exact interior knots (-> left bin), exact boundaries (-> identity),
+            # just inside / outside, zeros and parameters = 0 (near-identity spline)
+            tr = RationalQuadratic((T,), boundary=boundary, n_bins=n_bins)
+            hp = torch.randn(4, T, P)
+            bx, _ = tr.compute_bins(hp[..., :n_bins], -boundary, boundary)
+            by, _ = tr.compute_bins(hp[..., :n_bins] + hp[..., n_bins:2 * n_bins] / 1000,
+                                    -boundary, boundary)
+            xp = torch.zeros(4, T)
+            for t in range(T):
+                xp[0, t] = bx[0, t, 1 + t % (n_bins - 1)]      # interior x-knot
+                xp[1, t] = by[1, t, 1 + t % (n_bins - 1)]      # interior y-knot
+            xp[2] = torch.tensor([boundary, -boundary, boundary * 1.2, -boundary * 1.2,
+                                  np.nextafter(np.float32(boundary), np.float32(0)),
+                                  np.nextafter(np.float32(-boundary), np.float32(0)),
+                                  0.0, 1e-30])[:T]
+            xp[3] = torch.linspace(-boundary, boundary, T)
+            hz = torch.zeros(2, T, P)
+            xz = torch.randn(2, T) * boundary / 3
+            x = torch.cat([x, xp, xz])
+            h = torch.cat([h, hp, hz])
+            tag = f"B{int(boundary)}_K{n_bins}"
+            for k, v in rqs_case(T, boundary, n_bins, x, h).items():
+                out[f"{tag}_{k}"] = v
+            cases.append(tag)
+    out["cases"] = np.array(cases)
+    save("rqs.npz", **out)
+
+
+# ---------------------------------------------------------------- F3 masks
+def gen_masks():
+    out = {}
+    shapes = [(2,), (3,), (64,), (256,), (7, 11), (3, 5, 2), (1, 1), (5,)]
+    for es in shapes:
+        c = HalfSplit(es)
+        tag = "x".join(map(str, es))
+        out[f"src_{tag}"] = np32(c.source_mask).astype(np.uint8)
+        out[f"tgt_{tag}"] = np32(c.target_mask).astype(np.uint8)
+        out[f"S_{tag}"] = np.int64(c.source_event_size)
+        out[f"T_{tag}"] = np.int64(c.target_event_size)
+        p = ReversePermutationMatrix(es)
+        out[f"pfwd_{tag}"] = np32(p.forward_permutation).astype(np.int64)
+        out[f"pinv_{tag}"] = np32(p.inverse_permutation).astype(np.int64)
+    out["shapes"] = np.array(["x".join(map(str, s)) for s in shapes])
+    save("masks.npz", **out)
+
+
+# ---------------------------------------------------------------- F4/F7 flows
+def layer_trace(flow, x, context=None):
+    """Per-layer (z_i, ld_i) exactly as BijectiveComposition.forward iterates."""
+    zs, lds = [], []
+    cur = x
+    for layer in flow.bijection.layers:
+        cur, ld = layer.forward(cur, context=context)
+        zs.append(np32(cur).reshape(x.shape[0], -1))
+        lds.append(np32(ld))
+    return np.stack(zs), np.stack(lds)
+
+
+def flow_fixture(name, ctor, event_shape, n_rows, ctor_kwargs=None, context_shape=None,
+                 trace_rows=8, seed=0):
+    ctor_kwargs = dict(ctor_kwargs or {})
+    if context_shape is not None:
+        ctor_kwargs["context_shape"] = context_shape
+    torch.manual_seed(seed)
+    flow = Flow(ctor(event_shape, **ctor_kwargs))
+    es = flow.bijection.event_shape
+    D = int(np.prod(es))
+    out = {"event_shape": np.array(es, dtype=np.int64), "n_bijection_layers": np.int64(len(flow.bijection.layers)),
+           "layer_types": np.array([type(l).__name__ for l in flow.bijection.layers])}
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(n_rows, *es, generator=g)
+    x[: n_rows // 4] *= 3.0
+    z_in = torch.randn(n_rows, *es, generator=g)
+    ctx = ctx_init = None
+    if context_shape is not None:
+        ctx = torch.randn(n_rows, *context_shape, generator=g)
+        ctx_init = torch.randn(4096, *context_shape, generator=g)
+        out["context"] = np32(ctx)
+    out["x"] = np32(x)
+    out["z_in"] = np32(z_in)
+    x_init = torch.randn(4096, *es, generator=g)
+    for variant in ("fresh", "init"):
+        if variant == "init":
+            flow.train()
+            with torch.no_grad():
+                flow.log_prob(x_init, context=ctx_init)   # ActNorm data-dependent init
+        flow.eval()
+        sd = flow.state_dict()
+        for k, v in sd.items():
+            out[f"sd_{variant}/{k}"] = np32(v)
+        with torch.no_grad():
+            z, ld = flow.bijection.forward(x, context=ctx)
+            lp = flow.log_prob(x, context=ctx)
+            xr, ldr = flow.bijection.inverse(z_in, context=ctx)
+            base_lp = flow.base_log_prob(z_in)
+            tz, tl = layer_trace(flow, x[:trace_rows], None if ctx is None else ctx[:trace_rows])
+            # fp64 re-evaluation of the same weights: the fp32 noise floor
+            f64 = Flow(ctor(event_shape, **ctor_kwargs)).double()
+            f64.load_state_dict({k: v.double() for k, v in sd.items()})
+            f64.eval()
+            c64 = None if ctx is None else ctx.double()
+            z64, ld64 = f64.bijection.forward(x.double(), context=c64)
+            lp64 = f64.log_prob(x.double(), context=c64)
+            xr64, ldr64 = f64.bijection.inverse(z_in.double(), context=c64)
+        out.update({
+            f"{variant}/z": np32(z), f"{variant}/log_det": np32(ld), f"{variant}/log_prob": np32(lp),
+            f"{variant}/x_inv": np32(xr), f"{variant}/log_det_inv": np32(ldr),
+            f"{variant}/sample_log_prob": np32(base_lp + ldr),
+            f"{variant}/trace_z": tz, f"{variant}/trace_ld": tl,
+            f"{variant}/z64": np32(z64), f"{variant}/log_det64": np32(ld64),
+            f"{variant}/log_prob64": np32(lp64), f"{variant}/x_inv64": np32(xr64),
+            f"{variant}/log_det_inv64": np32(ldr64),
+        })
+    save(name, **out)
+
+
+def gen_flows():
+    flow_fixture("flow_realnvp3.npz", RealNVP, 3, 64)                       # config 1 (n_layers=2)
+    flow_fixture("flow_realnvp64.npz", RealNVP, 64, 64, dict(n_layers=8))   # config 2
+    flow_fixture("flow_nsf64.npz", CouplingRQNSF, 64, 64, dict(n_layers=8)) # config 3
+    flow_fixture("flow_realnvp256.npz", RealNVP, 256, 32, dict(n_layers=8), trace_rows=4)  # config 4
+    flow_fixture("flow_nice7.npz", NICE, 7, 32)
+    flow_fixture("flow_realnvp_7x11.npz", RealNVP, (7, 11), 16, trace_rows=4)   # test_cuda.py:14 shape
+    flow_fixture("flow_realnvp5_ctx3.npz", RealNVP, 5, 32, context_shape=(3,))
+    flow_fixture("flow_nsf6_ctx2.npz", CouplingRQNSF, 6, 32, context_shape=(2,))
+    flow_fixture("flow_nsf_3x5x2.npz", CouplingRQNSF, (3, 5, 2), 16, trace_rows=4)
+
+
+# ---------------------------------------------------------------- F5 gaussian
+def gen_gauss():
+    torch.manual_seed(0)
+    out = {}
+    for D in (3, 64):
+        loc = torch.randn(D)
+        scale = torch.rand(D) + 0.5
+        d = DiagonalGaussian(loc, scale)
+        v = torch.randn(50, D) * 2
+        out[f"D{D}_loc"] = np32(loc)
+        out[f"D{D}_log_scale"] = np32(d.log_scale)
+        out[f"D{D}_value"] = np32(v)
+        out[f"D{D}_log_prob"] = np32(d.log_prob(v))
+    # closed-form checks of the reference's own test (test/test_base_distributions.py:8-33)
+    d = DiagonalGaussian(torch.zeros(2), torch.ones(2))
+    v = torch.tensor([[0.0, 0.0], [1.0, -2.0]])
+    out["std2_value"] = np32(v)
+    out["std2_log_prob"] = np32(d.log_prob(v))
+    save("gauss.npz", **out)
+
+
+# ---------------------------------------------------------------- layers
+def gen_layers():
+    torch.manual_seed(0)
+    out = {}
+    # ActNorm data-dependent initialisation (layers.py:58-68)
+    for tag, n in (("n100", 100), ("n1", 1)):
+        a = ActNorm((7,))
+        a.train()
+        x = torch.randn(n, 7) * 3 + 1
+        with torch.no_grad():
+            z, ld = a.forward(x)
+        out[f"actnorm_{tag}_x"] = np32(x)
+        out[f"actnorm_{tag}_value"] = np32(a.value)
+        out[f"actnorm_{tag}_z"] = np32(z)
+        out[f"actnorm_{tag}_ld"] = np32(ld)
+    # single layers with batch shape (5, 2, 3) and event shape (3, 5, 2)
+    for cls, tag in ((ElementwiseAffine, "ea"), (AffineCoupling, "ac"), (RQSCoupling, "rc")):
+        torch.manual_seed(1)
+        layer = cls((3, 5, 2)).eval()
+        x = torch.randn(5, 2, 3, 3, 5, 2)
+        with torch.no_grad():
+            z, ld = layer.forward(x)
+            xi, ldi = layer.inverse(x)
+        for k, v in layer.state_dict().items():
+            out[f"{tag}_sd/{k}"] = np32(v)
+        out.update({f"{tag}_x": np32(x), f"{tag}_z": np32(z), f"{tag}_ld": np32(ld),
+                    f"{tag}_xinv": np32(xi), f"{tag}_ldinv": np32(ldi)})
+    save("layers.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows"]
+    for w in which:
+        globals()[f"gen_{w}"]()
