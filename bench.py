@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- log_prob evaluations/second of the coupling-flow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one ``Flow.log_prob`` pass over one device-resident batch of synthetic standard
+Gaussian rows, followed by the fp64 sum of the log-likelihood (and, for N > 1, its single
+RCCL all-reduce).  The workload is BASELINE.json configs[1]: RealNVP(D=64, 8 affine coupling
+layers), batch 2^20 per GPU, data-initialised weights (seed 0).  Batch rows are independent,
+so ranks shard the batch with no data-path collective besides that 8-byte all-reduce
+("scaling": "weak": every rank evaluates its own 2^20 rows).
+
+One JSON line is printed by rank 0.  Besides the contract keys it carries
+  roofline      the dominant libtfk kernel of the timed region: algorithmic bytes per launch
+                / its mean launch duration, measured with HIP events recorded on the launch
+                stream around every launch inside the timed region;
+  cpu_baseline  the CPU oracle (oracle/, a C port of the reference's algorithm; the Python
+                reference cannot travel to the GPU box) timed on this host's cores on a
+                bounded sample of the same workload, rank 0 at N = 1 only;
+  parity        max relative log_prob error of the HIP path vs the oracle on a row sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+WORKLOADS = {
+    # name: (arch, D, n_layers, rows per GPU, chunk rows)
+    "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
+    "nsf64": ("CouplingRQNSF", 64, 8, 1 << 20, 1 << 18),     # configs[2]
+    "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
+}
+
+
+class KernelTimer:
+    """Wraps the libtfk entry points of torchflows_amd.native: records a HIP event pair on the
+    current (= launch) stream around every call while ``active`` and keeps the algorithmic
+    byte count of the launch (SURVEY.md 8(d) per-row figures x rows)."""
+
+    def __init__(self, native):
+        self.native = native
+        self.active = False
+        self.records = []   # (name, bytes, start_event, end_event)
+        for fn, byte_fn in (("affine_coupling", self._coupling_bytes(2)),
+                            ("shift_coupling", self._coupling_bytes(1)),
+                            ("rqs_coupling", self._rqs_bytes),
+                            ("elementwise_affine", self._elementwise_bytes),
+                            ("permute", lambda a, k: 8 * a[0].numel()),
+                            ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0])):
+            self._wrap(fn, byte_fn)
+
+    @staticmethod
+    def _coupling_bytes(P):
+        def f(a, k):
+            x, h, out = a[0], a[1], a[2]
+            N, D = x.shape
+            T = a[5]
+            inplace = out.data_ptr() == x.data_ptr()
+            row = 4 * (2 * T + T * P) + 8 if inplace else 4 * (D + T * P + D) + 8
+            return N * row
+        return f
+
+    @staticmethod
+    def _rqs_bytes(a, k):
+        x, h, out = a[0], a[1], a[2]
+        N, D = x.shape
+        T, K = a[5], a[6]
+        P = 3 * K - 1
+        inplace = out.data_ptr() == x.data_ptr()
+        return N * (4 * (2 * T + T * P) + 8 if inplace else 4 * (D + T * P + D) + 8)
+
+    @staticmethod
+    def _elementwise_bytes(a, k):
+        x = a[0]
+        N, D = x.shape
+        return N * (8 * D + 8)
+
+    def _wrap(self, name, byte_fn):
+        inner = getattr(self.native, name)
+
+        def timed(*a, **k):
+            if not self.active:
+                return inner(*a, **k)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = inner(*a, **k)
+            e.record()
+            variant = name
+            if name.endswith("coupling"):
+                variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
+            self.records.append((variant, byte_fn(a, k), s, e))
+            return r
+        setattr(self.native, name, timed)
+
+    def summary(self):
+        agg = {}
+        for name, nbytes, s, e in self.records:
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += nbytes
+        for d in agg.values():
+            d["avg_us"] = 1e3 * d["ms"] / d["launches"]
+            d["bytes_per_launch"] = d["bytes"] // d["launches"]
+            d["GBps"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        return agg
+
+
+def make_flow(arch, D, n_layers):
+    """seed 0, data-initialised ActNorm (one train-mode forward on 4096 host rows), eval."""
+    import torchflows_amd as tfa
+    ctor = {"RealNVP": tfa.RealNVP, "CouplingRQNSF": tfa.CouplingRQNSF}[arch]
+    torch.manual_seed(0)
+    flow = tfa.Flow(ctor(D, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(4096, D))
+    return flow.eval()
+
+
+def cpu_baseline(arch, D, n_layers, flow_host, target_seconds=12.0):
+    """Time the CPU oracle (a port; OpenMP over rows, all host cores) on a bounded sample."""
+    from oracle import oracle as orc
+    sd = {k: v.detach().cpu().numpy() for k, v in flow_host.state_dict().items()}
+    ref = orc.preset_from_state_dict(arch, D, n_layers, sd)
+    threads = os.cpu_count() or 1
+    orc.set_num_threads(threads)
+    rng = np.random.default_rng(1234)
+    probe = rng.standard_normal((1 << 13, D)).astype(np.float32)
+    ref.log_prob(probe)                                   # warm-up (page in, thread pool)
+    t0 = time.perf_counter()
+    ref.log_prob(probe)
+    rate = probe.shape[0] / (time.perf_counter() - t0)
+    n = int(min(max(rate * target_seconds, 1 << 13), 1 << 22))
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    t0 = time.perf_counter()
+    ref.log_prob(x)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{n} rows of the same workload ({arch} D={D}, {n_layers} coupling layers), "
+                      f"oracle/oracle.c with OpenMP over rows, {dt:.1f} s"}, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="realnvp64", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from torchflows_amd import native
+    from torchflows_amd.distributed import sharded_log_likelihood
+    native.lib()
+    timer = KernelTimer(native)
+
+    arch, D, n_layers, rows, chunk = WORKLOADS[args.workload]
+    rows = args.rows or rows
+    flow_host = make_flow(arch, D, n_layers)
+    flow = make_flow(arch, D, n_layers).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(rows, D, device=dev, generator=gen)
+    step_rows = chunk or rows
+
+    def step():
+        lp, total = sharded_log_likelihood(flow, x, chunk_rows=step_rows)
+        return lp, total
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer.active = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lp, total = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        timer.active = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kernels = timer.summary()
+        dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
+        dom = kernels[dom_name]
+        result = {
+            "metric": "log_prob evals/sec (RealNVP D=64)" if args.workload == "realnvp64"
+                      else f"log_prob evals/sec ({args.workload})",
+            "value": world * rows * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{arch}(D={D}, n_layers={n_layers}) Flow.log_prob + fp64 sum"
+                                   f"{' + 8-byte RCCL all-reduce' if world > 1 else ''}, "
+                                   f"{rows} standard-Gaussian rows per GPU resident in HBM, "
+                                   f"data-initialised weights (seed 0)",
+                       "rows_per_gpu": rows, "parallelism": f"batch-sharded replicas x{world}"},
+            "roofline": {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
+                         "avg_us": dom["avg_us"], "launches": dom["launches"]},
+            "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                            "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
+            "libtfk_ms_per_step": sum(v["ms"] for v in kernels.values()) / args.steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref = cpu_baseline(arch, D, n_layers, flow_host)
+            result["cpu_baseline"] = base
+            idx = torch.arange(0, rows, max(rows // 2048, 1), device=dev)[:2048]
+            lp_ref = ref.log_prob(x[idx].cpu().numpy())
+            err = np.max(np.abs(lp[idx].cpu().numpy() - lp_ref) / np.maximum(1.0, np.abs(lp_ref)))
+            result["parity"] = {"log_prob_max_rel_vs_oracle": float(err), "rows_checked": int(idx.numel())}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/*
+ * tfk.h -- C-ABI of libtfk.so: MI355X (gfx950) kernels for the torchflows
+ * coupling-flow hot path (Bijection.forward / inverse with running log|det J|).
+ *
+ * The reference (davidnabergoj/torchflows v1.2.0) is pure Python over ATen and has
+ * no FFI of its own; each entry point below replaces the chain of ATen ops issued by
+ * the reference lines it cites (paths relative to the reference's torchflows/).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, a TFK_E* code otherwise, and never throws
+ *    across the boundary; tfk_last_error() gives the text (thread-local).
+ *  - All data pointers are CALLER-OWNED DEVICE pointers (hipMalloc'ed / torch
+ *    tensor.data_ptr()); the library never allocates, frees or synchronises.
+ *  - Work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default
+ *    stream): calls are asynchronous and safe to issue from several host threads on
+ *    different streams.
+ *  - Tensors are fp32, contiguous, row-major: x/z are (N, D) with D = prod(event
+ *    shape); log-dets are (N,).  N is int64, sizes inside a row are int32.
+ *  - `accumulate` != 0: logdet[n] += this layer's log-det (the running sum of
+ *    BijectiveComposition, bijections/base.py:210-222); 0: logdet[n] is overwritten.
+ *  - `tgt_idx` (device int32[T], ascending flat event indices, the True positions of
+ *    coupling.target_mask) may be NULL, meaning the contiguous tail [D-T, D) -- the
+ *    HalfSplit mask (conditioning/coupling_masks.py:78-81).
+ *  - z may alias x (in place): then only target positions are written.  Otherwise
+ *    every element of z is written (z = x.clone() then z[..., target] = ...,
+ *    layers_base.py:146-152).
+ *  - N == 0 is a successful no-op.
+ */
+#ifndef TFK_H
+#define TFK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFK_ABI_VERSION 1
+
+enum {
+    TFK_OK = 0,
+    TFK_EINVAL = 1,   /* bad argument (null pointer, size, alignment contract) */
+    TFK_ELAUNCH = 2,  /* HIP reported an error at launch */
+    TFK_ENODEV = 3    /* no usable gfx950 device */
+};
+
+int tfk_abi_version(void);
+const char *tfk_last_error(void);
+
+/* Name of the device the calling thread is on + its CU count; TFK_ENODEV if none. */
+int tfk_device_info(char *name, int32_t name_len, int32_t *compute_units);
+
+/* ---- affine coupling ------------------------------------------------------
+ * Replaces CouplingBijection.forward / inverse (layers_base.py:145-163) around
+ * Affine.forward / inverse (transformers/linear/affine.py:33-59):
+ *   u = h[n,t,0], beta = h[n,t,1]; alpha = expf(u/2 + log(1-1e-10)) + 1e-10;
+ *   fwd: z_t = alpha*x_t + beta, ld = +sum_t logf(alpha)
+ *   inv: x_t = (z_t - beta)/alpha, ld = -sum_t logf(alpha)
+ * h is the conditioner output (N, T, 2), exactly the reference's layout. */
+int tfk_affine_coupling_fwd(const float *x, const float *h, float *z, float *logdet,
+                            int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                            int32_t accumulate, void *stream);
+int tfk_affine_coupling_inv(const float *z, const float *h, float *x, float *logdet,
+                            int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                            int32_t accumulate, void *stream);
+
+/* ---- shift coupling (NICE) -------------------------------------------------
+ * Shift.forward / inverse (affine.py:137-159): z_t = x_t +/- h[n,t,0]; log-det 0
+ * (logdet is only zero-filled when accumulate == 0; it may be NULL otherwise). */
+int tfk_shift_coupling_fwd(const float *x, const float *h, float *z, float *logdet,
+                           int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                           int32_t accumulate, void *stream);
+int tfk_shift_coupling_inv(const float *z, const float *h, float *x, float *logdet,
+                           int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                           int32_t accumulate, void *stream);
+
+/* ---- rational-quadratic spline coupling ------------------------------------
+ * Replaces the same skeleton around MonotonicSpline.forward / inverse
+ * (transformers/spline/base.py:53-72) and RationalQuadratic.rqs_forward_1d /
+ * rqs_inverse_1d (transformers/spline/rational_quadratic.py:45-200).
+ * h is (N, T, 3K-1) = [u_x(K) | u_y(K) | u_d(K-1)] per element; K = n_bins
+ * (2 <= K <= 32); elements outside the strict box (-boundary, boundary) pass through
+ * with zero log-det.  No host synchronisation (the reference's torch.any / assert
+ * syncs are not reproduced; out-of-box handling is branch-free per element). */
+int tfk_rqs_coupling_fwd(const float *x, const float *h, float *z, float *logdet,
+                         int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                         int32_t K, float boundary, int32_t accumulate, void *stream);
+int tfk_rqs_coupling_inv(const float *z, const float *h, float *x, float *logdet,
+                         int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                         int32_t K, float boundary, int32_t accumulate, void *stream);
+
+/* ---- elementwise affine (ElementwiseAffine, ActNorm) -------------------------
+ * Replaces ElementwiseBijection.forward / inverse (layers_base.py:300-318) with
+ * global parameters value (D, 2) = [unconstrained alpha, beta] per element; the
+ * reference's repeat of value to (N, D, 2) is not materialised.
+ * inverse_affine == 0: Affine transformer (ElementwiseAffine, layers.py:19-26);
+ * inverse_affine != 0: InverseAffine (ActNorm in eval mode, layers.py:29-69), i.e.
+ *   _fwd computes (x - beta)/alpha with ld = -sum log alpha, _inv the affine map.
+ * The log-det is the same for every row; it is added to / stored in logdet[n]. */
+int tfk_elementwise_affine_fwd(const float *x, const float *value, float *z, float *logdet,
+                               int64_t N, int32_t D, int32_t inverse_affine,
+                               int32_t accumulate, void *stream);
+int tfk_elementwise_affine_inv(const float *z, const float *value, float *x, float *logdet,
+                               int64_t N, int32_t D, int32_t inverse_affine,
+                               int32_t accumulate, void *stream);
+
+/* ---- permutation -------------------------------------------------------------
+ * PermutationMatrix.project_flat / solve_flat (matrix/permutation.py:19-23):
+ * z[n, j] = x[n, perm[j]].  perm is a device int32[D]; NULL means the reversal
+ * [D-1..0] (ReversePermutationMatrix, permutation.py:34-37).  Pass the inverse
+ * permutation for Bijection.inverse.  Log-det is exactly 0 (not touched).
+ * z must not alias x. */
+int tfk_permute(const float *x, const int32_t *perm, float *z, int64_t N, int32_t D,
+                void *stream);
+
+/* ---- base density --------------------------------------------------------------
+ * DiagonalGaussian.log_prob (base_distributions/gaussian.py:46-54) fused with the
+ * final add of Flow.forward_with_log_prob (flows.py:647-648):
+ *   out[n] = sum_d -(0.5*((z-loc)/exp(log_scale))^2 + 0.5*log(2pi) + log_scale)
+ *            + (logdet_in ? logdet_in[n] : 0)
+ * out may alias logdet_in. */
+int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_scale,
+                           const float *logdet_in, float *out, int64_t N, int32_t D,
+                           void *stream);
+
+/* ---- reduction feeding the multi-GPU all-reduce --------------------------------
+ * out[0] = sum_n in[n] accumulated in fp64, deterministic (fixed tree).
+ * workspace: device buffer of at least tfk_sum_workspace_bytes(N) bytes. */
+int64_t tfk_sum_workspace_bytes(int64_t N);
+int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFK_H */

@@ -1,0 +1,232 @@
+"""Flow-level parity on the GPU: ``Flow.log_prob`` / ``bijection.inverse`` of this package,
+running on the HIP kernels, against (1) the reference's golden outputs and (2) the CPU
+oracle on seeded inputs, then size-independent properties at the BASELINE.json sizes.
+
+Tolerances: RealNVP / NICE log_prob and reconstructed x within 1e-5 relative (the
+north-star bound); RQ-spline flows within max(4e-5, 3 x the reference's own fp32-vs-fp64
+distance on the same inputs) -- the floor is printed next to each error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_of
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def normwise(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available()
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    native.lib()
+    return tfa
+
+
+def build_flow(pkg, arch, event_shape, n_layers, context_shape=None):
+    ctor = {"RealNVP": pkg.RealNVP, "CouplingRQNSF": pkg.CouplingRQNSF, "NICE": pkg.NICE}[arch]
+    kw = dict(n_layers=n_layers)
+    if context_shape is not None:
+        kw["context_shape"] = context_shape
+    return pkg.Flow(ctor(event_shape, **kw))
+
+
+FLOWS = [
+    ("flow_realnvp3.npz", "RealNVP", 2, None, False),
+    ("flow_realnvp64.npz", "RealNVP", 8, None, False),
+    ("flow_nsf64.npz", "CouplingRQNSF", 8, None, True),
+    ("flow_realnvp256.npz", "RealNVP", 8, None, False),
+    ("flow_nice7.npz", "NICE", 2, None, False),
+    ("flow_realnvp_7x11.npz", "RealNVP", 2, None, False),
+    ("flow_realnvp5_ctx3.npz", "RealNVP", 2, (3,), False),
+    ("flow_nsf6_ctx2.npz", "CouplingRQNSF", 2, (2,), True),
+    ("flow_nsf_3x5x2.npz", "CouplingRQNSF", 2, None, True),
+]
+
+
+@pytest.mark.parametrize("variant", ["fresh", "init"])
+@pytest.mark.parametrize("name,arch,n_layers,ctx_shape,spline", FLOWS)
+def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, variant):
+    from torchflows_amd import native
+    fx = load_golden(name)
+    es = tuple(int(v) for v in fx["event_shape"])
+    flow = build_flow(pkg, arch, es, n_layers, ctx_shape)
+    flow.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict_of(fx, variant).items()})
+    flow = flow.cuda().eval()
+    ctx = torch.from_numpy(fx["context"]).cuda() if ctx_shape else None
+    x = torch.from_numpy(fx["x"]).cuda()
+    z_in = torch.from_numpy(fx["z_in"]).cuda()
+    g = lambda k: fx[f"{variant}/{k}"]
+    before = native.calls
+    with torch.no_grad():
+        z, lp = flow.forward_with_log_prob(x, context=ctx)
+        xr, ldr = flow.bijection.inverse(z_in, context=ctx)
+    assert native.calls - before >= 2 * (3 * n_layers + 3), "the HIP kernels did not run"
+    assert lp.shape == x.shape[:1] and z.shape == x.shape and xr.shape == x.shape
+
+    tol = 4e-5 if spline else 1e-5
+    floor_lp = rel(g("log_prob"), g("log_prob64"))
+    floor_x = normwise(g("x_inv"), g("x_inv64"))
+    floor_ld = rel(g("log_det_inv"), g("log_det_inv64"))
+    e_lp = rel(lp.cpu().numpy(), g("log_prob"))
+    e_z = normwise(z.cpu().numpy(), g("z"))
+    e_x = normwise(xr.cpu().numpy(), g("x_inv"))
+    e_ld = rel(ldr.cpu().numpy(), g("log_det_inv"))
+    print(f"{name} {variant}: log_prob {e_lp:.2e} (floor {floor_lp:.2e}), z nw {e_z:.2e}, "
+          f"x_inv nw {e_x:.2e} (floor {floor_x:.2e}), log_det_inv {e_ld:.2e} (floor {floor_ld:.2e})")
+    assert e_lp < max(tol, 3 * floor_lp)
+    assert e_z < max(tol, 3 * normwise(g("z"), g("z64")))
+    assert e_x < max(tol, 3 * floor_x)
+    assert e_ld < max(tol, 3 * floor_ld)
+    # the caller's tensors are untouched
+    assert torch.equal(x.cpu(), torch.from_numpy(fx["x"]))
+    assert torch.equal(z_in.cpu(), torch.from_numpy(fx["z_in"]))
+
+
+@pytest.mark.parametrize("arch,D,n_layers,N", [
+    ("RealNVP", 64, 8, 4099), ("CouplingRQNSF", 64, 8, 2051), ("RealNVP", 256, 8, 1031),
+    ("RealNVP", 3, 2, 1000), ("NICE", 10, 3, 777)])
+def test_flow_vs_oracle_seeded(pkg, oracle, arch, D, n_layers, N):
+    torch.manual_seed(7)
+    flow = build_flow(pkg, arch, D, n_layers)
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(2048, D))          # data-dependent ActNorm init (ATen, host)
+    flow.eval()
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, n_layers, sd)
+    x = torch.randn(N, D)
+    x[: N // 8] *= 4.0
+    flow = flow.cuda()
+    with torch.no_grad():
+        z, lp = flow.forward_with_log_prob(x.cuda())
+        xr, ld = flow.bijection.inverse(x.cuda())
+    z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
+    xr_ref, ld_ref = ref.inverse(x.numpy())
+    tol = 4e-5 if arch == "CouplingRQNSF" else 1e-5
+    e = dict(lp=rel(lp.cpu().numpy(), lp_ref), z=normwise(z.cpu().numpy(), z_ref),
+             x=normwise(xr.cpu().numpy(), xr_ref), ld=rel(ld.cpu().numpy(), ld_ref))
+    print(arch, D, e)
+    assert max(e.values()) < tol, e
+
+
+def test_batch_and_event_shapes(pkg):
+    """Any batch rank, any event rank (reference test/constants.py grids)."""
+    torch.manual_seed(0)
+    for es in ((2,), (3,), (3, 5, 2)):
+        for bs in ((1,), (2,), (5,), (5, 2, 3)):
+            for ctor in (pkg.RealNVP, pkg.CouplingRQNSF):
+                flow = pkg.Flow(ctor(es)).eval()
+                x = torch.randn(*bs, *es)
+                with torch.no_grad():
+                    lp_host = flow.log_prob(x)                          # ATen composite, host
+                    lp_dev = flow.cuda().log_prob(x.cuda())             # HIP kernels
+                    z, ld = flow.bijection.forward(x.cuda())
+                    xr, ldr = flow.bijection.inverse(z)
+                assert lp_dev.shape == bs and z.shape == x.shape
+                assert rel(lp_dev.cpu().numpy(), lp_host.numpy()) < 4e-5
+                assert torch.allclose(xr.cpu(), x, atol=1e-3)          # reference data_atol
+                assert torch.allclose(ld, -ldr, atol=1e-3)             # reference log_det_atol
+
+
+def test_non_contiguous_input_and_layer_standalone(pkg):
+    from torchflows_amd.bijections.finite.autoregressive.layers import AffineCoupling, RQSCoupling, ActNorm
+    torch.manual_seed(1)
+    for cls in (AffineCoupling, RQSCoupling, ActNorm):
+        layer = cls((6,)).eval()
+        x = torch.randn(50, 12)[:, ::2]                     # strided view
+        with torch.no_grad():
+            z_h, ld_h = layer.forward(x)
+            z_d, ld_d = layer.cuda().forward(x.cuda())
+            x_d, ldi_d = layer.inverse(z_d)
+        assert rel(z_d.cpu().numpy(), z_h.numpy()) < 2e-5
+        assert rel(ld_d.cpu().numpy(), ld_h.numpy()) < 2e-5
+        assert torch.allclose(x_d.cpu(), x, atol=1e-4)
+
+
+def test_actnorm_train_mode_init_on_device(pkg, oracle):
+    """A freshly constructed flow is in training mode: the first forward sets every ActNorm
+    from the batch (reference layers.py:58-68).  Same statistics on the HIP path."""
+    torch.manual_seed(3)
+    flow_h = pkg.Flow(pkg.RealNVP(16, n_layers=2))
+    flow_d = pkg.Flow(pkg.RealNVP(16, n_layers=2))
+    flow_d.load_state_dict(flow_h.state_dict())
+    x = torch.randn(1024, 16) * 2 + 1
+    with torch.no_grad():
+        lp_h = flow_h.log_prob(x)
+        lp_d = flow_d.cuda().log_prob(x.cuda())
+    assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 2e-5
+    for (k, a), (_, b) in zip(flow_h.state_dict().items(), flow_d.state_dict().items()):
+        assert rel(b.cpu().numpy(), a.numpy()) < 2e-5, k
+
+
+def test_invert_swaps_direction_on_hip(pkg):
+    from torchflows_amd.bijections.base import invert
+    torch.manual_seed(0)
+    b = pkg.RealNVP(8, n_layers=2).eval().cuda()
+    x = torch.randn(33, 8, device="cuda")
+    with torch.no_grad():
+        z, ld = b.forward(x)
+        invert(b)
+        x2, ld2 = b.forward(z)          # now the inverse map
+    assert torch.allclose(x2, x, atol=1e-4) and torch.allclose(ld2, -ld, atol=1e-4)
+
+
+# ----------------------------------------------------------------- BASELINE.json sizes
+@pytest.mark.parametrize("arch,D,N,chunk", [
+    ("RealNVP", 64, 1 << 20, None),          # config 2
+    ("CouplingRQNSF", 64, 1 << 20, 1 << 18), # config 3 (h is 2.9 GiB/layer at 2^20: chunked)
+    ("RealNVP", 256, 1 << 19, None),         # config 4, one rank's shard
+])
+def test_full_size_properties(pkg, oracle, arch, D, N, chunk):
+    """At full size the oracle is too slow to check every row; check (a) a 4096-row random
+    subset against it, (b) round trip x -> z -> x, (c) ld_fwd = -ld_inv, (d) chunking
+    invariance (rows are independent), (e) the fp64 sum of log_prob."""
+    from torchflows_amd import native
+    torch.manual_seed(0)
+    flow = build_flow(pkg, arch, D, 8)
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(4096, D))
+    flow.eval()
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, 8, sd)
+    flow = flow.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn(N, D, device="cuda", generator=gen)
+    step = chunk or N
+    tol = 4e-5 if arch == "CouplingRQNSF" else 1e-5
+    lp = torch.empty(N, device="cuda")
+    with torch.no_grad():
+        for lo in range(0, N, step):
+            z, lp[lo:lo + step] = flow.forward_with_log_prob(x[lo:lo + step])
+            if lo == 0:
+                _, ld = flow.bijection.forward(x[:step])
+                xr, ldr = flow.bijection.inverse(z)
+                assert float((xr - x[:step]).abs().max()) < 1e-3
+                assert float((ld + ldr).abs().max()) < 1e-3
+                assert bool(torch.isfinite(z).all())
+        # chunking invariance: rows do not interact
+        lp_small = flow.log_prob(x[1000:1000 + 777])
+    assert torch.equal(lp_small, lp[1000:1000 + 777])
+    assert bool(torch.isfinite(lp).all())
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(0))[:4096]
+    lp_ref = ref.log_prob(x[idx.cuda()].cpu().numpy())
+    e = rel(lp[idx.cuda()].cpu().numpy(), lp_ref)
+    print(f"{arch} D={D} N={N}: log_prob vs oracle on 4096 rows: {e:.2e}")
+    assert e < tol
+    total = native.sum_f32(lp).item()
+    assert abs(total - float(lp.double().sum().item())) < 1e-6 * abs(total)

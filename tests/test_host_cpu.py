@@ -1,0 +1,320 @@
+"""CPU-side tests (run with -m "not gpu"): the host mirror of the plugin surface on its
+ATen composite path against the reference's golden outputs, the reference's own property
+tests re-pointed at this package, the C-ABI library's exports, and the 2-rank gloo path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, state_dict_of
+
+import torchflows_amd as tfa
+from torchflows_amd import native
+from torchflows_amd.bijections.base import BijectiveComposition, invert
+from torchflows_amd.bijections.finite.autoregressive.conditioning.coupling_masks import (
+    GraphicalCoupling, HalfSplit)
+from torchflows_amd.bijections.finite.autoregressive.layers import (
+    ActNorm, AffineCoupling, ElementwiseAffine, RQSCoupling, ShiftCoupling)
+from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import Affine
+from torchflows_amd.bijections.finite.autoregressive.transformers.spline.rational_quadratic import (
+    RationalQuadratic)
+from torchflows_amd.bijections.finite.matrix.permutation import (
+    RandomPermutationMatrix, ReversePermutationMatrix)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+# ------------------------------------------------------------------ C-ABI library
+def test_library_exports_every_declared_symbol():
+    """include/tfk.h <-> libtfk.so: every declared entry point is exported (no compute here)."""
+    header = open(os.path.join(ROOT, "include", "tfk.h")).read()
+    declared = set(re.findall(r"\b(tfk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+    L = ctypes.CDLL(native.LIB_PATH)
+    for s in native.SYMBOLS:
+        assert hasattr(L, s), s
+    assert native.lib().tfk_abi_version() == native.ABI_VERSION
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "torchflows_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_host_tensors_are_rejected_by_the_binding():
+    x = torch.zeros(4, 64)
+    with pytest.raises(native.NativeError):
+        native.affine_coupling(x, torch.zeros(4, 32, 2), x.clone(), torch.zeros(4), None, 32)
+    assert not native.eligible(x)                    # host tensors take the ATen path
+
+
+# ------------------------------------------------------------------ integer rules
+def test_masks_and_permutations_bit_exact_with_reference():
+    fx = load_golden("masks.npz")
+    for tag in fx["shapes"]:
+        es = tuple(int(t) for t in str(tag).split("x"))
+        c = HalfSplit(es)
+        assert np.array_equal(c.source_mask.numpy().astype(np.uint8), fx[f"src_{tag}"])
+        assert np.array_equal(c.target_mask.numpy().astype(np.uint8), fx[f"tgt_{tag}"])
+        assert c.source_event_size == int(fx[f"S_{tag}"]) and c.target_event_size == int(fx[f"T_{tag}"])
+        assert c.constant_shape == (c.source_event_size,) and c.target_shape == (c.target_event_size,)
+        assert c.target_is_tail and (c.source_is_head or c.source_event_size == 0)
+        assert np.array_equal(c.target_index.numpy(), np.nonzero(fx[f"tgt_{tag}"].reshape(-1))[0])
+        assert np.array_equal(c.source_index.numpy(), np.nonzero(fx[f"src_{tag}"].reshape(-1))[0])
+        p = ReversePermutationMatrix(es)
+        assert np.array_equal(p.forward_permutation.numpy(), fx[f"pfwd_{tag}"])
+        assert np.array_equal(p.inverse_permutation.numpy(), fx[f"pinv_{tag}"])
+        assert p._is_reversal
+    g = GraphicalCoupling((5,), [(0, 3), (1, 3), (0, 4)])
+    assert g.source_index.tolist() == [0, 1] and g.target_index.tolist() == [3, 4]
+    assert g.ignored_event_size == 1 and g.target_is_tail and g.source_is_head
+    g2 = GraphicalCoupling((5,), [(4, 0), (2, 1)])
+    assert not g2.target_is_tail and not g2.source_is_head
+    with pytest.raises(ValueError):
+        GraphicalCoupling((2, 2), [(0, 1)])
+
+
+# ------------------------------------------------------------------ golden: transformers
+@pytest.mark.parametrize("T", [2, 32, 128])
+def test_affine_transformer_golden(T):
+    fx = load_golden("affine.npz")
+    tr = Affine((T,))
+    x, h = torch.from_numpy(fx[f"T{T}_x"]), torch.from_numpy(fx[f"T{T}_h"])
+    z, ld = tr.forward(x, h)
+    xi, ldi = tr.inverse(x, h)
+    assert torch.equal(z, torch.from_numpy(fx[f"T{T}_z"]))          # same ATen ops: bit-exact
+    assert torch.equal(xi, torch.from_numpy(fx[f"T{T}_xinv"]))
+    assert rel(ld.numpy(), fx[f"T{T}_ld"]) < 1e-6 and rel(ldi.numpy(), fx[f"T{T}_ldinv"]) < 1e-6
+
+
+def test_rqs_transformer_golden():
+    fx = load_golden("rqs.npz")
+    for tag in fx["cases"]:
+        tag = str(tag)
+        K, B = int(tag.split("K")[1]), float(tag.split("_")[0][1:])
+        x, h = torch.from_numpy(fx[f"{tag}_x"]), torch.from_numpy(fx[f"{tag}_h"])
+        tr = RationalQuadratic((x.shape[1],), boundary=B, n_bins=K)
+        z, ld = tr.forward(x, h)
+        xi, ldi = tr.inverse(x, h)
+        assert rel(z.numpy(), fx[f"{tag}_z"]) < 1e-6 and rel(ld.numpy(), fx[f"{tag}_ld"]) < 2e-6
+        assert rel(xi.numpy(), fx[f"{tag}_xinv"]) < 1e-6 and rel(ldi.numpy(), fx[f"{tag}_ldinv"]) < 2e-6
+
+
+# ------------------------------------------------------------------ golden: whole flows
+FLOWS = [
+    ("flow_realnvp3.npz", tfa.RealNVP, {}, None),
+    ("flow_realnvp64.npz", tfa.RealNVP, dict(n_layers=8), None),
+    ("flow_nsf64.npz", tfa.CouplingRQNSF, dict(n_layers=8), None),
+    ("flow_realnvp256.npz", tfa.RealNVP, dict(n_layers=8), None),
+    ("flow_nice7.npz", tfa.NICE, {}, None),
+    ("flow_realnvp_7x11.npz", tfa.RealNVP, {}, None),
+    ("flow_realnvp5_ctx3.npz", tfa.RealNVP, {}, (3,)),
+    ("flow_nsf6_ctx2.npz", tfa.CouplingRQNSF, {}, (2,)),
+    ("flow_nsf_3x5x2.npz", tfa.CouplingRQNSF, {}, None),
+]
+
+
+@pytest.mark.parametrize("name,ctor,kw,ctx_shape", FLOWS)
+def test_flow_golden_aten_path(name, ctor, kw, ctx_shape):
+    """Same seed -> same initial weights and state-dict keys as the reference; same
+    weights -> same log_prob / inverse (ATen composite path on host tensors)."""
+    fx = load_golden(name)
+    es = tuple(int(v) for v in fx["event_shape"])
+    kw = dict(kw)
+    if ctx_shape:
+        kw["context_shape"] = ctx_shape
+    torch.manual_seed(0)
+    flow = tfa.Flow(ctor(es if len(es) > 1 else es[0], **kw))
+    assert [type(l).__name__ for l in flow.bijection.layers] == [str(t) for t in fx["layer_types"]]
+    fresh = state_dict_of(fx, "fresh")
+    sd = flow.state_dict()
+    assert list(sd.keys()) == list(fresh.keys())
+    for k, v in fresh.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        if k != "device_buffer" and v.ndim > 0:
+            assert np.array_equal(sd[k].numpy(), v), f"same-seed init differs at {k}"
+    ctx = torch.from_numpy(fx["context"]) if ctx_shape else None
+    for variant in ("fresh", "init"):
+        flow.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict_of(fx, variant).items()})
+        flow.eval()
+        with torch.no_grad():
+            z, lp = flow.forward_with_log_prob(torch.from_numpy(fx["x"]), context=ctx)
+            xr, ldr = flow.bijection.inverse(torch.from_numpy(fx["z_in"]), context=ctx)
+        g = lambda k: fx[f"{variant}/{k}"]
+        if ctor is tfa.CouplingRQNSF:
+            # per layer this path is bit-identical to the reference up to ATen's vector-body /
+            # scalar-tail split (the reference evaluates the gathered in-box subset, this
+            # package the whole tensor): 1-ulp differences that later layers amplify, i.e.
+            # the reference's own fp32 noise.  Bound: norm-wise 2e-5, log-dets 4e-5.
+            nw = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+            assert rel(lp.numpy(), g("log_prob")) < 4e-5
+            assert nw(z.numpy(), g("z")) < 2e-5 and nw(xr.numpy(), g("x_inv")) < 2e-5
+            assert rel(ldr.numpy(), g("log_det_inv")) < 4e-5
+        else:
+            assert rel(lp.numpy(), g("log_prob")) < 5e-6
+            assert rel(z.numpy(), g("z")) < 5e-6
+            assert rel(xr.numpy(), g("x_inv")) < 5e-6
+            assert rel(ldr.numpy(), g("log_det_inv")) < 5e-6
+
+
+def test_actnorm_data_dependent_init_golden():
+    fx = load_golden("layers.npz")
+    for tag in ("n100", "n1"):
+        a = ActNorm((7,))
+        assert a.training and a.first_training_batch_pass and not a.value.requires_grad
+        with torch.no_grad():
+            z, ld = a.forward(torch.from_numpy(fx[f"actnorm_{tag}_x"]))
+        assert not a.first_training_batch_pass
+        assert rel(a.value.numpy(), fx[f"actnorm_{tag}_value"]) < 1e-6
+        assert rel(z.numpy(), fx[f"actnorm_{tag}_z"]) < 1e-5
+        assert rel(ld.numpy(), fx[f"actnorm_{tag}_ld"]) < 1e-6
+
+
+def test_single_layers_with_batch_and_event_rank_golden():
+    fx = load_golden("layers.npz")
+    for cls, tag in ((ElementwiseAffine, "ea"), (AffineCoupling, "ac"), (RQSCoupling, "rc")):
+        layer = cls((3, 5, 2)).eval()
+        pre = f"{tag}_sd/"
+        layer.load_state_dict({k[len(pre):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(pre)})
+        x = torch.from_numpy(fx[f"{tag}_x"])
+        with torch.no_grad():
+            z, ld = layer.forward(x)
+            xi, ldi = layer.inverse(x)
+        assert ld.shape == (5, 2, 3) and z.shape == x.shape
+        assert rel(z.numpy(), fx[f"{tag}_z"]) < 2e-6 and rel(ld.numpy(), fx[f"{tag}_ld"]) < 5e-6
+        assert rel(xi.numpy(), fx[f"{tag}_xinv"]) < 2e-6 and rel(ldi.numpy(), fx[f"{tag}_ldinv"]) < 5e-6
+
+
+# ------------------------------------------------------------------ the reference's property tests
+BATCH_SHAPES = [(1,), (2,), (5,), (5, 2, 3)]
+EVENT_SHAPES = [(2,), (3,), (3, 5, 2)]
+CONTEXT_SHAPES = [None, (2,), (3,), (3, 5, 2)]
+
+
+@pytest.mark.parametrize("ctor", [tfa.RealNVP, tfa.NICE, tfa.CouplingRQNSF])
+@pytest.mark.parametrize("batch_shape", BATCH_SHAPES)
+@pytest.mark.parametrize("event_shape", EVENT_SHAPES)
+@pytest.mark.parametrize("context_shape", CONTEXT_SHAPES)
+def test_coupling_architectures_reconstruct(ctor, batch_shape, event_shape, context_shape):
+    """reference test/test_reconstruction_bijections.py:64-93,140-143 (train mode: ActNorm
+    initialises on the first forward); tolerances of test/constants.py:11-14."""
+    torch.manual_seed(0)
+    b = ctor(event_shape, context_shape=context_shape)
+    x = torch.randn(*batch_shape, *event_shape)
+    ctx = None if context_shape is None else torch.randn(*batch_shape, *context_shape)
+    z, ld_f = b.forward(x, context=ctx)
+    xr, ld_i = b.inverse(z, context=ctx)
+    assert z.shape == x.shape and ld_f.shape == batch_shape and ld_i.shape == batch_shape
+    assert torch.isfinite(z).all() and torch.isfinite(ld_f).all()
+    assert torch.allclose(x, xr, atol=1e-2)
+    assert torch.allclose(ld_f, -ld_i, atol=1e-2)
+
+
+@pytest.mark.parametrize("cls", [AffineCoupling, RQSCoupling, ShiftCoupling, ElementwiseAffine])
+def test_zero_parameters_give_identity(cls):
+    """reference test/test_identity_bijections.py:56-68"""
+    torch.manual_seed(0)
+    layer = cls((5,))
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.zero_()
+    x = torch.randn(20, 5)
+    z, ld = layer.forward(x)
+    xr, ldi = layer.inverse(x)
+    assert torch.allclose(z, x, atol=1e-2) and torch.allclose(xr, x, atol=1e-2)
+    assert torch.allclose(ld, torch.zeros(20), atol=1e-2) and torch.allclose(ldi, torch.zeros(20), atol=1e-2)
+
+
+@pytest.mark.parametrize("ctor", [tfa.RealNVP, tfa.CouplingRQNSF])
+def test_log_prob_is_differentiable(ctor):
+    """reference test/test_autograd_bijections.py:41-54 -- autograd runs on the ATen path."""
+    torch.manual_seed(0)
+    flow = tfa.Flow(ctor((4,)))
+    x = torch.randn(10, 4, requires_grad=True)
+    lp = flow.log_prob(x)
+    assert lp.shape == (10,) and torch.isfinite(lp).all()
+    lp.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert any(p.grad is not None for p in flow.parameters())
+
+
+def test_sample_and_log_prob_conventions():
+    """Flow.sample(return_log_prob=True) = log p(z) + log|dx/dz| (reference flows.py:710-712)."""
+    torch.manual_seed(0)
+    flow = tfa.Flow(tfa.RealNVP(3)).eval()
+    with torch.no_grad():
+        x = flow.sample(1000)
+        assert x.shape == (1000, 3)
+        x2, slp = flow.sample((7, 2), return_log_prob=True, no_grad=True)
+        assert x2.shape == (7, 2, 3) and slp.shape == (7, 2)
+        z2, ld_f = flow.bijection.forward(x2)
+        # log p(z) + log|dx/dz| with log|dx/dz| = -log|dz/dx|
+        assert torch.allclose(slp, flow.base_log_prob(z2) - ld_f, atol=1e-3)
+    cflow = tfa.Flow(tfa.RealNVP(3, context_shape=(2,))).eval()
+    with torch.no_grad():
+        xs = cflow.sample(5, context=torch.randn(5, 2))
+        assert xs.shape == (5, 3)
+        xs = cflow.sample(4, context=torch.randn(6, 2))
+        assert xs.shape == (4, 6, 3)
+        with pytest.raises(AssertionError):
+            cflow.log_prob(torch.randn(5, 3), context=torch.randn(4, 2))
+    with pytest.raises(ValueError):
+        tfa.Flow(tfa.RealNVP(3)).log_prob(torch.randn(5, 3), context=torch.randn(5, 2))
+
+
+def test_edge_list_drops_permutations_and_1d_fallback():
+    """SURVEY quirks Q7 and architectures.py:84-86."""
+    b = tfa.RealNVP(5, edge_list=[(0, 1)])
+    names = [type(l).__name__ for l in b.layers]
+    assert "ReversePermutationMatrix" not in names and len(names) == 3 * 2 + 3 - 2
+    one = tfa.RealNVP(1)
+    assert all(type(l).__name__ in ("ElementwiseAffine", "ActNorm", "ReversePermutationMatrix")
+               for l in one.layers)
+    with pytest.raises(ValueError):
+        AffineCoupling((1,))
+
+
+def test_invert_and_composition_api():
+    torch.manual_seed(0)
+    b = tfa.RealNVP(4).eval()
+    x = torch.randn(6, 4)
+    with torch.no_grad():
+        z, ld = b.forward(x)
+        invert(b)
+        x2, ld2 = b.forward(z)
+        b.invert()
+        z2, _ = b.forward(x)
+    assert torch.allclose(x2, x, atol=1e-4) and torch.allclose(ld2, -ld, atol=1e-4)
+    assert torch.equal(z2, z)
+    assert isinstance(b, BijectiveComposition) and float(b.regularization()) >= 0
+    with torch.no_grad():
+        zs, lds = b.batch_forward(x, batch_size=4)
+    assert torch.allclose(zs, z, atol=1e-6) and lds.shape == (6,)
+    p = RandomPermutationMatrix((4,))
+    y, l0 = p.forward(x)
+    xb, _ = p.inverse(y)
+    assert torch.equal(xb, x) and torch.all(l0 == 0)
+
+
+# ------------------------------------------------------------------ 2 ranks over gloo
+def test_sharded_log_likelihood_two_ranks_gloo():
+    """N > 1 path on CPU: each rank evaluates its shard, one all-reduce of the fp64 sum."""
+    script = os.path.join(ROOT, "tests", "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29653",
+                          script], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "DIST_OK" in out.stdout

@@ -1,0 +1,144 @@
+"""Conditioner nets: ``theta = f(x_A, context)`` for the transformer of a coupling layer.
+
+Interface and defaults follow the reference's ``conditioning/transforms.py``
+(``ConditionerTransform`` :11-118, ``TensorConditionerTransform`` :140-171, ``FeedForward``
+:274-307, ``Linear`` :310-312), including the ``sequential.{i}.weight`` state-dict names and
+the hidden width rule ``max(int(5 * log10(max(n_in, n_out))), 4)`` (:290-291).  The net is a
+pair of skinny GEMMs (32 -> 9 -> 64 for RealNVP D=64); they stay on PyTorch-ROCm
+(hipBLASLt/rocBLAS) -- this package adds no GEMM of its own.
+
+The construction order of parameters (and so the consumption of the global RNG) is kept the
+same as the reference's, so ``torch.manual_seed(s)`` followed by the same constructor gives
+the same initial weights; tests/ check this against the golden state dicts.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Type
+
+import torch
+import torch.nn as nn
+
+from torchflows_amd.bijections.finite.autoregressive.conditioning.context import (
+    Concatenation, ContextCombiner)
+from torchflows_amd.utils import event_size, get_batch_shape
+
+
+class ConditionerTransform(nn.Module):
+    """Predicts a parameter tensor of ``parameter_shape`` per batch element.
+
+    A boolean ``global_parameter_mask`` marks parameters that are learned constants
+    (``global_theta_flat``) rather than predicted; finite output bounds squash the result
+    (reference :107-113)."""
+
+    def __init__(self,
+                 input_event_shape: Optional[Sequence[int]],
+                 context_shape: Optional[Sequence[int]],
+                 parameter_shape: Sequence[int],
+                 context_combiner: ContextCombiner = None,
+                 global_parameter_mask: Optional[torch.Tensor] = None,
+                 initial_global_parameter_value: float = None,
+                 output_lower_bound: float = -math.inf,
+                 output_upper_bound: float = math.inf,
+                 **kwargs):
+        super().__init__()
+        if global_parameter_mask is not None and tuple(global_parameter_mask.shape) != tuple(parameter_shape):
+            raise ValueError(
+                f"Global parameter mask must have shape equal to the output parameter shape "
+                f"{parameter_shape}, but found {global_parameter_mask.shape}")
+        self.output_lower_bound = output_lower_bound
+        self.output_upper_bound = output_upper_bound
+        self.context_combiner = context_combiner or Concatenation(input_event_shape, context_shape)
+        self.input_event_shape = input_event_shape
+        self.context_shape = context_shape
+        self.n_input_event_dims = self.context_combiner.n_output_dims
+        self.parameter_shape = parameter_shape
+        self.global_parameter_mask = global_parameter_mask
+        self.n_transformer_parameters = event_size(parameter_shape)
+        self.n_global_parameters = 0 if global_parameter_mask is None else int(global_parameter_mask.sum())
+        self.n_predicted_parameters = self.n_transformer_parameters - self.n_global_parameters
+        if initial_global_parameter_value is None:
+            init = torch.randn(size=(self.n_global_parameters,))
+        else:
+            init = torch.full((self.n_global_parameters,), float(initial_global_parameter_value))
+        self.global_theta_flat = nn.Parameter(init)
+
+    def get_batch_shape(self, x: torch.Tensor, context: torch.Tensor):
+        if x is not None:
+            return get_batch_shape(x, self.input_event_shape)
+        if context is not None:
+            return get_batch_shape(context, self.context_shape)
+        raise ValueError("At least one of x or context must be provided.")
+
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        batch = self.get_batch_shape(x, context)
+        if self.n_global_parameters == 0:
+            out = self.predict_theta_flat(x, context).view(*batch, *self.parameter_shape)
+        else:
+            like = x if x is not None else context
+            out = torch.zeros(*batch, *self.parameter_shape, dtype=like.dtype, device=like.device)
+            out[..., self.global_parameter_mask] = self.global_theta_flat
+            if self.n_predicted_parameters > 0:
+                out[..., ~self.global_parameter_mask] = self.predict_theta_flat(x, context)
+        lo, hi = self.output_lower_bound, self.output_upper_bound
+        if lo > -math.inf and hi < math.inf:
+            out = torch.sigmoid(out) * (hi - lo) + lo
+        elif lo > -math.inf:
+            out = torch.exp(out) + lo
+        elif hi < math.inf:
+            out = hi - torch.exp(out)
+        return out
+
+    def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class TensorConditionerTransform(ConditionerTransform):
+    """One parameter tensor for the whole transformed part; optionally a random subset of
+    its entries is global (reference :140-171)."""
+
+    def __init__(self, input_event_shape, parameter_shape, context_shape=None,
+                 percentage_global_parameters: float = 0.0, **kwargs):
+        mask = None
+        if 0.0 < percentage_global_parameters <= 1.0:
+            n = event_size(parameter_shape)
+            chosen = torch.randperm(n)[: int(n * percentage_global_parameters)]
+            mask = torch.zeros(n, dtype=torch.bool)
+            mask[chosen] = True
+            mask = mask.view(*parameter_shape)
+        kwargs = {**kwargs, "global_parameter_mask": mask}
+        super().__init__(input_event_shape=input_event_shape, parameter_shape=parameter_shape,
+                         context_shape=context_shape, **kwargs)
+
+
+class FeedForward(TensorConditionerTransform):
+    """``Linear, (nonlinearity, Linear)*`` on ``[x_A || context]`` (reference :274-307)."""
+
+    def __init__(self, input_event_shape, parameter_shape, context_shape=None,
+                 n_hidden: int = None, n_layers: int = 2,
+                 nonlinearity: Type[nn.Module] = nn.Tanh, **kwargs):
+        super().__init__(input_event_shape=input_event_shape, context_shape=context_shape,
+                         parameter_shape=parameter_shape, **kwargs)
+        n_in, n_out = self.n_input_event_dims, self.n_predicted_parameters
+        if n_hidden is None:
+            n_hidden = max(int(5 * math.log10(max(n_in, n_out))), 4)
+        if n_layers < 1:
+            raise ValueError("n_layers must be at least 1")
+        widths = [n_in] + [n_hidden] * (n_layers - 1) + [n_out]
+        modules = []
+        for i in range(n_layers):
+            modules.append(nn.Linear(widths[i], widths[i + 1]))
+            if i < n_layers - 1:
+                modules.append(nonlinearity())
+        modules.append(nn.Unflatten(dim=-1, unflattened_size=(n_out,)))
+        self.sequential = nn.Sequential(*modules)
+
+    def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        return self.sequential(self.context_combiner(x, context))
+
+
+class Linear(FeedForward):
+    """Single affine map (reference :310-312)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs, n_layers=1)

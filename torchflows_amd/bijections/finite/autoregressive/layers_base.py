@@ -1,0 +1,254 @@
+"""Layer skeletons: a conditioner predicts parameters, a transformer applies them.
+
+Constructor signatures and attribute names follow the reference's ``layers_base.py``
+(``AutoregressiveBijection`` :14-48, ``CouplingBijection`` :51-163, ``ElementwiseBijection``
+:237-318) so user code and state dicts carry over.  Two execution paths:
+
+* **HIP** (fp32, HIP device, no autograd): ``_native_step`` enqueues one libtfk kernel per
+  layer on the shared row buffer of the enclosing composition -- no ``clone``, no
+  boolean-mask gather/scatter, no ``repeat`` of batch-constant parameters, log-det reduced
+  in-kernel and accumulated into the running sum.  The conditioner MLP stays on
+  PyTorch-ROCm GEMMs; for the HalfSplit mask its input is a strided view of the rows
+  (no gather copy).
+* **ATen composite** (autograd / fp64 / host tensors): index-based gather and scatter
+  with pre-registered index buffers instead of the reference's per-call ``nonzero``.
+"""
+from __future__ import annotations
+
+from typing import Any, Optional, Sequence, Tuple, Type, Union
+
+import torch
+import torch.nn as nn
+
+from torchflows_amd import native
+from torchflows_amd.bijections.base import (Bijection, FORWARD, INVERSE, RowState, _params_ok,
+                                            forward_method, inverse_method)
+from torchflows_amd.bijections.finite.autoregressive.conditioning.coupling_masks import (
+    PartialCoupling, make_coupling)
+from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import (
+    ConditionerTransform, FeedForward, Linear)
+from torchflows_amd.bijections.finite.autoregressive.transformers.base import (
+    ScalarTransformer, TensorTransformer)
+from torchflows_amd.utils import as_rows, get_batch_shape
+
+
+class AutoregressiveBijection(Bijection):
+    """conditioner_transform -> h, transformer(x, h) (reference :14-48)."""
+
+    def __init__(self, event_shape, transformer: Union[TensorTransformer, ScalarTransformer],
+                 conditioner_transform: Optional[ConditionerTransform],
+                 l2_regularization: bool = False, l2_coef: float = 0.01, **kwargs):
+        super().__init__(event_shape=event_shape, **kwargs)
+        self.conditioner_transform = conditioner_transform
+        self.transformer = transformer
+        self.l2_regularization = l2_regularization
+        self.l2_coef = l2_coef
+
+    def regularization(self, *aux: Any) -> torch.Tensor:
+        if self.l2_regularization and self.l2_coef > 0:
+            return self.sq_norm_param() * self.l2_coef
+        return torch.tensor(0.0)
+
+    # run a single layer natively when it is called on its own (outside a composition)
+    def _native_standalone(self, x: torch.Tensor, context, d: int):
+        rows, batch = as_rows(x, self.event_shape)
+        state = RowState(rows, batch)
+        self._native_step(state, context, d)
+        state.zero_logdet_if_unwritten()
+        out = state.rows if state.owned else state.rows.clone()
+        return out.view(x.shape), state.logdet.view(batch)
+
+
+class CouplingBijection(AutoregressiveBijection):
+    """``x = (x_A, x_B)``: ``x_A`` passes through and conditions the transform of ``x_B``
+    (reference :51-163).  The inverse needs one conditioner pass too, because the
+    conditioner only ever sees the untouched part."""
+
+    def __init__(self,
+                 event_shape: Sequence[int],
+                 transformer_class: Type[TensorTransformer],
+                 context_shape: Optional[Sequence[int]] = None,
+                 coupling: PartialCoupling = None,
+                 conditioner_transform_class: Type[ConditionerTransform] = FeedForward,
+                 coupling_kwargs: dict = None,
+                 conditioner_kwargs: dict = None,
+                 transformer_kwargs: dict = None,
+                 l2_regularization: bool = True,
+                 **kwargs):
+        coupling = coupling if coupling is not None else make_coupling(event_shape, **(coupling_kwargs or {}))
+        transformer = transformer_class(event_shape=coupling.target_shape, **(transformer_kwargs or {}))
+        conditioner_transform = conditioner_transform_class(
+            input_event_shape=coupling.constant_shape,
+            context_shape=context_shape,
+            parameter_shape=transformer.parameter_shape,
+            **(conditioner_kwargs or {}))
+        super().__init__(event_shape=event_shape, transformer=transformer,
+                         conditioner_transform=conditioner_transform, context_shape=context_shape,
+                         l2_regularization=l2_regularization, **kwargs)
+        self.coupling = coupling
+        # gather lists move with .to(device) once; not part of the state dict (the reference
+        # keeps its masks as plain attributes, coupling_masks.py:22-24)
+        self.register_buffer("_source_index", coupling.source_index.long(), persistent=False)
+        self.register_buffer("_target_index", coupling.target_index.long(), persistent=False)
+        self.register_buffer("_target_index32", coupling.target_index.clone(), persistent=False)
+        self._target_is_tail = coupling.target_is_tail
+        self._source_is_head = coupling.source_is_head
+
+    # -- ATen composite path ---------------------------------------------------
+    def get_constant_part(self, x: torch.Tensor) -> torch.Tensor:
+        batch = get_batch_shape(x, self.event_shape)
+        return x.reshape(*batch, -1).index_select(-1, self._source_index)
+
+    def get_transformed_part(self, x: torch.Tensor) -> torch.Tensor:
+        batch = get_batch_shape(x, self.event_shape)
+        return x.reshape(*batch, -1).index_select(-1, self._target_index)
+
+    def partition_and_predict_parameters(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        batch = get_batch_shape(x, self.event_shape)
+        h = self.conditioner_transform(self.get_constant_part(x), context=context)
+        return h.view(*batch, *self.transformer.parameter_shape)
+
+    def _aten_apply(self, x: torch.Tensor, context, transform) -> Tuple[torch.Tensor, torch.Tensor]:
+        batch = get_batch_shape(x, self.event_shape)
+        h = self.partition_and_predict_parameters(x, context)
+        moved, log_det = transform(self.get_transformed_part(x), h)
+        flat = x.reshape(*batch, -1)
+        out = flat.index_copy(-1, self._target_index, moved.reshape(*batch, -1))
+        return out.view(x.shape), log_det
+
+    # -- HIP path ------------------------------------------------------------------
+    def _native_ok(self, x, context) -> bool:
+        return (self.transformer.native_kind in ("affine", "inverse_affine", "shift", "rqs")
+                and native.eligible(x, context) and _params_ok(self))
+
+    def _native_step(self, state: RowState, context, d: int) -> None:
+        rows = state.rows
+        N, D = rows.shape
+        S, T = self.coupling.source_event_size, self.coupling.target_event_size
+        # conditioner input: a strided view for the HalfSplit mask, one gather otherwise
+        x_a = rows[:, :S] if self._source_is_head else rows.index_select(1, self._source_index)
+        ctx = None if context is None else context.reshape(N, *self.context_shape)
+        h = self.conditioner_transform(x_a, context=ctx).reshape(N, -1).contiguous()
+        out = rows if state.owned else state.out_buffer()
+        tgt = None if self._target_is_tail else self._target_index32
+        acc = state.started
+        kind = self.transformer.native_kind
+        if kind in ("affine", "inverse_affine"):
+            inv = (d == INVERSE) != (kind == "inverse_affine")
+            native.affine_coupling(rows, h, out, state.logdet, tgt, T, accumulate=acc, inverse=inv)
+        elif kind == "rqs":
+            tr = self.transformer
+            native.rqs_coupling(rows, h, out, state.logdet, tgt, T, tr.n_bins, tr.boundary,
+                                accumulate=acc, inverse=(d == INVERSE))
+        elif kind == "shift":
+            native.shift_coupling(rows, h, out, state.logdet, tgt, T, accumulate=acc,
+                                  inverse=(d == INVERSE))
+        else:
+            raise native.NativeError(f"no kernel for transformer kind {kind!r}")
+        state.started = True
+        state.commit(out)
+
+    # -- public maps ---------------------------------------------------------------
+    @forward_method
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(x, context):
+            return self._native_standalone(x, context, FORWARD)
+        return self._aten_apply(x, context, self.transformer.forward)
+
+    @inverse_method
+    def inverse(self, z: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(z, context):
+            return self._native_standalone(z, context, INVERSE)
+        return self._aten_apply(z, context, self.transformer.inverse)
+
+
+class ElementwiseBijection(AutoregressiveBijection):
+    """One scalar transformer per event element.  Without a context the parameters are a
+    learned tensor ``value`` of ``transformer.parameter_shape``; with a context they are
+    predicted from it by a (default: linear) conditioner (reference :237-318)."""
+
+    def __init__(self,
+                 event_shape: Sequence[int],
+                 transformer_class: Type[ScalarTransformer],
+                 context_shape: Optional[Sequence[int]] = None,
+                 transformer_kwargs: dict = None,
+                 fill_value: Union[float, torch.Tensor] = None,
+                 conditioner_transform_class: Type[ConditionerTransform] = Linear,
+                 conditioner_kwargs: dict = None,
+                 **kwargs):
+        transformer = transformer_class(event_shape=event_shape, **(transformer_kwargs or {}))
+        if context_shape is None:
+            if fill_value is None:
+                init = torch.randn(*transformer.parameter_shape)
+            elif isinstance(fill_value, torch.Tensor):
+                if fill_value.shape != transformer.parameter_shape:
+                    raise ValueError("Shape of fill_value must match the transformer parameter shape")
+                init = fill_value
+            else:
+                init = torch.full(size=tuple(transformer.parameter_shape), fill_value=fill_value)
+            super().__init__(event_shape=event_shape, context_shape=None, transformer=transformer,
+                             conditioner_transform=None, **kwargs)
+            self.register_parameter("value", nn.Parameter(init))
+            self.use_global_parameters = True
+        else:
+            conditioner_transform = conditioner_transform_class(
+                input_event_shape=None, context_shape=context_shape,
+                parameter_shape=transformer.parameter_shape, **(conditioner_kwargs or {}))
+            super().__init__(event_shape=event_shape, context_shape=context_shape,
+                             transformer=transformer, conditioner_transform=conditioner_transform,
+                             **kwargs)
+            self.register_buffer("value", torch.empty(size=()))
+            self.use_global_parameters = False
+
+    def prepare_h(self, context: torch.Tensor, batch_shape) -> torch.Tensor:
+        if self.use_global_parameters:
+            # broadcast view -- the reference repeats value to (N, D, 2) (layers_base.py:303)
+            return self.value.expand(*batch_shape, *self.value.shape)
+        if context is None:
+            raise RuntimeError("Context must be provided")
+        return self.conditioner_transform(x=None, context=context)
+
+    # -- HIP path --------------------------------------------------------------------
+    def _native_ok(self, x, context) -> bool:
+        return (self.transformer.native_kind in ("affine", "inverse_affine")
+                and native.eligible(x, context) and _params_ok(self))
+
+    def _native_step(self, state: RowState, context, d: int) -> None:
+        rows = state.rows
+        N, D = rows.shape
+        kind = self.transformer.native_kind
+        if kind not in ("affine", "inverse_affine"):
+            raise native.NativeError(f"no elementwise kernel for transformer kind {kind!r}")
+        out = rows if state.owned else state.out_buffer()
+        inverse_affine = (kind == "inverse_affine")
+        if self.use_global_parameters:
+            native.elementwise_affine(rows, self.value.detach().reshape(D, 2).contiguous(), out,
+                                      state.logdet, inverse_affine, accumulate=state.started,
+                                      inverse=(d == INVERSE))
+        else:
+            # context-conditioned parameters: h (N, D, 2) from the conditioner; this is the
+            # affine-coupling kernel with every position a target
+            if context is None:
+                raise RuntimeError("Context must be provided")
+            h = self.conditioner_transform(x=None, context=context.reshape(N, *self.context_shape))
+            h = h.reshape(N, -1).contiguous()
+            inv = (d == INVERSE) != inverse_affine
+            native.affine_coupling(rows, h, out, state.logdet, None, D, accumulate=state.started,
+                                   inverse=inv)
+        state.started = True
+        state.commit(out)
+
+    # -- public maps -------------------------------------------------------------------
+    @forward_method
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(x, context):
+            return self._native_standalone(x, context, FORWARD)
+        h = self.prepare_h(context, get_batch_shape(x, self.event_shape))
+        return self.transformer.forward(x, h)
+
+    @inverse_method
+    def inverse(self, z: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(z, context):
+            return self._native_standalone(z, context, INVERSE)
+        h = self.prepare_h(context, get_batch_shape(z, self.event_shape))
+        return self.transformer.inverse(z, h)

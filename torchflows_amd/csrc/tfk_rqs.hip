@@ -1,0 +1,364 @@
+// tfk_rqs.hip -- rational-quadratic spline coupling (Neural Spline Flow layer).
+//
+// Replaces CouplingBijection.forward/inverse (layers_base.py:145-163) around
+// MonotonicSpline.forward/inverse (spline/base.py:53-72) and
+// RationalQuadratic.rqs_forward_1d / rqs_inverse_1d (rational_quadratic.py:45-200).
+//
+// Data movement (the kernel is priced against HBM: 4*(D + T*P + D) + 8 bytes/row):
+//   * h is (N, T, P = 3K-1) contiguous, i.e. one flat stream of P-float parameter
+//     records, 92 B each for K = 8 -- not 16-byte aligned per record.  A workgroup
+//     takes a tile of R = 256/T rows = up to 256 records (23.5 KB for K = 8), pulls it
+//     from HBM with fully coalesced 16-byte loads (1 KiB per wave-instruction) and
+//     parks it in LDS; each lane then reads its own record with ds_read_b32 at a
+//     P-dword stride, which is bank-conflict-free for odd P (23, 11, 47).
+//   * one lane = one spline element: 2 softmaxes (K exps each), knot cumsum, bin
+//     search by compare/select (no indexed registers), only the two derivatives
+//     delta_k, delta_k+1 that the selected bin needs (fetched from LDS by index).
+//   * per-row log-det: __shfl_xor inside the T-lane group when T is a power of two
+//     <= 64 (T = 32 for D = 64), LDS otherwise.  No atomics, deterministic.
+//   * out-of-box elements (strict (-B, B), spline/base.py:29-33) pass through with
+//     zero log-det, branch per lane; no host sync (the reference's torch.any / assert
+//     syncs have no counterpart).
+// Arithmetic keeps the reference's fp32 op order, including ATen's CPU softmax
+// (e * (1/sum)); built with -ffp-contract=off.
+#include <cmath>
+
+#include "tfk_common.h"
+
+namespace tfk {
+
+struct RqsConst {
+    float minimum;   // -boundary
+    float maximum;   // +boundary
+    float span;      // maximum - minimum (python double, cast once)
+    float scale;     // 1 - min_bin_size * n_bins (python double, cast once)
+    float c;         // boundary_u_delta = log(expm1(1 - min_delta))
+};
+
+// F.softplus, beta = 1, threshold = 20
+__device__ __forceinline__ float softplus20(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+
+// rational_quadratic.py:56-63
+__device__ __forceinline__ float rqs_log_det(float s, float dk, float dk1, float xi, float q,
+                                             float term1)
+{
+    const float omx = 1.0f - xi;
+    const float inner = dk1 * (xi * xi) + (2.0f * s) * q + dk * (omx * omx);
+    const float log_num = 2.0f * logf(s) + logf(inner);
+    const float log_den = 2.0f * logf(s + term1 * q);
+    return log_num - log_den;
+}
+
+// torch.clip: NaN passes through
+__device__ __forceinline__ float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+// One in-box element.  p -> its P = 3K-1 parameters in LDS.  KT > 0: compile-time K,
+// everything in registers; KT == 0: run-time K, streamed from LDS (no local arrays).
+template <int KT, bool INVERSE>
+__device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const RqsConst &C,
+                                         float &out, float &ld)
+{
+    const int K = KT > 0 ? KT : Krt;
+    int k = 0;
+    float bxk = C.minimum, bxk1 = C.maximum, byk = C.minimum, byk1 = C.maximum;
+
+    if constexpr (KT > 0) {
+        float ex[KT], ey[KT];
+        float mx = 0.0f, my = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float ux = p[j];
+            const float uy = ux + p[KT + j] / 1000.0f;     // rational_quadratic.py:76
+            ex[j] = ux;
+            ey[j] = uy;
+            mx = j ? fmaxf(mx, ux) : ux;
+            my = j ? fmaxf(my, uy) : uy;
+        }
+        float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {                     // softmax numerators, :46
+            ex[j] = expf(ex[j] - mx);
+            ey[j] = expf(ey[j] - my);
+            sx += ex[j];
+            sy += ey[j];
+        }
+        const float rx = 1.0f / sx, ry = 1.0f / sy;
+        float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+        bool prev_below = true;                            // knot 0 = minimum < v (in box)
+#pragma unroll
+        for (int j = 1; j <= KT; ++j) {
+            runx = runx + (kRqsMinBin + C.scale * (ex[j - 1] * rx));   // :47-48
+            runy = runy + (kRqsMinBin + C.scale * (ey[j - 1] * ry));
+            const float kx = (j == KT) ? C.maximum : C.span * runx + C.minimum;   // :50-52
+            const float ky = (j == KT) ? C.maximum : C.span * runy + C.minimum;
+            // searchsorted(knots, v) - 1, right=False: last knot strictly below v (:82/:147)
+            const bool below = (INVERSE ? ky : kx) < v;
+            const bool sel = prev_below && !below;
+            k = sel ? j - 1 : k;
+            bxk = sel ? prevx : bxk;
+            bxk1 = sel ? kx : bxk1;
+            byk = sel ? prevy : byk;
+            byk1 = sel ? ky : byk1;
+            prev_below = below;
+            prevx = kx;
+            prevy = ky;
+        }
+    } else {
+        float mx = p[0], my = p[0] + p[K] / 1000.0f;
+        for (int j = 1; j < K; ++j) {
+            mx = fmaxf(mx, p[j]);
+            my = fmaxf(my, p[j] + p[K + j] / 1000.0f);
+        }
+        float sx = 0.0f, sy = 0.0f;
+        for (int j = 0; j < K; ++j) {
+            sx += expf(p[j] - mx);
+            sy += expf((p[j] + p[K + j] / 1000.0f) - my);
+        }
+        const float rx = 1.0f / sx, ry = 1.0f / sy;
+        float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+        bool prev_below = true;
+        for (int j = 1; j <= K; ++j) {
+            const float e_x = expf(p[j - 1] - mx);
+            const float e_y = expf((p[j - 1] + p[K + j - 1] / 1000.0f) - my);
+            runx = runx + (kRqsMinBin + C.scale * (e_x * rx));
+            runy = runy + (kRqsMinBin + C.scale * (e_y * ry));
+            const float kx = (j == K) ? C.maximum : C.span * runx + C.minimum;
+            const float ky = (j == K) ? C.maximum : C.span * runy + C.minimum;
+            const bool below = (INVERSE ? ky : kx) < v;
+            const bool sel = prev_below && !below;
+            k = sel ? j - 1 : k;
+            bxk = sel ? prevx : bxk;
+            bxk1 = sel ? kx : bxk1;
+            byk = sel ? prevy : byk;
+            byk1 = sel ? ky : byk1;
+            prev_below = below;
+            prevx = kx;
+            prevy = ky;
+        }
+    }
+
+    const float wk = bxk1 - bxk;                           // bin_sizes = bins[1:] - bins[:-1], :53
+    const float hk = byk1 - byk;
+    // u_d = pad(h[2K:], (1, 1), value = c) (:127); only delta_k and delta_k+1 are used.
+    // (the discarded LDS reads at k == 0 / k == K-1 stay inside the padded tile)
+    const float udk = (k == 0) ? C.c : p[2 * K + k - 1];
+    const float udk1 = (k == K - 1) ? C.c : p[2 * K + k];
+    const float dk = kRqsMinDelta + softplus20(C.c + udk / 1000.0f);    // :77
+    const float dk1 = kRqsMinDelta + softplus20(C.c + udk1 / 1000.0f);
+    const float s = hk / wk;                               // :94 / :159
+    const float term1 = dk1 + dk - 2.0f * s;               // :97 / :162
+
+    if (!INVERSE) {
+        float xi = (v - bxk) / wk;                         // :99
+        xi = clip01(xi);                                   // :100
+        const float q = xi * (1.0f - xi);                  // :101
+        const float num0 = hk * (s * (xi * xi) + dk * q);  // :104
+        const float den0 = s + term1 * q;                  // :105
+        out = byk + num0 / den0;                           // :106
+        ld = rqs_log_det(s, dk, dk1, xi, q, term1);        // :109
+    } else {
+        const float term0 = v - byk;                       // :164
+        const float term2 = hk * dk;                       // :165
+        const float a = (hk * s - term2) + term0 * term1;  // :167
+        const float b = term2 - term0 * term1;             // :168
+        const float c = (-s) * term0;                      // :169
+        float r = sqrtf(b * b - (4.0f * a) * c);           // :171
+        r = r < 0.0f ? 0.0f : r;
+        float xi = (2.0f * c) / ((-b) - r);                // :173
+        xi = clip01(xi);                                   // :174
+        const float q = xi * (1.0f - xi);                  // :175
+        out = xi * wk + bxk;                               // :178
+        ld = -rqs_log_det(s, dk, dk1, xi, q, term1);       // :181
+    }
+}
+
+constexpr int kTile = kBlock;   // spline elements (parameter records) per LDS tile
+
+// Dynamic LDS layout: [kTile * P + 4 floats of records | kTile floats of log-dets |
+//                      D bytes of target mask (only tgt_idx && !inplace)]
+template <int KT, bool INVERSE>
+__global__ __launch_bounds__(kBlock) void k_rqs_coupling(
+    const float *x, const float *__restrict__ h, float *z, float *logdet, long long N, int D,
+    const int *__restrict__ tgt_idx, int T, int T_shift, int Krt, RqsConst C, int accumulate,
+    int inplace, int h_vec_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = KT > 0 ? KT : Krt;
+    const int P = 3 * K - 1;
+    float *rec = lds;
+    float *ld_s = lds + kTile * P + 4;
+    unsigned char *is_tgt = reinterpret_cast<unsigned char *>(ld_s + kTile);
+    const int tid = threadIdx.x;
+    const bool use_mask = (tgt_idx != nullptr) && !inplace;
+    if (use_mask) {
+        for (int e = tid; e < D; e += kBlock) is_tgt[e] = 0;
+        __syncthreads();
+        for (int t = tid; t < T; t += kBlock) is_tgt[tgt_idx[t]] = 1;
+    }
+
+    const int R = T <= kTile ? kTile / T : 1;          // rows per tile
+    const int chunks = T <= kTile ? 1 : (T + kTile - 1) / kTile;
+    const long long n_tiles = (N + R - 1) / R;
+    const bool shfl_reduce = (T_shift >= 0) && (T <= kWave);
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row0 = tile * R;
+        const int rows = (int)((N - row0) < (long long)R ? (N - row0) : (long long)R);
+        float ld_thread = 0.0f;    // T > kTile: this thread's share of the (single) row
+
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int cbase = ch * kTile;
+            const int E = (chunks == 1) ? rows * T : ((T - cbase) < kTile ? (T - cbase) : kTile);
+            const long long hoff = (row0 * (long long)T + cbase) * P;    // floats
+            const int nfl = E * P;
+
+            __syncthreads();   // previous tile's readers are done with rec / ld_s
+            if (h_vec_ok && (hoff & 3) == 0) {
+                const float4 *src = reinterpret_cast<const float4 *>(h + hoff);
+                float4 *dst = reinterpret_cast<float4 *>(rec);
+                const int nv = nfl >> 2;
+                for (int i = tid; i < nv; i += kBlock) dst[i] = src[i];
+                for (int i = (nv << 2) + tid; i < nfl; i += kBlock) rec[i] = h[hoff + i];
+            } else {
+                for (int i = tid; i < nfl; i += kBlock) rec[i] = h[hoff + i];
+            }
+            __syncthreads();
+
+            float ld = 0.0f;
+            long long row = row0;
+            int t = cbase + tid;
+            if (chunks == 1) {
+                const int r = T_shift >= 0 ? (tid >> T_shift) : (tid / T);
+                t = tid - r * T;
+                row = row0 + r;
+            }
+            if (tid < E) {
+                const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
+                const float v = x[row * D + idx];
+                float o = v;                                       // spline/base.py:54-55
+                if (v > C.minimum && v < C.maximum)                // strict, base.py:29-33
+                    rqs_eval<KT, INVERSE>(rec + tid * P, K, v, C, o, ld);
+                z[row * D + idx] = o;
+            }
+
+            if (chunks > 1) {
+                ld_thread += ld;
+            } else if (shfl_reduce) {
+                const float sum = group_sum(ld, T);                 // sum_except_batch, base.py:59
+                if (tid < E && t == 0)
+                    logdet[row] = accumulate ? logdet[row] + sum : sum;
+            } else {
+                ld_s[tid] = ld;
+                __syncthreads();
+                if (tid < rows) {
+                    float sum = 0.0f;
+                    for (int j = 0; j < T; ++j) sum += ld_s[tid * T + j];
+                    logdet[row0 + tid] = accumulate ? logdet[row0 + tid] + sum : sum;
+                }
+            }
+        }
+
+        if (chunks > 1) {
+            __syncthreads();
+            ld_s[tid] = ld_thread;
+            __syncthreads();
+            for (int o = kBlock / 2; o > 0; o >>= 1) {
+                if (tid < o) ld_s[tid] += ld_s[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) logdet[row0] = accumulate ? logdet[row0] + ld_s[0] : ld_s[0];
+        }
+
+        if (!inplace) {                                            // clone, layers_base.py:146
+            const int total = rows * D;
+            for (int e = tid; e < total; e += kBlock) {
+                const int r = e / D;
+                const int c = e - r * D;
+                const bool tgt = tgt_idx ? (is_tgt[c] != 0) : (c >= D - T);
+                if (!tgt) z[(row0 + r) * D + c] = x[(row0 + r) * D + c];
+            }
+        }
+    }
+}
+
+template <bool INVERSE>
+static int rqs_coupling(const float *x, const float *h, float *z, float *logdet, int64_t N,
+                        int32_t D, const int32_t *tgt_idx, int32_t T, int32_t K, float boundary,
+                        int32_t accumulate, void *stream, const char *fn)
+{
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D <= 0) return fail(TFK_EINVAL, "%s: D = %d must be positive", fn, D);
+    if (T <= 0 || T > D) return fail(TFK_EINVAL, "%s: T = %d must be in [1, D = %d]", fn, T, D);
+    if (K < 2 || K > 32) return fail(TFK_EINVAL, "%s: n_bins K = %d must be in [2, 32]", fn, K);
+    if (!(boundary > 0.0f)) return fail(TFK_EINVAL, "%s: boundary must be positive", fn);
+    if (N == 0) return TFK_OK;
+    if (!x || !h || !z || !logdet) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    const bool inplace = (x == z);
+    const int P = 3 * K - 1;
+    size_t lds = ((size_t)kTile * P + 4 + kTile) * sizeof(float);
+    if (tgt_idx && !inplace) lds += (size_t)D;
+    if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: LDS tile of %zu bytes exceeds 160 KiB", fn, lds);
+    if (lds > 64 * 1024) {
+        // large K (run-time-K kernel only): opt in to more than 64 KiB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rqs_coupling<0, INVERSE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+
+    RqsConst C;
+    C.minimum = -boundary;
+    C.maximum = boundary;
+    C.span = (float)((double)boundary - (double)(-boundary));
+    C.scale = (float)(1.0 - 1e-3 * (double)K);
+    C.c = (float)std::log(std::expm1(1.0 - 1e-5));
+
+    int T_shift = -1;
+    if ((T & (T - 1)) == 0) {
+        T_shift = 0;
+        while ((1 << T_shift) < T) ++T_shift;
+    }
+    const int R = T <= kTile ? kTile / T : 1;
+    const int64_t n_tiles = (N + R - 1) / R;
+    // LDS-bound residency: 160 KiB / tile; cap the grid there and stride the rest
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int64_t grid = n_tiles < (int64_t)kCUs * per_cu ? n_tiles : (int64_t)kCUs * per_cu;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int h_vec_ok = aligned16(h) ? 1 : 0;
+
+#define TFK_RQS_LAUNCH(KT_)                                                                       \
+    hipLaunchKernelGGL((k_rqs_coupling<KT_, INVERSE>), dim3((unsigned)grid), dim3(kBlock), lds, s, \
+                       x, h, z, logdet, (long long)N, D, tgt_idx, T, T_shift, K, C, accumulate,    \
+                       inplace ? 1 : 0, h_vec_ok)
+    if (K == 8) TFK_RQS_LAUNCH(8);
+    else if (K == 4) TFK_RQS_LAUNCH(4);
+    else TFK_RQS_LAUNCH(0);
+#undef TFK_RQS_LAUNCH
+    return check_launch(fn);
+}
+
+}  // namespace tfk
+
+extern "C" {
+
+int tfk_rqs_coupling_fwd(const float *x, const float *h, float *z, float *logdet, int64_t N,
+                         int32_t D, const int32_t *tgt_idx, int32_t T, int32_t K, float boundary,
+                         int32_t accumulate, void *stream)
+{
+    return tfk::rqs_coupling<false>(x, h, z, logdet, N, D, tgt_idx, T, K, boundary, accumulate,
+                                    stream, "tfk_rqs_coupling_fwd");
+}
+
+int tfk_rqs_coupling_inv(const float *z, const float *h, float *x, float *logdet, int64_t N,
+                         int32_t D, const int32_t *tgt_idx, int32_t T, int32_t K, float boundary,
+                         int32_t accumulate, void *stream)
+{
+    return tfk::rqs_coupling<true>(z, h, x, logdet, N, D, tgt_idx, T, K, boundary, accumulate,
+                                   stream, "tfk_rqs_coupling_inv");
+}
+
+}  // extern "C"

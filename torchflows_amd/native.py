@@ -1,0 +1,264 @@
+"""ctypes binding of libtfk.so (C-ABI declared in include/tfk.h).
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``), the
+current HIP stream and the device guard.  No torch types cross the boundary.
+
+The product path never falls back: if the library is missing or a call fails the
+error is raised (``NativeError``).  Nothing in this package imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtfk.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# every symbol include/tfk.h declares (tests check the built library exports all of them)
+SYMBOLS = (
+    "tfk_abi_version", "tfk_last_error", "tfk_device_info",
+    "tfk_affine_coupling_fwd", "tfk_affine_coupling_inv",
+    "tfk_shift_coupling_fwd", "tfk_shift_coupling_inv",
+    "tfk_rqs_coupling_fwd", "tfk_rqs_coupling_inv",
+    "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
+    "tfk_permute", "tfk_diag_gauss_logprob",
+    "tfk_sum_workspace_bytes", "tfk_sum_f32",
+)
+
+ABI_VERSION = 1
+
+
+class NativeError(RuntimeError):
+    """libtfk is missing, mismatched, or a kernel call was rejected."""
+
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+
+_lib: Optional[C.CDLL] = None
+calls = 0   # number of kernel entry points invoked (tests assert the HIP path really ran)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libtfk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-C", CSRC, "-B"], check=True, stdout=out)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def _bind(L: C.CDLL) -> None:
+    coupling = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
+    for n in ("tfk_affine_coupling_fwd", "tfk_affine_coupling_inv",
+              "tfk_shift_coupling_fwd", "tfk_shift_coupling_inv"):
+        getattr(L, n).argtypes = coupling
+    rqs = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, C.c_float, _i32, _vp]
+    L.tfk_rqs_coupling_fwd.argtypes = rqs
+    L.tfk_rqs_coupling_inv.argtypes = rqs
+    ew = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
+    L.tfk_elementwise_affine_fwd.argtypes = ew
+    L.tfk_elementwise_affine_inv.argtypes = ew
+    L.tfk_permute.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp]
+    L.tfk_diag_gauss_logprob.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
+    L.tfk_sum_workspace_bytes.argtypes = [_i64]
+    L.tfk_sum_workspace_bytes.restype = _i64
+    L.tfk_sum_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
+    L.tfk_last_error.restype = C.c_char_p
+    L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises NativeError (never falls back) if it cannot be used."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:   # e.g. libamdhip64 not loadable
+            raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+        missing = [s for s in SYMBOLS if not hasattr(L, s)]
+        if missing:
+            raise NativeError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
+        if L.tfk_abi_version() != ABI_VERSION:
+            raise NativeError(f"{LIB_PATH} has ABI {L.tfk_abi_version()}, expected {ABI_VERSION}")
+        _bind(L)
+        _lib = L
+    return _lib
+
+
+def available() -> bool:
+    try:
+        lib()
+        return True
+    except NativeError:
+        return False
+
+
+def eligible(*tensors: Optional[torch.Tensor]) -> bool:
+    """True when the HIP path applies: fp32 tensors on a HIP device, no autograd needed.
+    (Training / fp64 / host tensors take the ATen composite path, as SURVEY.md app. B.)"""
+    seen = False
+    for t in tensors:
+        if t is None:
+            continue
+        seen = True
+        if t.device.type != "cuda" or t.dtype != torch.float32:
+            return False
+        if t.requires_grad and torch.is_grad_enabled():
+            return False
+    return seen
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeError(f"{what} failed (code {rc}): {lib().tfk_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor], what: str) -> Optional[int]:
+    if t is None:
+        return None
+    if t.device.type != "cuda":
+        raise NativeError(f"{what}: tensor is on {t.device}, the kernels need a HIP device")
+    if not t.is_contiguous():
+        raise NativeError(f"{what}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _f32(t: Optional[torch.Tensor], what: str) -> Optional[int]:
+    if t is not None and t.dtype != torch.float32:
+        raise NativeError(f"{what}: expected float32, got {t.dtype}")
+    return _ptr(t, what)
+
+
+def _idx(t: Optional[torch.Tensor], what: str) -> Optional[int]:
+    if t is not None and t.dtype != torch.int32:
+        raise NativeError(f"{what}: expected int32 indices, got {t.dtype}")
+    return _ptr(t, what)
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _rows(x: torch.Tensor, what: str):
+    if x.dim() != 2:
+        raise NativeError(f"{what}: expected a (N, D) tensor, got shape {tuple(x.shape)}")
+    return x.shape[0], x.shape[1]
+
+
+def _coupling(name, x, h, out, logdet, tgt_idx, T, P, accumulate, extra=()):
+    global calls
+    N, D = _rows(x, name)
+    if out.shape != x.shape:
+        raise NativeError(f"{name}: out shape {tuple(out.shape)} != x shape {tuple(x.shape)}")
+    if h.numel() != N * T * P:
+        raise NativeError(f"{name}: h has {h.numel()} elements, expected N*T*P = {N}*{T}*{P}")
+    if logdet is not None and logdet.numel() != N:
+        raise NativeError(f"{name}: logdet has {logdet.numel()} elements, expected {N}")
+    if tgt_idx is not None and tgt_idx.numel() != T:
+        raise NativeError(f"{name}: tgt_idx has {tgt_idx.numel()} entries, expected T = {T}")
+    fn = getattr(lib(), name)
+    args = (_f32(x, name), _f32(h, name), _f32(out, name), _f32(logdet, name), N, D,
+            _idx(tgt_idx, name), T, *extra, 1 if accumulate else 0)
+    with torch.cuda.device(x.device):
+        rc = fn(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+
+
+def affine_coupling(x, h, out, logdet, tgt_idx, T, accumulate=False, inverse=False):
+    """x, out: (N, D); h: (N, T, 2); logdet: (N,).  tgt_idx None = contiguous tail."""
+    _coupling("tfk_affine_coupling_inv" if inverse else "tfk_affine_coupling_fwd",
+              x, h, out, logdet, tgt_idx, T, 2, accumulate)
+
+
+def shift_coupling(x, h, out, logdet, tgt_idx, T, accumulate=False, inverse=False):
+    _coupling("tfk_shift_coupling_inv" if inverse else "tfk_shift_coupling_fwd",
+              x, h, out, logdet, tgt_idx, T, 1, accumulate)
+
+
+def rqs_coupling(x, h, out, logdet, tgt_idx, T, n_bins, boundary, accumulate=False,
+                 inverse=False):
+    """h: (N, T, 3*n_bins - 1)."""
+    _coupling("tfk_rqs_coupling_inv" if inverse else "tfk_rqs_coupling_fwd",
+              x, h, out, logdet, tgt_idx, T, 3 * n_bins - 1, accumulate,
+              extra=(int(n_bins), C.c_float(float(boundary))))
+
+
+def elementwise_affine(x, value, out, logdet, inverse_affine, accumulate=False, inverse=False):
+    """value: (D, 2) global parameters; inverse_affine selects the ActNorm transformer."""
+    global calls
+    name = "tfk_elementwise_affine_inv" if inverse else "tfk_elementwise_affine_fwd"
+    N, D = _rows(x, name)
+    if value.numel() != 2 * D:
+        raise NativeError(f"{name}: value has {value.numel()} elements, expected 2*D = {2 * D}")
+    if out.shape != x.shape or logdet.numel() != N:
+        raise NativeError(f"{name}: bad out/logdet shape")
+    args = (_f32(x, name), _f32(value, name), _f32(out, name), _f32(logdet, name), N, D,
+            1 if inverse_affine else 0, 1 if accumulate else 0)
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), name)(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+
+
+def permute(x, perm, out):
+    """out[n, j] = x[n, perm[j]]; perm None = reversal."""
+    global calls
+    N, D = _rows(x, "tfk_permute")
+    if out.shape != x.shape:
+        raise NativeError("tfk_permute: bad out shape")
+    if perm is not None and perm.numel() != D:
+        raise NativeError(f"tfk_permute: perm has {perm.numel()} entries, expected D = {D}")
+    args = (_f32(x, "tfk_permute"), _idx(perm, "tfk_permute"), _f32(out, "tfk_permute"), N, D)
+    with torch.cuda.device(x.device):
+        rc = lib().tfk_permute(*args, _stream(x))
+    calls += 1
+    _check(rc, "tfk_permute")
+
+
+def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
+    global calls
+    name = "tfk_diag_gauss_logprob"
+    N, D = _rows(z, name)
+    if loc.numel() != D or log_scale.numel() != D or out.numel() != N:
+        raise NativeError(f"{name}: bad parameter/out shape")
+    args = (_f32(z, name), _f32(loc, name), _f32(log_scale, name), _f32(logdet_in, name),
+            _f32(out, name), N, D)
+    with torch.cuda.device(z.device):
+        rc = lib().tfk_diag_gauss_logprob(*args, _stream(z))
+    calls += 1
+    _check(rc, name)
+
+
+def sum_f32(values: torch.Tensor) -> torch.Tensor:
+    """fp64 sum of an fp32 vector as a 1-element float64 device tensor (feeds the all-reduce)."""
+    global calls
+    v = values.reshape(-1)
+    N = v.numel()
+    _f32(v, "tfk_sum_f32")
+    out = torch.empty(1, dtype=torch.float64, device=v.device)
+    ws = torch.empty(int(lib().tfk_sum_workspace_bytes(N)), dtype=torch.uint8, device=v.device)
+    with torch.cuda.device(v.device):
+        rc = lib().tfk_sum_f32(_f32(v, "tfk_sum_f32"), out.data_ptr(), ws.data_ptr(), N, _stream(v))
+    calls += 1
+    _check(rc, "tfk_sum_f32")
+    return out
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = _i32(0)
+    rc = lib().tfk_device_info(name, 256, C.byref(cus))
+    _check(rc, "tfk_device_info")
+    return name.value.decode(), int(cus.value)

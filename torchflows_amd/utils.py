@@ -1,0 +1,43 @@
+"""Shape helpers shared by the host-side mirror of the torchflows plugin surface.
+
+Events may have any rank and so may batches (reference: torchflows/utils.py:37-87,
+158-159); the HIP kernels always see ``(N, D)`` with ``N = prod(batch_shape)`` and
+``D = prod(event_shape)``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence, Tuple
+
+import torch
+
+
+def event_size(event_shape: Sequence[int]) -> int:
+    return int(math.prod(tuple(event_shape)))
+
+
+def get_batch_shape(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Size:
+    """Leading dims of ``x`` once the trailing ``event_shape`` is removed (utils.py:86-87)."""
+    return x.shape[: x.dim() - len(event_shape)]
+
+
+def flatten_event(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tensor:
+    """``(*batch, *event) -> (*batch, D)`` (utils.py:37-46)."""
+    return x.reshape(*get_batch_shape(x, event_shape), -1)
+
+
+def unflatten_event(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tensor:
+    """``(*batch, D) -> (*batch, *event)`` (utils.py:49-58)."""
+    return x.reshape(*x.shape[:-1], *event_shape)
+
+
+def sum_except_batch(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tensor:
+    """Sum over the trailing event dims (utils.py:158-159)."""
+    n = len(event_shape)
+    return x.sum(dim=tuple(range(x.dim() - n, x.dim()))) if n else x
+
+
+def as_rows(x: torch.Tensor, event_shape: Sequence[int]) -> Tuple[torch.Tensor, torch.Size]:
+    """Contiguous ``(N, D)`` view/copy of ``x`` plus its batch shape -- what the kernels take."""
+    batch = get_batch_shape(x, event_shape)
+    return x.reshape(-1, event_size(event_shape)).contiguous(), batch
