@@ -221,7 +221,8 @@ def test_full_size_properties(pkg, oracle, arch, D, N, chunk):
                 assert bool(torch.isfinite(z).all())
         # chunking invariance: rows do not interact
         lp_small = flow.log_prob(x[1000:1000 + 777])
-    assert torch.equal(lp_small, lp[1000:1000 + 777])
+    # (not bitwise: the conditioner GEMMs are rocBLAS/hipBLASLt, which picks kernels by M)
+    assert torch.allclose(lp_small, lp[1000:1000 + 777], rtol=tol, atol=tol)
     assert bool(torch.isfinite(lp).all())
     idx = torch.randperm(N, generator=torch.Generator().manual_seed(0))[:4096]
     lp_ref = ref.log_prob(x[idx.cuda()].cpu().numpy())
