@@ -130,27 +130,40 @@ def make_flow(arch, D, n_layers):
     return flow.eval()
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: affinity mask, capped by a cgroup-v2 CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(arch, D, n_layers, flow_host, target_seconds=12.0):
-    """Time the CPU oracle (a port; OpenMP over rows, all host cores) on a bounded sample."""
+    """Time the CPU oracle (a port; OpenMP over rows, all usable host cores) on a bounded
+    sample: batches of 2^16 rows of the same workload until ~target_seconds have elapsed."""
     from oracle import oracle as orc
     sd = {k: v.detach().cpu().numpy() for k, v in flow_host.state_dict().items()}
     ref = orc.preset_from_state_dict(arch, D, n_layers, sd)
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     orc.set_num_threads(threads)
     rng = np.random.default_rng(1234)
-    probe = rng.standard_normal((1 << 13, D)).astype(np.float32)
-    ref.log_prob(probe)                                   # warm-up (page in, thread pool)
-    t0 = time.perf_counter()
-    ref.log_prob(probe)
-    rate = probe.shape[0] / (time.perf_counter() - t0)
-    n = int(min(max(rate * target_seconds, 1 << 13), 1 << 22))
-    x = rng.standard_normal((n, D)).astype(np.float32)
-    t0 = time.perf_counter()
-    ref.log_prob(x)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "evals/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{n} rows of the same workload ({arch} D={D}, {n_layers} coupling layers), "
-                      f"oracle/oracle.c with OpenMP over rows, {dt:.1f} s"}, ref
+    x = rng.standard_normal((1 << 16, D)).astype(np.float32)
+    ref.log_prob(x[:4096])                                # warm-up (page in, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref.log_prob(x)
+        n += x.shape[0]
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or n >= (1 << 26):
+            break
+    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} rows ({n // x.shape[0]} batches of 2^16) of the same workload ({arch} D={D}, "
+                      f"{n_layers} coupling layers), oracle/oracle.c, OpenMP over rows on "
+                      f"{threads} threads, {dt:.1f} s"}, ref
 
 
 def main():
@@ -218,6 +231,13 @@ def main():
         kernels = timer.summary()
         dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
         dom = kernels[dom_name]
+        traffic = None     # PMC counters need their own rocprofv3 passes: read the committed summary
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(dom_name)
+            if traffic is not None and rows != WORKLOADS[args.workload][3]:
+                traffic = None
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             "metric": "log_prob evals/sec (RealNVP D=64)" if args.workload == "realnvp64"
                       else f"log_prob evals/sec ({args.workload})",
@@ -238,7 +258,7 @@ def main():
                                    f"data-initialised weights (seed 0)",
                        "rows_per_gpu": rows, "parallelism": f"batch-sharded replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
                          "avg_us": dom["avg_us"], "launches": dom["launches"]},
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
