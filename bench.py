@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak (= fp32-input MFMA peak), same guide
 WORKLOADS = {
     # name: (arch, D, n_layers, rows per GPU, chunk rows)
     "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
@@ -57,7 +58,8 @@ class KernelTimer:
                             ("rqs_coupling", self._rqs_bytes),
                             ("elementwise_affine", self._elementwise_bytes),
                             ("permute", lambda a, k: 8 * a[0].numel()),
-                            ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0])):
+                            ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0]),
+                            ("flow_run", self._flow_bytes)):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -81,6 +83,15 @@ class KernelTimer:
         return N * (4 * (2 * T + T * P) + 8 if inplace else 4 * (D + T * P + D) + 8)
 
     @staticmethod
+    def _flow_bytes(a, k):
+        # rows in (4*D) [+ rows out] [+ logdet r/w] [+ logprob w]
+        x, z, logdet, logprob = a[0], a[1], a[2], a[5]
+        N, D = x.shape
+        acc = k.get("accumulate", False)
+        return N * (4 * D + (4 * D if z is not None else 0) + ((8 if acc else 4) if logdet is not None else 0)
+                    + (4 if logprob is not None else 0))
+
+    @staticmethod
     def _elementwise_bytes(a, k):
         x = a[0]
         N, D = x.shape
@@ -100,21 +111,39 @@ class KernelTimer:
             variant = name
             if name.endswith("coupling"):
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
-            self.records.append((variant, byte_fn(a, k), s, e))
+            flops = self._flow_flops(a) if name == "flow_run" else 0
+            self.records.append((variant, byte_fn(a, k), s, e, flops))
             return r
         setattr(self.native, name, timed)
 
+    @staticmethod
+    def _flow_flops(a):
+        """Algorithmic conditioner FLOPs of one flow_run launch: 2*(S*H + H*T*P) per row and
+        coupling op; the transform's own transcendentals are not counted."""
+        x, ops = a[0], a[6]
+        N, D = x.shape
+        half = D // 2
+        per_row = 0
+        for kind, _, H, _ in ops:
+            if kind in (2, 3):
+                per_row += 2 * (half * H + H * half * 2)
+            elif kind in (4, 5):
+                per_row += 2 * (half * H + H * half)
+        return N * per_row
+
     def summary(self):
         agg = {}
-        for name, nbytes, s, e in self.records:
-            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+        for name, nbytes, s, e, flops in self.records:
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["bytes"] += nbytes
+            d["flops"] += flops
         for d in agg.values():
             d["avg_us"] = 1e3 * d["ms"] / d["launches"]
             d["bytes_per_launch"] = d["bytes"] // d["launches"]
             d["GBps"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            d["TFLOPs"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         return agg
 
 
@@ -174,8 +203,12 @@ def main():
     ap.add_argument("--workload", default="realnvp64", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
     args = ap.parse_args()
 
+    if args.no_fused:
+        os.environ["TORCHFLOWS_AMD_FUSED"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,6 +271,20 @@ def main():
                 traffic = None
         except (OSError, KeyError, ValueError):
             pass
+        if dom_name == "flow_run":
+            # conditioner fused in-kernel: h never reaches HBM, the kernel is fp32-VALU-bound
+            # (report against the fp32 vector peak, and say so)
+            roofline = {"bound": "valu", "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
+                        "note": "fused flow program (conditioner in-kernel): fp32 vector-ALU bound; "
+                                "achieved = algorithmic conditioner FLOPs 2*(S*H+H*T*P) per row-layer / "
+                                "launch time, transcendentals of the transform not counted",
+                        "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
+        else:
+            roofline = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
+        roofline.update({"kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
+                         "avg_us": dom["avg_us"], "launches": dom["launches"]})
         result = {
             "metric": "log_prob evals/sec (RealNVP D=64)" if args.workload == "realnvp64"
                       else f"log_prob evals/sec ({args.workload})",
@@ -257,10 +304,7 @@ def main():
                                    f"{rows} standard-Gaussian rows per GPU resident in HBM, "
                                    f"data-initialised weights (seed 0)",
                        "rows_per_gpu": rows, "parallelism": f"batch-sharded replicas x{world}"},
-            "roofline": {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
-                         "avg_us": dom["avg_us"], "launches": dom["launches"]},
+            "roofline": roofline,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                             "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
             "libtfk_ms_per_step": sum(v["ms"] for v in kernels.values()) / args.steps,

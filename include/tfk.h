@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 1
+#define TFK_ABI_VERSION 2
 
 enum {
     TFK_OK = 0,
@@ -129,6 +129,41 @@ int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_sc
  * workspace: device buffer of at least tfk_sum_workspace_bytes(N) bytes. */
 int64_t tfk_sum_workspace_bytes(int64_t N);
 int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *stream);
+
+/* ---- fused flow program (conditioner in-kernel, layers folded) -----------------
+ * Runs a chain of layers on rows held in registers: ONE launch replaces the Python loop of
+ * BijectiveComposition.forward / inverse (bijections/base.py:203-232) over
+ * ElementwiseAffine / ActNorm (layers.py:19-69), ReversePermutationMatrix
+ * (matrix/permutation.py:34-37, folded into the weight order) and Affine / Shift couplings
+ * (layers.py:102-139) INCLUDING their FeedForward(tanh) conditioner
+ * (conditioning/transforms.py:274-307): h never exists in HBM.
+ * Supported: D a power of two in [16, 512], HalfSplit mask, no context.
+ *
+ * ops (HOST pointer): n_ops x int32[4] = {kind, src_plane, H, param_offset};
+ * params (device, 16-byte aligned, n_params % 4 == 0) holds, at param_offset (floats,
+ * multiple of 4), in PHYSICAL element order (plane A = positions [0, D/2), B = the rest):
+ *   TFK_OP_EW_MULADD / TFK_OP_EW_SUBDIV : alpha[D] | beta[D] | logdet_const | pad[3]
+ *        z = alpha*x + beta   /   z = (x - beta)/alpha;   logdet += logdet_const
+ *   coupling (affine P=2 / shift P=1)   : W1t[H][D/2] | b1[H padded to 4] | W2t[H][D/2*P] | b2[D/2*P]
+ *        src_plane = which plane feeds the conditioner (the other one is transformed);
+ *        W1t[k][m] multiplies physical source element m; W2t[k][m*P + p], b2[m*P + p]
+ *        produce parameter p of physical target element m.
+ * Outputs (each may be NULL, at least one must not): z rows (physical order), logdet
+ * (accumulate as elsewhere), logprob[n] = diag-Gaussian log-density of the final rows
+ * (gauss_loc / gauss_log_scale given in physical order) + the chain's log-det. */
+enum {
+    TFK_OP_EW_MULADD = 0,
+    TFK_OP_EW_SUBDIV = 1,
+    TFK_OP_AFFINE_FWD = 2,
+    TFK_OP_AFFINE_INV = 3,
+    TFK_OP_SHIFT_FWD = 4,
+    TFK_OP_SHIFT_INV = 5
+};
+int tfk_flow_supported(int32_t D);
+int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,
+                 const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                 const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                 int32_t accumulate, void *stream);
 
 #ifdef __cplusplus
 }

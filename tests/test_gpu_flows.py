@@ -74,7 +74,8 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     with torch.no_grad():
         z, lp = flow.forward_with_log_prob(x, context=ctx)
         xr, ldr = flow.bijection.inverse(z_in, context=ctx)
-    assert native.calls - before >= 2 * (3 * n_layers + 3), "the HIP kernels did not run"
+    # fused flow programs: >= 1 launch per call; layer by layer: one per layer
+    assert native.calls - before >= 2, "the HIP kernels did not run"
     assert lp.shape == x.shape[:1] and z.shape == x.shape and xr.shape == x.shape
 
     tol = 4e-5 if spline else 1e-5

@@ -1,0 +1,202 @@
+"""Fused flow programs (tfk_flow_run: conditioner in-kernel, permutations / elementwise layers
+folded) against the layer-by-layer HIP path, the CPU oracle and the golden fixtures.
+
+Bars: log_prob / log_det within 1e-5 relative, rows within 1e-5 norm-wise and 2e-5
+elementwise (the in-kernel dot products sum in a different order than rocBLAS; both are a
+few ulp from the exact sum, and 3L+3 layers amplify that).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_of
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def normwise(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available()
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    native.lib()
+    return tfa
+
+
+def data_init(flow, D):
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(2048, D))
+    return flow.eval()
+
+
+def run_both(flow, x, monkeypatch):
+    """(fused results, layer-by-layer results) of log_prob, forward, inverse on the device."""
+    from torchflows_amd import native
+    out = []
+    for fused_on in ("1", "0"):
+        monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", fused_on)
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        before = native.calls
+        with torch.no_grad():
+            z, lp = flow.forward_with_log_prob(x)
+            lp_only = flow.log_prob(x)
+            z2, ld = flow.bijection.forward(x)
+            xr, ldi = flow.bijection.inverse(x)
+        out.append(dict(z=z, lp=lp, lp_only=lp_only, z2=z2, ld=ld, xr=xr, ldi=ldi,
+                        launches=native.calls - before))
+    return out
+
+
+@pytest.mark.parametrize("arch", ["RealNVP", "NICE"])
+@pytest.mark.parametrize("D", [16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("n_layers", [1, 2, 8])
+def test_fused_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, arch, D, n_layers):
+    torch.manual_seed(D + n_layers)
+    ctor = getattr(pkg, arch)
+    flow = data_init(pkg.Flow(ctor(D, n_layers=n_layers)), D)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, n_layers, sd)
+    flow = flow.cuda()
+    N = 1000 + D
+    x = torch.randn(N, D)
+    x[:50] *= 3
+    fused, layer = run_both(flow, x.cuda(), monkeypatch)
+    # the fused path really is a handful of launches, the other one is 3L+3 kernels + GEMMs
+    assert fused["launches"] < layer["launches"]
+    if D <= 64 and n_layers % 2 == 0:   # whole program in one LDS block, no final reordering
+        assert fused["launches"] == 4, fused["launches"]
+    z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
+    _, ld_ref = ref.forward(x.numpy())
+    xr_ref, ldi_ref = ref.inverse(x.numpy())
+    for name, got in (("fused", fused), ("layerwise", layer)):
+        e = dict(lp=rel(got["lp"].cpu().numpy(), lp_ref), lp_only=rel(got["lp_only"].cpu().numpy(), lp_ref),
+                 z=normwise(got["z"].cpu().numpy(), z_ref), z2=normwise(got["z2"].cpu().numpy(), z_ref),
+                 ld=rel(got["ld"].cpu().numpy(), ld_ref), xr=normwise(got["xr"].cpu().numpy(), xr_ref),
+                 ldi=rel(got["ldi"].cpu().numpy(), ldi_ref))
+        print(arch, D, n_layers, name, {k: f"{v:.1e}" for k, v in e.items()})
+        assert max(e.values()) < 1e-5, (name, e)
+    assert rel(fused["z"].cpu().numpy(), layer["z"].cpu().numpy()) < 2e-5
+    assert rel(fused["xr"].cpu().numpy(), layer["xr"].cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("name,arch,n_layers", [("flow_realnvp64.npz", "RealNVP", 8),
+                                                ("flow_realnvp256.npz", "RealNVP", 8)])
+@pytest.mark.parametrize("variant", ["fresh", "init"])
+def test_fused_golden(pkg, monkeypatch, name, arch, n_layers, variant):
+    from torchflows_amd import fused, native
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    fx = load_golden(name)
+    D = int(fx["event_shape"][0])
+    flow = pkg.Flow(pkg.RealNVP(D, n_layers=n_layers))
+    flow.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict_of(fx, variant).items()})
+    flow = flow.cuda().eval()
+    assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is not None
+    before = native.calls
+    with torch.no_grad():
+        lp = flow.log_prob(torch.from_numpy(fx["x"]).cuda())
+        launches = native.calls - before
+        xr, ldr = flow.bijection.inverse(torch.from_numpy(fx["z_in"]).cuda())
+    g = lambda k: fx[f"{variant}/{k}"]
+    assert launches == (1 if D == 64 else launches)
+    assert rel(lp.cpu().numpy(), g("log_prob")) < 1e-5
+    assert normwise(xr.cpu().numpy(), g("x_inv")) < 1e-5
+    assert rel(ldr.cpu().numpy(), g("log_det_inv")) < max(1e-5, 3 * rel(g("log_det_inv"), g("log_det_inv64")))
+
+
+def test_segmented_program_matches_single_launch(pkg, monkeypatch):
+    """A program split over several launches (small LDS budget) gives the same result."""
+    from torchflows_amd import fused
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    torch.manual_seed(0)
+    flow = data_init(pkg.Flow(pkg.RealNVP(64, n_layers=5)), 64).cuda()
+    x = torch.randn(777, 64, device="cuda")
+    res = []
+    for budget in (40 * 1024, 6 * 1024, 4 * 1024):
+        monkeypatch.setattr(fused, "MAX_PARAM_BYTES", budget)
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        chain = fused.get_compiled(flow.bijection, 0, x.device)
+        with torch.no_grad():
+            z, lp = flow.forward_with_log_prob(x)
+            lp2 = flow.log_prob(x)
+            xr, ldi = flow.bijection.inverse(x)
+        res.append((len(chain.segments), z, lp, lp2, xr, ldi))
+    assert res[0][0] == 1 and res[1][0] > 1 and res[2][0] > res[1][0]
+    for r in res[1:]:
+        for a, b in zip(r[1:], res[0][1:]):
+            assert torch.equal(a, b)          # same arithmetic, only the launch boundaries move
+
+
+def test_odd_layer_count_keeps_logical_order(pkg, oracle, monkeypatch):
+    """With an odd number of reversals the physical order at the end is reversed: the rows
+    handed back must still be in logical order, and the base density must see it too."""
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    torch.manual_seed(1)
+    from torchflows_amd.base_distributions.gaussian import DiagonalGaussian
+    D = 32
+    b = pkg.RealNVP(D, n_layers=3)
+    base = DiagonalGaussian(torch.randn(D), torch.rand(D) + 0.5)
+    flow = data_init(pkg.Flow(b, base_distribution=base), D)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict("RealNVP", D, 3, sd)
+    x = torch.randn(500, D)
+    flow = flow.cuda()
+    with torch.no_grad():
+        z, lp = flow.forward_with_log_prob(x.cuda())
+        lp_only = flow.log_prob(x.cuda())
+    z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
+    assert normwise(z.cpu().numpy(), z_ref) < 1e-5
+    assert rel(lp.cpu().numpy(), lp_ref) < 1e-5 and rel(lp_only.cpu().numpy(), lp_ref) < 1e-5
+
+
+def test_cache_follows_parameter_updates_and_train_mode(pkg, monkeypatch):
+    from torchflows_amd import fused
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    torch.manual_seed(2)
+    flow = pkg.Flow(pkg.RealNVP(16, n_layers=2)).cuda()
+    x = torch.randn(300, 16, device="cuda")
+    # train mode, ActNorm not initialised yet: not compilable, layer-by-layer path initialises it
+    assert flow.training
+    assert fused.get_compiled(flow.bijection, 0, x.device) is None
+    with torch.no_grad():
+        lp_train = flow.log_prob(x)
+    flow.eval()
+    assert fused.get_compiled(flow.bijection, 0, x.device) is not None
+    with torch.no_grad():
+        lp_eval = flow.log_prob(x)
+        assert torch.allclose(lp_eval, lp_train, rtol=2e-5, atol=2e-5)
+        flow.bijection.layers[0].value.mul_(0.5)          # in-place update (an optimizer step)
+        lp_new = flow.log_prob(x)
+        monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "0")
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        lp_layer = flow.log_prob(x)
+    assert not torch.allclose(lp_new, lp_eval)
+    assert torch.allclose(lp_new, lp_layer, rtol=2e-5, atol=2e-5)
+
+
+def test_flow_run_argument_checks(pkg):
+    from torchflows_amd import native
+    x = torch.zeros(8, 64, device="cuda")
+    params = torch.zeros(132, device="cuda")
+    lp = torch.empty(8, device="cuda")
+    native.flow_run(x, None, lp, None, None, None, [(0, 0, 0, 0)], params)       # fine
+    with pytest.raises(native.NativeError):      # parameters run past the block
+        native.flow_run(x, None, lp, None, None, None, [(0, 0, 0, 8)], params)
+    with pytest.raises(native.NativeError):      # unknown op
+        native.flow_run(x, None, lp, None, None, None, [(9, 0, 0, 0)], params)
+    with pytest.raises(native.NativeError):      # D not supported
+        native.flow_run(torch.zeros(8, 24, device="cuda"), None, lp, None, None, None, [], params)
+    with pytest.raises(native.NativeError):      # no output
+        native.flow_run(x, None, None, None, None, None, [(0, 0, 0, 0)], params)

@@ -157,6 +157,16 @@ class BijectiveComposition(Bijection):
             plan.append((layer, d))
         return plan
 
+    def _run_fused(self, x: torch.Tensor, d: int):
+        """Whole chain as flow programs (conditioner in-kernel); None if not compilable."""
+        from torchflows_amd import fused
+        chain = fused.get_compiled(self, d, x.device)
+        if chain is None:
+            return None
+        rows, batch = as_rows(x, self.event_shape)
+        out, ld, _ = fused.run_chain(chain, rows, want_rows=True)
+        return out.view(x.shape), ld.view(batch)
+
     def _run_native(self, plan, x: torch.Tensor, context):
         rows, batch = as_rows(x, self.event_shape)
         state = RowState(rows, batch)
@@ -170,6 +180,10 @@ class BijectiveComposition(Bijection):
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):
         if not kwargs and native.eligible(x, context) and _params_ok(self):
+            if context is None:
+                fused_out = self._run_fused(x, FORWARD)
+                if fused_out is not None:
+                    return fused_out
             plan = self._native_plan(self.layers, "forward")
             if plan is not None:
                 return self._run_native(plan, x, context)
@@ -183,6 +197,10 @@ class BijectiveComposition(Bijection):
     def inverse(self, z: torch.Tensor, context: torch.Tensor = None, **kwargs):
         order = list(self.layers)[::-1]
         if not kwargs and native.eligible(z, context) and _params_ok(self):
+            if context is None:
+                fused_out = self._run_fused(z, INVERSE)
+                if fused_out is not None:
+                    return fused_out
             plan = self._native_plan(order, "inverse")
             if plan is not None:
                 return self._run_native(plan, z, context)

@@ -56,7 +56,9 @@ class ActNorm(ElementwiseInverseAffine):
             scale = torch.ones_like(shift)
         else:
             scale = x.std(dim=dims)[..., None].to(self.value)
-        self.value.data = torch.cat([self.transformer.unconstrain_scale(scale), shift], dim=-1)
+        # copy_ (not ``.data =``) so the parameter's version counter moves and cached flow
+        # programs (torchflows_amd/fused.py) are rebuilt
+        self.value.copy_(torch.cat([self.transformer.unconstrain_scale(scale), shift], dim=-1))
         self.first_training_batch_pass = False
 
     @forward_method

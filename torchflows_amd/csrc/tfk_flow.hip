@@ -1,0 +1,320 @@
+// tfk_flow.hip -- fused "flow program" interpreter: a whole chain of layers in ONE launch.
+//
+// conditioner-in-kernel fusion + layer folding.  The host (torchflows_amd/
+// fused.py) compiles a BijectiveComposition made of
+//     ElementwiseAffine / ActNorm        (layers_base.py:237-318, layers.py:19-69)
+//     ReversePermutationMatrix           (matrix/permutation.py:8-37)
+//     Affine / Shift coupling with a FeedForward(tanh) conditioner on the HalfSplit mask
+//                                        (layers_base.py:51-163, conditioning/transforms.py:274-307)
+// into a short list of ops over PHYSICAL element positions: the reversals are folded into
+// the order in which weights are packed (they only decide which half is the conditioner's
+// input and in which order the weights are stored), so no data ever moves for them.
+//
+// Execution model (D = 8*G, G in {2..64} a power of two):
+//   * a row lives in the registers of G consecutive lanes of one wavefront: lane j holds
+//     a = elements [4j, 4j+4) of plane A (first half) and b = the same of plane B;
+//   * every op of the program is applied to the registers; rows are read once (16-byte
+//     coalesced loads) and written at most once -- h, x_A copies, per-layer log-dets never
+//     exist in HBM: 4*D + 4 bytes per log_prob evaluation instead of ~15 KB;
+//   * the program's parameters (a few KB to tens of KB) are staged in LDS once per
+//     workgroup and read as broadcast ds_read_b128 (all row-groups of a wave read the same
+//     weights; the G lanes of a group read G consecutive float4 = conflict-free);
+//   * conditioner: hidden_k = tanh(b1_k + sum_s W1[k,s] x_s) -- each lane does its 4-element
+//     partial dot product, the G partials are summed with DPP (quad_perm / row mirrors) or
+//     ds_swizzle butterflies; hidden_k is immediately folded into the lane's 8 (affine) or 4
+//     (shift) output accumulators, so no hidden vector is ever stored;
+//   * per-row log-det stays in a register and is reduced with the same butterflies.
+// With the conditioner in the kernel the work is fp32-VALU-bound, not HBM-bound.
+//
+// Arithmetic: the transform itself keeps the reference's op order (affine.py:33-59,
+// -ffp-contract=off); the dot products use fmaf and a different (tree) summation order than
+// ATen's GEMM -- both are within a few ulp of the exact sum.
+#include <cmath>
+
+#include "tfk_common.h"
+
+namespace tfk {
+
+constexpr int kMaxOps = 96;
+
+struct FlowOp {
+    int kind;        // TFK_OP_*
+    int src_plane;   // coupling: 0 = plane A conditions plane B, 1 = the opposite
+    int H;           // coupling: hidden width of the conditioner
+    int offset;      // first float of this op's parameters in the staged block (multiple of 4)
+};
+
+struct FlowProgram {
+    int n_ops;
+    int pad[3];
+    FlowOp op[kMaxOps];
+};
+
+// ---- cross-lane sums inside a G-lane group (result in every lane of the group) ----------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+    if (G >= 2) v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+    if (G >= 4) v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+    if (G >= 8) v = dpp_add<0x141>(v);    // row_half_mirror: i <-> 7 - i   (quads are uniform)
+    if (G >= 16) v = dpp_add<0x140>(v);   // row_mirror: i <-> 15 - i       (halves are uniform)
+    if (G >= 32) v += __shfl_xor(v, 16, kWave);
+    if (G >= 64) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4 w, const float4 s) {
+    return fmaf(w.w, s.w, fmaf(w.z, s.z, fmaf(w.y, s.y, w.x * s.x)));
+}
+
+// One op on the registers of one row.  prm = this op's parameters in LDS.
+template <int G>
+__device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int j, float4 &a,
+                                         float4 &b, float &ld)
+{
+    constexpr int D = 8 * G, HALF = 4 * G;
+    if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
+        // alpha[D] | beta[D] | log-det constant (already signed)
+        const float4 al_a = *reinterpret_cast<const float4 *>(prm + 4 * j);
+        const float4 al_b = *reinterpret_cast<const float4 *>(prm + HALF + 4 * j);
+        const float4 be_a = *reinterpret_cast<const float4 *>(prm + D + 4 * j);
+        const float4 be_b = *reinterpret_cast<const float4 *>(prm + D + HALF + 4 * j);
+        if (op.kind == TFK_OP_EW_MULADD) {                  // affine.py:48
+            a.x = al_a.x * a.x + be_a.x; a.y = al_a.y * a.y + be_a.y;
+            a.z = al_a.z * a.z + be_a.z; a.w = al_a.w * a.w + be_a.w;
+            b.x = al_b.x * b.x + be_b.x; b.y = al_b.y * b.y + be_b.y;
+            b.z = al_b.z * b.z + be_b.z; b.w = al_b.w * b.w + be_b.w;
+        } else {                                            // affine.py:59
+            a.x = (a.x - be_a.x) / al_a.x; a.y = (a.y - be_a.y) / al_a.y;
+            a.z = (a.z - be_a.z) / al_a.z; a.w = (a.w - be_a.w) / al_a.w;
+            b.x = (b.x - be_b.x) / al_b.x; b.y = (b.y - be_b.y) / al_b.y;
+            b.z = (b.z - be_b.z) / al_b.z; b.w = (b.w - be_b.w) / al_b.w;
+        }
+        ld = ld + prm[2 * D];                               // base.py:222
+        return;
+    }
+    // coupling: W1t[H][HALF] | b1[H4] | W2t[H][HALF*P] | b2[HALF*P]   (physical order)
+    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
+    const int H = op.H, H4 = (H + 3) & ~3;
+    const float4 src = op.src_plane ? b : a;
+    float4 tgt = op.src_plane ? a : b;
+    const float *W1t = prm;
+    const float *b1 = prm + H * HALF;
+    if (affine) {
+        const float *W2t = b1 + H4;
+        const float *b2 = W2t + H * (2 * HALF);
+        float4 acc0 = *reinterpret_cast<const float4 *>(b2 + 8 * j);      // (u0, be0, u1, be1)
+        float4 acc1 = *reinterpret_cast<const float4 *>(b2 + 8 * j + 4);  // (u2, be2, u3, be3)
+        for (int k = 0; k < H; ++k) {
+            const float4 w1 = *reinterpret_cast<const float4 *>(W1t + k * HALF + 4 * j);
+            const float hk = tanhf(group_allsum<G>(dot4(w1, src)) + b1[k]);   // transforms.py:293-304
+            const float4 w2a = *reinterpret_cast<const float4 *>(W2t + k * (2 * HALF) + 8 * j);
+            const float4 w2b = *reinterpret_cast<const float4 *>(W2t + k * (2 * HALF) + 8 * j + 4);
+            acc0.x = fmaf(w2a.x, hk, acc0.x); acc0.y = fmaf(w2a.y, hk, acc0.y);
+            acc0.z = fmaf(w2a.z, hk, acc0.z); acc0.w = fmaf(w2a.w, hk, acc0.w);
+            acc1.x = fmaf(w2b.x, hk, acc1.x); acc1.y = fmaf(w2b.y, hk, acc1.y);
+            acc1.z = fmaf(w2b.z, hk, acc1.z); acc1.w = fmaf(w2b.w, hk, acc1.w);
+        }
+        const float a0 = aff_alpha(acc0.x), a1 = aff_alpha(acc0.z);
+        const float a2 = aff_alpha(acc1.x), a3 = aff_alpha(acc1.z);
+        float part = logf(a0);                               // affine.py:42
+        part += logf(a1);
+        part += logf(a2);
+        part += logf(a3);
+        part = group_allsum<G>(part);
+        if (op.kind == TFK_OP_AFFINE_FWD) {
+            tgt.x = a0 * tgt.x + acc0.y; tgt.y = a1 * tgt.y + acc0.w;
+            tgt.z = a2 * tgt.z + acc1.y; tgt.w = a3 * tgt.w + acc1.w;
+            ld = ld + part;
+        } else {
+            tgt.x = (tgt.x - acc0.y) / a0; tgt.y = (tgt.y - acc0.w) / a1;
+            tgt.z = (tgt.z - acc1.y) / a2; tgt.w = (tgt.w - acc1.w) / a3;
+            ld = ld + (-part);
+        }
+        if (op.src_plane) a = tgt; else b = tgt;
+    } else {                                                 // shift (NICE), affine.py:137-159
+        const float *W2t = b1 + H4;
+        const float *b2 = W2t + H * HALF;
+        float4 acc = *reinterpret_cast<const float4 *>(b2 + 4 * j);
+        for (int k = 0; k < H; ++k) {
+            const float4 w1 = *reinterpret_cast<const float4 *>(W1t + k * HALF + 4 * j);
+            const float hk = tanhf(group_allsum<G>(dot4(w1, src)) + b1[k]);
+            const float4 w2 = *reinterpret_cast<const float4 *>(W2t + k * HALF + 4 * j);
+            acc.x = fmaf(w2.x, hk, acc.x); acc.y = fmaf(w2.y, hk, acc.y);
+            acc.z = fmaf(w2.z, hk, acc.z); acc.w = fmaf(w2.w, hk, acc.w);
+        }
+        if (op.kind == TFK_OP_SHIFT_FWD) {
+            tgt.x += acc.x; tgt.y += acc.y; tgt.z += acc.z; tgt.w += acc.w;
+        } else {
+            tgt.x -= acc.x; tgt.y -= acc.y; tgt.z -= acc.z; tgt.w -= acc.w;
+        }
+        if (op.src_plane) a = tgt; else b = tgt;
+    }
+}
+
+// Dynamic LDS: the launch's parameter block (n_params floats) [+ 3*D floats for the base].
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_flow_run(
+    const float4 *__restrict__ x, float4 *z, float *logdet, const float *__restrict__ gauss_loc,
+    const float *__restrict__ gauss_log_scale, float *logprob, long long N,
+    const float *__restrict__ params, int n_params, FlowProgram prog, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 8 * G, HALF = 4 * G;
+    {   // stage the parameter block (16-byte coalesced loads)
+        const float4 *src = reinterpret_cast<const float4 *>(params);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < (n_params >> 2); i += kBlock) dst[i] = src[i];
+    }
+    float *base_s = lds + n_params;                   // loc[D] | scale[D] | log_scale[D]
+    if (logprob) {
+        for (int e = threadIdx.x; e < D; e += kBlock) {
+            base_s[e] = gauss_loc[e];
+            base_s[D + e] = expf(gauss_log_scale[e]);
+            base_s[2 * D + e] = gauss_log_scale[e];
+        }
+    }
+    __syncthreads();
+
+    const int j = threadIdx.x & (G - 1);
+    constexpr int rows_per_block = kBlock / G;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    for (long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G; row < N;
+         row += stride) {
+        float4 a = x[row * (2 * G) + j];
+        float4 b = x[row * (2 * G) + G + j];
+        // running log-det: continues the previous launch's sum so that the layer-order fp32
+        // accumulation of base.py:210-222 is the same however the program is segmented
+        float ld = (logdet && accumulate) ? logdet[row] : 0.0f;
+        for (int o = 0; o < prog.n_ops; ++o)
+            apply_op<G>(prog.op[o], lds + prog.op[o].offset, j, a, b, ld);
+        if (z) {
+            z[row * (2 * G) + j] = a;
+            z[row * (2 * G) + G + j] = b;
+        }
+        float acc = 0.0f;
+        if (logprob) {                                          // gaussian.py:46-54
+            auto term = [&](float v, int e) {
+                const float t = (v - base_s[e]) / base_s[D + e];
+                float q = 0.5f * (t * t);
+                q = q + kHalfLog2Pi;
+                q = q + base_s[2 * D + e];
+                acc += -q;
+            };
+            term(a.x, 4 * j); term(a.y, 4 * j + 1); term(a.z, 4 * j + 2); term(a.w, 4 * j + 3);
+            term(b.x, HALF + 4 * j); term(b.y, HALF + 4 * j + 1);
+            term(b.z, HALF + 4 * j + 2); term(b.w, HALF + 4 * j + 3);
+            acc = group_allsum<G>(acc);
+        }
+        if (j == 0) {
+            if (logdet) logdet[row] = ld;
+            if (logprob) logprob[row] = acc + ld;               // flows.py:648
+        }
+    }
+}
+
+template <int G>
+static int launch_flow(const float *x, float *z, float *logdet, const float *loc,
+                       const float *log_scale, float *logprob, int64_t N, const float *params,
+                       int n_params, const FlowProgram &prog, int accumulate, hipStream_t s,
+                       const char *fn)
+{
+    constexpr int D = 8 * G;
+    const size_t lds = ((size_t)n_params + (logprob ? 3 * D : 0)) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run<G>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+    int per_cu = lds ? (int)((160 * 1024) / lds) : 8;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const int64_t want = (N + (kBlock / G) - 1) / (kBlock / G);
+    const int64_t cap = (int64_t)kCUs * per_cu;
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL((k_flow_run<G>), dim3(grid), dim3(kBlock), lds, s,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(z), logdet,
+                       loc, log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
+    return check_launch(fn);
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+extern "C" {
+
+int tfk_flow_supported(int32_t D)
+{
+    return (D >= 16 && D <= 512 && (D & (D - 1)) == 0) ? 1 : 0;
+}
+
+int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,
+                 const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                 const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                 int32_t accumulate, void *stream)
+{
+    const char *fn = "tfk_flow_run";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!tfk_flow_supported(D))
+        return fail(TFK_EINVAL, "%s: D = %d is not a power of two in [16, 512]", fn, D);
+    if (n_ops < 0 || n_ops > kMaxOps)
+        return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOps);
+    if (n_params < 0 || (n_params & 3))
+        return fail(TFK_EINVAL, "%s: n_params = %lld must be a non-negative multiple of 4", fn, (long long)n_params);
+    if (N == 0) return TFK_OK;
+    if (!x || (n_ops > 0 && (!ops || !params)))
+        return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!z && !logdet && !logprob) return fail(TFK_EINVAL, "%s: no output requested", fn);
+    if (logprob && (!gauss_loc || !gauss_log_scale))
+        return fail(TFK_EINVAL, "%s: logprob needs gauss_loc and gauss_log_scale", fn);
+    if (!aligned16(x) || (z && !aligned16(z)) || !aligned16(params))
+        return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
+
+    FlowProgram prog;
+    prog.n_ops = n_ops;
+    const int HALF = D / 2;
+    for (int i = 0; i < n_ops; ++i) {
+        FlowOp &o = prog.op[i];
+        o.kind = ops[4 * i];
+        o.src_plane = ops[4 * i + 1];
+        o.H = ops[4 * i + 2];
+        o.offset = ops[4 * i + 3];
+        int64_t need;
+        if (o.kind == TFK_OP_EW_MULADD || o.kind == TFK_OP_EW_SUBDIV) {
+            need = 2 * (int64_t)D + 4;
+        } else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
+            const int P = (o.kind <= TFK_OP_AFFINE_INV) ? 2 : 1;
+            if (o.H < 1 || o.H > 4096) return fail(TFK_EINVAL, "%s: op %d: hidden width %d", fn, i, o.H);
+            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            need = (int64_t)o.H * HALF + ((o.H + 3) & ~3) + (int64_t)o.H * HALF * P + (int64_t)HALF * P;
+        } else {
+            return fail(TFK_EINVAL, "%s: op %d: unknown kind %d", fn, i, o.kind);
+        }
+        if (o.offset < 0 || (o.offset & 3) || o.offset + need > n_params)
+            return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats",
+                        fn, i, o.offset, (long long)(o.offset + need), (long long)n_params);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = (int)n_params;
+    switch (D / 8) {
+    case 2: return launch_flow<2>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    case 4: return launch_flow<4>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    case 8: return launch_flow<8>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    case 16: return launch_flow<16>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    case 32: return launch_flow<32>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    default: return launch_flow<64>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, np, prog, accumulate, s, fn);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Host-side compiler from a ``BijectiveComposition`` to libtfk *flow programs*.
+
+``tfk_flow_run`` (csrc/tfk_flow.hip) keeps each row in registers and applies a list of ops
+to it, with the conditioner MLP evaluated in-kernel -- one launch for a whole chain of
+layers.  This module turns the reference-shaped layer objects into that
+list:
+
+* permutation layers emit nothing: the compiler tracks ``pos[l]`` = physical position of
+  logical element ``l`` and packs every later layer's parameters in physical order;
+* ElementwiseAffine / ActNorm become ``alpha*x+beta`` / ``(x-beta)/alpha`` ops with
+  ``alpha = exp(u/2 + log(1-1e-10)) + 1e-10`` and ``sum log alpha`` evaluated once per
+  compilation (they are batch-constant; the reference recomputes them per row);
+* Affine / Shift couplings on the HalfSplit mask whose conditioner is the default
+  ``FeedForward`` (Linear, Tanh, Linear) become coupling ops; after the folded reversals
+  the conditioner's input must still be exactly one half ("plane") of the physical row.
+
+Anything else (other masks, context, deeper / non-tanh conditioners, RQ splines, ActNorm
+that still has to initialise itself from data) makes ``compile_chain`` return ``None`` and
+the composition runs layer by layer (bijections/base.py).  Programs are cached per
+(direction, device) and rebuilt when any parameter version changes.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from torchflows_amd import native
+
+OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV = range(6)
+FORWARD, INVERSE = 0, 1
+
+# parameters staged in LDS per launch; 40 KB keeps 4 workgroups (16 waves) per CU and holds
+# the whole RealNVP(64, n_layers=8) program (35.8 KB)
+MAX_PARAM_BYTES = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS", 40 * 1024))
+MAX_OPS = 96
+
+
+def enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_FUSED", "1") != "0"
+
+
+@dataclass
+class Segment:
+    ops: List[Tuple[int, int, int, int]]      # (kind, src_plane, H, offset)
+    params: torch.Tensor                      # fp32 device block, numel % 4 == 0
+
+
+@dataclass
+class CompiledChain:
+    D: int
+    segments: List[Segment]
+    pos: torch.Tensor          # int64 (D,): physical position of logical element l at the end
+    identity_out: bool         # pos == arange(D)
+    version: int
+
+
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    r = (-t.numel()) % 4
+    return t if r == 0 else torch.cat([t, t.new_zeros(r)])
+
+
+def _flatten(layers, attr: str):
+    """[(layer, direction)] with nested compositions expanded; None if a layer's bound
+    forward/inverse is not one of the tagged implementations."""
+    from torchflows_amd.bijections.base import BijectiveComposition, method_direction
+    out = []
+    for layer in layers:
+        d = method_direction(getattr(layer, attr))
+        if d is None:
+            return None
+        if isinstance(layer, BijectiveComposition):
+            inner = layer.layers if d == FORWARD else list(layer.layers)[::-1]
+            sub = _flatten(inner, "forward" if d == FORWARD else "inverse")
+            if sub is None:
+                return None
+            out.extend(sub)
+        else:
+            out.append((layer, d))
+    return out
+
+
+def _params_version(module: nn.Module) -> int:
+    v = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        v += t._version
+    return v
+
+
+def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
+    from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
+    kind = layer.transformer.native_kind
+    if kind not in ("affine", "inverse_affine") or not layer.use_global_parameters:
+        return None
+    if isinstance(layer, ActNorm) and layer.training and layer.first_training_batch_pass:
+        return None                       # must see a batch first (layers.py:58-68)
+    value = layer.value.detach().reshape(D, 2)
+    alpha = layer.transformer.constrain_scale(value[:, 0])
+    beta = value[:, 1]
+    subdiv = (d == INVERSE) != (kind == "inverse_affine")
+    ld = torch.log(alpha).sum()
+    ld = -ld if subdiv else ld
+    alpha_p = torch.empty_like(alpha)
+    beta_p = torch.empty_like(beta)
+    alpha_p[pos] = alpha
+    beta_p[pos] = beta
+    block = torch.cat([alpha_p, beta_p, ld.reshape(1), ld.new_zeros(3)])
+    return (OP_EW_SUBDIV if subdiv else OP_EW_MULADD, 0, 0), block
+
+
+def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
+    kind = layer.transformer.native_kind
+    if kind not in ("affine", "inverse_affine", "shift") or layer.context_shape is not None:
+        return None
+    half = D // 2
+    c = layer.coupling
+    if not (c.source_is_head and c.target_is_tail and c.source_event_size == half
+            and c.target_event_size == half):
+        return None
+    ct = layer.conditioner_transform
+    if type(ct) is not FeedForward or ct.n_global_parameters != 0:
+        return None
+    if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
+        return None
+    mods = list(ct.sequential)
+    if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
+        return None
+    P = 2 if kind != "shift" else 1
+    W1, b1 = mods[0].weight.detach(), mods[0].bias.detach()          # (H, S), (H,)
+    W2, b2 = mods[2].weight.detach(), mods[2].bias.detach()          # (T*P, H), (T*P,)
+    H = W1.shape[0]
+    if W1.shape[1] != half or W2.shape[0] != half * P or W2.shape[1] != H:
+        return None
+    src_pos, tgt_pos = pos[:half], pos[half:]
+    plane = int(src_pos[0].item()) // half
+    if not bool(((src_pos // half) == plane).all()) or not bool(((tgt_pos // half) == 1 - plane).all()):
+        return None
+    W1t = torch.empty_like(W1)
+    W1t[:, src_pos - plane * half] = W1
+    m_t = tgt_pos - (1 - plane) * half
+    W2p = torch.empty(half, P, H, dtype=W2.dtype, device=W2.device)
+    W2p[m_t] = W2.reshape(half, P, H)
+    b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
+    b2p[m_t] = b2.reshape(half, P)
+    block = torch.cat([W1t.reshape(-1), _pad4(b1), W2p.permute(2, 0, 1).reshape(-1), b2p.reshape(-1)])
+    if kind == "shift":
+        op = OP_SHIFT_FWD if d == FORWARD else OP_SHIFT_INV
+    else:
+        op = OP_AFFINE_FWD if (d == FORWARD) != (kind == "inverse_affine") else OP_AFFINE_INV
+    return (op, plane, H), block
+
+
+def compile_chain(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
+    """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None."""
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import (
+        CouplingBijection, ElementwiseBijection)
+    from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
+
+    D = composition.n_dim
+    if not enabled() or not native.lib().tfk_flow_supported(D):
+        return None
+    order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
+    plan = _flatten(order, "forward" if direction == FORWARD else "inverse")
+    if plan is None:
+        return None
+    pos = torch.arange(D, device=device)
+    items = []                                   # [(op triple, block)]
+    with torch.no_grad():
+        for layer, d in plan:
+            if isinstance(layer, PermutationMatrix):
+                perm = (layer._fwd_index if d == FORWARD else layer._inv_index).to(device)
+                pos = pos[perm]                  # new logical j = old logical perm[j]
+                continue
+            if isinstance(layer, ElementwiseBijection):
+                item = _elementwise_op(layer, d, pos, D)
+            elif isinstance(layer, CouplingBijection):
+                item = _coupling_op(layer, d, pos, D)
+            else:
+                item = None
+            if item is None:
+                return None
+            items.append(item)
+    # pack into launches whose parameter block fits the LDS budget
+    segments: List[Segment] = []
+    ops, blocks, used = [], [], 0
+    for (kind, plane, H), block in items:
+        n = block.numel()
+        if n * 4 > 150 * 1024:
+            return None                          # a single op larger than LDS: not fusable here
+        if ops and ((used + n) * 4 > MAX_PARAM_BYTES or len(ops) == MAX_OPS):
+            segments.append(Segment(ops, torch.cat(blocks).contiguous()))
+            ops, blocks, used = [], [], 0
+        ops.append((kind, plane, H, used))
+        blocks.append(block.float())
+        used += n
+    if ops:
+        segments.append(Segment(ops, torch.cat(blocks).contiguous()))
+    identity = bool(torch.equal(pos, torch.arange(D, device=device)))
+    return CompiledChain(D, segments, pos, identity, _params_version(composition))
+
+
+def get_compiled(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
+    """Cached ``compile_chain``; recompiles when a parameter / buffer was modified in place."""
+    cache = composition.__dict__.setdefault("_tfk_compiled", {})
+    key = (direction, str(device), bool(composition.training))
+    hit = cache.get(key)
+    version = _params_version(composition)
+    if hit is not None and hit[0] == version:
+        return hit[1]
+    chain = compile_chain(composition, direction, device)
+    cache[key] = (version, chain)
+    return chain
+
+
+def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None):
+    """Apply the compiled chain to ``rows`` (N, D).  Returns ``(out_rows or None, logdet or
+    None, logprob or None)``; with ``base`` (loc, log_scale in logical order) the final launch
+    also evaluates the diagonal-Gaussian log-density and adds the log-det (flows.py:647-648)."""
+    N, D = rows.shape
+    dev = rows.device
+    n_seg = len(chain.segments)
+    logprob = torch.empty(N, dtype=torch.float32, device=dev) if base is not None else None
+    logdet = torch.empty(N, dtype=torch.float32, device=dev) if (base is None or n_seg > 1) else None
+    cur = rows
+    buf = None
+    if n_seg == 0:                               # only permutations: nothing to launch
+        out = rows[:, chain.pos] if want_rows else None
+        ld = torch.zeros(N, dtype=torch.float32, device=dev)
+        lp = None
+        if base is not None:
+            native.diag_gauss_logprob(rows[:, chain.pos].contiguous(), base[0], base[1], ld, logprob)
+            lp = logprob
+        return out, ld, lp
+    loc_p = ls_p = None
+    if base is not None:
+        loc_p = torch.empty_like(base[0])
+        ls_p = torch.empty_like(base[1])
+        loc_p[chain.pos] = base[0]
+        ls_p[chain.pos] = base[1]
+    for i, seg in enumerate(chain.segments):
+        last = i == n_seg - 1
+        need_rows = (not last) or want_rows
+        out = None
+        if need_rows:
+            if buf is None:
+                buf = torch.empty_like(rows)
+            out = buf                             # in place from the second segment on
+        native.flow_run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
+                        loc_p if last else None, ls_p if last else None,
+                        logprob if last else None, seg.ops, seg.params, accumulate=(i > 0))
+        if need_rows:
+            cur = out
+    out_rows = None
+    if want_rows:
+        if chain.identity_out:
+            out_rows = cur
+        else:                                     # logical l <- physical pos[l]
+            out_rows = torch.empty_like(cur)
+            native.permute(cur, chain.pos.to(torch.int32), out_rows)
+    return out_rows, logdet, logprob

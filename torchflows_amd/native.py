@@ -28,9 +28,10 @@ SYMBOLS = (
     "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32",
+    "tfk_flow_supported", "tfk_flow_run",
 )
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NativeError(RuntimeError):
@@ -70,6 +71,9 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_sum_workspace_bytes.argtypes = [_i64]
     L.tfk_sum_workspace_bytes.restype = _i64
     L.tfk_sum_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
+    L.tfk_flow_supported.argtypes = [_i32]
+    L.tfk_flow_run.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_i32), _i32,
+                               _vp, _i64, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -237,6 +241,26 @@ def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
             _f32(out, name), N, D)
     with torch.cuda.device(z.device):
         rc = lib().tfk_diag_gauss_logprob(*args, _stream(z))
+    calls += 1
+    _check(rc, name)
+
+
+def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
+    """Fused flow program (tfk_flow_run).  ops: list of (kind, src_plane, H, offset) tuples
+    (host side), params: fp32 device block.  z / logdet / logprob may be None."""
+    global calls
+    name = "tfk_flow_run"
+    N, D = _rows(x, name)
+    flat = [int(v) for op in ops for v in op]
+    ops_arr = (_i32 * max(len(flat), 1))(*flat)
+    for t, n in ((z, N * D), (logdet, N), (logprob, N), (gauss_loc, D), (gauss_log_scale, D)):
+        if t is not None and t.numel() != n:
+            raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
+    args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
+            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
+            _f32(params, name), params.numel(), 1 if accumulate else 0)
+    with torch.cuda.device(x.device):
+        rc = lib().tfk_flow_run(*args, _stream(x))
     calls += 1
     _check(rc, name)
 
