@@ -68,14 +68,35 @@ __device__ __forceinline__ float group_allsum(float v) {
     return v;
 }
 
+// tanh of a hidden pre-activation, branch-free: 1 - 2 / (1 + exp(2x)) with the hardware
+// exp2 and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each).  Absolute error <= ~2e-7, which
+// is what matters for a conditioner activation (it is multiplied by O(1) weights and added);
+// ocml's tanhf is a two-branch routine that diverges across the rows of a wave and costs
+// ~4x as many instructions.  Saturates correctly: exp2(+big) = inf -> 1, exp2(-big) = 0 -> -1.
+__device__ __forceinline__ float tanh_act(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+// n / d as q = n*r, q += r*(n - d*q) with r = v_rcp_f32(d): the Newton step of the IEEE division
+// expansion without its range scaling.  Correctly rounded except for quotients or divisors
+// within a few binades of overflow / underflow (not reachable here: d is a scale factor
+// exp(u/2)+1e-10 or a std-dev, n a data value); 4 instructions instead of ~10.
+__device__ __forceinline__ float div_fast(float n, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ float dot4(const float4 w, const float4 s) {
     return fmaf(w.w, s.w, fmaf(w.z, s.z, fmaf(w.y, s.y, w.x * s.x)));
 }
 
-// One op on the registers of one row.  prm = this op's parameters in LDS.
-template <int G>
-__device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int j, float4 &a,
-                                         float4 &b, float &ld)
+// One op on the registers of R rows (the weights are read from LDS once for all of them).
+// prm = this op's parameters in LDS.
+template <int G, int R>
+__device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int j, float4 (&a)[R],
+                                         float4 (&b)[R], float (&ld)[R])
 {
     constexpr int D = 8 * G, HALF = 4 * G;
     if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
@@ -84,82 +105,110 @@ __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int 
         const float4 al_b = *reinterpret_cast<const float4 *>(prm + HALF + 4 * j);
         const float4 be_a = *reinterpret_cast<const float4 *>(prm + D + 4 * j);
         const float4 be_b = *reinterpret_cast<const float4 *>(prm + D + HALF + 4 * j);
-        if (op.kind == TFK_OP_EW_MULADD) {                  // affine.py:48
-            a.x = al_a.x * a.x + be_a.x; a.y = al_a.y * a.y + be_a.y;
-            a.z = al_a.z * a.z + be_a.z; a.w = al_a.w * a.w + be_a.w;
-            b.x = al_b.x * b.x + be_b.x; b.y = al_b.y * b.y + be_b.y;
-            b.z = al_b.z * b.z + be_b.z; b.w = al_b.w * b.w + be_b.w;
-        } else {                                            // affine.py:59
-            a.x = (a.x - be_a.x) / al_a.x; a.y = (a.y - be_a.y) / al_a.y;
-            a.z = (a.z - be_a.z) / al_a.z; a.w = (a.w - be_a.w) / al_a.w;
-            b.x = (b.x - be_b.x) / al_b.x; b.y = (b.y - be_b.y) / al_b.y;
-            b.z = (b.z - be_b.z) / al_b.z; b.w = (b.w - be_b.w) / al_b.w;
+        const float ldc = prm[2 * D];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (op.kind == TFK_OP_EW_MULADD) {                  // affine.py:48
+                a[r].x = al_a.x * a[r].x + be_a.x; a[r].y = al_a.y * a[r].y + be_a.y;
+                a[r].z = al_a.z * a[r].z + be_a.z; a[r].w = al_a.w * a[r].w + be_a.w;
+                b[r].x = al_b.x * b[r].x + be_b.x; b[r].y = al_b.y * b[r].y + be_b.y;
+                b[r].z = al_b.z * b[r].z + be_b.z; b[r].w = al_b.w * b[r].w + be_b.w;
+            } else {                                            // affine.py:59
+                a[r].x = div_fast(a[r].x - be_a.x, al_a.x); a[r].y = div_fast(a[r].y - be_a.y, al_a.y);
+                a[r].z = div_fast(a[r].z - be_a.z, al_a.z); a[r].w = div_fast(a[r].w - be_a.w, al_a.w);
+                b[r].x = div_fast(b[r].x - be_b.x, al_b.x); b[r].y = div_fast(b[r].y - be_b.y, al_b.y);
+                b[r].z = div_fast(b[r].z - be_b.z, al_b.z); b[r].w = div_fast(b[r].w - be_b.w, al_b.w);
+            }
+            ld[r] = ld[r] + ldc;                                // base.py:222
         }
-        ld = ld + prm[2 * D];                               // base.py:222
         return;
     }
     // coupling: W1t[H][HALF] | b1[H4] | W2t[H][HALF*P] | b2[HALF*P]   (physical order)
     const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
     const int H = op.H, H4 = (H + 3) & ~3;
-    const float4 src = op.src_plane ? b : a;
-    float4 tgt = op.src_plane ? a : b;
+    float4 src[R], tgt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        src[r] = op.src_plane ? b[r] : a[r];
+        tgt[r] = op.src_plane ? a[r] : b[r];
+    }
     const float *W1t = prm;
     const float *b1 = prm + H * HALF;
     if (affine) {
         const float *W2t = b1 + H4;
         const float *b2 = W2t + H * (2 * HALF);
-        float4 acc0 = *reinterpret_cast<const float4 *>(b2 + 8 * j);      // (u0, be0, u1, be1)
-        float4 acc1 = *reinterpret_cast<const float4 *>(b2 + 8 * j + 4);  // (u2, be2, u3, be3)
+        float4 acc0[R], acc1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc0[r] = *reinterpret_cast<const float4 *>(b2 + 8 * j);      // (u0, be0, u1, be1)
+            acc1[r] = *reinterpret_cast<const float4 *>(b2 + 8 * j + 4);  // (u2, be2, u3, be3)
+        }
         for (int k = 0; k < H; ++k) {
             const float4 w1 = *reinterpret_cast<const float4 *>(W1t + k * HALF + 4 * j);
-            const float hk = tanhf(group_allsum<G>(dot4(w1, src)) + b1[k]);   // transforms.py:293-304
+            const float b1k = b1[k];
             const float4 w2a = *reinterpret_cast<const float4 *>(W2t + k * (2 * HALF) + 8 * j);
             const float4 w2b = *reinterpret_cast<const float4 *>(W2t + k * (2 * HALF) + 8 * j + 4);
-            acc0.x = fmaf(w2a.x, hk, acc0.x); acc0.y = fmaf(w2a.y, hk, acc0.y);
-            acc0.z = fmaf(w2a.z, hk, acc0.z); acc0.w = fmaf(w2a.w, hk, acc0.w);
-            acc1.x = fmaf(w2b.x, hk, acc1.x); acc1.y = fmaf(w2b.y, hk, acc1.y);
-            acc1.z = fmaf(w2b.z, hk, acc1.z); acc1.w = fmaf(w2b.w, hk, acc1.w);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float hk = tanh_act(group_allsum<G>(dot4(w1, src[r])) + b1k);   // transforms.py:293-304
+                acc0[r].x = fmaf(w2a.x, hk, acc0[r].x); acc0[r].y = fmaf(w2a.y, hk, acc0[r].y);
+                acc0[r].z = fmaf(w2a.z, hk, acc0[r].z); acc0[r].w = fmaf(w2a.w, hk, acc0[r].w);
+                acc1[r].x = fmaf(w2b.x, hk, acc1[r].x); acc1[r].y = fmaf(w2b.y, hk, acc1[r].y);
+                acc1[r].z = fmaf(w2b.z, hk, acc1[r].z); acc1[r].w = fmaf(w2b.w, hk, acc1[r].w);
+            }
         }
-        const float a0 = aff_alpha(acc0.x), a1 = aff_alpha(acc0.z);
-        const float a2 = aff_alpha(acc1.x), a3 = aff_alpha(acc1.z);
-        float part = logf(a0);                               // affine.py:42
-        part += logf(a1);
-        part += logf(a2);
-        part += logf(a3);
-        part = group_allsum<G>(part);
-        if (op.kind == TFK_OP_AFFINE_FWD) {
-            tgt.x = a0 * tgt.x + acc0.y; tgt.y = a1 * tgt.y + acc0.w;
-            tgt.z = a2 * tgt.z + acc1.y; tgt.w = a3 * tgt.w + acc1.w;
-            ld = ld + part;
-        } else {
-            tgt.x = (tgt.x - acc0.y) / a0; tgt.y = (tgt.y - acc0.w) / a1;
-            tgt.z = (tgt.z - acc1.y) / a2; tgt.w = (tgt.w - acc1.w) / a3;
-            ld = ld + (-part);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float a0 = aff_alpha(acc0[r].x), a1 = aff_alpha(acc0[r].z);
+            const float a2 = aff_alpha(acc1[r].x), a3 = aff_alpha(acc1[r].z);
+            float part = logf(a0);                               // affine.py:42
+            part += logf(a1);
+            part += logf(a2);
+            part += logf(a3);
+            part = group_allsum<G>(part);
+            if (op.kind == TFK_OP_AFFINE_FWD) {
+                tgt[r].x = a0 * tgt[r].x + acc0[r].y; tgt[r].y = a1 * tgt[r].y + acc0[r].w;
+                tgt[r].z = a2 * tgt[r].z + acc1[r].y; tgt[r].w = a3 * tgt[r].w + acc1[r].w;
+                ld[r] = ld[r] + part;
+            } else {
+                tgt[r].x = div_fast(tgt[r].x - acc0[r].y, a0); tgt[r].y = div_fast(tgt[r].y - acc0[r].w, a1);
+                tgt[r].z = div_fast(tgt[r].z - acc1[r].y, a2); tgt[r].w = div_fast(tgt[r].w - acc1[r].w, a3);
+                ld[r] = ld[r] + (-part);
+            }
+            if (op.src_plane) a[r] = tgt[r]; else b[r] = tgt[r];
         }
-        if (op.src_plane) a = tgt; else b = tgt;
     } else {                                                 // shift (NICE), affine.py:137-159
         const float *W2t = b1 + H4;
         const float *b2 = W2t + H * HALF;
-        float4 acc = *reinterpret_cast<const float4 *>(b2 + 4 * j);
+        float4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = *reinterpret_cast<const float4 *>(b2 + 4 * j);
         for (int k = 0; k < H; ++k) {
             const float4 w1 = *reinterpret_cast<const float4 *>(W1t + k * HALF + 4 * j);
-            const float hk = tanhf(group_allsum<G>(dot4(w1, src)) + b1[k]);
+            const float b1k = b1[k];
             const float4 w2 = *reinterpret_cast<const float4 *>(W2t + k * HALF + 4 * j);
-            acc.x = fmaf(w2.x, hk, acc.x); acc.y = fmaf(w2.y, hk, acc.y);
-            acc.z = fmaf(w2.z, hk, acc.z); acc.w = fmaf(w2.w, hk, acc.w);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float hk = tanh_act(group_allsum<G>(dot4(w1, src[r])) + b1k);
+                acc[r].x = fmaf(w2.x, hk, acc[r].x); acc[r].y = fmaf(w2.y, hk, acc[r].y);
+                acc[r].z = fmaf(w2.z, hk, acc[r].z); acc[r].w = fmaf(w2.w, hk, acc[r].w);
+            }
         }
-        if (op.kind == TFK_OP_SHIFT_FWD) {
-            tgt.x += acc.x; tgt.y += acc.y; tgt.z += acc.z; tgt.w += acc.w;
-        } else {
-            tgt.x -= acc.x; tgt.y -= acc.y; tgt.z -= acc.z; tgt.w -= acc.w;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (op.kind == TFK_OP_SHIFT_FWD) {
+                tgt[r].x += acc[r].x; tgt[r].y += acc[r].y; tgt[r].z += acc[r].z; tgt[r].w += acc[r].w;
+            } else {
+                tgt[r].x -= acc[r].x; tgt[r].y -= acc[r].y; tgt[r].z -= acc[r].z; tgt[r].w -= acc[r].w;
+            }
+            if (op.src_plane) a[r] = tgt[r]; else b[r] = tgt[r];
         }
-        if (op.src_plane) a = tgt; else b = tgt;
     }
 }
 
 // Dynamic LDS: the launch's parameter block (n_params floats) [+ 3*D floats for the base].
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_flow_run(
+template <int G, int BLOCK, int R>
+__global__ __launch_bounds__(BLOCK) void k_flow_run(
     const float4 *__restrict__ x, float4 *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
     const float *__restrict__ params, int n_params, FlowProgram prog, int accumulate)
@@ -169,11 +218,11 @@ __global__ __launch_bounds__(kBlock) void k_flow_run(
     {   // stage the parameter block (16-byte coalesced loads)
         const float4 *src = reinterpret_cast<const float4 *>(params);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < (n_params >> 2); i += kBlock) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
     }
     float *base_s = lds + n_params;                   // loc[D] | scale[D] | log_scale[D]
     if (logprob) {
-        for (int e = threadIdx.x; e < D; e += kBlock) {
+        for (int e = threadIdx.x; e < D; e += BLOCK) {
             base_s[e] = gauss_loc[e];
             base_s[D + e] = expf(gauss_log_scale[e]);
             base_s[2 * D + e] = gauss_log_scale[e];
@@ -182,40 +231,87 @@ __global__ __launch_bounds__(kBlock) void k_flow_run(
     __syncthreads();
 
     const int j = threadIdx.x & (G - 1);
-    constexpr int rows_per_block = kBlock / G;
+    constexpr int rows_per_pass = BLOCK / G;           // rows one workgroup covers per r
+    constexpr int rows_per_block = R * rows_per_pass;
     const long long stride = (long long)gridDim.x * rows_per_block;
-    for (long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G; row < N;
-         row += stride) {
-        float4 a = x[row * (2 * G) + j];
-        float4 b = x[row * (2 * G) + G + j];
-        // running log-det: continues the previous launch's sum so that the layer-order fp32
-        // accumulation of base.py:210-222 is the same however the program is segmented
-        float ld = (logdet && accumulate) ? logdet[row] : 0.0f;
+    for (long long row0 = (long long)blockIdx.x * rows_per_block + threadIdx.x / G; row0 < N;
+         row0 += stride) {
+        float4 a[R], b[R];
+        float ld[R];
+        long long row[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            row[r] = row0 + (long long)r * rows_per_pass;
+            const long long rr = row[r] < N ? row[r] : N - 1;     // tail: compute a valid row, store nothing
+            a[r] = x[rr * (2 * G) + j];
+            b[r] = x[rr * (2 * G) + G + j];
+            // running log-det: continues the previous launch's sum so that the layer-order fp32
+            // accumulation of base.py:210-222 is the same however the program is segmented
+            ld[r] = (logdet && accumulate) ? logdet[rr] : 0.0f;
+        }
         for (int o = 0; o < prog.n_ops; ++o)
-            apply_op<G>(prog.op[o], lds + prog.op[o].offset, j, a, b, ld);
-        if (z) {
-            z[row * (2 * G) + j] = a;
-            z[row * (2 * G) + G + j] = b;
-        }
-        float acc = 0.0f;
-        if (logprob) {                                          // gaussian.py:46-54
-            auto term = [&](float v, int e) {
-                const float t = (v - base_s[e]) / base_s[D + e];
-                float q = 0.5f * (t * t);
-                q = q + kHalfLog2Pi;
-                q = q + base_s[2 * D + e];
-                acc += -q;
-            };
-            term(a.x, 4 * j); term(a.y, 4 * j + 1); term(a.z, 4 * j + 2); term(a.w, 4 * j + 3);
-            term(b.x, HALF + 4 * j); term(b.y, HALF + 4 * j + 1);
-            term(b.z, HALF + 4 * j + 2); term(b.w, HALF + 4 * j + 3);
-            acc = group_allsum<G>(acc);
-        }
-        if (j == 0) {
-            if (logdet) logdet[row] = ld;
-            if (logprob) logprob[row] = acc + ld;               // flows.py:648
+            apply_op<G, R>(prog.op[o], lds + prog.op[o].offset, j, a, b, ld);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.0f;
+            if (logprob) {                                          // gaussian.py:46-54
+                auto term = [&](float v, int e) {
+                    const float t = div_fast(v - base_s[e], base_s[D + e]);
+                    float q = 0.5f * (t * t);
+                    q = q + kHalfLog2Pi;
+                    q = q + base_s[2 * D + e];
+                    acc += -q;
+                };
+                term(a[r].x, 4 * j); term(a[r].y, 4 * j + 1); term(a[r].z, 4 * j + 2); term(a[r].w, 4 * j + 3);
+                term(b[r].x, HALF + 4 * j); term(b[r].y, HALF + 4 * j + 1);
+                term(b[r].z, HALF + 4 * j + 2); term(b[r].w, HALF + 4 * j + 3);
+                acc = group_allsum<G>(acc);
+            }
+            if (row[r] < N) {
+                if (z) {
+                    z[row[r] * (2 * G) + j] = a[r];
+                    z[row[r] * (2 * G) + G + j] = b[r];
+                }
+                if (j == 0) {
+                    if (logdet) logdet[row[r]] = ld[r];
+                    if (logprob) logprob[row[r]] = acc + ld[r];     // flows.py:648
+                }
+            }
         }
     }
+}
+
+template <int G, int BLOCK, int R>
+static int launch_flow_b(const float *x, float *z, float *logdet, const float *loc,
+                         const float *log_scale, float *logprob, int64_t N, const float *params,
+                         int n_params, const FlowProgram &prog, int accumulate, hipStream_t s,
+                         const char *fn)
+{
+    constexpr int D = 8 * G;
+    const size_t lds = ((size_t)n_params + (logprob ? 3 * D : 0)) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run<G, BLOCK, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+    // residency: 32 waves per CU and 160 KiB of LDS; the parameter block is per workgroup,
+    // so big workgroups share it between more waves
+    int per_cu = 2048 / BLOCK;
+    if (lds && (int)((160 * 1024) / lds) < per_cu) per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    constexpr int rows_per_block = R * (BLOCK / G);
+    const int64_t want = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * per_cu;
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL((k_flow_run<G, BLOCK, R>), dim3(grid), dim3(BLOCK), lds, s,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(z), logdet,
+                       loc, log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
+    return check_launch(fn);
 }
 
 template <int G>
@@ -224,28 +320,13 @@ static int launch_flow(const float *x, float *z, float *logdet, const float *loc
                        int n_params, const FlowProgram &prog, int accumulate, hipStream_t s,
                        const char *fn)
 {
-    constexpr int D = 8 * G;
-    const size_t lds = ((size_t)n_params + (logprob ? 3 * D : 0)) * sizeof(float);
-    if (lds > 160 * 1024)
-        return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run<G>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
-        }
-    }
-    int per_cu = lds ? (int)((160 * 1024) / lds) : 8;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    const int64_t want = (N + (kBlock / G) - 1) / (kBlock / G);
-    const int64_t cap = (int64_t)kCUs * per_cu;
-    const int grid = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((k_flow_run<G>), dim3(grid), dim3(kBlock), lds, s,
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(z), logdet,
-                       loc, log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
-    return check_launch(fn);
+    // enough rows to fill the chip with 1024-thread workgroups (2 per CU)? else stay small
+    // (each thread then carries two rows: the weights come out of LDS once for both)
+    if (N * G >= (int64_t)kCUs * 2 * 1024 * 2)
+        return launch_flow_b<G, 1024, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
+                                         prog, accumulate, s, fn);
+    return launch_flow_b<G, kBlock, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
+                                       prog, accumulate, s, fn);
 }
 
 }  // namespace tfk
