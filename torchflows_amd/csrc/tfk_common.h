@@ -30,6 +30,48 @@ __device__ __forceinline__ float aff_alpha(float u) {
     return expf(u * 0.5f + kAffC0) + kAffMinScale;
 }
 
+// ---- lean math: same values as the ocml routines on the ranges used here ----------------
+// (measured on gfx950: ocml expf = 12 VALU ops, logf = 11, log1pf = 121 (!), IEEE '/' = 9)
+
+// n / d as q = n*r, q += r*(n - d*q) with r = v_rcp_f32(d): the quotient-correction step of the
+// IEEE division expansion without its range scaling and reciprocal refinement.  Within half an
+// ulp plus ~1e-7 ulp of n/d, i.e. the correctly rounded quotient except on near-ties, for
+// operands whose quotient and reciprocal are normal numbers (true everywhere it is used: the
+// divisors are scale factors, bin widths and softmax sums).  4 ops.
+__device__ __forceinline__ float div_fast(float n, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
+// v / 1000 (the reference divides its spline logits by 1000, rational_quadratic.py:76-77)
+__device__ __forceinline__ float div_1000(float v) {
+    const float r = 1.0f / 1000.0f;                  // compile-time constant
+    const float q = v * r;
+    return fmaf(fmaf(-1000.0f, q, v), r, q);
+}
+
+// expf for arguments that cannot overflow (x <= ~88): ocml's own argument reduction
+// (x*log2(e) split hi/lo, v_exp_f32, ldexp) without its overflow / underflow selects --
+// bit-identical to expf on that range, underflows to denormals / 0 through ldexp.  9 ops.
+__device__ __forceinline__ float exp_noovf(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;    // 0x3fb8aa3b
+    const float L2E_LO = 1.925963033500011079e-08f;     // 0x32a5705f
+    const float t = x * L2E_HI;
+    const float n = __builtin_rintf(t);
+    const float e = fmaf(L2E_LO, x, fmaf(x, L2E_HI, -t));
+    const float f = (t - n) + e;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// log1p(y) for y >= 0: log(u) + (y - (u - 1)) / u with u = fl(1 + y) -- the second term gives
+// back what rounding 1 + y lost, so the result is within ~1 ulp like log1pf, at 1/7 of its cost.
+__device__ __forceinline__ float log1p_pos(float y) {
+    const float u = 1.0f + y;
+    const float lost = y - (u - 1.0f);
+    return logf(u) + lost * __builtin_amdgcn_rcpf(u);
+}
+
 // sum over the G (power of two, <= 64) consecutive lanes that share a row
 __device__ __forceinline__ float group_sum(float v, int G) {
     for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);

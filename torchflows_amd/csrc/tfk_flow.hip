@@ -78,16 +78,6 @@ __device__ __forceinline__ float tanh_act(float x) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
-// n / d as q = n*r, q += r*(n - d*q) with r = v_rcp_f32(d): the Newton step of the IEEE division
-// expansion without its range scaling.  Correctly rounded except for quotients or divisors
-// within a few binades of overflow / underflow (not reachable here: d is a scale factor
-// exp(u/2)+1e-10 or a std-dev, n a data value); 4 instructions instead of ~10.
-__device__ __forceinline__ float div_fast(float n, float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float q = n * r;
-    return fmaf(fmaf(-d, q, n), r, q);
-}
-
 __device__ __forceinline__ float dot4(const float4 w, const float4 s) {
     return fmaf(w.w, s.w, fmaf(w.z, s.z, fmaf(w.y, s.y, w.x * s.x)));
 }

@@ -35,8 +35,10 @@ struct RqsConst {
     float c;         // boundary_u_delta = log(expm1(1 - min_delta))
 };
 
-// F.softplus, beta = 1, threshold = 20
-__device__ __forceinline__ float softplus20(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+// F.softplus, beta = 1, threshold = 20: log1p(exp(v)) below the threshold
+__device__ __forceinline__ float softplus20(float v) {
+    return v > 20.0f ? v : log1p_pos(exp_noovf(fminf(v, 20.0f)));
+}
 
 // rational_quadratic.py:56-63
 __device__ __forceinline__ float rqs_log_det(float s, float dk, float dk1, float xi, float q,
@@ -68,7 +70,7 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
             const float ux = p[j];
-            const float uy = ux + p[KT + j] / 1000.0f;     // rational_quadratic.py:76
+            const float uy = ux + div_1000(p[KT + j]);      // rational_quadratic.py:76
             ex[j] = ux;
             ey[j] = uy;
             mx = j ? fmaxf(mx, ux) : ux;
@@ -77,12 +79,12 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
         float sx = 0.0f, sy = 0.0f;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {                     // softmax numerators, :46
-            ex[j] = expf(ex[j] - mx);
-            ey[j] = expf(ey[j] - my);
+            ex[j] = exp_noovf(ex[j] - mx);                 // argument <= 0
+            ey[j] = exp_noovf(ey[j] - my);
             sx += ex[j];
             sy += ey[j];
         }
-        const float rx = 1.0f / sx, ry = 1.0f / sy;
+        const float rx = div_fast(1.0f, sx), ry = div_fast(1.0f, sy);
         float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
         bool prev_below = true;                            // knot 0 = minimum < v (in box)
 #pragma unroll
@@ -104,22 +106,22 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
             prevy = ky;
         }
     } else {
-        float mx = p[0], my = p[0] + p[K] / 1000.0f;
+        float mx = p[0], my = p[0] + div_1000(p[K]);
         for (int j = 1; j < K; ++j) {
             mx = fmaxf(mx, p[j]);
-            my = fmaxf(my, p[j] + p[K + j] / 1000.0f);
+            my = fmaxf(my, p[j] + div_1000(p[K + j]));
         }
         float sx = 0.0f, sy = 0.0f;
         for (int j = 0; j < K; ++j) {
-            sx += expf(p[j] - mx);
-            sy += expf((p[j] + p[K + j] / 1000.0f) - my);
+            sx += exp_noovf(p[j] - mx);
+            sy += exp_noovf((p[j] + div_1000(p[K + j])) - my);
         }
-        const float rx = 1.0f / sx, ry = 1.0f / sy;
+        const float rx = div_fast(1.0f, sx), ry = div_fast(1.0f, sy);
         float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
         bool prev_below = true;
         for (int j = 1; j <= K; ++j) {
-            const float e_x = expf(p[j - 1] - mx);
-            const float e_y = expf((p[j - 1] + p[K + j - 1] / 1000.0f) - my);
+            const float e_x = exp_noovf(p[j - 1] - mx);
+            const float e_y = exp_noovf((p[j - 1] + div_1000(p[K + j - 1])) - my);
             runx = runx + (kRqsMinBin + C.scale * (e_x * rx));
             runy = runy + (kRqsMinBin + C.scale * (e_y * ry));
             const float kx = (j == K) ? C.maximum : C.span * runx + C.minimum;
@@ -143,18 +145,18 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
     // (the discarded LDS reads at k == 0 / k == K-1 stay inside the padded tile)
     const float udk = (k == 0) ? C.c : p[2 * K + k - 1];
     const float udk1 = (k == K - 1) ? C.c : p[2 * K + k];
-    const float dk = kRqsMinDelta + softplus20(C.c + udk / 1000.0f);    // :77
-    const float dk1 = kRqsMinDelta + softplus20(C.c + udk1 / 1000.0f);
-    const float s = hk / wk;                               // :94 / :159
+    const float dk = kRqsMinDelta + softplus20(C.c + div_1000(udk));    // :77
+    const float dk1 = kRqsMinDelta + softplus20(C.c + div_1000(udk1));
+    const float s = div_fast(hk, wk);                      // :94 / :159
     const float term1 = dk1 + dk - 2.0f * s;               // :97 / :162
 
     if (!INVERSE) {
-        float xi = (v - bxk) / wk;                         // :99
+        float xi = div_fast(v - bxk, wk);                  // :99
         xi = clip01(xi);                                   // :100
         const float q = xi * (1.0f - xi);                  // :101
         const float num0 = hk * (s * (xi * xi) + dk * q);  // :104
         const float den0 = s + term1 * q;                  // :105
-        out = byk + num0 / den0;                           // :106
+        out = byk + div_fast(num0, den0);                  // :106
         ld = rqs_log_det(s, dk, dk1, xi, q, term1);        // :109
     } else {
         const float term0 = v - byk;                       // :164
@@ -164,7 +166,7 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
         const float c = (-s) * term0;                      // :169
         float r = sqrtf(b * b - (4.0f * a) * c);           // :171
         r = r < 0.0f ? 0.0f : r;
-        float xi = (2.0f * c) / ((-b) - r);                // :173
+        float xi = div_fast(2.0f * c, (-b) - r);           // :173
         xi = clip01(xi);                                   // :174
         const float q = xi * (1.0f - xi);                  // :175
         out = xi * wk + bxk;                               // :178
