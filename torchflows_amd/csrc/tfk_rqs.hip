@@ -25,6 +25,10 @@
 
 #include "tfk_common.h"
 
+#ifndef TFK_ABLATE
+#define TFK_ABLATE 0
+#endif
+
 namespace tfk {
 
 struct RqsConst {
@@ -54,10 +58,11 @@ __device__ __forceinline__ float rqs_log_det(float s, float dk, float dk1, float
 // torch.clip: NaN passes through
 __device__ __forceinline__ float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
-// One in-box element.  p -> its P = 3K-1 parameters in LDS.  KT > 0: compile-time K,
-// everything in registers; KT == 0: run-time K, streamed from LDS (no local arrays).
-template <int KT, bool INVERSE>
-__device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const RqsConst &C,
+// One in-box element.  p = its P = 3K-1 parameters: a pointer into LDS, or (REGS) a register
+// array.  KT > 0: compile-time K, everything in registers; KT == 0: run-time K, streamed from
+// LDS (no local arrays).
+template <int KT, bool INVERSE, bool REGS = false, typename PT = const float *>
+__device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const RqsConst &C,
                                          float &out, float &ld)
 {
     const int K = KT > 0 ? KT : Krt;
@@ -143,8 +148,17 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
     const float hk = byk1 - byk;
     // u_d = pad(h[2K:], (1, 1), value = c) (:127); only delta_k and delta_k+1 are used.
     // (the discarded LDS reads at k == 0 / k == K-1 stay inside the padded tile)
-    const float udk = (k == 0) ? C.c : p[2 * K + k - 1];
-    const float udk1 = (k == K - 1) ? C.c : p[2 * K + k];
+    float udk = C.c, udk1 = C.c;
+    if constexpr (REGS) {           // registers cannot be indexed by k: select instead
+#pragma unroll
+        for (int j = 0; j < KT - 1; ++j) {
+            udk = (k == j + 1) ? p[2 * KT + j] : udk;
+            udk1 = (k == j) ? p[2 * KT + j] : udk1;
+        }
+    } else {
+        udk = (k == 0) ? C.c : p[2 * K + k - 1];
+        udk1 = (k == K - 1) ? C.c : p[2 * K + k];
+    }
     const float dk = kRqsMinDelta + softplus20(C.c + div_1000(udk));    // :77
     const float dk1 = kRqsMinDelta + softplus20(C.c + div_1000(udk1));
     const float s = div_fast(hk, wk);                      // :94 / :159
@@ -174,12 +188,14 @@ __device__ __forceinline__ void rqs_eval(const float *p, int Krt, float v, const
     }
 }
 
-constexpr int kTile = kBlock;   // spline elements (parameter records) per LDS tile
+// TILE = threads per workgroup = spline elements (parameter records) per LDS tile.
+// TILE = 64: every wavefront is its own workgroup with its own 5.9 KB tile -- no cross-wave
+// barrier, up to 7 independent waves per SIMD whose load / evaluate phases interleave freely.
 
-// Dynamic LDS layout: [kTile * P + 4 floats of records | kTile floats of log-dets |
+// Dynamic LDS layout: [TILE * P + 4 floats of records | TILE floats of log-dets |
 //                      D bytes of target mask (only tgt_idx && !inplace)]
-template <int KT, bool INVERSE>
-__global__ __launch_bounds__(kBlock) void k_rqs_coupling(
+template <int KT, bool INVERSE, int TILE>
+__global__ __launch_bounds__(TILE) void k_rqs_coupling(
     const float *x, const float *__restrict__ h, float *z, float *logdet, long long N, int D,
     const int *__restrict__ tgt_idx, int T, int T_shift, int Krt, RqsConst C, int accumulate,
     int inplace, int h_vec_ok)
@@ -188,41 +204,44 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling(
     const int K = KT > 0 ? KT : Krt;
     const int P = 3 * K - 1;
     float *rec = lds;
-    float *ld_s = lds + kTile * P + 4;
-    unsigned char *is_tgt = reinterpret_cast<unsigned char *>(ld_s + kTile);
+    float *ld_s = lds + TILE * P + 4;
+    unsigned char *is_tgt = reinterpret_cast<unsigned char *>(ld_s + TILE);
     const int tid = threadIdx.x;
     const bool use_mask = (tgt_idx != nullptr) && !inplace;
     if (use_mask) {
-        for (int e = tid; e < D; e += kBlock) is_tgt[e] = 0;
+        for (int e = tid; e < D; e += TILE) is_tgt[e] = 0;
         __syncthreads();
-        for (int t = tid; t < T; t += kBlock) is_tgt[tgt_idx[t]] = 1;
+        for (int t = tid; t < T; t += TILE) is_tgt[tgt_idx[t]] = 1;
     }
 
-    const int R = T <= kTile ? kTile / T : 1;          // rows per tile
-    const int chunks = T <= kTile ? 1 : (T + kTile - 1) / kTile;
+    const int R = T <= TILE ? TILE / T : 1;          // rows per tile
+    const int chunks = T <= TILE ? 1 : (T + TILE - 1) / TILE;
     const long long n_tiles = (N + R - 1) / R;
     const bool shfl_reduce = (T_shift >= 0) && (T <= kWave);
 
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row0 = tile * R;
         const int rows = (int)((N - row0) < (long long)R ? (N - row0) : (long long)R);
-        float ld_thread = 0.0f;    // T > kTile: this thread's share of the (single) row
+        float ld_thread = 0.0f;    // T > TILE: this thread's share of the (single) row
 
         for (int ch = 0; ch < chunks; ++ch) {
-            const int cbase = ch * kTile;
-            const int E = (chunks == 1) ? rows * T : ((T - cbase) < kTile ? (T - cbase) : kTile);
+            const int cbase = ch * TILE;
+            const int E = (chunks == 1) ? rows * T : ((T - cbase) < TILE ? (T - cbase) : TILE);
             const long long hoff = (row0 * (long long)T + cbase) * P;    // floats
             const int nfl = E * P;
 
             __syncthreads();   // previous tile's readers are done with rec / ld_s
+#if TFK_ABLATE == 2      /* timing experiment only: tile loaded once, then evaluated from stale LDS */
+            if (tile == (long long)blockIdx.x)
+#endif
             if (h_vec_ok && (hoff & 3) == 0) {
                 const float4 *src = reinterpret_cast<const float4 *>(h + hoff);
                 float4 *dst = reinterpret_cast<float4 *>(rec);
                 const int nv = nfl >> 2;
-                for (int i = tid; i < nv; i += kBlock) dst[i] = src[i];
-                for (int i = (nv << 2) + tid; i < nfl; i += kBlock) rec[i] = h[hoff + i];
+                for (int i = tid; i < nv; i += TILE) dst[i] = src[i];
+                for (int i = (nv << 2) + tid; i < nfl; i += TILE) rec[i] = h[hoff + i];
             } else {
-                for (int i = tid; i < nfl; i += kBlock) rec[i] = h[hoff + i];
+                for (int i = tid; i < nfl; i += TILE) rec[i] = h[hoff + i];
             }
             __syncthreads();
 
@@ -238,8 +257,12 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling(
                 const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
                 const float v = x[row * D + idx];
                 float o = v;                                       // spline/base.py:54-55
+#if TFK_ABLATE == 1      /* timing experiment only: no spline evaluation */
+                o = v + rec[tid * P];
+#else
                 if (v > C.minimum && v < C.maximum)                // strict, base.py:29-33
                     rqs_eval<KT, INVERSE>(rec + tid * P, K, v, C, o, ld);
+#endif
                 z[row * D + idx] = o;
             }
 
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling(
             __syncthreads();
             ld_s[tid] = ld_thread;
             __syncthreads();
-            for (int o = kBlock / 2; o > 0; o >>= 1) {
+            for (int o = TILE / 2; o > 0; o >>= 1) {
                 if (tid < o) ld_s[tid] += ld_s[tid + o];
                 __syncthreads();
             }
@@ -273,13 +296,111 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling(
 
         if (!inplace) {                                            // clone, layers_base.py:146
             const int total = rows * D;
-            for (int e = tid; e < total; e += kBlock) {
+            for (int e = tid; e < total; e += TILE) {
                 const int r = e / D;
                 const int c = e - r * D;
                 const bool tgt = tgt_idx ? (is_tgt[c] != 0) : (c >= D - T);
                 if (!tgt) z[(row0 + r) * D + c] = x[(row0 + r) * D + c];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA pipeline (the fast path: compile-time K, T a power of two <= 64, 16-byte
+// aligned tiles).  Per tile of 256 records (23 KiB for K = 8):
+//   1. barrier: the tile's DMA has landed (its s_waitcnt vmcnt(0) is the only thing that
+//      orders an LDS-DMA against ds_reads);
+//   2. every lane copies its own record LDS -> registers (P ds_read_b32 at a P-dword stride,
+//      conflict-free for odd P);
+//   3. barrier: the LDS tile is free again -> global_load_lds_dwordx4 for the NEXT tile is
+//      issued right away (no VGPR staging, 1 KiB per wave-instruction, six in flight per
+//      wave) together with the prefetch of the next tile's inputs x;
+//   4. ~500 VALU ops per element run out of registers while that DMA is in flight.
+// A single 23 KiB buffer per workgroup keeps 6 workgroups = 6 waves per SIMD resident.
+// Dynamic LDS: (256*P + 8) floats [+ D bytes of target mask].
+// ---------------------------------------------------------------------------
+template <int KT, bool INVERSE>
+__global__ __launch_bounds__(kBlock) void k_rqs_coupling_dma(
+    const float *x, const float *__restrict__ h, float *z, float *logdet, long long N, int D,
+    const int *__restrict__ tgt_idx, int T, int T_shift, RqsConst C, int accumulate, int inplace)
+{
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int P = 3 * KT - 1;
+    constexpr int BUF = kBlock * P + 8;                 // floats (16-byte multiple)
+    unsigned char *is_tgt = reinterpret_cast<unsigned char *>(lds + BUF);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool use_mask = (tgt_idx != nullptr) && !inplace;
+    if (use_mask) {
+        for (int e = tid; e < D; e += kBlock) is_tgt[e] = 0;
+        __syncthreads();
+        for (int t = tid; t < T; t += kBlock) is_tgt[tgt_idx[t]] = 1;
+    }
+    const int R = kBlock >> T_shift;                    // rows per tile
+    const long long n_tiles = (N + R - 1) / R;
+    const int r = tid >> T_shift, t = tid & (T - 1);
+    const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
+
+    auto issue = [&](long long tile) {                  // this wave's share of a tile's records
+        const long long row0 = tile * R;
+        const int rows = (int)((N - row0) < (long long)R ? (N - row0) : (long long)R);
+        const int nbytes = rows * T * P * 4;            // multiple of 16 (host checks T*P % 4 == 0)
+        const char *src = reinterpret_cast<const char *>(h + row0 * (long long)T * P);
+        for (int c = w; c * 1024 < nbytes; c += kBlock / 64) {
+            const int off = c * 1024 + lane * 16;
+            if (off < nbytes)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + off),
+                                                 (lptr_t)(reinterpret_cast<char *>(lds) + c * 1024),
+                                                 16, 0, 0);
+        }
+    };
+
+    long long tile = blockIdx.x;
+    float v_cur = 0.0f;
+    if (tile < n_tiles) {
+        issue(tile);
+        const long long row = tile * R + r;
+        if (row < N) v_cur = x[row * D + idx];
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                 // (1) this tile's DMA has landed
+        float p[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) p[j] = lds[tid * P + j];   // (2)
+        __syncthreads();                                 // (3) everyone holds its record
+        const long long nxt = tile + gridDim.x;
+        float v_nxt = 0.0f;
+        if (nxt < n_tiles) {
+            issue(nxt);
+            const long long rown = nxt * R + r;
+            if (rown < N) v_nxt = x[rown * D + idx];
+        }
+        const long long row0 = tile * R;
+        const long long row = row0 + r;
+        const bool live = row < N;
+        float ld = 0.0f;
+        if (live) {                                      // (4)
+            const float v = v_cur;
+            float o = v;                                       // spline/base.py:54-55
+            if (v > C.minimum && v < C.maximum)                // strict, base.py:29-33
+                rqs_eval<KT, INVERSE, true, float[P]>(p, KT, v, C, o, ld);
+            z[row * D + idx] = o;
+        }
+        const float sum = group_sum(ld, T);                     // sum_except_batch, base.py:59
+        if (live && t == 0) logdet[row] = accumulate ? logdet[row] + sum : sum;
+        if (!inplace) {                                         // clone, layers_base.py:146
+            const int rows = (int)((N - row0) < (long long)R ? (N - row0) : (long long)R);
+            const int total = rows * D;
+            for (int e = tid; e < total; e += kBlock) {
+                const int rr = e / D;
+                const int c = e - rr * D;
+                const bool tgt = tgt_idx ? (is_tgt[c] != 0) : (c >= D - T);
+                if (!tgt) z[(row0 + rr) * D + c] = x[(row0 + rr) * D + c];
+            }
+        }
+        v_cur = v_nxt;
     }
 }
 
@@ -297,12 +418,15 @@ static int rqs_coupling(const float *x, const float *h, float *z, float *logdet,
     if (!x || !h || !z || !logdet) return fail(TFK_EINVAL, "%s: null pointer", fn);
     const bool inplace = (x == z);
     const int P = 3 * K - 1;
-    size_t lds = ((size_t)kTile * P + 4 + kTile) * sizeof(float);
+    // one wavefront per workgroup unless a row needs more than 64 lanes' worth of shuffles
+    const int tile = 256;   // (64 = one wavefront per workgroup measured slower: 293 vs 229 us at C3)
+    size_t lds = ((size_t)tile * P + 4 + tile) * sizeof(float);
     if (tgt_idx && !inplace) lds += (size_t)D;
     if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: LDS tile of %zu bytes exceeds 160 KiB", fn, lds);
     if (lds > 64 * 1024) {
         // large K (run-time-K kernel only): opt in to more than 64 KiB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rqs_coupling<0, INVERSE>),
+        hipError_t e = hipFuncSetAttribute(tile == 64 ? reinterpret_cast<const void *>(&k_rqs_coupling<0, INVERSE, 64>)
+                                                      : reinterpret_cast<const void *>(&k_rqs_coupling<0, INVERSE, 256>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -322,23 +446,49 @@ static int rqs_coupling(const float *x, const float *h, float *z, float *logdet,
         T_shift = 0;
         while ((1 << T_shift) < T) ++T_shift;
     }
-    const int R = T <= kTile ? kTile / T : 1;
+    const int R = T <= tile ? tile / T : 1;
     const int64_t n_tiles = (N + R - 1) / R;
     // LDS-bound residency: 160 KiB / tile; cap the grid there and stride the rest
     int per_cu = (int)((160 * 1024) / lds);
+    const int max_blocks = 2048 / tile > 28 ? 28 : 2048 / tile;     // 32 waves per CU, ~7 per SIMD by VGPRs
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > max_blocks) per_cu = max_blocks;
     int64_t grid = n_tiles < (int64_t)kCUs * per_cu ? n_tiles : (int64_t)kCUs * per_cu;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int h_vec_ok = aligned16(h) ? 1 : 0;
 
-#define TFK_RQS_LAUNCH(KT_)                                                                       \
-    hipLaunchKernelGGL((k_rqs_coupling<KT_, INVERSE>), dim3((unsigned)grid), dim3(kBlock), lds, s, \
+    // fast path: LDS-DMA double buffering
+    if ((K == 8 || K == 4) && T_shift >= 0 && T <= 64 && ((T * P) & 3) == 0 && h_vec_ok) {
+        size_t lds2 = ((size_t)kBlock * P + 8) * sizeof(float) + ((tgt_idx && !inplace) ? (size_t)D : 0);
+        if (lds2 <= 64 * 1024) {
+            const int Rr = kBlock >> T_shift;
+            const int64_t tiles = (N + Rr - 1) / Rr;
+            int pc = (int)((160 * 1024) / lds2);
+            if (pc > 8) pc = 8;
+            const int64_t g = tiles < (int64_t)kCUs * pc ? tiles : (int64_t)kCUs * pc;
+            if (K == 8)
+                hipLaunchKernelGGL((k_rqs_coupling_dma<8, INVERSE>), dim3((unsigned)g), dim3(kBlock), lds2, s,
+                                   x, h, z, logdet, (long long)N, D, tgt_idx, T, T_shift, C, accumulate, inplace ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_rqs_coupling_dma<4, INVERSE>), dim3((unsigned)g), dim3(kBlock), lds2, s,
+                                   x, h, z, logdet, (long long)N, D, tgt_idx, T, T_shift, C, accumulate, inplace ? 1 : 0);
+            return check_launch(fn);
+        }
+    }
+
+#define TFK_RQS_LAUNCH(KT_, TILE_)                                                                  \
+    hipLaunchKernelGGL((k_rqs_coupling<KT_, INVERSE, TILE_>), dim3((unsigned)grid), dim3(TILE_), lds, s, \
                        x, h, z, logdet, (long long)N, D, tgt_idx, T, T_shift, K, C, accumulate,    \
                        inplace ? 1 : 0, h_vec_ok)
-    if (K == 8) TFK_RQS_LAUNCH(8);
-    else if (K == 4) TFK_RQS_LAUNCH(4);
-    else TFK_RQS_LAUNCH(0);
+    if (tile == 64) {
+        if (K == 8) TFK_RQS_LAUNCH(8, 64);
+        else if (K == 4) TFK_RQS_LAUNCH(4, 64);
+        else TFK_RQS_LAUNCH(0, 64);
+    } else {
+        if (K == 8) TFK_RQS_LAUNCH(8, 256);
+        else if (K == 4) TFK_RQS_LAUNCH(4, 256);
+        else TFK_RQS_LAUNCH(0, 256);
+    }
 #undef TFK_RQS_LAUNCH
     return check_launch(fn);
 }

@@ -16,7 +16,8 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtfk.so")
+# TORCHFLOWS_AMD_LIB: load another build of the same ABI (kernel experiments / ablations)
+LIB_PATH = os.environ.get("TORCHFLOWS_AMD_LIB") or os.path.join(_PKG, "lib", "libtfk.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 # every symbol include/tfk.h declares (tests check the built library exports all of them)
