@@ -124,11 +124,11 @@ class KernelTimer:
         N, D = x.shape
         half = D // 2
         per_row = 0
-        for kind, _, H, _ in ops:
-            if kind in (2, 3):
-                per_row += 2 * (half * H + H * half * 2)
-            elif kind in (4, 5):
-                per_row += 2 * (half * H + H * half)
+        for op in ops:
+            kind, H = op[0], op[2]
+            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23}.get(kind)
+            if P is not None:
+                per_row += 2 * (half * H + H * half * P)
         return N * per_row
 
     def summary(self):
@@ -234,7 +234,9 @@ def main():
     flow = make_flow(arch, D, n_layers).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(rows, D, device=dev, generator=gen)
-    step_rows = chunk or rows
+    # the layer-by-layer path materialises h (2.9 KB per row per RQS layer): evaluate in chunks;
+    # the fused programs never hold h, so they take the whole batch at once
+    step_rows = (chunk or rows) if args.no_fused else rows
 
     def step():
         lp, total = sharded_log_likelihood(flow, x, chunk_rows=step_rows)

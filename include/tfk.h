@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 2
+#define TFK_ABI_VERSION 3
 
 enum {
     TFK_OK = 0,
@@ -139,7 +139,10 @@ int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *
  * (conditioning/transforms.py:274-307): h never exists in HBM.
  * Supported: D a power of two in [16, 512], HalfSplit mask, no context.
  *
- * ops (HOST pointer): n_ops x int32[4] = {kind, src_plane, H, param_offset};
+ * ops (HOST pointer): n_ops x int32[8] = {kind, src_plane, H, param_offset, K,
+ *   boundary, scale, c} -- the last three are fp32 bit patterns and only used by RQS ops
+ *   (K = n_bins = 8, boundary = spline box half-width, scale = 1 - 1e-3*K,
+ *   c = log(expm1(1 - 1e-5)), rational_quadratic.py:20,36-38);
  * params (device, 16-byte aligned, n_params % 4 == 0) holds, at param_offset (floats,
  * multiple of 4), in PHYSICAL element order (plane A = positions [0, D/2), B = the rest):
  *   TFK_OP_EW_MULADD / TFK_OP_EW_SUBDIV : alpha[D] | beta[D] | logdet_const | pad[3]
@@ -148,6 +151,10 @@ int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *
  *        src_plane = which plane feeds the conditioner (the other one is transformed);
  *        W1t[k][m] multiplies physical source element m; W2t[k][m*P + p], b2[m*P + p]
  *        produce parameter p of physical target element m.
+ *   RQS coupling (TFK_OP_RQS_FWD / _INV, layers.py:154-163 + spline/rational_quadratic.py):
+ *        W1t[H][D/2] | b1[H padded to 4] | W2t[H][4][D/8][24] | b2[4][D/8][24]
+ *        target element m = 4*j + e lives at [e][j]; its 23 parameters [u_x(8) | u_y(8) | u_d(7)]
+ *        are padded to 24 floats; H <= 32.
  * Outputs (each may be NULL, at least one must not): z rows (physical order), logdet
  * (accumulate as elsewhere), logprob[n] = diag-Gaussian log-density of the final rows
  * (gauss_loc / gauss_log_scale given in physical order) + the chain's log-det. */
@@ -157,7 +164,9 @@ enum {
     TFK_OP_AFFINE_FWD = 2,
     TFK_OP_AFFINE_INV = 3,
     TFK_OP_SHIFT_FWD = 4,
-    TFK_OP_SHIFT_INV = 5
+    TFK_OP_SHIFT_INV = 5,
+    TFK_OP_RQS_FWD = 6,
+    TFK_OP_RQS_INV = 7
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

@@ -92,6 +92,58 @@ def test_fused_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, arch, D, n_layer
     assert rel(fused["xr"].cpu().numpy(), layer["xr"].cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("D", [16, 64, 128, 256])
+@pytest.mark.parametrize("n_layers", [1, 2, 8])
+def test_fused_spline_flow_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, D, n_layers):
+    """CouplingRQNSF as fused flow programs (conditioner + 23-parameter GEMM + spline in one
+    kernel).  Spline bar: 4e-5 (see tests/test_gpu_kernels.py for why not 1e-5)."""
+    from torchflows_amd import fused
+    torch.manual_seed(D + n_layers)
+    flow = data_init(pkg.Flow(pkg.CouplingRQNSF(D, n_layers=n_layers)), D)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict("CouplingRQNSF", D, n_layers, sd)
+    flow = flow.cuda()
+    N = 700 + D
+    x = torch.randn(N, D)
+    x[:40] *= 30                                   # some rows leave the spline box
+    got_fused, got_layer = run_both(flow, x.cuda(), monkeypatch)
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    flow.bijection.__dict__.pop("_tfk_compiled", None)
+    if D <= 128:
+        assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is not None
+        assert got_fused["launches"] < got_layer["launches"]
+    else:       # D = 256: one coupling's 17 x 128 x 24 weights (209 KB) exceed the LDS -> layer by layer
+        assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is None
+    z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
+    xr_ref, ldi_ref = ref.inverse(x.numpy())
+    for name, got in (("fused", got_fused), ("layerwise", got_layer)):
+        e = dict(lp=rel(got["lp"].cpu().numpy(), lp_ref), lp_only=rel(got["lp_only"].cpu().numpy(), lp_ref),
+                 z=normwise(got["z"].cpu().numpy(), z_ref), xr=normwise(got["xr"].cpu().numpy(), xr_ref),
+                 ldi=rel(got["ldi"].cpu().numpy(), ldi_ref))
+        print("NSF", D, n_layers, name, {k: f"{v:.1e}" for k, v in e.items()})
+        # log-dets sum T = D/2 spline terms per layer: bound per 32 terms, as in test_gpu_kernels
+        tol = {k: 4e-5 * (max(1.0, D / 64) if k in ("lp", "lp_only", "ldi") else 1.0) for k in e}
+        assert all(e[k] < tol[k] for k in e), (name, e)
+
+
+@pytest.mark.parametrize("variant", ["fresh", "init"])
+def test_fused_spline_golden(pkg, monkeypatch, variant):
+    from torchflows_amd import fused
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    fx = load_golden("flow_nsf64.npz")
+    flow = pkg.Flow(pkg.CouplingRQNSF(64, n_layers=8))
+    flow.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict_of(fx, variant).items()})
+    flow = flow.cuda().eval()
+    assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is not None
+    with torch.no_grad():
+        lp = flow.log_prob(torch.from_numpy(fx["x"]).cuda())
+        xr, ldr = flow.bijection.inverse(torch.from_numpy(fx["z_in"]).cuda())
+    g = lambda k: fx[f"{variant}/{k}"]
+    assert rel(lp.cpu().numpy(), g("log_prob")) < max(4e-5, 3 * rel(g("log_prob"), g("log_prob64")))
+    assert normwise(xr.cpu().numpy(), g("x_inv")) < max(4e-5, 3 * normwise(g("x_inv"), g("x_inv64")))
+    assert rel(ldr.cpu().numpy(), g("log_det_inv")) < max(4e-5, 3 * rel(g("log_det_inv"), g("log_det_inv64")))
+
+
 @pytest.mark.parametrize("name,arch,n_layers", [("flow_realnvp64.npz", "RealNVP", 8),
                                                 ("flow_realnvp256.npz", "RealNVP", 8)])
 @pytest.mark.parametrize("variant", ["fresh", "init"])

@@ -30,18 +30,26 @@
 // -ffp-contract=off); the dot products use fmaf and a different (tree) summation order than
 // ATen's GEMM -- both are within a few ulp of the exact sum.
 #include <cmath>
+#include <cstring>
 
 #include "tfk_common.h"
+#include "tfk_spline.h"
 
 namespace tfk {
 
 constexpr int kMaxOps = 96;
+constexpr int kMaxHidden = 32;     // conditioner width an RQS op may have (activations parked in LDS)
+constexpr int kRqsPad = 24;        // 3*8-1 = 23 spline parameters per element, padded to 6 float4
 
 struct FlowOp {
     int kind;        // TFK_OP_*
     int src_plane;   // coupling: 0 = plane A conditions plane B, 1 = the opposite
     int H;           // coupling: hidden width of the conditioner
     int offset;      // first float of this op's parameters in the staged block (multiple of 4)
+    int K;           // RQS: number of bins (8)
+    float boundary;  // RQS: spline box half-width
+    float scale;     // RQS: 1 - min_bin_size * K  (python double, cast once)
+    float c;         // RQS: boundary_u_delta = log(expm1(1 - min_delta))
 };
 
 struct FlowProgram {
@@ -86,7 +94,7 @@ __device__ __forceinline__ float dot4(const float4 w, const float4 s) {
 // prm = this op's parameters in LDS.
 template <int G, int R>
 __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int j, float4 (&a)[R],
-                                         float4 (&b)[R], float (&ld)[R])
+                                         float4 (&b)[R], float (&ld)[R], float *hk_s)
 {
     constexpr int D = 8 * G, HALF = 4 * G;
     if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
@@ -113,9 +121,73 @@ __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int 
         }
         return;
     }
-    // coupling: W1t[H][HALF] | b1[H4] | W2t[H][HALF*P] | b2[HALF*P]   (physical order)
-    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
     const int H = op.H, H4 = (H + 3) & ~3;
+    if (op.kind == TFK_OP_RQS_FWD || op.kind == TFK_OP_RQS_INV) {
+        // RQ-spline coupling (layers.py:154-163): W1t[H][HALF] | b1[H4] | W2t[H][4][G][24] | b2[4][G][24]
+        // -- the 4 target elements of lane j are (e, j), e = 0..3, physical position 4j + e;
+        // 23 spline parameters each, padded to 24 so a lane's slices are 6 aligned float4 and
+        // the G lanes of a group read 96-byte-strided slices (bank-conflict-free).
+        const float *W1t = prm;
+        const float *b1 = prm + H * HALF;
+        const float *W2t = b1 + H4;
+        const float *b2 = W2t + H * HALF * kRqsPad;
+        RqsConst C;
+        C.minimum = -op.boundary;
+        C.maximum = op.boundary;
+        C.span = op.boundary + op.boundary;
+        C.scale = op.scale;
+        C.c = op.c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 src = op.src_plane ? b[r] : a[r];
+            float4 tgt = op.src_plane ? a[r] : b[r];
+            // conditioner layer 1: the hidden activations go to this row-group's LDS scratch
+            // (same wave writes and reads them: program order, no barrier)
+            for (int k = 0; k < H; ++k) {
+                const float4 w1 = *reinterpret_cast<const float4 *>(W1t + k * HALF + 4 * j);
+                const float hk = tanh_act(group_allsum<G>(dot4(w1, src)) + b1[k]);
+                if (j == 0) hk_s[k] = hk;
+            }
+            float part = 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                // conditioner layer 2 for this element: its 23 (+1 pad) spline parameters
+                float p[kRqsPad];
+                const float4 *bb = reinterpret_cast<const float4 *>(b2 + (e * G + j) * kRqsPad);
+#pragma unroll
+                for (int i = 0; i < kRqsPad / 4; ++i) {
+                    const float4 q = bb[i];
+                    p[4 * i] = q.x; p[4 * i + 1] = q.y; p[4 * i + 2] = q.z; p[4 * i + 3] = q.w;
+                }
+                for (int k = 0; k < H; ++k) {
+                    const float hk = hk_s[k];
+                    const float4 *ww = reinterpret_cast<const float4 *>(W2t + ((k * 4 + e) * G + j) * kRqsPad);
+#pragma unroll
+                    for (int i = 0; i < kRqsPad / 4; ++i) {
+                        const float4 q = ww[i];
+                        p[4 * i] = fmaf(q.x, hk, p[4 * i]);
+                        p[4 * i + 1] = fmaf(q.y, hk, p[4 * i + 1]);
+                        p[4 * i + 2] = fmaf(q.z, hk, p[4 * i + 2]);
+                        p[4 * i + 3] = fmaf(q.w, hk, p[4 * i + 3]);
+                    }
+                }
+                const float v = e == 0 ? tgt.x : (e == 1 ? tgt.y : (e == 2 ? tgt.z : tgt.w));
+                float o = v, l = 0.0f;                          // spline/base.py:54-55
+                if (v > C.minimum && v < C.maximum) {           // strict box, base.py:29-33
+                    if (op.kind == TFK_OP_RQS_FWD)
+                        rqs_eval<8, false, true, float[kRqsPad]>(p, 8, v, C, o, l);
+                    else
+                        rqs_eval<8, true, true, float[kRqsPad]>(p, 8, v, C, o, l);
+                }
+                if (e == 0) tgt.x = o; else if (e == 1) tgt.y = o; else if (e == 2) tgt.z = o; else tgt.w = o;
+                part += l;
+            }
+            ld[r] = ld[r] + group_allsum<G>(part);              // base.py:59 + :222
+            if (op.src_plane) a[r] = tgt; else b[r] = tgt;
+        }
+        return;
+    }
+    // affine / shift coupling: W1t[H][HALF] | b1[H4] | W2t[H][HALF*P] | b2[HALF*P]   (physical order)
+    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
     float4 src[R], tgt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -211,6 +283,8 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run(
         for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
     }
     float *base_s = lds + n_params;                   // loc[D] | scale[D] | log_scale[D]
+    // per row-group scratch for RQS ops (hidden activations), after the base block
+    float *hk_s = lds + n_params + 3 * (8 * G) + (threadIdx.x / G) * kMaxHidden;
     if (logprob) {
         for (int e = threadIdx.x; e < D; e += BLOCK) {
             base_s[e] = gauss_loc[e];
@@ -240,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run(
             ld[r] = (logdet && accumulate) ? logdet[rr] : 0.0f;
         }
         for (int o = 0; o < prog.n_ops; ++o)
-            apply_op<G, R>(prog.op[o], lds + prog.op[o].offset, j, a, b, ld);
+            apply_op<G, R>(prog.op[o], lds + prog.op[o].offset, j, a, b, ld, hk_s);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float acc = 0.0f;
@@ -278,7 +352,10 @@ static int launch_flow_b(const float *x, float *z, float *logdet, const float *l
                          const char *fn)
 {
     constexpr int D = 8 * G;
-    const size_t lds = ((size_t)n_params + (logprob ? 3 * D : 0)) * sizeof(float);
+    bool has_rqs = false;
+    for (int i = 0; i < prog.n_ops; ++i)
+        has_rqs = has_rqs || prog.op[i].kind == TFK_OP_RQS_FWD || prog.op[i].kind == TFK_OP_RQS_INV;
+    const size_t lds = ((size_t)n_params + 3 * D + (has_rqs ? (BLOCK / G) * kMaxHidden : 0)) * sizeof(float);
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
     if (lds > 64 * 1024) {
@@ -311,6 +388,16 @@ static int launch_flow(const float *x, float *z, float *logdet, const float *loc
                        const char *fn)
 {
     // enough rows to fill the chip with 1024-thread workgroups (2 per CU)? else stay small
+    // programs with RQ-spline ops are register-heavy (23 parameters + the spline state per
+    // element): 512-thread workgroups, one row per thread
+    for (int i = 0; i < prog.n_ops; ++i)
+        if (prog.op[i].kind == TFK_OP_RQS_FWD || prog.op[i].kind == TFK_OP_RQS_INV) {
+            if (N * G >= (int64_t)kCUs * 512)
+                return launch_flow_b<G, 512, 1>(x, z, logdet, loc, log_scale, logprob, N, params,
+                                                n_params, prog, accumulate, s, fn);
+            return launch_flow_b<G, kBlock, 1>(x, z, logdet, loc, log_scale, logprob, N, params,
+                                               n_params, prog, accumulate, s, fn);
+        }
     // (each thread then carries two rows: the weights come out of LDS once for both)
     if (N * G >= (int64_t)kCUs * 2 * 1024 * 2)
         return launch_flow_b<G, 1024, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
@@ -357,10 +444,15 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
     const int HALF = D / 2;
     for (int i = 0; i < n_ops; ++i) {
         FlowOp &o = prog.op[i];
-        o.kind = ops[4 * i];
-        o.src_plane = ops[4 * i + 1];
-        o.H = ops[4 * i + 2];
-        o.offset = ops[4 * i + 3];
+        const int32_t *rec = ops + 8 * i;
+        o.kind = rec[0];
+        o.src_plane = rec[1];
+        o.H = rec[2];
+        o.offset = rec[3];
+        o.K = rec[4];
+        memcpy(&o.boundary, rec + 5, 4);
+        memcpy(&o.scale, rec + 6, 4);
+        memcpy(&o.c, rec + 7, 4);
         int64_t need;
         if (o.kind == TFK_OP_EW_MULADD || o.kind == TFK_OP_EW_SUBDIV) {
             need = 2 * (int64_t)D + 4;
@@ -369,6 +461,12 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
             if (o.H < 1 || o.H > 4096) return fail(TFK_EINVAL, "%s: op %d: hidden width %d", fn, i, o.H);
             if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             need = (int64_t)o.H * HALF + ((o.H + 3) & ~3) + (int64_t)o.H * HALF * P + (int64_t)HALF * P;
+        } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
+            if (o.H < 1 || o.H > kMaxHidden) return fail(TFK_EINVAL, "%s: op %d: hidden width %d not in [1, %d]", fn, i, o.H, kMaxHidden);
+            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            if (o.K != 8) return fail(TFK_EINVAL, "%s: op %d: fused RQS supports n_bins = 8, got %d", fn, i, o.K);
+            if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
+            need = (int64_t)o.H * HALF + ((o.H + 3) & ~3) + (int64_t)o.H * HALF * kRqsPad + (int64_t)HALF * kRqsPad;
         } else {
             return fail(TFK_EINVAL, "%s: op %d: unknown kind %d", fn, i, o.kind);
         }

@@ -30,7 +30,10 @@ import torch.nn as nn
 
 from torchflows_amd import native
 
-OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV = range(6)
+OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
+    OP_RQS_FWD, OP_RQS_INV = range(8)
+RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
+MAX_HIDDEN_RQS = 32
 FORWARD, INVERSE = 0, 1
 
 # parameters staged in LDS per launch; 40 KB keeps 4 workgroups (16 waves) per CU and holds
@@ -45,7 +48,7 @@ def enabled() -> bool:
 
 @dataclass
 class Segment:
-    ops: List[Tuple[int, int, int, int]]      # (kind, src_plane, H, offset)
+    ops: List[tuple]                          # (kind, src_plane, H, offset[, K, boundary, scale, c])
     params: torch.Tensor                      # fp32 device block, numel % 4 == 0
 
 
@@ -114,8 +117,10 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
 def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
     kind = layer.transformer.native_kind
-    if kind not in ("affine", "inverse_affine", "shift") or layer.context_shape is not None:
+    if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
         return None
+    if kind == "rqs" and layer.transformer.n_bins != 8:
+        return None                       # the fused spline op is built for the default 8 bins
     half = D // 2
     c = layer.coupling
     if not (c.source_is_head and c.target_is_tail and c.source_event_size == half
@@ -130,7 +135,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
     if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
             and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
         return None
-    P = 2 if kind != "shift" else 1
+    P = {"shift": 1, "rqs": 23}.get(kind, 2)
     W1, b1 = mods[0].weight.detach(), mods[0].bias.detach()          # (H, S), (H,)
     W2, b2 = mods[2].weight.detach(), mods[2].bias.detach()          # (T*P, H), (T*P,)
     H = W1.shape[0]
@@ -147,6 +152,25 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
     W2p[m_t] = W2.reshape(half, P, H)
     b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
+    if kind == "rqs":
+        if H > MAX_HIDDEN_RQS:
+            return None
+        G = D // 8
+        # physical target m = 4*j + e  ->  [k][e][j][24] (23 parameters + 1 pad)
+        W2q = torch.zeros(half, RQS_PAD, H, dtype=W2.dtype, device=W2.device)
+        W2q[:, :P] = W2p
+        b2q = torch.zeros(half, RQS_PAD, dtype=b2.dtype, device=b2.device)
+        b2q[:, :P] = b2p
+        W2t = W2q.reshape(G, 4, RQS_PAD, H).permute(3, 1, 0, 2).reshape(-1)
+        b2t = b2q.reshape(G, 4, RQS_PAD).permute(1, 0, 2).reshape(-1)
+        block = torch.cat([W1t.reshape(-1), _pad4(b1), W2t, b2t])
+        tr = layer.transformer
+        op = OP_RQS_FWD if d == FORWARD else OP_RQS_INV
+        import math
+        import numpy as np
+        scale = float(np.float32(1.0 - tr.min_bin_size * tr.n_bins))
+        c = float(np.float32(math.log(math.expm1(1 - tr.min_delta))))
+        return (op, plane, H, 8, float(tr.boundary), scale, c), block
     block = torch.cat([W1t.reshape(-1), _pad4(b1), W2p.permute(2, 0, 1).reshape(-1), b2p.reshape(-1)])
     if kind == "shift":
         op = OP_SHIFT_FWD if d == FORWARD else OP_SHIFT_INV
@@ -188,14 +212,20 @@ def compile_chain(composition, direction: int, device: torch.device) -> Optional
     # pack into launches whose parameter block fits the LDS budget
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
-    for (kind, plane, H), block in items:
+    for head, block in items:
+        kind, plane, H = head[:3]
+        extra = tuple(head[3:])
         n = block.numel()
         if n * 4 > 150 * 1024:
             return None                          # a single op larger than LDS: not fusable here
-        if ops and ((used + n) * 4 > MAX_PARAM_BYTES or len(ops) == MAX_OPS):
+        # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
+        # gets a launch of its own, and the small elementwise ops around it ride along
+        small = kind in (OP_EW_MULADD, OP_EW_SUBDIV)
+        over = (used + n) * 4 > MAX_PARAM_BYTES
+        if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
             segments.append(Segment(ops, torch.cat(blocks).contiguous()))
             ops, blocks, used = [], [], 0
-        ops.append((kind, plane, H, used))
+        ops.append((kind, plane, H, used) + extra)
         blocks.append(block.float())
         used += n
     if ops:

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 import subprocess
 from typing import Optional
 
@@ -32,7 +33,7 @@ SYMBOLS = (
     "tfk_flow_supported", "tfk_flow_run",
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeError(RuntimeError):
@@ -247,12 +248,19 @@ def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
 
 
 def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
-    """Fused flow program (tfk_flow_run).  ops: list of (kind, src_plane, H, offset) tuples
-    (host side), params: fp32 device block.  z / logdet / logprob may be None."""
+    """Fused flow program (tfk_flow_run).  ops: list of (kind, src_plane, H, offset[, K,
+    boundary, scale, c]) tuples (host side), params: fp32 device block.  z / logdet / logprob
+    may be None."""
     global calls
     name = "tfk_flow_run"
     N, D = _rows(x, name)
-    flat = [int(v) for op in ops for v in op]
+    flat = []
+    for op in ops:
+        kind, plane, H, off = (int(v) for v in op[:4])
+        K = int(op[4]) if len(op) > 4 else 0
+        fl = [float(v) for v in op[5:8]] + [0.0] * (3 - len(op[5:8]))
+        bits = struct.unpack("<3i", struct.pack("<3f", *fl))
+        flat += [kind, plane, H, off, K, *bits]
     ops_arr = (_i32 * max(len(flat), 1))(*flat)
     for t, n in ((z, N * D), (logdet, N), (logprob, N), (gauss_loc, D), (gauss_log_scale, D)):
         if t is not None and t.numel() != n:
