@@ -90,6 +90,21 @@ int tfk_rqs_coupling_inv(const float *z, const float *h, float *x, float *logdet
                          int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
                          int32_t K, float boundary, int32_t accumulate, void *stream);
 
+/* ---- invertible 1x1 convolution coupling (Glow) -------------------------------
+ * The same skeleton around Invertible1x1ConvolutionTransformer
+ * (transformers/linear/convolution.py:8-70) + LUTransformer (transformers/linear/matrix.py:
+ * 11-99).  The T target positions are an image of n_channels x (T / n_channels) pixels,
+ * channel-major; h is (N, n + n(n-1)) per SAMPLE = [diag logits | U above the diagonal
+ * (triu row-major) | L below the diagonal (tril row-major)], U_ii = exp(h_i)/10 + 1,
+ * off-diagonals h/10, unit-diagonal L.  fwd: y = L U x per pixel, log-det = sum log U_ii
+ * once per sample (the reference does not scale it by the pixel count).  n_channels <= 16. */
+int tfk_conv1x1_coupling_fwd(const float *x, const float *h, float *z, float *logdet,
+                             int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                             int32_t n_channels, int32_t accumulate, void *stream);
+int tfk_conv1x1_coupling_inv(const float *z, const float *h, float *x, float *logdet,
+                             int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
+                             int32_t n_channels, int32_t accumulate, void *stream);
+
 /* ---- elementwise affine (ElementwiseAffine, ActNorm) -------------------------
  * Replaces ElementwiseBijection.forward / inverse (layers_base.py:300-318) with
  * global parameters value (D, 2) = [unconstrained alpha, beta] per element; the

@@ -68,6 +68,123 @@ void orc_reverse_permutation(int D, int32_t *fwd, int32_t *inv)
     for (int j = 0; j < D; ++j) inv[fwd[j]] = j;
 }
 
+void orc_checkerboard_mask(int C, int H, int W, int invert, uint8_t *source_mask,
+                           uint8_t *target_mask)
+{
+    /* multiscale/coupling.py:17-22 */
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < H * W; ++i) {
+            uint8_t m = (uint8_t)(i % 2);
+            if (invert) m = (uint8_t)!m;
+            source_mask[c * H * W + i] = m;
+            target_mask[c * H * W + i] = (uint8_t)!m;
+        }
+}
+
+void orc_channelwise_mask(int C, int H, int W, int invert, uint8_t *source_mask,
+                          uint8_t *target_mask)
+{
+    /* multiscale/coupling.py:49-54 */
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < H * W; ++i) {
+            uint8_t m = (uint8_t)(c < C / 2);
+            if (invert) m = (uint8_t)!m;
+            source_mask[c * H * W + i] = m;
+            target_mask[c * H * W + i] = (uint8_t)!m;
+        }
+}
+
+void orc_squeeze_index(int C, int H, int W, int32_t *idx)
+{
+    /* multiscale/base.py:148-153: cat of x[::2, ::2], x[::2, 1::2], x[1::2, ::2], x[1::2, 1::2] */
+    int n = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int di = q / 2, dj = q % 2;
+        for (int c = 0; c < C; ++c)
+            for (int i = di; i < H; i += 2)
+                for (int j = dj; j < W; j += 2)
+                    idx[n++] = (c * H + i) * W + j;
+    }
+}
+
+/* ---- invertible 1x1 convolution --------------------------------------------- */
+
+#define ORC_MAX_CH 64
+
+/* matrix.py:20-50: L (unit lower), U from h */
+static void lu_extract(const float *h, int n, float *L, float *U, float *log_diag)
+{
+    const int n_off = n * (n - 1) / 2;
+    memset(L, 0, sizeof(float) * (size_t)n * n);
+    memset(U, 0, sizeof(float) * (size_t)n * n);
+    for (int i = 0; i < n; ++i) {
+        const float ud = expf(h[i]) / 10.0f + 1.0f;          /* :31-32 */
+        U[i * n + i] = ud;
+        L[i * n + i] = 1.0f;
+        log_diag[i] = logf(ud);
+    }
+    int k = 0;
+    for (int r = 0; r < n; ++r)                               /* triu_indices(offset=1) */
+        for (int c = r + 1; c < n; ++c) U[r * n + c] = h[n + k++] / 10.0f;
+    k = 0;
+    for (int r = 1; r < n; ++r)                               /* tril_indices(offset=-1) */
+        for (int c = 0; c < r; ++c) L[r * n + c] = h[n + n_off + k++] / 10.0f;
+}
+
+void orc_conv1x1_fwd(const float *x, const float *h, float *y, float *logdet,
+                     int64_t N, int n, int HW)
+{
+    const int P = n + n * (n - 1);
+    float L[ORC_MAX_CH * ORC_MAX_CH], U[ORC_MAX_CH * ORC_MAX_CH], ldg[ORC_MAX_CH], t[ORC_MAX_CH];
+    for (int64_t s = 0; s < N; ++s) {
+        lu_extract(h + s * P, n, L, U, ldg);
+        float ld = 0.0f;
+        for (int i = 0; i < n; ++i) ld += ldg[i];              /* matrix.py:52-64 */
+        logdet[s] = ld;
+        for (int p = 0; p < HW; ++p) {
+            const float *xs = x + s * (int64_t)n * HW + p;
+            float *ys = y + s * (int64_t)n * HW + p;
+            for (int r = 0; r < n; ++r) {                      /* t = U x */
+                float acc = 0.0f;
+                for (int c = r; c < n; ++c) acc += U[r * n + c] * xs[(int64_t)c * HW];
+                t[r] = acc;
+            }
+            for (int r = 0; r < n; ++r) {                      /* y = L t  (matrix.py:66-73) */
+                float acc = 0.0f;
+                for (int c = 0; c <= r; ++c) acc += L[r * n + c] * t[c];
+                ys[(int64_t)r * HW] = acc;
+            }
+        }
+    }
+}
+
+void orc_conv1x1_inv(const float *y, const float *h, float *x, float *logdet,
+                     int64_t N, int n, int HW)
+{
+    const int P = n + n * (n - 1);
+    float L[ORC_MAX_CH * ORC_MAX_CH], U[ORC_MAX_CH * ORC_MAX_CH], ldg[ORC_MAX_CH], t[ORC_MAX_CH];
+    for (int64_t s = 0; s < N; ++s) {
+        lu_extract(h + s * P, n, L, U, ldg);
+        float ld = 0.0f;
+        for (int i = 0; i < n; ++i) ld += ldg[i];
+        logdet[s] = -ld;                                       /* matrix.py:82 */
+        for (int p = 0; p < HW; ++p) {
+            const float *ys = y + s * (int64_t)n * HW + p;
+            float *xs = x + s * (int64_t)n * HW + p;
+            for (int r = 0; r < n; ++r) {                      /* L t = y  (:78) */
+                float acc = ys[(int64_t)r * HW];
+                for (int c = 0; c < r; ++c) acc -= L[r * n + c] * t[c];
+                t[r] = acc;
+            }
+            for (int r = n - 1; r >= 0; --r) {                 /* U x = t  (:79) */
+                float acc = t[r];
+                for (int c = r + 1; c < n; ++c) acc -= U[r * n + c] * xs[(int64_t)c * HW];
+                xs[(int64_t)r * HW] = acc / U[r * n + r];
+            }
+        }
+    }
+}
+
 /* ---- affine ------------------------------------------------------------- */
 
 /* affine.py:33-34 constrain_scale: exp(c0 + u / 2) + m  (u/2 first, then +c0) */

@@ -38,6 +38,20 @@ int orc_mask_to_index(const uint8_t *mask, int D, int32_t *idx);
  * scatter of arange. bijections/finite/matrix/permutation.py:8-37 */
 void orc_reverse_permutation(int D, int32_t *fwd, int32_t *inv);
 
+/* Checkerboard (bijections/finite/multiscale/coupling.py:6-31): source = arange(h*w) % 2
+ * reshaped (h, w), repeated over channels, inverted on request; target = ~source. */
+void orc_checkerboard_mask(int C, int H, int W, int invert, uint8_t *source_mask,
+                           uint8_t *target_mask);
+
+/* ChannelWiseHalfSplit (multiscale/coupling.py:34-63): source = channel < C/2. */
+void orc_channelwise_mask(int C, int H, int W, int invert, uint8_t *source_mask,
+                          uint8_t *target_mask);
+
+/* Squeeze.forward as a gather list over the flat (C,H,W) event: out[j] = in[idx[j]],
+ * sub-lattices in the order (even,even),(even,odd),(odd,even),(odd,odd)
+ * (multiscale/base.py:136-154). */
+void orc_squeeze_index(int C, int H, int W, int32_t *idx);
+
 /* ---- transformers ------------------------------------------------------ */
 
 /* Affine.forward / inverse on (N,T) with h (N,T,2) interleaved.
@@ -58,6 +72,15 @@ void orc_rqs_fwd(const float *x, const float *h, float *z, float *logdet,
 void orc_rqs_inv(const float *z, const float *h, float *x, float *logdet,
                  float *logdet_el, int32_t *bin_idx,
                  int64_t N, int T, int K, float boundary);
+
+/* Invertible1x1ConvolutionTransformer + LUTransformer
+ * (transformers/linear/convolution.py:33-70, transformers/linear/matrix.py:20-82) on
+ * x (N, n, HW) channel-major with h (N, n + n(n-1)); logdet (N,) OVERWRITTEN with
+ * +/- sum log U_ii (not scaled by HW). */
+void orc_conv1x1_fwd(const float *x, const float *h, float *y, float *logdet,
+                     int64_t N, int n, int HW);
+void orc_conv1x1_inv(const float *y, const float *h, float *x, float *logdet,
+                     int64_t N, int n, int HW);
 
 /* Knots of M spline elements: bin_x, bin_y, delta each (M, K+1).
  * rational_quadratic.py:45-54, :75-77 */

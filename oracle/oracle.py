@@ -78,6 +78,11 @@ def lib() -> C.CDLL:
         L.orc_mask_to_index.argtypes = [_u8p, C.c_int, _i32p]
         L.orc_mask_to_index.restype = C.c_int
         L.orc_reverse_permutation.argtypes = [C.c_int, _i32p, _i32p]
+        L.orc_checkerboard_mask.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+        L.orc_channelwise_mask.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+        L.orc_squeeze_index.argtypes = [C.c_int, C.c_int, C.c_int, _i32p]
+        for name in ("orc_conv1x1_fwd", "orc_conv1x1_inv"):
+            getattr(L, name).argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int]
         for name in ("orc_affine_fwd", "orc_affine_inv"):
             getattr(L, name).argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int]
         for name in ("orc_rqs_fwd", "orc_rqs_inv"):
@@ -139,6 +144,37 @@ def reverse_permutation(D: int):
     i = np.zeros(D, np.int32)
     lib().orc_reverse_permutation(D, _ip(f), _ip(i))
     return f, i
+
+
+def image_mask(kind: str, shape, invert: bool = False):
+    """(source, target) boolean masks of shape (C, H, W); kind = 'checkerboard' | 'channel_wise'."""
+    Cc, H, W = (int(v) for v in shape)
+    s = np.zeros(Cc * H * W, np.uint8)
+    t = np.zeros_like(s)
+    fn = lib().orc_checkerboard_mask if kind == "checkerboard" else lib().orc_channelwise_mask
+    fn(Cc, H, W, int(invert), s.ctypes.data_as(_u8p), t.ctypes.data_as(_u8p))
+    return s.reshape(Cc, H, W).astype(bool), t.reshape(Cc, H, W).astype(bool)
+
+
+def squeeze_index(shape) -> np.ndarray:
+    Cc, H, W = (int(v) for v in shape)
+    idx = np.zeros(Cc * H * W, np.int32)
+    lib().orc_squeeze_index(Cc, H, W, _ip(idx))
+    return idx
+
+
+def conv1x1(x, h, inverse: bool = False):
+    """x: (N, n, *pixels) channel-major, h: (N, n + n(n-1)).  Returns (y, logdet (N,))."""
+    x = _f32(x)
+    h = _f32(h)
+    N, n = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    assert h.shape == (N, n + n * (n - 1))
+    y = np.empty_like(x)
+    ld = np.empty(N, np.float32)
+    fn = lib().orc_conv1x1_inv if inverse else lib().orc_conv1x1_fwd
+    fn(_fp(x), _fp(h), _fp(y), _fp(ld), N, n, HW)
+    return y, ld
 
 
 # --------------------------------------------------------------------------

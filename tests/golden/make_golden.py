@@ -283,7 +283,94 @@ def gen_layers():
     save("layers.npz", **out)
 
 
+# ---------------------------------------------------------------- F6 image path
+def gen_image():
+    from torchflows.bijections.finite.multiscale.coupling import Checkerboard, ChannelWiseHalfSplit
+    from torchflows.bijections.finite.multiscale.base import (
+        Squeeze, CheckerboardCoupling, ChannelWiseCoupling, Invertible1x1ConvolutionalCoupling)
+    from torchflows.bijections.finite.multiscale.architectures import AffineGlow
+    from torchflows.bijections.finite.autoregressive.transformers.linear.convolution import (
+        Invertible1x1ConvolutionTransformer)
+    from torchflows.bijections.finite.autoregressive.transformers.linear.matrix import LUTransformer
+    out = {}
+    shapes = [(3, 32, 32), (12, 16, 16), (6, 16, 16), (24, 8, 8), (12, 8, 8), (1, 4, 4), (3, 8, 8), (2, 2, 6)]
+    for es in shapes:
+        tag = "x".join(map(str, es))
+        for inv in (False, True):
+            c = Checkerboard(es, invert=inv)
+            out[f"ckb{int(inv)}_src_{tag}"] = np32(c.source_mask).astype(np.uint8)
+            out[f"ckb{int(inv)}_shapes_{tag}"] = np.array([*c.constant_shape, *c.target_shape], dtype=np.int64)
+            if es[0] > 1:
+                w = ChannelWiseHalfSplit(es, invert=inv)
+                out[f"chw{int(inv)}_src_{tag}"] = np32(w.source_mask).astype(np.uint8)
+                out[f"chw{int(inv)}_shapes_{tag}"] = np.array([*w.constant_shape, *w.target_shape], dtype=np.int64)
+        sq = Squeeze(es)
+        idx = torch.arange(int(np.prod(es)), dtype=torch.float32).view(1, *es)
+        out[f"squeeze_fwd_{tag}"] = np32(sq.forward(idx)[0]).reshape(-1).astype(np.int64)
+    out["shapes"] = np.array(["x".join(map(str, s)) for s in shapes])
+    save("image_masks.npz", **out)
+
+    out = {}
+    torch.manual_seed(0)
+    # LU / 1x1 convolution transformers with explicit parameters
+    for n in (1, 2, 3, 6, 12):
+        lu = LUTransformer((n,))
+        x = torch.randn(10, n)
+        h = torch.randn(10, *lu.parameter_shape)
+        y, ld = lu.forward(x, h)
+        xi, ldi = lu.inverse(x, h)
+        out.update({f"lu{n}_x": np32(x), f"lu{n}_h": np32(h), f"lu{n}_y": np32(y), f"lu{n}_ld": np32(ld),
+                    f"lu{n}_xinv": np32(xi), f"lu{n}_ldinv": np32(ldi)})
+    for n, hw in ((3, (4, 4)), (6, (8, 8))):
+        tr = Invertible1x1ConvolutionTransformer((n, *hw))
+        x = torch.randn(5, n, *hw)
+        h = torch.randn(5, *tr.parameter_shape)
+        y, ld = tr.forward(x, h)
+        xi, ldi = tr.inverse(x, h)
+        out.update({f"conv{n}_x": np32(x), f"conv{n}_h": np32(h), f"conv{n}_y": np32(y), f"conv{n}_ld": np32(ld),
+                    f"conv{n}_xinv": np32(xi), f"conv{n}_ldinv": np32(ldi)})
+    # single convolutional coupling layers, eval mode (BatchNorm running statistics)
+    from torchflows.bijections.finite.autoregressive.transformers.linear.affine import Affine as RefAffine
+    for tag, ctor, es in (("ckb", lambda: CheckerboardCoupling((3, 8, 8), RefAffine), (3, 8, 8)),
+                          ("ckb_alt", lambda: CheckerboardCoupling((3, 8, 8), RefAffine, alternate=True), (3, 8, 8)),
+                          ("chw", lambda: ChannelWiseCoupling((4, 4, 4), RefAffine), (4, 4, 4)),
+                          ("chw_alt", lambda: ChannelWiseCoupling((4, 4, 4), RefAffine, alternate=True), (4, 4, 4)),
+                          ("c1x1", lambda: Invertible1x1ConvolutionalCoupling((4, 4, 4)), (4, 4, 4))):
+        torch.manual_seed(3)
+        layer = ctor().eval()
+        x = torch.randn(6, *es)
+        with torch.no_grad():
+            z, ld = layer.forward(x)
+            xi, ldi = layer.inverse(x)
+        for k, v in layer.state_dict().items():
+            out[f"{tag}_sd/{k}"] = np32(v)
+        out.update({f"{tag}_x": np32(x), f"{tag}_z": np32(z), f"{tag}_ld": np32(ld),
+                    f"{tag}_xinv": np32(xi), f"{tag}_ldinv": np32(ldi)})
+    save("image_layers.npz", **out)
+
+    # a whole (small) Glow: two blocks on (3, 8, 8)
+    torch.manual_seed(0)
+    flow = Flow(AffineGlow((3, 8, 8), n_layers=2))
+    out = {"n_params": np.int64(sum(p.numel() for p in flow.parameters()))}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 3, 8, 8, generator=g)
+    z_in = torch.randn(8, 3, 8, 8, generator=g)
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(64, 3, 8, 8, generator=g))     # ActNorm init + BatchNorm statistics
+    flow.eval()
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(x)
+        lp = flow.log_prob(x)
+        xr, ldr = flow.bijection.inverse(z_in)
+    for k, v in flow.state_dict().items():
+        out[f"sd/{k}"] = np32(v)
+    out.update({"x": np32(x), "z_in": np32(z_in), "z": np32(z), "log_det": np32(ld), "log_prob": np32(lp),
+                "x_inv": np32(xr), "log_det_inv": np32(ldr)})
+    save("flow_glow_3x8x8.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows"]
+    which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows", "image"]
     for w in which:
         globals()[f"gen_{w}"]()

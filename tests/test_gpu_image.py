@@ -1,0 +1,134 @@
+"""Image / multiscale path on the HIP kernels: the 1x1
+convolution kernel against the oracle, masked couplings / squeeze / ActNorm on images and a
+whole Glow against the reference's golden outputs and against the package's own ATen path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def native():
+    assert torch.cuda.is_available()
+    from torchflows_amd import native as nat
+    nat.lib()
+    return nat
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+@pytest.mark.parametrize("N,C,n,HW", [(64, 12, 6, 256), (33, 4, 2, 16), (5, 24, 12, 64), (7, 3, 2, 9),
+                                      (9, 32, 16, 4), (1000, 2, 1, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_conv1x1_coupling_vs_oracle(native, oracle, N, C, n, HW, masked, inverse):
+    """rows = images (C, HW) channel-major; the target is n whole channels."""
+    rng = np.random.default_rng(N + C + n)
+    D, T = C * HW, n * HW
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    h = rng.standard_normal((N, n + n * (n - 1))).astype(np.float32)
+    if masked:          # the FIRST n channels are the target (channel-wise split, inverted)
+        tgt = np.arange(0, T, dtype=np.int32)
+    else:               # the last n channels (contiguous tail)
+        tgt = np.arange(D - T, D, dtype=np.int32)
+    yb, ld = oracle.conv1x1(x[:, tgt].reshape(N, n, HW), h, inverse=inverse)
+    expect = x.copy()
+    expect[:, tgt] = yb.reshape(N, T)
+    out = torch.full((N, D), float("nan"), device="cuda")
+    logdet = torch.full((N,), float("nan"), device="cuda")
+    tgt_d = dev(tgt, torch.int32) if masked else None
+    native.conv1x1_coupling(dev(x), dev(h), out, logdet, tgt_d, T, n, accumulate=False, inverse=inverse)
+    tol = 1e-5 if not inverse else 1e-4       # the triangular solves amplify rounding by cond(LU)
+    assert rel(out.cpu().numpy(), expect) < tol
+    assert rel(logdet.cpu().numpy(), ld) < 1e-5
+    untouched = np.setdiff1d(np.arange(D), tgt)
+    assert np.array_equal(out.cpu().numpy()[:, untouched], x[:, untouched])
+    run = rng.standard_normal(N).astype(np.float32)
+    buf, logdet2 = dev(x), dev(run)
+    native.conv1x1_coupling(buf, dev(h), buf, logdet2, tgt_d, T, n, accumulate=True, inverse=inverse)
+    assert torch.equal(buf, out)
+    assert rel(logdet2.cpu().numpy(), run + ld) < 1e-5
+    with pytest.raises(native.NativeError):
+        native.conv1x1_coupling(dev(x), torch.zeros(N, 17 * 17, device="cuda"), out, logdet, None, T, 17)
+
+
+def test_image_layers_golden_on_hip(native):
+    from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import Affine
+    from torchflows_amd.bijections.finite.multiscale import (
+        ChannelWiseCoupling, CheckerboardCoupling, Invertible1x1ConvolutionalCoupling)
+    fx = load_golden("image_layers.npz")
+    layers = {
+        "ckb": lambda: CheckerboardCoupling((3, 8, 8), Affine),
+        "ckb_alt": lambda: CheckerboardCoupling((3, 8, 8), Affine, alternate=True),
+        "chw": lambda: ChannelWiseCoupling((4, 4, 4), Affine),
+        "chw_alt": lambda: ChannelWiseCoupling((4, 4, 4), Affine, alternate=True),
+        "c1x1": lambda: Invertible1x1ConvolutionalCoupling((4, 4, 4)),
+    }
+    for tag, make in layers.items():
+        layer = make().eval()
+        pre = f"{tag}_sd/"
+        layer.load_state_dict({k[len(pre):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(pre)})
+        layer = layer.cuda()
+        x = torch.from_numpy(fx[f"{tag}_x"]).cuda()
+        before = native.calls
+        with torch.no_grad():
+            z, ld = layer.forward(x)
+            xi, ldi = layer.inverse(x)
+        assert native.calls - before == 2, tag            # one libtfk kernel per call
+        assert rel(z.cpu().numpy(), fx[f"{tag}_z"]) < 1e-5, tag
+        assert rel(ld.cpu().numpy(), fx[f"{tag}_ld"]) < 1e-5, tag
+        assert rel(xi.cpu().numpy(), fx[f"{tag}_xinv"]) < 1e-4, tag
+        assert rel(ldi.cpu().numpy(), fx[f"{tag}_ldinv"]) < 1e-5, tag
+
+
+def test_affine_glow_golden_on_hip(native):
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    fx = load_golden("flow_glow_3x8x8.npz")
+    flow = tfa.Flow(AffineGlow((3, 8, 8), n_layers=2))
+    flow.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")})
+    flow = flow.cuda().eval()
+    before = native.calls
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(torch.from_numpy(fx["x"]).cuda())
+        lp = flow.log_prob(torch.from_numpy(fx["x"]).cuda())
+        xr, ldr = flow.bijection.inverse(torch.from_numpy(fx["z_in"]).cuda())
+    assert native.calls - before > 30
+    assert rel(z.cpu().numpy(), fx["z"]) < 2e-5 and rel(ld.cpu().numpy(), fx["log_det"]) < 2e-5
+    assert rel(lp.cpu().numpy(), fx["log_prob"]) < 1e-5
+    assert rel(xr.cpu().numpy(), fx["x_inv"]) < 1e-4 and rel(ldr.cpu().numpy(), fx["log_det_inv"]) < 2e-5
+
+
+@pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])
+def test_glow_hip_vs_host_config5(native, event_shape, n):
+    """Config 5 model (AffineGlow on 32x32x3, 3.2 M parameters), HIP path vs this package's
+    ATen path on the host, plus the reference's round-trip property."""
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    torch.manual_seed(0)
+    flow = tfa.Flow(AffineGlow(event_shape))
+    x = torch.randn(n, *event_shape)
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(64, *event_shape))       # ActNorm init, BatchNorm statistics
+    flow.eval()
+    with torch.no_grad():
+        lp_h = flow.log_prob(x)
+        flow = flow.cuda()
+        lp_d = flow.log_prob(x.cuda())
+        z, ld = flow.bijection.forward(x.cuda())
+        xr, ldr = flow.bijection.inverse(z)
+    assert lp_d.shape == (n,)
+    assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 2e-5      # MIOpen vs host convolutions inside
+    assert torch.allclose(xr.cpu(), x, atol=1e-3) and torch.allclose(ld, -ldr, atol=1e-3)

@@ -1,0 +1,145 @@
+"""Image / multiscale path on the ATen composite path
+against the reference's golden outputs, plus the reference's own property tests
+(test/test_convolutional_architectures.py, test_squeeze_bijection.py,
+test_channel_wise_coupling.py, test_invertible_convolution.py, test_lu_matrix_transformer.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+import torchflows_amd as tfa
+from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import Affine
+from torchflows_amd.bijections.finite.autoregressive.transformers.linear.convolution import (
+    Invertible1x1ConvolutionTransformer)
+from torchflows_amd.bijections.finite.autoregressive.transformers.linear.matrix import LUTransformer
+from torchflows_amd.bijections.finite.multiscale import (
+    AffineGlow, ChannelWiseCoupling, ChannelWiseHalfSplit, Checkerboard, CheckerboardCoupling,
+    Invertible1x1ConvolutionalCoupling, MultiscaleNICE, MultiscaleRealNVP, ShiftGlow, Squeeze)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def test_image_masks_bit_exact_with_reference():
+    fx = load_golden("image_masks.npz")
+    for tag in fx["shapes"]:
+        es = tuple(int(t) for t in str(tag).split("x"))
+        for inv in (0, 1):
+            c = Checkerboard(es, invert=bool(inv))
+            assert np.array_equal(c.source_mask.numpy().astype(np.uint8), fx[f"ckb{inv}_src_{tag}"])
+            assert tuple(fx[f"ckb{inv}_shapes_{tag}"]) == (*c.constant_shape, *c.target_shape)
+            if es[0] > 1:
+                w = ChannelWiseHalfSplit(es, invert=bool(inv))
+                assert np.array_equal(w.source_mask.numpy().astype(np.uint8), fx[f"chw{inv}_src_{tag}"])
+                assert tuple(fx[f"chw{inv}_shapes_{tag}"]) == (*w.constant_shape, *w.target_shape)
+                if not inv:
+                    assert w.target_is_tail and w.source_is_head      # the vectorised kernel layout
+        sq = Squeeze(es)
+        assert np.array_equal(sq._fwd_index.numpy(), fx[f"squeeze_fwd_{tag}"])
+    with pytest.raises(ValueError):
+        ChannelWiseHalfSplit((1, 4, 4))
+    with pytest.raises(ValueError):
+        Squeeze((3, 5, 4))
+
+
+def test_lu_and_conv1x1_transformers_golden():
+    fx = load_golden("image_layers.npz")
+    for n in (1, 2, 3, 6, 12):
+        tr = LUTransformer((n,))
+        x, h = torch.from_numpy(fx[f"lu{n}_x"]), torch.from_numpy(fx[f"lu{n}_h"])
+        y, ld = tr.forward(x, h)
+        xi, ldi = tr.inverse(x, h)
+        assert rel(y.numpy(), fx[f"lu{n}_y"]) < 1e-6 and rel(ld.numpy(), fx[f"lu{n}_ld"]) < 1e-6
+        assert rel(xi.numpy(), fx[f"lu{n}_xinv"]) < 1e-5 and rel(ldi.numpy(), fx[f"lu{n}_ldinv"]) < 1e-6
+    for n, hw in ((3, (4, 4)), (6, (8, 8))):
+        tr = Invertible1x1ConvolutionTransformer((n, *hw))
+        x, h = torch.from_numpy(fx[f"conv{n}_x"]), torch.from_numpy(fx[f"conv{n}_h"])
+        y, ld = tr.forward(x, h)
+        xi, ldi = tr.inverse(x, h)
+        assert rel(y.numpy(), fx[f"conv{n}_y"]) < 1e-6 and rel(ld.numpy(), fx[f"conv{n}_ld"]) < 1e-6
+        assert rel(xi.numpy(), fx[f"conv{n}_xinv"]) < 1e-5 and rel(ldi.numpy(), fx[f"conv{n}_ldinv"]) < 1e-6
+
+
+LAYERS = {
+    "ckb": lambda: CheckerboardCoupling((3, 8, 8), Affine),
+    "ckb_alt": lambda: CheckerboardCoupling((3, 8, 8), Affine, alternate=True),
+    "chw": lambda: ChannelWiseCoupling((4, 4, 4), Affine),
+    "chw_alt": lambda: ChannelWiseCoupling((4, 4, 4), Affine, alternate=True),
+    "c1x1": lambda: Invertible1x1ConvolutionalCoupling((4, 4, 4)),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(LAYERS))
+def test_convolutional_coupling_layers_golden(tag):
+    """Same state-dict keys as the reference, same outputs with the same weights."""
+    fx = load_golden("image_layers.npz")
+    layer = LAYERS[tag]().eval()
+    pre = f"{tag}_sd/"
+    ref_sd = {k[len(pre):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(pre)}
+    assert list(layer.state_dict().keys()) == list(ref_sd.keys())
+    layer.load_state_dict(ref_sd)
+    x = torch.from_numpy(fx[f"{tag}_x"])
+    with torch.no_grad():
+        z, ld = layer.forward(x)
+        xi, ldi = layer.inverse(x)
+    assert rel(z.numpy(), fx[f"{tag}_z"]) < 2e-6 and rel(ld.numpy(), fx[f"{tag}_ld"]) < 5e-6
+    assert rel(xi.numpy(), fx[f"{tag}_xinv"]) < 2e-5 and rel(ldi.numpy(), fx[f"{tag}_ldinv"]) < 5e-6
+
+
+def test_affine_glow_golden():
+    fx = load_golden("flow_glow_3x8x8.npz")
+    torch.manual_seed(0)
+    flow = tfa.Flow(AffineGlow((3, 8, 8), n_layers=2))
+    ref_sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")}
+    assert list(flow.state_dict().keys()) == list(ref_sd.keys())
+    assert sum(p.numel() for p in flow.parameters()) == int(fx["n_params"])
+    flow.load_state_dict(ref_sd)
+    flow.eval()
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(torch.from_numpy(fx["x"]))
+        lp = flow.log_prob(torch.from_numpy(fx["x"]))
+        xr, ldr = flow.bijection.inverse(torch.from_numpy(fx["z_in"]))
+    assert rel(z.numpy(), fx["z"]) < 1e-5 and rel(ld.numpy(), fx["log_det"]) < 1e-5
+    assert rel(lp.numpy(), fx["log_prob"]) < 1e-5
+    assert rel(xr.numpy(), fx["x_inv"]) < 1e-4 and rel(ldr.numpy(), fx["log_det_inv"]) < 1e-5
+
+
+@pytest.mark.parametrize("ctor", [AffineGlow, MultiscaleRealNVP, MultiscaleNICE, ShiftGlow])
+@pytest.mark.parametrize("event_shape", [(1, 28, 28), (3, 28, 28), (3, 8, 8)])
+def test_multiscale_architectures_reconstruct(ctor, event_shape):
+    """reference test/test_convolutional_architectures.py:34-41 (n_layers=2, atol 1e-3)."""
+    torch.manual_seed(0)
+    b = ctor(event_shape, n_layers=2)
+    x = torch.randn(3, *event_shape)
+    with torch.no_grad():
+        z, ld = b.forward(x)
+        b.eval()
+        z, ld = b.forward(x)
+        xr, ldi = b.inverse(z)
+    assert z.shape == x.shape and ld.shape == (3,)
+    assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+    assert torch.allclose(x, xr, atol=1e-3) and torch.allclose(ld, -ldi, atol=1e-3)
+
+
+def test_too_small_images_are_rejected():
+    """reference test/test_convolutional_architectures.py:92-95"""
+    with pytest.raises(ValueError):
+        AffineGlow((3, 4, 4), n_layers=3)
+    with pytest.raises(ValueError):
+        AffineGlow((3, 7, 7))
+    assert AffineGlow((3, 32, 32)).n_blocks == 3 and AffineGlow((3, 4, 4)).n_blocks == 2
+
+
+def test_squeeze_roundtrip_and_layout():
+    """reference test/test_squeeze_bijection.py:11-21"""
+    sq = Squeeze((3, 4, 6))
+    x = torch.randn(5, 2, 3, 4, 6)
+    z, ld = sq.forward(x)
+    assert z.shape == (5, 2, 12, 2, 3) and ld.shape == (5, 2) and torch.all(ld == 0)
+    assert torch.equal(z[..., 0:3, :, :], x[..., ::2, ::2]) and torch.equal(z[..., 9:12, :, :], x[..., 1::2, 1::2])
+    xr, _ = sq.inverse(z)
+    assert torch.equal(xr, x)

@@ -210,3 +210,35 @@ def test_flow_golden(oracle, name, arch, n_layers, C, spline, variant):
     for i, t in enumerate(fx["layer_types"]):
         if str(t) == "ReversePermutationMatrix":
             assert np.all(tl[i] == 0)
+
+
+# ------------------------------------------------------------------ image path (config 5)
+def test_image_masks_and_squeeze_bit_exact(oracle):
+    fx = load_golden("image_masks.npz")
+    for tag in fx["shapes"]:
+        es = tuple(int(t) for t in str(tag).split("x"))
+        for inv in (0, 1):
+            s, t = oracle.image_mask("checkerboard", es, bool(inv))
+            assert np.array_equal(s, fx[f"ckb{inv}_src_{tag}"].astype(bool)) and np.array_equal(t, ~s)
+            if es[0] > 1:
+                s, t = oracle.image_mask("channel_wise", es, bool(inv))
+                assert np.array_equal(s, fx[f"chw{inv}_src_{tag}"].astype(bool)) and np.array_equal(t, ~s)
+        assert np.array_equal(oracle.squeeze_index(es), fx[f"squeeze_fwd_{tag}"])
+
+
+def test_conv1x1_golden(oracle):
+    fx = load_golden("image_layers.npz")
+    for key in ("lu1", "lu2", "lu3", "lu6", "lu12", "conv3", "conv6"):
+        x, h = fx[f"{key}_x"], fx[f"{key}_h"]
+        y, ld = oracle.conv1x1(x, h)
+        xi, ldi = oracle.conv1x1(x, h, inverse=True)
+        assert rel(y, fx[f"{key}_y"]) < 2e-6 and rel(ld, fx[f"{key}_ld"]) < 2e-6
+        assert rel(xi, fx[f"{key}_xinv"]) < 2e-6 and rel(ldi, fx[f"{key}_ldinv"]) < 2e-6
+        # round trip (reference test/test_lu_matrix_transformer.py:7-30)
+        xr, ldr = oracle.conv1x1(y, h, inverse=True)
+        assert rel(xr, x) < 1e-4 and rel(ldr, -ld) < 1e-6
+    # the log-det does not scale with the number of pixels (reference quirk Q9)
+    x, h = fx["conv6_x"], fx["conv6_h"]
+    _, ld_img = oracle.conv1x1(x, h)
+    _, ld_vec = oracle.conv1x1(x[:, :, 0, 0], h)
+    assert np.array_equal(ld_img, ld_vec)

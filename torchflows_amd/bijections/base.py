@@ -154,6 +154,9 @@ class BijectiveComposition(Bijection):
             d = method_direction(getattr(layer, attr))
             if d is None or not hasattr(layer, "_native_step"):
                 return None
+            supported = getattr(layer, "_native_supported", None)
+            if supported is not None and not supported():
+                return None
             plan.append((layer, d))
         return plan
 

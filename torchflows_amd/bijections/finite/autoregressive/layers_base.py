@@ -97,11 +97,13 @@ class CouplingBijection(AutoregressiveBijection):
     # -- ATen composite path ---------------------------------------------------
     def get_constant_part(self, x: torch.Tensor) -> torch.Tensor:
         batch = get_batch_shape(x, self.event_shape)
-        return x.reshape(*batch, -1).index_select(-1, self._source_index)
+        part = x.reshape(*batch, -1).index_select(-1, self._source_index)
+        return part.view(*batch, *self.coupling.constant_shape)
 
     def get_transformed_part(self, x: torch.Tensor) -> torch.Tensor:
         batch = get_batch_shape(x, self.event_shape)
-        return x.reshape(*batch, -1).index_select(-1, self._target_index)
+        part = x.reshape(*batch, -1).index_select(-1, self._target_index)
+        return part.view(*batch, *self.coupling.target_shape)
 
     def partition_and_predict_parameters(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         batch = get_batch_shape(x, self.event_shape)
@@ -117,16 +119,27 @@ class CouplingBijection(AutoregressiveBijection):
         return out.view(x.shape), log_det
 
     # -- HIP path ------------------------------------------------------------------
+    def _native_supported(self) -> bool:
+        """Is there a libtfk kernel for this layer's transformer?"""
+        kind = self.transformer.native_kind
+        if kind == "conv1x1":
+            return self.transformer.n_channels <= 16     # channels are kept in registers
+        if kind == "rqs":
+            return 2 <= self.transformer.n_bins <= 32
+        return kind in ("affine", "inverse_affine", "shift")
+
     def _native_ok(self, x, context) -> bool:
-        return (self.transformer.native_kind in ("affine", "inverse_affine", "shift", "rqs")
-                and native.eligible(x, context) and _params_ok(self))
+        return self._native_supported() and native.eligible(x, context) and _params_ok(self)
 
     def _native_step(self, state: RowState, context, d: int) -> None:
         rows = state.rows
         N, D = rows.shape
         S, T = self.coupling.source_event_size, self.coupling.target_event_size
-        # conditioner input: a strided view for the HalfSplit mask, one gather otherwise
+        # conditioner input: a strided view for a leading-block source (HalfSplit, channel-wise
+        # split), one gather otherwise; reshaped to what the conditioner expects (an image for
+        # the convolutional couplings)
         x_a = rows[:, :S] if self._source_is_head else rows.index_select(1, self._source_index)
+        x_a = x_a.reshape(N, *self.coupling.constant_shape)
         ctx = None if context is None else context.reshape(N, *self.context_shape)
         h = self.conditioner_transform(x_a, context=ctx).reshape(N, -1).contiguous()
         out = rows if state.owned else state.out_buffer()
@@ -143,6 +156,9 @@ class CouplingBijection(AutoregressiveBijection):
         elif kind == "shift":
             native.shift_coupling(rows, h, out, state.logdet, tgt, T, accumulate=acc,
                                   inverse=(d == INVERSE))
+        elif kind == "conv1x1":
+            native.conv1x1_coupling(rows, h, out, state.logdet, tgt, T, self.transformer.n_channels,
+                                    accumulate=acc, inverse=(d == INVERSE))
         else:
             raise native.NativeError(f"no kernel for transformer kind {kind!r}")
         state.started = True
@@ -209,9 +225,11 @@ class ElementwiseBijection(AutoregressiveBijection):
         return self.conditioner_transform(x=None, context=context)
 
     # -- HIP path --------------------------------------------------------------------
+    def _native_supported(self) -> bool:
+        return self.transformer.native_kind in ("affine", "inverse_affine")
+
     def _native_ok(self, x, context) -> bool:
-        return (self.transformer.native_kind in ("affine", "inverse_affine")
-                and native.eligible(x, context) and _params_ok(self))
+        return self._native_supported() and native.eligible(x, context) and _params_ok(self)
 
     def _native_step(self, state: RowState, context, d: int) -> None:
         rows = state.rows

@@ -1,0 +1,90 @@
+"""Convolutional conditioner for image couplings (reference
+``multiscale/conditioning/classic.py``: ``ConvModifier`` :8-42, ``ConvNet`` :45-122,
+``ConvNetConditioner`` :125-145).
+
+``ConvModifier`` brings any image to ``(4, 32, 32)`` with one convolution, three
+``conv3x3 -> ReLU -> maxpool -> BatchNorm`` blocks follow, a second modifier maps to
+``(1, 10, 10)`` and a linear layer produces the parameters, squashed into (-2, 2) by a
+sigmoid.  All of it stays on PyTorch-ROCm (MIOpen convolutions); module and attribute names
+match the reference so state dicts carry over.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import (
+    TensorConditionerTransform)
+
+
+def _axis_plan(size: int, target: int):
+    """kernel extent and padding of the single convolution that maps ``size`` to ``target``."""
+    if size >= target:
+        return size - target + 1, 0
+    kernel = 1 if (target - size) % 2 == 0 else 2
+    return kernel, ((target - size) + kernel - 1) // 2
+
+
+class ConvModifier(nn.Module):
+    def __init__(self, image_shape, c_target: int = 4, h_target: int = 32, w_target: int = 32):
+        super().__init__()
+        c, h, w = image_shape
+        kh, ph = _axis_plan(h, h_target)
+        kw, pw = _axis_plan(w, w_target)
+        self.conv = nn.Conv2d(in_channels=c, out_channels=c_target, kernel_size=(kh, kw),
+                              padding=(ph, pw))
+        self.output_shape = (c_target, h_target, w_target)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class ConvNet(nn.Module):
+    class ConvNetBlock(nn.Module):
+        def __init__(self, in_channels, out_channels, input_height, input_width, use_pooling: bool = True):
+            super().__init__()
+            self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, padding=1)
+            self.bn = nn.BatchNorm2d(out_channels)
+            self.pool = nn.MaxPool2d(2) if use_pooling else nn.Identity()
+            shrink = 2 if use_pooling else 1
+            self.output_shape = (out_channels, input_height // shrink, input_width // shrink)
+
+        def forward(self, x):
+            return self.bn(self.pool(torch.relu(self.conv(x))))
+
+    def __init__(self, input_shape, n_outputs: int, kernels: Tuple[int, ...] = None):
+        super().__init__()
+        kernels = (8, 8, 4) if kernels is None else tuple(kernels)
+        assert len(kernels) >= 1
+        reducer = ConvModifier(input_shape)
+        stages = []
+        shape = reducer.output_shape
+        for width in kernels:
+            block = self.ConvNetBlock(shape[0], width, shape[1], shape[2],
+                                      use_pooling=min(shape[1], shape[2]) >= 2)
+            stages.append(block)
+            shape = block.output_shape
+        self.blocks = nn.ModuleList([reducer] + stages)
+        side = 10
+        self.blocks.append(ConvModifier(image_shape=shape, c_target=1, h_target=side, w_target=side))
+        self.linear = nn.Linear(in_features=side * side, out_features=n_outputs)
+
+    def forward(self, x):
+        lead = x.shape[:-3]
+        x = x.reshape(-1, *x.shape[-3:])            # conv2d wants exactly one batch axis
+        for block in self.blocks:
+            x = block(x)
+        return self.linear(x.reshape(*lead, -1))
+
+
+class ConvNetConditioner(TensorConditionerTransform):
+    def __init__(self, input_event_shape, parameter_shape, kernels: Tuple[int, ...] = None, **kwargs):
+        super().__init__(input_event_shape=input_event_shape, parameter_shape=parameter_shape,
+                         output_lower_bound=-2.0, output_upper_bound=2.0, **kwargs)
+        self.network = ConvNet(input_shape=input_event_shape, n_outputs=self.n_transformer_parameters,
+                               kernels=kernels)
+
+    def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        return self.network(x)

@@ -27,6 +27,7 @@ SYMBOLS = (
     "tfk_affine_coupling_fwd", "tfk_affine_coupling_inv",
     "tfk_shift_coupling_fwd", "tfk_shift_coupling_inv",
     "tfk_rqs_coupling_fwd", "tfk_rqs_coupling_inv",
+    "tfk_conv1x1_coupling_fwd", "tfk_conv1x1_coupling_inv",
     "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32",
@@ -65,6 +66,9 @@ def _bind(L: C.CDLL) -> None:
     rqs = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, C.c_float, _i32, _vp]
     L.tfk_rqs_coupling_fwd.argtypes = rqs
     L.tfk_rqs_coupling_inv.argtypes = rqs
+    conv = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]
+    L.tfk_conv1x1_coupling_fwd.argtypes = conv
+    L.tfk_conv1x1_coupling_inv.argtypes = conv
     ew = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
     L.tfk_elementwise_affine_fwd.argtypes = ew
     L.tfk_elementwise_affine_inv.argtypes = ew
@@ -199,6 +203,25 @@ def rqs_coupling(x, h, out, logdet, tgt_idx, T, n_bins, boundary, accumulate=Fal
     _coupling("tfk_rqs_coupling_inv" if inverse else "tfk_rqs_coupling_fwd",
               x, h, out, logdet, tgt_idx, T, 3 * n_bins - 1, accumulate,
               extra=(int(n_bins), C.c_float(float(boundary))))
+
+
+def conv1x1_coupling(x, h, out, logdet, tgt_idx, T, n_channels, accumulate=False, inverse=False):
+    """Invertible 1x1 convolution on the T target positions (n_channels x T/n_channels pixels,
+    channel-major); h: (N, n + n(n-1)) LU parameters per sample."""
+    global calls
+    name = "tfk_conv1x1_coupling_inv" if inverse else "tfk_conv1x1_coupling_fwd"
+    N, D = _rows(x, name)
+    n = int(n_channels)
+    if out.shape != x.shape or logdet.numel() != N or h.numel() != N * (n + n * (n - 1)):
+        raise NativeError(f"{name}: bad out / logdet / h shape")
+    if tgt_idx is not None and tgt_idx.numel() != T:
+        raise NativeError(f"{name}: tgt_idx has {tgt_idx.numel()} entries, expected T = {T}")
+    args = (_f32(x, name), _f32(h, name), _f32(out, name), _f32(logdet, name), N, D,
+            _idx(tgt_idx, name), T, n, 1 if accumulate else 0)
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), name)(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
 
 
 def elementwise_affine(x, value, out, logdet, inverse_affine, accumulate=False, inverse=False):
