@@ -41,6 +41,7 @@ WORKLOADS = {
     "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
     "nsf64": ("CouplingRQNSF", 64, 8, 1 << 20, 1 << 18),     # configs[2]
     "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
+    "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 13),  # configs[4] (3 blocks, 3.2 M params)
 }
 
 
@@ -57,6 +58,7 @@ class KernelTimer:
                             ("shift_coupling", self._coupling_bytes(1)),
                             ("rqs_coupling", self._rqs_bytes),
                             ("elementwise_affine", self._elementwise_bytes),
+                            ("conv1x1_coupling", self._conv1x1_bytes),
                             ("permute", lambda a, k: 8 * a[0].numel()),
                             ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0]),
                             ("flow_run", self._flow_bytes)):
@@ -92,6 +94,14 @@ class KernelTimer:
                     + (4 if logprob is not None else 0))
 
     @staticmethod
+    def _conv1x1_bytes(a, k):
+        x, h, out = a[0], a[1], a[2]
+        N, D = x.shape
+        T = a[5]
+        inplace = out.data_ptr() == x.data_ptr()
+        return N * ((8 * T if inplace else 8 * D) + 4 * (h.numel() // N) + 8)
+
+    @staticmethod
     def _elementwise_bytes(a, k):
         x = a[0]
         N, D = x.shape
@@ -109,7 +119,7 @@ class KernelTimer:
             r = inner(*a, **k)
             e.record()
             variant = name
-            if name.endswith("coupling"):
+            if name.endswith("coupling") and name != "conv1x1_coupling":
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
             flops = self._flow_flops(a) if name == "flow_run" else 0
             self.records.append((variant, byte_fn(a, k), s, e, flops))
@@ -150,12 +160,14 @@ class KernelTimer:
 def make_flow(arch, D, n_layers):
     """seed 0, data-initialised ActNorm (one train-mode forward on 4096 host rows), eval."""
     import torchflows_amd as tfa
-    ctor = {"RealNVP": tfa.RealNVP, "CouplingRQNSF": tfa.CouplingRQNSF}[arch]
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    ctor = {"RealNVP": tfa.RealNVP, "CouplingRQNSF": tfa.CouplingRQNSF, "AffineGlow": AffineGlow}[arch]
     torch.manual_seed(0)
     flow = tfa.Flow(ctor(D, n_layers=n_layers))
+    shape = D if isinstance(D, tuple) else (D,)
     flow.train()
     with torch.no_grad():
-        flow.log_prob(torch.randn(4096, D))
+        flow.log_prob(torch.randn(512 if isinstance(D, tuple) else 4096, *shape))
     return flow.eval()
 
 
@@ -233,10 +245,10 @@ def main():
     flow_host = make_flow(arch, D, n_layers)
     flow = make_flow(arch, D, n_layers).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(rows, D, device=dev, generator=gen)
+    x = torch.randn(rows, *(D if isinstance(D, tuple) else (D,)), device=dev, generator=gen)
     # the layer-by-layer path materialises h (2.9 KB per row per RQS layer): evaluate in chunks;
     # the fused programs never hold h, so they take the whole batch at once
-    step_rows = (chunk or rows) if args.no_fused else rows
+    step_rows = (chunk or rows) if (args.no_fused or isinstance(D, tuple)) else rows
 
     def step():
         lp, total = sharded_log_likelihood(flow, x, chunk_rows=step_rows)
@@ -311,7 +323,7 @@ def main():
                             "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
             "libtfk_ms_per_step": sum(v["ms"] for v in kernels.values()) / args.steps,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not isinstance(D, tuple):
             base, ref = cpu_baseline(arch, D, n_layers, flow_host)
             result["cpu_baseline"] = base
             idx = torch.arange(0, rows, max(rows // 2048, 1), device=dev)[:2048]

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Profiling recipe run on the GPU box (see profiles/README.md). Usage: bash tools/profile.sh <tag> [bench args]
+# Profiling recipe run on the GPU box (see profiles/README.md).
+# Usage: bash tools/profile.sh <tag> [bench.py args]   -> gpurun_out/prof_<tag>/
 set -e
 TAG=${1:-r01}; shift || true
 cd "$GRAFT_REPO_ROOT"
@@ -8,7 +9,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # 1) kernel trace + stats (per-kernel durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
-# 2) HBM read bytes (FETCH_SIZE needs 3 TCC slots) and 3) write bytes, separate passes
+# 2) HBM read bytes (FETCH_SIZE needs 3 TCC slots), 3) write bytes, 4) VALU / LDS activity: separate passes
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_write.json 2> $OUT/write.err
-find $OUT -name "*.csv" | head -30
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_sq.json 2> $OUT/sq.err
+python tools/summarize_profile.py $OUT
