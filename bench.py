@@ -323,6 +323,40 @@ def main():
                             "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
             "libtfk_ms_per_step": sum(v["ms"] for v in kernels.values()) / args.steps,
         }
+        if world == 1 and dom_name == "flow_run":
+            # the same workload layer by layer (one libtfk kernel per reference layer, conditioner
+            # GEMMs on PyTorch-ROCm): its transform kernels are the HBM-bound ones, so their
+            # roofline is reported next to the fused program's
+            os.environ["TORCHFLOWS_AMD_FUSED"] = "0"
+            flow.bijection.__dict__.pop("_tfk_compiled", None)
+            timer.records = []
+            lw_rows = chunk or rows
+            with torch.no_grad():
+                sharded_log_likelihood(flow, x, chunk_rows=lw_rows)
+                torch.cuda.synchronize()
+                timer.active = True
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    sharded_log_likelihood(flow, x, chunk_rows=lw_rows)
+                torch.cuda.synchronize()
+                lw_elapsed = time.perf_counter() - t1
+                timer.active = False
+            os.environ["TORCHFLOWS_AMD_FUSED"] = "1"
+            lw = timer.summary()
+            lw_name = max(lw, key=lambda k: lw[k]["ms"])
+            tr = None
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(lw_name)
+                if rows != WORKLOADS[args.workload][3]:
+                    tr = None
+            except (OSError, KeyError, ValueError):
+                pass
+            result["roofline_layerwise"] = {
+                "bound": "hbm", "achieved": lw[lw_name]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": lw[lw_name]["GBps"] / HBM_PEAK_GBS, "traffic": tr, "kernel": lw_name,
+                "bytes_per_launch": lw[lw_name]["bytes_per_launch"], "avg_us": lw[lw_name]["avg_us"],
+                "launches": lw[lw_name]["launches"], "evals_per_s": rows * 3 / lw_elapsed,
+                "note": "same workload with TORCHFLOWS_AMD_FUSED=0 (bench.py --no-fused), 3 steps"}
         if world == 1 and not args.no_cpu_baseline and not isinstance(D, tuple):
             base, ref = cpu_baseline(arch, D, n_layers, flow_host)
             result["cpu_baseline"] = base

@@ -160,8 +160,11 @@ int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *
  *   c = log(expm1(1 - 1e-5)), rational_quadratic.py:20,36-38);
  * params (device, 16-byte aligned, n_params % 4 == 0) holds, at param_offset (floats,
  * multiple of 4), in PHYSICAL element order (plane A = positions [0, D/2), B = the rest):
- *   TFK_OP_EW_MULADD / TFK_OP_EW_SUBDIV : alpha[D] | beta[D] | logdet_const | pad[3]
- *        z = alpha*x + beta   /   z = (x - beta)/alpha;   logdet += logdet_const
+ *   TFK_OP_EW_MULADD : alpha[D] | beta[D] | logdet_const | pad[3]
+ *        z = alpha*x + beta;   logdet += logdet_const
+ *   TFK_OP_EW_SUBDIV : alpha[D] | beta[D] | logdet_const | pad[3] | 1/alpha[D]
+ *        z = (x - beta)/alpha (evaluated with the packed reciprocal + one residual
+ *        correction: the IEEE quotient except on near-ties);   logdet += logdet_const
  *   coupling (affine P=2 / shift P=1)   : W1t[H][D/2] | b1[H padded to 4] | W2t[H][D/2*P] | b2[D/2*P]
  *        src_plane = which plane feeds the conditioner (the other one is transformed);
  *        W1t[k][m] multiplies physical source element m; W2t[k][m*P + p], b2[m*P + p]

@@ -25,11 +25,6 @@ constexpr float kRqsMinDelta = 1e-5f;
 // gaussian.py:26,53: 0.5 * log(2 * pi)
 constexpr float kHalfLog2Pi = 0.9189385332046727f;
 
-// constrain_scale, affine.py:33-34: exp(c0 + u / 2) + m   (u / 2 == u * 0.5 exactly)
-__device__ __forceinline__ float aff_alpha(float u) {
-    return expf(u * 0.5f + kAffC0) + kAffMinScale;
-}
-
 // ---- lean math: same values as the ocml routines on the ranges used here ----------------
 // (measured on gfx950: ocml expf = 12 VALU ops, logf = 11, log1pf = 121 (!), IEEE '/' = 9)
 
@@ -62,6 +57,13 @@ __device__ __forceinline__ float exp_noovf(float x) {
     const float e = fmaf(L2E_LO, x, fmaf(x, L2E_HI, -t));
     const float f = (t - n) + e;
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// constrain_scale, affine.py:33-34: exp(c0 + u / 2) + m   (u / 2 == u * 0.5 exactly).
+// exp_noovf == expf bit for bit wherever expf is finite, and overflows / underflows to the same
+// inf / 0 through ldexp.
+__device__ __forceinline__ float aff_alpha(float u) {
+    return exp_noovf(u * 0.5f + kAffC0) + kAffMinScale;
 }
 
 // log1p(y) for y >= 0: log(u) + (y - (u - 1)) / u with u = fl(1 + y) -- the second term gives

@@ -86,6 +86,10 @@ __device__ __forceinline__ float tanh_act(float x) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
+// 4-element dot product, scalar FMAs on purpose: on gfx950 packed fp32 ops (v_pk_mul_f32 /
+// v_pk_fma_f32) issue slower than the two scalar ops they replace -- measured here: the
+// packed form of this function made the whole RealNVP program 29 % slower, and building with
+// -fno-slp-vectorize (no compiler-made v_pk_*) gained another 7-10 % on every kernel.
 __device__ __forceinline__ float dot4(const float4 w, const float4 s) {
     return fmaf(w.w, s.w, fmaf(w.z, s.z, fmaf(w.y, s.y, w.x * s.x)));
 }
@@ -104,6 +108,17 @@ __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int 
         const float4 be_a = *reinterpret_cast<const float4 *>(prm + D + 4 * j);
         const float4 be_b = *reinterpret_cast<const float4 *>(prm + D + HALF + 4 * j);
         const float ldc = prm[2 * D];
+        // (x - beta) / alpha with the correctly rounded reciprocal r = 1/alpha packed by the host:
+        // q = n*r; q += r*(n - alpha*q) -- the IEEE quotient except on near-ties (see div_fast)
+        float4 ra_a = al_a, ra_b = al_b;
+        if (op.kind == TFK_OP_EW_SUBDIV) {
+            ra_a = *reinterpret_cast<const float4 *>(prm + 2 * D + 4 + 4 * j);
+            ra_b = *reinterpret_cast<const float4 *>(prm + 2 * D + 4 + HALF + 4 * j);
+        }
+        auto quot = [](float n, float d, float r) {
+            const float q = n * r;
+            return fmaf(fmaf(-d, q, n), r, q);
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (op.kind == TFK_OP_EW_MULADD) {                  // affine.py:48
@@ -112,10 +127,10 @@ __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int 
                 b[r].x = al_b.x * b[r].x + be_b.x; b[r].y = al_b.y * b[r].y + be_b.y;
                 b[r].z = al_b.z * b[r].z + be_b.z; b[r].w = al_b.w * b[r].w + be_b.w;
             } else {                                            // affine.py:59
-                a[r].x = div_fast(a[r].x - be_a.x, al_a.x); a[r].y = div_fast(a[r].y - be_a.y, al_a.y);
-                a[r].z = div_fast(a[r].z - be_a.z, al_a.z); a[r].w = div_fast(a[r].w - be_a.w, al_a.w);
-                b[r].x = div_fast(b[r].x - be_b.x, al_b.x); b[r].y = div_fast(b[r].y - be_b.y, al_b.y);
-                b[r].z = div_fast(b[r].z - be_b.z, al_b.z); b[r].w = div_fast(b[r].w - be_b.w, al_b.w);
+                a[r].x = quot(a[r].x - be_a.x, al_a.x, ra_a.x); a[r].y = quot(a[r].y - be_a.y, al_a.y, ra_a.y);
+                a[r].z = quot(a[r].z - be_a.z, al_a.z, ra_a.z); a[r].w = quot(a[r].w - be_a.w, al_a.w, ra_a.w);
+                b[r].x = quot(b[r].x - be_b.x, al_b.x, ra_b.x); b[r].y = quot(b[r].y - be_b.y, al_b.y, ra_b.y);
+                b[r].z = quot(b[r].z - be_b.z, al_b.z, ra_b.z); b[r].w = quot(b[r].w - be_b.w, al_b.w, ra_b.w);
             }
             ld[r] = ld[r] + ldc;                                // base.py:222
         }
@@ -454,8 +469,10 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
         memcpy(&o.scale, rec + 6, 4);
         memcpy(&o.c, rec + 7, 4);
         int64_t need;
-        if (o.kind == TFK_OP_EW_MULADD || o.kind == TFK_OP_EW_SUBDIV) {
+        if (o.kind == TFK_OP_EW_MULADD) {
             need = 2 * (int64_t)D + 4;
+        } else if (o.kind == TFK_OP_EW_SUBDIV) {
+            need = 3 * (int64_t)D + 4;
         } else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
             const int P = (o.kind <= TFK_OP_AFFINE_INV) ? 2 : 1;
             if (o.H < 1 || o.H > 4096) return fail(TFK_EINVAL, "%s: op %d: hidden width %d", fn, i, o.H);

@@ -87,9 +87,10 @@ def _flatten(layers, attr: str):
 
 
 def _params_version(module: nn.Module) -> int:
+    """Changes whenever a parameter / buffer is modified in place or replaced by another tensor."""
     v = 0
     for t in list(module.parameters()) + list(module.buffers()):
-        v += t._version
+        v = (v * 1000003 + t._version + (t.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
     return v
 
 
@@ -110,8 +111,10 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
     beta_p = torch.empty_like(beta)
     alpha_p[pos] = alpha
     beta_p[pos] = beta
-    block = torch.cat([alpha_p, beta_p, ld.reshape(1), ld.new_zeros(3)])
-    return (OP_EW_SUBDIV if subdiv else OP_EW_MULADD, 0, 0), block
+    parts = [alpha_p, beta_p, ld.reshape(1), ld.new_zeros(3)]
+    if subdiv:
+        parts.append(1.0 / alpha_p)           # correctly rounded reciprocal for the in-kernel quotient
+    return (OP_EW_SUBDIV if subdiv else OP_EW_MULADD, 0, 0), torch.cat(parts)
 
 
 def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
