@@ -46,6 +46,8 @@ WORKLOADS = {
 
 
 class KernelTimer:
+    true_hidden = {}     # D -> conditioner hidden width, filled in by main() for the FLOP count
+
     """Wraps the libtfk entry points of torchflows_amd.native: records a HIP event pair on the
     current (= launch) stream around every call while ``active`` and keeps the algorithmic
     byte count of the launch (SURVEY.md 8(d) per-row figures x rows)."""
@@ -61,7 +63,7 @@ class KernelTimer:
                             ("conv1x1_coupling", self._conv1x1_bytes),
                             ("permute", lambda a, k: 8 * a[0].numel()),
                             ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0]),
-                            ("flow_run", self._flow_bytes)):
+                            ("flow_run", self._flow_bytes), ("flow_run_mfma", self._flow_bytes)):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -121,21 +123,25 @@ class KernelTimer:
             variant = name
             if name.endswith("coupling") and name != "conv1x1_coupling":
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
-            flops = self._flow_flops(a) if name == "flow_run" else 0
+            flops = self._flow_flops(a, name == "flow_run_mfma") if name.startswith("flow_run") else 0
             self.records.append((variant, byte_fn(a, k), s, e, flops))
             return r
         setattr(self.native, name, timed)
 
     @staticmethod
-    def _flow_flops(a):
+    def _flow_flops(a, mfma=False):
         """Algorithmic conditioner FLOPs of one flow_run launch: 2*(S*H + H*T*P) per row and
-        coupling op; the transform's own transcendentals are not counted."""
+        coupling op; the transform's own transcendentals are not counted.
+        (The matrix-core ops record ceil(H/4) instead of H; H is recovered as 4*steps rounded
+        down to the true width by the caller-provided table below.)"""
         x, ops = a[0], a[6]
         N, D = x.shape
         half = D // 2
         per_row = 0
         for op in ops:
             kind, H = op[0], op[2]
+            if mfma and kind in (2, 3, 4, 5):
+                H = KernelTimer.true_hidden.get(D, 4 * H)
             P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23}.get(kind)
             if P is not None:
                 per_row += 2 * (half * H + H * half * P)
@@ -243,6 +249,10 @@ def main():
     arch, D, n_layers, rows, chunk = WORKLOADS[args.workload]
     rows = args.rows or rows
     flow_host = make_flow(arch, D, n_layers)
+    for layer in flow_host.bijection.modules():
+        seq = getattr(getattr(layer, "conditioner_transform", None), "sequential", None)
+        if seq is not None and not isinstance(D, tuple):
+            KernelTimer.true_hidden[D] = seq[0].out_features
     flow = make_flow(arch, D, n_layers).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(rows, *(D if isinstance(D, tuple) else (D,)), device=dev, generator=gen)
@@ -285,14 +295,16 @@ def main():
                 traffic = None
         except (OSError, KeyError, ValueError):
             pass
-        if dom_name == "flow_run":
+        if dom_name.startswith("flow_run"):
             # conditioner fused in-kernel: h never reaches HBM, the kernel is fp32-VALU-bound
             # (report against the fp32 vector peak, and say so)
             roofline = {"bound": "valu", "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
-                        "note": "fused flow program (conditioner in-kernel): fp32 vector-ALU bound; "
-                                "achieved = algorithmic conditioner FLOPs 2*(S*H+H*T*P) per row-layer / "
-                                "launch time, transcendentals of the transform not counted",
+                        "note": "fused flow program (conditioner in-kernel" +
+                                (", GEMMs as v_mfma_f32_16x16x4_f32" if dom_name == "flow_run_mfma" else "") +
+                                "): fp32 vector-ALU bound; achieved = algorithmic conditioner FLOPs "
+                                "2*(S*H+H*T*P) per row-layer / launch time, transcendentals of the "
+                                "transform not counted; peak = fp32 vector = fp32-input MFMA peak",
                         "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
         else:
             roofline = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -323,7 +335,7 @@ def main():
                             "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
             "libtfk_ms_per_step": sum(v["ms"] for v in kernels.values()) / args.steps,
         }
-        if world == 1 and dom_name == "flow_run":
+        if world == 1 and dom_name.startswith("flow_run"):
             # the same workload layer by layer (one libtfk kernel per reference layer, conditioner
             # GEMMs on PyTorch-ROCm): its transform kernels are the HBM-bound ones, so their
             # roofline is reported next to the fused program's

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 3
+#define TFK_ABI_VERSION 4
 
 enum {
     TFK_OK = 0,
@@ -191,6 +191,22 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
                  const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                  const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
                  int32_t accumulate, void *stream);
+
+/* ---- fused flow program, conditioner GEMMs on the matrix cores --------------------
+ * Same semantics and outputs as tfk_flow_run for chains of elementwise ops and affine / shift
+ * couplings, with the two conditioner GEMMs issued as v_mfma_f32_16x16x4_f32 (fp32 in / fp32
+ * accumulate: numerically an fmaf chain).  D must be 64 or 128, hidden width <= 16.
+ * ops (HOST pointer): n_ops x int32[4] = {kind, src_plane, gemm2_steps = ceil(H/4), param_offset}.
+ * Elementwise ops use the parameter layout of tfk_flow_run; a coupling op holds
+ *   A1[D/8][64] | b1[4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],  T2 = D/16 (affine), D/32 (shift)
+ * i.e. the MFMA A-operands per lane, with the row / column permutations that make the
+ * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
+ * packed by torchflows_amd/fused.py:_pack_mfma). */
+int tfk_flow_mfma_supported(int32_t D);
+int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
+                      const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                      const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                      int32_t accumulate, void *stream);
 
 #ifdef __cplusplus
 }

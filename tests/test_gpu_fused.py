@@ -46,8 +46,9 @@ def run_both(flow, x, monkeypatch):
     """(fused results, layer-by-layer results) of log_prob, forward, inverse on the device."""
     from torchflows_amd import native
     out = []
-    for fused_on in ("1", "0"):
+    for fused_on, mfma_on in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", fused_on)
+        monkeypatch.setenv("TORCHFLOWS_AMD_MFMA", mfma_on)
         flow.bijection.__dict__.pop("_tfk_compiled", None)
         before = native.calls
         with torch.no_grad():
@@ -57,6 +58,7 @@ def run_both(flow, x, monkeypatch):
             xr, ldi = flow.bijection.inverse(x)
         out.append(dict(z=z, lp=lp, lp_only=lp_only, z2=z2, ld=ld, xr=xr, ldi=ldi,
                         launches=native.calls - before))
+    monkeypatch.setenv("TORCHFLOWS_AMD_MFMA", "1")
     return out
 
 
@@ -73,7 +75,8 @@ def test_fused_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, arch, D, n_layer
     N = 1000 + D
     x = torch.randn(N, D)
     x[:50] *= 3
-    fused, layer = run_both(flow, x.cuda(), monkeypatch)
+    fused, fused_valu, layer = run_both(flow, x.cuda(), monkeypatch)
+    # D = 64 / 128 take the matrix-core kernel first, the others the vector-ALU one in both runs
     # the fused path really is a handful of launches, the other one is 3L+3 kernels + GEMMs
     assert fused["launches"] < layer["launches"]
     if D <= 64 and n_layers % 2 == 0:   # whole program in one LDS block, no final reordering
@@ -81,7 +84,7 @@ def test_fused_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, arch, D, n_layer
     z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
     _, ld_ref = ref.forward(x.numpy())
     xr_ref, ldi_ref = ref.inverse(x.numpy())
-    for name, got in (("fused", fused), ("layerwise", layer)):
+    for name, got in (("fused", fused), ("fused-valu", fused_valu), ("layerwise", layer)):
         e = dict(lp=rel(got["lp"].cpu().numpy(), lp_ref), lp_only=rel(got["lp_only"].cpu().numpy(), lp_ref),
                  z=normwise(got["z"].cpu().numpy(), z_ref), z2=normwise(got["z2"].cpu().numpy(), z_ref),
                  ld=rel(got["ld"].cpu().numpy(), ld_ref), xr=normwise(got["xr"].cpu().numpy(), xr_ref),
@@ -106,7 +109,7 @@ def test_fused_spline_flow_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, D, n
     N = 700 + D
     x = torch.randn(N, D)
     x[:40] *= 30                                   # some rows leave the spline box
-    got_fused, got_layer = run_both(flow, x.cuda(), monkeypatch)
+    got_fused, _, got_layer = run_both(flow, x.cuda(), monkeypatch)
     monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
     flow.bijection.__dict__.pop("_tfk_compiled", None)
     if D <= 128:
@@ -172,6 +175,7 @@ def test_segmented_program_matches_single_launch(pkg, monkeypatch):
     """A program split over several launches (small LDS budget) gives the same result."""
     from torchflows_amd import fused
     monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    monkeypatch.setenv("TORCHFLOWS_AMD_MFMA", "0")     # vector-ALU programs: bitwise invariant
     torch.manual_seed(0)
     flow = data_init(pkg.Flow(pkg.RealNVP(64, n_layers=5)), 64).cuda()
     x = torch.randn(777, 64, device="cuda")
@@ -189,6 +193,24 @@ def test_segmented_program_matches_single_launch(pkg, monkeypatch):
     for r in res[1:]:
         for a, b in zip(r[1:], res[0][1:]):
             assert torch.equal(a, b)          # same arithmetic, only the launch boundaries move
+    # matrix-core programs keep per-lane log-det partial sums that are combined at the end of a
+    # launch, so moving the launch boundaries changes the association of the fp32 sum: close,
+    # not bitwise
+    monkeypatch.setenv("TORCHFLOWS_AMD_MFMA", "1")
+    res_m = []
+    for budget in (52 * 1024, 12 * 1024):
+        monkeypatch.setattr(fused, "MAX_PARAM_BYTES_MFMA", budget)
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        chain = fused.get_compiled(flow.bijection, 0, x.device)
+        assert all(seg.mfma for seg in chain.segments)
+        with torch.no_grad():
+            z, lp = flow.forward_with_log_prob(x)
+            xr, ldi = flow.bijection.inverse(x)
+        res_m.append((len(chain.segments), z, lp, xr, ldi))
+    assert res_m[0][0] == 1 and res_m[1][0] > 1
+    for a, b, ref in zip(res_m[1][1:], res_m[0][1:], (res[0][1], res[0][2], res[0][4], res[0][5])):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-6)
+        assert torch.allclose(a, ref, rtol=1e-5, atol=1e-5)
 
 
 def test_odd_layer_count_keeps_logical_order(pkg, oracle, monkeypatch):

@@ -1,0 +1,312 @@
+// tfk_flow_mfma.hip -- fused flow programs with the conditioner GEMMs on the matrix cores.
+//
+// Same contract as tfk_flow.hip (rows in registers, a list of ops applied to them, one launch
+// for a whole chain of ElementwiseAffine / ActNorm / folded reversals / affine or shift
+// couplings with their FeedForward(tanh) conditioner), but the two conditioner GEMMs run as
+// v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bit-for-bit an fmaf chain, so the
+// numerics are those of the VALU version).
+//
+// The register layout is chosen so that NOTHING has to move between the steps of a layer
+// (D = 8*EPL, EPL = elements per lane per plane = 8 or 16):
+//   * a wavefront owns 16 rows; lane l = (q = l >> 4, j = l & 15) holds, of row j, the
+//     elements [EPL*q, EPL*(q+1)) of plane A (first half of the row) and of plane B
+//     -- 32..64 contiguous bytes per plane: coalesced 16-byte loads;
+//   * that is exactly the B-operand layout of the MFMA (lane supplies B[k = l>>4][j = l&15]):
+//     step s of GEMM 1 feeds element EPL*q + s of the source plane as k = 4 s + q, with the
+//     columns of W1 permuted to match when the weights are packed;
+//   * the D-output layout (lane (q, j), register r <-> row 4q + r, column j) leaves lane
+//     (q, j) with 4 hidden pre-activations of ITS row; packing W1's rows as "D-row 4q+r <->
+//     hidden unit 4r+q" makes register r the B-operand of GEMM 2's step r without a move;
+//   * GEMM 2 is tiled so that D-row 4q+r of tile t is parameter (r & 1) of target element
+//     EPL*q + 2t + (r >> 1) (affine) / EPL*q + 4t + r (shift): every lane receives the
+//     parameters of exactly the target elements it holds.
+// Each hidden activation is computed once (4 tanh per lane instead of one per lane per unit),
+// there is no cross-lane reduction inside a layer (per-lane log-det partial sums are combined
+// once at the end with two ds_bpermute steps), and the matrix pipe runs beside the vector
+// pipe that evaluates exp / log of the transform.
+#include <cstring>
+
+#include "tfk_common.h"
+
+namespace tfk {
+
+constexpr int kMaxOpsM = 96;
+
+struct MOp {
+    int kind;        // TFK_OP_*
+    int src_plane;   // coupling: which plane feeds the conditioner
+    int steps2;      // coupling: k-steps of GEMM 2 = ceil(H / 4)
+    int offset;      // first float of the op's parameters in the staged block
+};
+
+struct MProgram {
+    int n_ops;
+    int pad[3];
+    MOp op[kMaxOpsM];
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float tanh_act_m(float x) {       // see tanh_act in tfk_flow.hip
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+// Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
+//   A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4]
+// Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
+template <int EPL>
+__device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int lane, int q,
+                                           float (&a)[EPL], float (&b)[EPL], float &ld)
+{
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
+        const float *al = prm, *be = prm + D, *ra = prm + 2 * D + 4;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int ia = EPL * q + e, ib = HALF + EPL * q + e;
+            if (op.kind == TFK_OP_EW_MULADD) {                      // affine.py:48
+                a[e] = al[ia] * a[e] + be[ia];
+                b[e] = al[ib] * b[e] + be[ib];
+            } else {                                                // affine.py:59
+                const float na = a[e] - be[ia], nb = b[e] - be[ib];
+                const float qa = na * ra[ia], qb = nb * ra[ib];
+                a[e] = fmaf(fmaf(-al[ia], qa, na), ra[ia], qa);
+                b[e] = fmaf(fmaf(-al[ib], qb, nb), ra[ib], qb);
+            }
+        }
+        if (q == 0) ld = ld + prm[2 * D];                           // base.py:222 (once per row)
+        return;
+    }
+    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
+    const int T2 = affine ? EPL / 2 : EPL / 4;
+    const float *A1 = prm;
+    const float *b1 = prm + EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + T2 * op.steps2 * 64;
+
+    // GEMM 1: hidden pre-activations of the 16 rows of this wave
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);      // bias of units 4r + q
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const float src = op.src_plane ? b[s] : a[s];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src, acc, 0, 0, 0);
+    }
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);        // transforms.py:293-304
+
+    // GEMM 2 + transform, two (affine) or four (shift) target elements per tile
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < EPL / 2; ++t) {
+        if (!affine && t >= EPL / 4) break;
+        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+        for (int r = 0; r < op.steps2; ++r) {
+            const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
+        }
+        if (affine) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
+                const float be = o[2 * i + 1];
+                part += logf(al);                                   // affine.py:42
+                float v = op.src_plane ? a[e] : b[e];
+                if (op.kind == TFK_OP_AFFINE_FWD) v = al * v + be;  // affine.py:48
+                else v = div_fast(v - be, al);                      // affine.py:59
+                if (op.src_plane) a[e] = v; else b[e] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * t + i;
+                float v = op.src_plane ? a[e] : b[e];
+                v = (op.kind == TFK_OP_SHIFT_FWD) ? v + o[i] : v - o[i];    // affine.py:150,158
+                if (op.src_plane) a[e] = v; else b[e] = v;
+            }
+        }
+    }
+    if (op.kind == TFK_OP_AFFINE_FWD) ld = ld + part;
+    else if (op.kind == TFK_OP_AFFINE_INV) ld = ld + (-part);
+}
+
+// Dynamic LDS: the parameter block [+ 3*D floats of base density].
+template <int EPL, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
+    const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
+    const float *__restrict__ gauss_log_scale, float *logprob, long long N,
+    const float *__restrict__ params, int n_params, MProgram prog, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(params);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
+    }
+    float *base_s = lds + n_params;                   // loc[D] | scale[D] | log_scale[D]
+    if (logprob) {
+        for (int e = threadIdx.x; e < D; e += BLOCK) {
+            base_s[e] = gauss_loc[e];
+            base_s[D + e] = expf(gauss_log_scale[e]);
+            base_s[2 * D + e] = gauss_log_scale[e];
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * 16; row0 < N; row0 += stride) {
+        const long long row = row0 + j;
+        const long long rr = row < N ? row : N - 1;    // tail: compute a valid row, store nothing
+        float a[EPL], b[EPL];
+        const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+        const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const float4 va = pa[i], vb = pb[i];
+            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+        }
+        // per-lane share of the row's log-det; lane q == 0 carries the running value
+        float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
+        for (int o = 0; o < prog.n_ops; ++o)
+            apply_op_m<EPL>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
+        float lp = 0.0f;
+        if (logprob) {                                              // gaussian.py:46-54
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int ia = EPL * q + e, ib = HALF + EPL * q + e;
+                const float ta = div_fast(a[e] - base_s[ia], base_s[D + ia]);
+                const float tb = div_fast(b[e] - base_s[ib], base_s[D + ib]);
+                float ua = 0.5f * (ta * ta), ub = 0.5f * (tb * tb);
+                ua = ua + kHalfLog2Pi; ub = ub + kHalfLog2Pi;
+                ua = ua + base_s[2 * D + ia]; ub = ub + base_s[2 * D + ib];
+                lp += -ua;
+                lp += -ub;
+            }
+        }
+        // combine the four lanes of a row (l, l^16, l^32, l^48)
+        ld += __shfl_xor(ld, 16, kWave);
+        ld += __shfl_xor(ld, 32, kWave);
+        if (logprob) {
+            lp += __shfl_xor(lp, 16, kWave);
+            lp += __shfl_xor(lp, 32, kWave);
+        }
+        if (row < N) {
+            if (z) {
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + EPL * q);
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+                    qb[i] = make_float4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+                }
+            }
+            if (q == 0) {
+                if (logdet) logdet[row] = ld;
+                if (logprob) logprob[row] = lp + ld;                // flows.py:648
+            }
+        }
+    }
+}
+
+template <int EPL, int BLOCK>
+static int launch_mb(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                     float *logprob, int64_t N, const float *params, int n_params,
+                     const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
+{
+    constexpr int D = 8 * EPL;
+    const size_t lds = ((size_t)n_params + 3 * D) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+    int per_cu = 2048 / BLOCK;                       // 32 waves per CU
+    if ((int)((160 * 1024) / lds) < per_cu) per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const int64_t want = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * per_cu;
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
+                       log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
+    return check_launch(fn);
+}
+
+// the parameter block is per workgroup: with a whole program resident (~50 KB for RealNVP
+// D = 64, 8 layers) 512-thread workgroups keep 3 x 8 waves per CU, 256-thread ones only 3 x 4
+template <int EPL>
+static int launch_m(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                    float *logprob, int64_t N, const float *params, int n_params,
+                    const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
+{
+    if (N >= (int64_t)kCUs * 3 * 128)
+        return launch_mb<EPL, 512>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
+    return launch_mb<EPL, kBlock>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+extern "C" {
+
+int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128) ? 1 : 0; }
+
+int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
+                      const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                      const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                      int32_t accumulate, void *stream)
+{
+    const char *fn = "tfk_flow_run_mfma";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64 or 128", fn, D);
+    if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
+    if (n_params < 0 || (n_params & 3)) return fail(TFK_EINVAL, "%s: n_params must be a non-negative multiple of 4", fn);
+    if (N == 0) return TFK_OK;
+    if (!x || (n_ops > 0 && (!ops || !params))) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!z && !logdet && !logprob) return fail(TFK_EINVAL, "%s: no output requested", fn);
+    if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
+    if (!aligned16(x) || (z && !aligned16(z)) || !aligned16(params))
+        return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
+    const int EPL = D / 8;
+    MProgram prog;
+    prog.n_ops = n_ops;
+    for (int i = 0; i < n_ops; ++i) {
+        MOp &o = prog.op[i];
+        const int32_t *rec = ops + 4 * i;
+        o.kind = rec[0];
+        o.src_plane = rec[1];
+        o.steps2 = rec[2];
+        o.offset = rec[3];
+        int64_t need;
+        if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
+        else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
+        else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
+            if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
+            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            const int T2 = (o.kind <= TFK_OP_AFFINE_INV) ? EPL / 2 : EPL / 4;
+            need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+        } else return fail(TFK_EINVAL, "%s: op %d: kind %d is not supported on the MFMA path", fn, i, o.kind);
+        if (o.offset < 0 || (o.offset & 3) || o.offset + need > n_params)
+            return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i,
+                        o.offset, (long long)(o.offset + need), (long long)n_params);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (EPL == 8)
+        return launch_m<8>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+    return launch_m<16>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+}
+
+}  // extern "C"

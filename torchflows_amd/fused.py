@@ -39,6 +39,9 @@ FORWARD, INVERSE = 0, 1
 # parameters staged in LDS per launch; 40 KB keeps 4 workgroups (16 waves) per CU and holds
 # the whole RealNVP(64, n_layers=8) program (35.8 KB)
 MAX_PARAM_BYTES = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS", 40 * 1024))
+# the matrix-core layout stores MFMA A-operands per lane (zero-padded to 16 hidden units):
+# RealNVP(64, n_layers=8) is 49 KB; its kernel runs 512-thread workgroups, 3 per CU
+MAX_PARAM_BYTES_MFMA = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS_MFMA", 52 * 1024))
 MAX_OPS = 96
 
 
@@ -46,10 +49,15 @@ def enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_FUSED", "1") != "0"
 
 
+def mfma_enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_MFMA", "1") != "0"
+
+
 @dataclass
 class Segment:
     ops: List[tuple]                          # (kind, src_plane, H, offset[, K, boundary, scale, c])
     params: torch.Tensor                      # fp32 device block, numel % 4 == 0
+    mfma: bool = False                        # packed for tfk_flow_run_mfma (matrix-core conditioner)
 
 
 @dataclass
@@ -117,7 +125,52 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
     return (OP_EW_SUBDIV if subdiv else OP_EW_MULADD, 0, 0), torch.cat(parts)
 
 
-def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
+def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p):
+    """Parameter block of one affine / shift coupling for tfk_flow_run_mfma
+    (csrc/tfk_flow_mfma.hip): A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4].
+    Lane l = (q = l >> 4, i = l & 15).  GEMM 1: D-row i <-> hidden unit 4*(i & 3) + (i >> 2),
+    k-step s of lane-group q <-> physical source element EPL*q + s.  GEMM 2, tile t: D-row
+    i = 4*q2 + r <-> parameter (r & 1) of target element EPL*q2 + 2t + (r >> 1) (affine) or
+    target element EPL*q2 + 4t + r (shift); k-step r' of lane-group q <-> hidden unit 4r' + q."""
+    half, EPL = D // 2, D // 8
+    dev, dt = W1t.device, W1t.dtype
+    P = W2p.shape[1]
+    steps2 = (H + 3) // 4
+    W1pad = torch.zeros(16, half, dtype=dt, device=dev)
+    W1pad[:H] = W1t
+    b1pad = torch.zeros(16, dtype=dt, device=dev)
+    b1pad[:H] = b1
+    W2pad = torch.zeros(half, P, 16, dtype=dt, device=dev)
+    W2pad[:, :, :H] = W2p
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)])            # (EPL, 64)
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    b1m = b1pad[4 * rr + qq]                                                       # (4, 4): [q][r]
+    q2, r2 = il >> 2, il & 3
+    T2 = EPL // 2 if P == 2 else EPL // 4
+    A2, b2m = [], []
+    for t in range(T2):
+        if P == 2:
+            m_l, p_l = EPL * q2 + 2 * t + (r2 >> 1), r2 & 1
+            m_b, p_b = EPL * qq + 2 * t + (rr >> 1), rr & 1
+        else:
+            m_l, p_l = EPL * q2 + 4 * t + r2, torch.zeros_like(r2)
+            m_b, p_b = EPL * qq + 4 * t + rr, torch.zeros_like(rr)
+        for r1 in range(steps2):
+            A2.append(W2pad[m_l, p_l, 4 * r1 + ql])                               # (64,)
+        b2m.append(b2p[m_b, p_b])                                                  # (4, 4)
+    block = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1),
+                       torch.stack(b2m).reshape(-1)])
+    if kind == "shift":
+        op = OP_SHIFT_FWD if d == FORWARD else OP_SHIFT_INV
+    else:
+        op = OP_AFFINE_FWD if (d == FORWARD) != (kind == "inverse_affine") else OP_AFFINE_INV
+    return (op, plane, steps2), block
+
+
+def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
     kind = layer.transformer.native_kind
     if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
@@ -155,6 +208,10 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
     W2p[m_t] = W2.reshape(half, P, H)
     b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
+    if mfma:
+        if kind == "rqs" or H > 16:
+            return None
+        return _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
     if kind == "rqs":
         if H > MAX_HIDDEN_RQS:
             return None
@@ -182,8 +239,11 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int):
     return (op, plane, H), block
 
 
-def compile_chain(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
-    """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None."""
+def compile_chain(composition, direction: int, device: torch.device,
+                  mfma: Optional[bool] = None) -> Optional[CompiledChain]:
+    """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None.
+    ``mfma`` None: use the matrix-core kernel when the chain qualifies (D in {64, 128}, affine /
+    shift couplings, hidden width <= 16), else the vector-ALU one."""
     from torchflows_amd.bijections.finite.autoregressive.layers_base import (
         CouplingBijection, ElementwiseBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
@@ -191,6 +251,12 @@ def compile_chain(composition, direction: int, device: torch.device) -> Optional
     D = composition.n_dim
     if not enabled() or not native.lib().tfk_flow_supported(D):
         return None
+    if mfma is None:
+        if mfma_enabled() and native.lib().tfk_flow_mfma_supported(D):
+            chain = compile_chain(composition, direction, device, mfma=True)
+            if chain is not None:
+                return chain
+        mfma = False
     order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
     plan = _flatten(order, "forward" if direction == FORWARD else "inverse")
     if plan is None:
@@ -206,7 +272,7 @@ def compile_chain(composition, direction: int, device: torch.device) -> Optional
             if isinstance(layer, ElementwiseBijection):
                 item = _elementwise_op(layer, d, pos, D)
             elif isinstance(layer, CouplingBijection):
-                item = _coupling_op(layer, d, pos, D)
+                item = _coupling_op(layer, d, pos, D, mfma=mfma)
             else:
                 item = None
             if item is None:
@@ -224,15 +290,15 @@ def compile_chain(composition, direction: int, device: torch.device) -> Optional
         # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
         # gets a launch of its own, and the small elementwise ops around it ride along
         small = kind in (OP_EW_MULADD, OP_EW_SUBDIV)
-        over = (used + n) * 4 > MAX_PARAM_BYTES
+        over = (used + n) * 4 > (MAX_PARAM_BYTES_MFMA if mfma else MAX_PARAM_BYTES)
         if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
-            segments.append(Segment(ops, torch.cat(blocks).contiguous()))
+            segments.append(Segment(ops, torch.cat(blocks).contiguous(), mfma))
             ops, blocks, used = [], [], 0
         ops.append((kind, plane, H, used) + extra)
         blocks.append(block.float())
         used += n
     if ops:
-        segments.append(Segment(ops, torch.cat(blocks).contiguous()))
+        segments.append(Segment(ops, torch.cat(blocks).contiguous(), mfma))
     identity = bool(torch.equal(pos, torch.arange(D, device=device)))
     return CompiledChain(D, segments, pos, identity, _params_version(composition))
 
@@ -283,9 +349,10 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
             if buf is None:
                 buf = torch.empty_like(rows)
             out = buf                             # in place from the second segment on
-        native.flow_run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
-                        loc_p if last else None, ls_p if last else None,
-                        logprob if last else None, seg.ops, seg.params, accumulate=(i > 0))
+        run = native.flow_run_mfma if seg.mfma else native.flow_run
+        run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
+            loc_p if last else None, ls_p if last else None,
+            logprob if last else None, seg.ops, seg.params, accumulate=(i > 0))
         if need_rows:
             cur = out
     out_rows = None

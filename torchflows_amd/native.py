@@ -32,9 +32,10 @@ SYMBOLS = (
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32",
     "tfk_flow_supported", "tfk_flow_run",
+    "tfk_flow_mfma_supported", "tfk_flow_run_mfma",
 )
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NativeError(RuntimeError):
@@ -80,6 +81,8 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_flow_supported.argtypes = [_i32]
     L.tfk_flow_run.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_i32), _i32,
                                _vp, _i64, _i32, _vp]
+    L.tfk_flow_mfma_supported.argtypes = [_i32]
+    L.tfk_flow_run_mfma.argtypes = L.tfk_flow_run.argtypes
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -293,6 +296,26 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
             _f32(params, name), params.numel(), 1 if accumulate else 0)
     with torch.cuda.device(x.device):
         rc = lib().tfk_flow_run(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+
+
+def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
+    """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
+    ops: list of (kind, src_plane, gemm2_steps, offset); params packed by fused._pack_mfma."""
+    global calls
+    name = "tfk_flow_run_mfma"
+    N, D = _rows(x, name)
+    flat = [int(v) for op in ops for v in op[:4]]
+    ops_arr = (_i32 * max(len(flat), 1))(*flat)
+    for t, n in ((z, N * D), (logdet, N), (logprob, N), (gauss_loc, D), (gauss_log_scale, D)):
+        if t is not None and t.numel() != n:
+            raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
+    args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
+            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
+            _f32(params, name), params.numel(), 1 if accumulate else 0)
+    with torch.cuda.device(x.device):
+        rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
     _check(rc, name)
 
