@@ -54,10 +54,10 @@ __global__ __launch_bounds__(kBlock) void k_affine_half_v4(
                 o.z = (xt.z - h1.y) / a2;
                 o.w = (xt.w - h1.w) / a3;
             }
-            acc += logf(a0);                        // affine.py:42,47
-            acc += logf(a1);
-            acc += logf(a2);
-            acc += logf(a3);
+            acc += log_normal(a0);                        // affine.py:42,47
+            acc += log_normal(a1);
+            acc += log_normal(a2);
+            acc += log_normal(a3);
             if (!INPLACE) zr[j] = xs;
             zr[Sv + j] = o;
         }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_coupling_generic(
                 const float a = aff_alpha(hr[2 * t]);
                 const float b = hr[2 * t + 1];
                 o = (MODE == 0) ? a * v + b : (v - b) / a;
-                acc += logf(a);
+                acc += log_normal(a);
             } else {
                 o = (MODE == 2) ? v + hr[t] : v - hr[t];     // affine.py:150,158
             }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_elementwise_affine(
         const float a = aff_alpha(value[2 * e]);
         alpha_s[e] = a;
         beta_s[e] = value[2 * e + 1];
-        part += logf(a);
+        part += log_normal(a);
     }
     red[threadIdx.x] = part;
     __syncthreads();

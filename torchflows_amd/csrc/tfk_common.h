@@ -50,13 +50,26 @@ __device__ __forceinline__ float div_1000(float v) {
 // (x*log2(e) split hi/lo, v_exp_f32, ldexp) without its overflow / underflow selects --
 // bit-identical to expf on that range, underflows to denormals / 0 through ldexp.  9 ops.
 __device__ __forceinline__ float exp_noovf(float x) {
-    const float L2E_HI = 1.44269502162933349609375f;    // 0x3fb8aa3b
-    const float L2E_LO = 1.925963033500011079e-08f;     // 0x32a5705f
+    const float L2E_HI = __int_as_float(0x3fb8aa3b);    // 1.44269502
+    const float L2E_LO = __int_as_float(0x32a5705f);    // 1.92596303e-08
     const float t = x * L2E_HI;
     const float n = __builtin_rintf(t);
     const float e = fmaf(L2E_LO, x, fmaf(x, L2E_HI, -t));
     const float f = (t - n) + e;
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// logf for positive NORMAL arguments (and +inf / NaN, passed through): ocml's own sequence
+// v_log_f32 -> * ln2 split hi/lo -> add, without its denormal pre-scaling -- bit-identical to
+// logf on that domain.  Every log on this path takes a scale factor alpha >= 1e-10, a spline
+// slope, or 1 + exp(.) >= 1.  7 ops instead of 13.
+__device__ __forceinline__ float log_normal(float x) {
+    const float LN2_HI = __int_as_float(0x3f317217);    // 0.693147123
+    const float LN2_LO = __int_as_float(0x3377d1cf);    // 5.77e-08
+    const float r = __builtin_amdgcn_logf(x);           // log2(x), v_log_f32
+    const float hi = r * LN2_HI;
+    const float y = hi + fmaf(r, LN2_LO, fmaf(r, LN2_HI, -hi));
+    return __builtin_fabsf(r) < __builtin_inff() ? y : r;
 }
 
 // constrain_scale, affine.py:33-34: exp(c0 + u / 2) + m   (u / 2 == u * 0.5 exactly).
@@ -71,7 +84,7 @@ __device__ __forceinline__ float aff_alpha(float u) {
 __device__ __forceinline__ float log1p_pos(float y) {
     const float u = 1.0f + y;
     const float lost = y - (u - 1.0f);
-    return logf(u) + lost * __builtin_amdgcn_rcpf(u);
+    return log_normal(u) + lost * __builtin_amdgcn_rcpf(u);
 }
 
 // sum over the G (power of two, <= 64) consecutive lanes that share a row

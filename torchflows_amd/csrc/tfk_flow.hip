@@ -238,10 +238,10 @@ __device__ __forceinline__ void apply_op(const FlowOp op, const float *prm, int 
         for (int r = 0; r < R; ++r) {
             const float a0 = aff_alpha(acc0[r].x), a1 = aff_alpha(acc0[r].z);
             const float a2 = aff_alpha(acc1[r].x), a3 = aff_alpha(acc1[r].z);
-            float part = logf(a0);                               // affine.py:42
-            part += logf(a1);
-            part += logf(a2);
-            part += logf(a3);
+            float part = log_normal(a0);                               // affine.py:42
+            part += log_normal(a1);
+            part += log_normal(a2);
+            part += log_normal(a3);
             part = group_allsum<G>(part);
             if (op.kind == TFK_OP_AFFINE_FWD) {
                 tgt[r].x = a0 * tgt[r].x + acc0[r].y; tgt[r].y = a1 * tgt[r].y + acc0[r].w;

@@ -52,6 +52,60 @@ __device__ __forceinline__ float tanh_act_m(float x) {       // see tanh_act in 
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
+// One coupling op with the roles of the planes fixed: src feeds the conditioner, tgt is
+// transformed (a uniform branch in apply_op_m picks the roles, so no per-element selects).
+template <int EPL>
+__device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lane, int q,
+                                         const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+{
+    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
+    const int T2 = affine ? EPL / 2 : EPL / 4;
+    const float *A1 = prm;
+    const float *b1 = prm + EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + T2 * op.steps2 * 64;
+
+    // GEMM 1: hidden pre-activations of the 16 rows of this wave
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);      // bias of units 4r + q
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src[s], acc, 0, 0, 0);
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);        // transforms.py:293-304
+
+    // GEMM 2 + transform, two (affine) or four (shift) target elements per tile
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < EPL / 2; ++t) {
+        if (!affine && t >= EPL / 4) break;
+        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+        for (int r = 0; r < op.steps2; ++r) {
+            const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
+        }
+        if (affine) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
+                const float be = o[2 * i + 1];
+                part += log_normal(al);                             // affine.py:42
+                if (op.kind == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
+                else tgt[e] = div_fast(tgt[e] - be, al);                       // affine.py:59
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * t + i;
+                tgt[e] = (op.kind == TFK_OP_SHIFT_FWD) ? tgt[e] + o[i] : tgt[e] - o[i];   // affine.py:150,158
+            }
+        }
+    }
+    if (op.kind == TFK_OP_AFFINE_FWD) ld = ld + part;
+    else if (op.kind == TFK_OP_AFFINE_INV) ld = ld + (-part);
+}
+
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
 //   A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4]
 // Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
@@ -78,58 +132,8 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
         if (q == 0) ld = ld + prm[2 * D];                           // base.py:222 (once per row)
         return;
     }
-    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
-    const int T2 = affine ? EPL / 2 : EPL / 4;
-    const float *A1 = prm;
-    const float *b1 = prm + EPL * 64;
-    const float *A2 = b1 + 16;
-    const float *b2 = A2 + T2 * op.steps2 * 64;
-
-    // GEMM 1: hidden pre-activations of the 16 rows of this wave
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);      // bias of units 4r + q
-#pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-        const float src = op.src_plane ? b[s] : a[s];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src, acc, 0, 0, 0);
-    }
-    float hid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);        // transforms.py:293-304
-
-    // GEMM 2 + transform, two (affine) or four (shift) target elements per tile
-    float part = 0.0f;
-#pragma unroll
-    for (int t = 0; t < EPL / 2; ++t) {
-        if (!affine && t >= EPL / 4) break;
-        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
-        for (int r = 0; r < op.steps2; ++r) {
-            const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
-        }
-        if (affine) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = 2 * t + i;
-                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
-                const float be = o[2 * i + 1];
-                part += logf(al);                                   // affine.py:42
-                float v = op.src_plane ? a[e] : b[e];
-                if (op.kind == TFK_OP_AFFINE_FWD) v = al * v + be;  // affine.py:48
-                else v = div_fast(v - be, al);                      // affine.py:59
-                if (op.src_plane) a[e] = v; else b[e] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = 4 * t + i;
-                float v = op.src_plane ? a[e] : b[e];
-                v = (op.kind == TFK_OP_SHIFT_FWD) ? v + o[i] : v - o[i];    // affine.py:150,158
-                if (op.src_plane) a[e] = v; else b[e] = v;
-            }
-        }
-    }
-    if (op.kind == TFK_OP_AFFINE_FWD) ld = ld + part;
-    else if (op.kind == TFK_OP_AFFINE_INV) ld = ld + (-part);
+    if (op.src_plane) couple_m<EPL>(op, prm, lane, q, b, a, ld);   // plane B conditions plane A
+    else couple_m<EPL>(op, prm, lane, q, a, b, ld);
 }
 
 // Dynamic LDS: the parameter block [+ 3*D floats of base density].

@@ -28,8 +28,8 @@ __device__ __forceinline__ float rqs_log_det(float s, float dk, float dk1, float
 {
     const float omx = 1.0f - xi;
     const float inner = dk1 * (xi * xi) + (2.0f * s) * q + dk * (omx * omx);
-    const float log_num = 2.0f * logf(s) + logf(inner);
-    const float log_den = 2.0f * logf(s + term1 * q);
+    const float log_num = 2.0f * log_normal(s) + log_normal(inner);
+    const float log_den = 2.0f * log_normal(s + term1 * q);
     return log_num - log_den;
 }
 
