@@ -168,7 +168,10 @@ def test_fused_golden(pkg, monkeypatch, name, arch, n_layers, variant):
     assert launches == (1 if D == 64 else launches)
     assert rel(lp.cpu().numpy(), g("log_prob")) < 1e-5
     assert normwise(xr.cpu().numpy(), g("x_inv")) < 1e-5
-    assert rel(ldr.cpu().numpy(), g("log_det_inv")) < max(1e-5, 3 * rel(g("log_det_inv"), g("log_det_inv64")))
+    # log-dets sum D/2 terms per layer that largely cancel: 1e-5 per 32 terms (as in
+    # test_gpu_kernels), or 3x the reference's own fp32-vs-fp64 distance if that is larger
+    assert rel(ldr.cpu().numpy(), g("log_det_inv")) < max(1e-5 * max(1.0, D / 64),
+                                                          3 * rel(g("log_det_inv"), g("log_det_inv64")))
 
 
 def test_segmented_program_matches_single_launch(pkg, monkeypatch):

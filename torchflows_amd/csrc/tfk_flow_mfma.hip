@@ -7,7 +7,7 @@
 // numerics are those of the VALU version).
 //
 // The register layout is chosen so that NOTHING has to move between the steps of a layer
-// (D = 8*EPL, EPL = elements per lane per plane = 8 or 16):
+// (D = 8*EPL, EPL = elements per lane per plane = 8, 16 or 32):
 //   * a wavefront owns 16 rows; lane l = (q = l >> 4, j = l & 15) holds, of row j, the
 //     elements [EPL*q, EPL*(q+1)) of plane A (first half of the row) and of plane B
 //     -- 32..64 contiguous bytes per plane: coalesced 16-byte loads;
@@ -78,27 +78,28 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
     float part = 0.0f;
 #pragma unroll
     for (int t = 0; t < EPL / 2; ++t) {
-        if (!affine && t >= EPL / 4) break;
-        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
-        for (int r = 0; r < op.steps2; ++r) {
-            const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
-        }
-        if (affine) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = 2 * t + i;
-                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
-                const float be = o[2 * i + 1];
-                part += log_normal(al);                             // affine.py:42
-                if (op.kind == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
-                else tgt[e] = div_fast(tgt[e] - be, al);                       // affine.py:59
+        if (affine || t < EPL / 4) {            // shift couplings have half as many tiles
+            f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+            for (int r = 0; r < op.steps2; ++r) {
+                const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
             }
-        } else {
+            if (affine) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = 4 * t + i;
-                tgt[e] = (op.kind == TFK_OP_SHIFT_FWD) ? tgt[e] + o[i] : tgt[e] - o[i];   // affine.py:150,158
+                for (int i = 0; i < 2; ++i) {
+                    const int e = 2 * t + i;
+                    const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
+                    const float be = o[2 * i + 1];
+                    part += log_normal(al);                             // affine.py:42
+                    if (op.kind == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
+                    else tgt[e] = div_fast(tgt[e] - be, al);                       // affine.py:59
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (4 * t + i) % EPL;     // (t < EPL/4 here; the modulo keeps the index static-safe)
+                    tgt[e] = (op.kind == TFK_OP_SHIFT_FWD) ? tgt[e] + o[i] : tgt[e] - o[i];   // affine.py:150,158
+                }
             }
         }
     }
@@ -266,7 +267,7 @@ using namespace tfk;
 
 extern "C" {
 
-int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128) ? 1 : 0; }
+int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128 || D == 256) ? 1 : 0; }
 
 int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
@@ -275,7 +276,7 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
 {
     const char *fn = "tfk_flow_run_mfma";
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
-    if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64 or 128", fn, D);
+    if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
     if (n_params < 0 || (n_params & 3)) return fail(TFK_EINVAL, "%s: n_params must be a non-negative multiple of 4", fn);
     if (N == 0) return TFK_OK;
@@ -310,6 +311,8 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (EPL == 8)
         return launch_m<8>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+    if (EPL == 32)
+        return launch_m<32>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
     return launch_m<16>(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
 }
 
