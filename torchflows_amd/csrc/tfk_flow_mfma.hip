@@ -52,14 +52,15 @@ __device__ __forceinline__ float tanh_act_m(float x) {       // see tanh_act in 
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
-// One coupling op with the roles of the planes fixed: src feeds the conditioner, tgt is
-// transformed (a uniform branch in apply_op_m picks the roles, so no per-element selects).
-template <int EPL>
+// One coupling op with the kind and the roles of the planes fixed at compile time (src feeds
+// the conditioner, tgt is transformed): straight-line code, the scheduler is free to slide the
+// vector work of one tile under the MFMAs of the next.  apply_op_m dispatches once per op.
+template <int EPL, int KIND>
 __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lane, int q,
                                          const float (&src)[EPL], float (&tgt)[EPL], float &ld)
 {
-    const bool affine = (op.kind == TFK_OP_AFFINE_FWD || op.kind == TFK_OP_AFFINE_INV);
-    const int T2 = affine ? EPL / 2 : EPL / 4;
+    constexpr bool affine = (KIND == TFK_OP_AFFINE_FWD || KIND == TFK_OP_AFFINE_INV);
+    constexpr int T2 = affine ? EPL / 2 : EPL / 4;
     const float *A1 = prm;
     const float *b1 = prm + EPL * 64;
     const float *A2 = b1 + 16;
@@ -77,34 +78,34 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
     // GEMM 2 + transform, two (affine) or four (shift) target elements per tile
     float part = 0.0f;
 #pragma unroll
-    for (int t = 0; t < EPL / 2; ++t) {
-        if (affine || t < EPL / 4) {            // shift couplings have half as many tiles
-            f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
-            for (int r = 0; r < op.steps2; ++r) {
-                const float hr = r == 0 ? hid[0] : (r == 1 ? hid[1] : (r == 2 ? hid[2] : hid[3]));
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + r) * 64 + lane], hr, o, 0, 0, 0);
+    for (int t = 0; t < T2; ++t) {
+        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+        // (hidden width <= 16: up to four k-steps; the unused ones are skipped uniformly)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+        if (op.steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
+        if (op.steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
+        if (op.steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+        if constexpr (affine) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
+                const float be = o[2 * i + 1];
+                part += log_normal(al);                             // affine.py:42
+                if constexpr (KIND == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
+                else tgt[e] = div_fast(tgt[e] - be, al);                              // affine.py:59
             }
-            if (affine) {
+        } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int e = 2 * t + i;
-                    const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
-                    const float be = o[2 * i + 1];
-                    part += log_normal(al);                             // affine.py:42
-                    if (op.kind == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
-                    else tgt[e] = div_fast(tgt[e] - be, al);                       // affine.py:59
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = (4 * t + i) % EPL;     // (t < EPL/4 here; the modulo keeps the index static-safe)
-                    tgt[e] = (op.kind == TFK_OP_SHIFT_FWD) ? tgt[e] + o[i] : tgt[e] - o[i];   // affine.py:150,158
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * t + i;
+                if constexpr (KIND == TFK_OP_SHIFT_FWD) tgt[e] = tgt[e] + o[i];       // affine.py:150
+                else tgt[e] = tgt[e] - o[i];                                          // affine.py:158
             }
         }
     }
-    if (op.kind == TFK_OP_AFFINE_FWD) ld = ld + part;
-    else if (op.kind == TFK_OP_AFFINE_INV) ld = ld + (-part);
+    if constexpr (KIND == TFK_OP_AFFINE_FWD) ld = ld + part;
+    else if constexpr (KIND == TFK_OP_AFFINE_INV) ld = ld + (-part);
 }
 
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
@@ -116,25 +117,56 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
-        const float *al = prm, *be = prm + D, *ra = prm + 2 * D + 4;
+        // this lane's EPL columns of each plane: float4 reads (the address depends on q only)
+        float al_a[EPL], al_b[EPL], be_a[EPL], be_b[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int ia = EPL * q + e, ib = HALF + EPL * q + e;
-            if (op.kind == TFK_OP_EW_MULADD) {                      // affine.py:48
-                a[e] = al[ia] * a[e] + be[ia];
-                b[e] = al[ib] * b[e] + be[ib];
-            } else {                                                // affine.py:59
-                const float na = a[e] - be[ia], nb = b[e] - be[ib];
-                const float qa = na * ra[ia], qb = nb * ra[ib];
-                a[e] = fmaf(fmaf(-al[ia], qa, na), ra[ia], qa);
-                b[e] = fmaf(fmaf(-al[ib], qb, nb), ra[ib], qb);
+        for (int i = 0; i < EPL / 4; ++i) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(prm + EPL * q + 4 * i);
+            const float4 v1 = *reinterpret_cast<const float4 *>(prm + HALF + EPL * q + 4 * i);
+            const float4 v2 = *reinterpret_cast<const float4 *>(prm + D + EPL * q + 4 * i);
+            const float4 v3 = *reinterpret_cast<const float4 *>(prm + D + HALF + EPL * q + 4 * i);
+            al_a[4 * i] = v0.x; al_a[4 * i + 1] = v0.y; al_a[4 * i + 2] = v0.z; al_a[4 * i + 3] = v0.w;
+            al_b[4 * i] = v1.x; al_b[4 * i + 1] = v1.y; al_b[4 * i + 2] = v1.z; al_b[4 * i + 3] = v1.w;
+            be_a[4 * i] = v2.x; be_a[4 * i + 1] = v2.y; be_a[4 * i + 2] = v2.z; be_a[4 * i + 3] = v2.w;
+            be_b[4 * i] = v3.x; be_b[4 * i + 1] = v3.y; be_b[4 * i + 2] = v3.z; be_b[4 * i + 3] = v3.w;
+        }
+        if (op.kind == TFK_OP_EW_MULADD) {                          // affine.py:48
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                a[e] = al_a[e] * a[e] + be_a[e];
+                b[e] = al_b[e] * b[e] + be_b[e];
+            }
+        } else {                                                    // affine.py:59
+            const float *ra = prm + 2 * D + 4;
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(ra + EPL * q + 4 * i);
+                const float4 r1 = *reinterpret_cast<const float4 *>(ra + HALF + EPL * q + 4 * i);
+                const float ra_a[4] = {r0.x, r0.y, r0.z, r0.w}, ra_b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * i + k;
+                    const float na = a[e] - be_a[e], nb = b[e] - be_b[e];
+                    const float qa = na * ra_a[k], qb = nb * ra_b[k];
+                    a[e] = fmaf(fmaf(-al_a[e], qa, na), ra_a[k], qa);
+                    b[e] = fmaf(fmaf(-al_b[e], qb, nb), ra_b[k], qb);
+                }
             }
         }
         if (q == 0) ld = ld + prm[2 * D];                           // base.py:222 (once per row)
         return;
     }
-    if (op.src_plane) couple_m<EPL>(op, prm, lane, q, b, a, ld);   // plane B conditions plane A
-    else couple_m<EPL>(op, prm, lane, q, a, b, ld);
+    // (src_plane 1: plane B conditions plane A)
+    switch (op.kind * 2 + op.src_plane) {
+    case TFK_OP_AFFINE_FWD * 2: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, a, b, ld); break;
+    case TFK_OP_AFFINE_FWD * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_AFFINE_INV * 2: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, a, b, ld); break;
+    case TFK_OP_AFFINE_INV * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_SHIFT_FWD * 2: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, a, b, ld); break;
+    case TFK_OP_SHIFT_FWD * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_SHIFT_INV * 2: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, a, b, ld); break;
+    default: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); break;
+    }
 }
 
 // Dynamic LDS: the parameter block [+ 3*D floats of base density].
