@@ -196,9 +196,11 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * Same semantics and outputs as tfk_flow_run for chains of elementwise ops and affine / shift
  * couplings, with the two conditioner GEMMs issued as v_mfma_f32_16x16x4_f32 (fp32 in / fp32
  * accumulate: numerically an fmaf chain).  D must be 64, 128 or 256, hidden width <= 16.
- * ops (HOST pointer): n_ops x int32[4] = {kind, src_plane, gemm2_steps = ceil(H/4), param_offset}.
+ * ops (HOST pointer): n_ops x int32[8] = {kind, src_plane, gemm2_steps = ceil(H/4), param_offset,
+ *   K, boundary, scale, c} (the last four as in tfk_flow_run, RQS ops only).
  * Elementwise ops use the parameter layout of tfk_flow_run; a coupling op holds
- *   A1[D/8][64] | b1[4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],  T2 = D/16 (affine), D/32 (shift)
+ *   A1[D/8][64] | b1[4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],
+ *   T2 = D/16 (affine), D/32 (shift), 6*D/8 (RQS, n_bins = 8: 6 tiles of 4 parameters per element)
  * i.e. the MFMA A-operands per lane, with the row / column permutations that make the
  * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
  * packed by torchflows_amd/fused.py:_pack_mfma). */

@@ -91,7 +91,10 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     assert e_lp < max(tol, 3 * floor_lp)
     assert e_z < max(tol, 3 * normwise(g("z"), g("z64")))
     assert e_x < max(tol, 3 * floor_x)
-    assert e_ld < max(tol, 3 * floor_ld)
+    # log-dets sum D/2 terms per layer that largely cancel: the bound is per 32 terms (as in
+    # test_gpu_kernels), or 3x the reference's own fp32-vs-fp64 distance if that is larger
+    D = int(np.prod(es))
+    assert e_ld < max(tol * max(1.0, D / 64), 3 * floor_ld)
     # the caller's tensors are untouched
     assert torch.equal(x.cpu(), torch.from_numpy(fx["x"]))
     assert torch.equal(z_in.cpu(), torch.from_numpy(fx["z_in"]))

@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "tfk_common.h"
+#include "tfk_spline.h"
 
 namespace tfk {
 
@@ -37,6 +38,10 @@ struct MOp {
     int src_plane;   // coupling: which plane feeds the conditioner
     int steps2;      // coupling: k-steps of GEMM 2 = ceil(H / 4)
     int offset;      // first float of the op's parameters in the staged block
+    int K;           // RQS: number of bins (8)
+    float boundary;  // RQS: spline box half-width
+    float scale;     // RQS: 1 - min_bin_size * K
+    float c;         // RQS: boundary_u_delta
 };
 
 struct MProgram {
@@ -108,6 +113,61 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
     else if constexpr (KIND == TFK_OP_AFFINE_INV) ld = ld + (-part);
 }
 
+// RQ-spline coupling on the matrix cores (layers.py:154-163): GEMM 1 as above; GEMM 2 produces,
+// for each of this lane's EPL target elements, its 23 (+1 pad) spline parameters as 6 tiles of
+// 4 (D-row 4q+r of tile 6e+c <-> parameter 4c+r of target element EPL*q+e), i.e. the record
+// lands in 24 registers of the lane that owns the element; rqs_eval then runs out of registers.
+// The element loop is a run-time loop (one copy of the ~500-op spline per variant).
+template <int EPL, bool INVERSE>
+__device__ __forceinline__ void couple_rqs_m(const MOp op, const float *prm, int lane, int q,
+                                             const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+{
+    constexpr int T2 = EPL * 6;
+    const float *A1 = prm;
+    const float *b1 = prm + EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + T2 * op.steps2 * 64;
+    RqsConst C;
+    C.minimum = -op.boundary;
+    C.maximum = op.boundary;
+    C.span = op.boundary + op.boundary;
+    C.scale = op.scale;
+    C.c = op.c;
+
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src[s], acc, 0, 0, 0);
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);
+
+    float part = 0.0f;
+    for (int e = 0; e < EPL; ++e) {
+        float p[24];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int t = e * 6 + c;
+            f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+            if (op.steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
+            if (op.steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
+            if (op.steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+            p[4 * c] = o[0]; p[4 * c + 1] = o[1]; p[4 * c + 2] = o[2]; p[4 * c + 3] = o[3];
+        }
+        float v = tgt[0];
+#pragma unroll
+        for (int i = 1; i < EPL; ++i) v = (e == i) ? tgt[i] : v;
+        float out = v, l = 0.0f;                                    // spline/base.py:54-55
+        if (v > C.minimum && v < C.maximum)                         // strict box, base.py:29-33
+            rqs_eval<8, INVERSE, true, float[24]>(p, 8, v, C, out, l);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) tgt[i] = (e == i) ? out : tgt[i];
+        part += l;
+    }
+    ld = ld + part;                                                 // base.py:59 + :222
+}
+
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
 //   A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4]
 // Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
@@ -165,7 +225,11 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
     case TFK_OP_SHIFT_FWD * 2: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, a, b, ld); break;
     case TFK_OP_SHIFT_FWD * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, b, a, ld); break;
     case TFK_OP_SHIFT_INV * 2: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, a, b, ld); break;
-    default: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_SHIFT_INV * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_RQS_FWD * 2: couple_rqs_m<EPL, false>(op, prm, lane, q, a, b, ld); break;
+    case TFK_OP_RQS_FWD * 2 + 1: couple_rqs_m<EPL, false>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_RQS_INV * 2: couple_rqs_m<EPL, true>(op, prm, lane, q, a, b, ld); break;
+    default: couple_rqs_m<EPL, true>(op, prm, lane, q, b, a, ld); break;
     }
 }
 
@@ -322,11 +386,15 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     prog.n_ops = n_ops;
     for (int i = 0; i < n_ops; ++i) {
         MOp &o = prog.op[i];
-        const int32_t *rec = ops + 4 * i;
+        const int32_t *rec = ops + 8 * i;
         o.kind = rec[0];
         o.src_plane = rec[1];
         o.steps2 = rec[2];
         o.offset = rec[3];
+        o.K = rec[4];
+        memcpy(&o.boundary, rec + 5, 4);
+        memcpy(&o.scale, rec + 6, 4);
+        memcpy(&o.c, rec + 7, 4);
         int64_t need;
         if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
@@ -334,6 +402,13 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
             if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
             if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             const int T2 = (o.kind <= TFK_OP_AFFINE_INV) ? EPL / 2 : EPL / 4;
+            need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+        } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
+            if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
+            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            if (o.K != 8) return fail(TFK_EINVAL, "%s: op %d: fused RQS supports n_bins = 8, got %d", fn, i, o.K);
+            if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
+            const int T2 = EPL * 6;
             need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
         } else return fail(TFK_EINVAL, "%s: op %d: kind %d is not supported on the MFMA path", fn, i, o.kind);
         if (o.offset < 0 || (o.offset & 3) || o.offset + need > n_params)

@@ -149,6 +149,22 @@ def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p)
     qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
     b1m = b1pad[4 * rr + qq]                                                       # (4, 4): [q][r]
     q2, r2 = il >> 2, il & 3
+    if kind == "rqs":
+        # 23 spline parameters per element padded to 24: tile 6e + c holds parameters 4c .. 4c+3
+        # of target element EPL*q2 + e
+        W2q = torch.zeros(half, 24, 16, dtype=dt, device=dev)
+        W2q[:, :P] = W2pad
+        b2q = torch.zeros(half, 24, dtype=dt, device=dev)
+        b2q[:, :P] = b2p
+        A2, b2m = [], []
+        for e in range(EPL):
+            for c in range(6):
+                for r1 in range(steps2):
+                    A2.append(W2q[EPL * q2 + e, 4 * c + r2, 4 * r1 + ql])
+                b2m.append(b2q[EPL * qq + e, 4 * c + rr])
+        block = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1),
+                           torch.stack(b2m).reshape(-1)])
+        return (OP_RQS_FWD if d == FORWARD else OP_RQS_INV, plane, steps2), block
     T2 = EPL // 2 if P == 2 else EPL // 4
     A2, b2m = [], []
     for t in range(T2):
@@ -209,9 +225,16 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
     if mfma:
-        if kind == "rqs" or H > 16:
+        if H > 16:
             return None
-        return _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
+        head, block = _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
+        if kind == "rqs":
+            import math
+            import numpy as np
+            tr = layer.transformer
+            head = head + (8, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)),
+                           float(np.float32(math.log(math.expm1(1 - tr.min_delta)))))
+        return head, block
     if kind == "rqs":
         if H > MAX_HIDDEN_RQS:
             return None

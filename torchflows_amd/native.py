@@ -273,13 +273,9 @@ def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
     _check(rc, name)
 
 
-def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
-    """Fused flow program (tfk_flow_run).  ops: list of (kind, src_plane, H, offset[, K,
-    boundary, scale, c]) tuples (host side), params: fp32 device block.  z / logdet / logprob
-    may be None."""
-    global calls
-    name = "tfk_flow_run"
-    N, D = _rows(x, name)
+def _pack_ops(ops):
+    """Host-side op records: int32[8] each = kind, src_plane, H (or GEMM-2 steps), offset, K and
+    the fp32 bit patterns of boundary, scale, c (spline ops only)."""
     flat = []
     for op in ops:
         kind, plane, H, off = (int(v) for v in op[:4])
@@ -287,7 +283,17 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
         fl = [float(v) for v in op[5:8]] + [0.0] * (3 - len(op[5:8]))
         bits = struct.unpack("<3i", struct.pack("<3f", *fl))
         flat += [kind, plane, H, off, K, *bits]
-    ops_arr = (_i32 * max(len(flat), 1))(*flat)
+    return (_i32 * max(len(flat), 1))(*flat)
+
+
+def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
+    """Fused flow program (tfk_flow_run).  ops: list of (kind, src_plane, H, offset[, K,
+    boundary, scale, c]) tuples (host side), params: fp32 device block.  z / logdet / logprob
+    may be None."""
+    global calls
+    name = "tfk_flow_run"
+    N, D = _rows(x, name)
+    ops_arr = _pack_ops(ops)
     for t, n in ((z, N * D), (logdet, N), (logprob, N), (gauss_loc, D), (gauss_log_scale, D)):
         if t is not None and t.numel() != n:
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
@@ -306,8 +312,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
     global calls
     name = "tfk_flow_run_mfma"
     N, D = _rows(x, name)
-    flat = [int(v) for op in ops for v in op[:4]]
-    ops_arr = (_i32 * max(len(flat), 1))(*flat)
+    ops_arr = _pack_ops(ops)
     for t, n in ((z, N * D), (logdet, N), (logprob, N), (gauss_loc, D), (gauss_log_scale, D)):
         if t is not None and t.numel() != n:
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
