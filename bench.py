@@ -223,10 +223,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true",
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
+    ap.add_argument("--no-mfma", action="store_true",
+                    help="fused flow programs on the VALU interpreter (k_flow_run) instead of k_flow_run_mfma")
     args = ap.parse_args()
 
     if args.no_fused:
         os.environ["TORCHFLOWS_AMD_FUSED"] = "0"
+    if args.no_mfma:
+        os.environ["TORCHFLOWS_AMD_MFMA"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -195,7 +195,8 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
 /* ---- fused flow program, conditioner GEMMs on the matrix cores --------------------
  * Same semantics and outputs as tfk_flow_run for chains of elementwise ops and affine / shift
  * couplings, with the two conditioner GEMMs issued as v_mfma_f32_16x16x4_f32 (fp32 in / fp32
- * accumulate: numerically an fmaf chain).  D must be 64, 128 or 256, hidden width <= 16.
+ * accumulate: numerically an fmaf chain).  D must be 64, 128 or 256 (RQS ops: 64 or 128),
+ * hidden width <= 16.
  * ops (HOST pointer): n_ops x int32[8] = {kind, src_plane, gemm2_steps = ceil(H/4), param_offset,
  *   K, boundary, scale, c} (the last four as in tfk_flow_run, RQS ops only).
  * Elementwise ops use the parameter layout of tfk_flow_run; a coupling op holds

@@ -14,3 +14,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_sq.json 2> $OUT/sq.err
 python tools/summarize_profile.py $OUT
+# raw traces are large (gpurun_out/ merges back at most 64 MiB): keep the summaries only
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq

@@ -32,6 +32,7 @@
 namespace tfk {
 
 constexpr int kMaxOpsM = 96;
+constexpr int kMaxEplRqs = 16;   // RQS couplings on this kernel: D <= 128
 
 struct MOp {
     int kind;        // TFK_OP_*
@@ -177,39 +178,36 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
-        // this lane's EPL columns of each plane: float4 reads (the address depends on q only)
-        float al_a[EPL], al_b[EPL], be_a[EPL], be_b[EPL];
+        // this lane's EPL columns of each plane, four at a time: float4 reads (the address depends
+        // on q only); chunked so that D = 256 (64 row registers per lane) does not spill
+        const bool sub = (op.kind == TFK_OP_EW_SUBDIV);
+        const float *ra = prm + 2 * D + 4;                          // 1/alpha (SUBDIV only)
 #pragma unroll
         for (int i = 0; i < EPL / 4; ++i) {
             const float4 v0 = *reinterpret_cast<const float4 *>(prm + EPL * q + 4 * i);
             const float4 v1 = *reinterpret_cast<const float4 *>(prm + HALF + EPL * q + 4 * i);
             const float4 v2 = *reinterpret_cast<const float4 *>(prm + D + EPL * q + 4 * i);
             const float4 v3 = *reinterpret_cast<const float4 *>(prm + D + HALF + EPL * q + 4 * i);
-            al_a[4 * i] = v0.x; al_a[4 * i + 1] = v0.y; al_a[4 * i + 2] = v0.z; al_a[4 * i + 3] = v0.w;
-            al_b[4 * i] = v1.x; al_b[4 * i + 1] = v1.y; al_b[4 * i + 2] = v1.z; al_b[4 * i + 3] = v1.w;
-            be_a[4 * i] = v2.x; be_a[4 * i + 1] = v2.y; be_a[4 * i + 2] = v2.z; be_a[4 * i + 3] = v2.w;
-            be_b[4 * i] = v3.x; be_b[4 * i + 1] = v3.y; be_b[4 * i + 2] = v3.z; be_b[4 * i + 3] = v3.w;
-        }
-        if (op.kind == TFK_OP_EW_MULADD) {                          // affine.py:48
+            const float al_a[4] = {v0.x, v0.y, v0.z, v0.w}, al_b[4] = {v1.x, v1.y, v1.z, v1.w};
+            const float be_a[4] = {v2.x, v2.y, v2.z, v2.w}, be_b[4] = {v3.x, v3.y, v3.z, v3.w};
+            if (!sub) {                                             // affine.py:48
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                a[e] = al_a[e] * a[e] + be_a[e];
-                b[e] = al_b[e] * b[e] + be_b[e];
-            }
-        } else {                                                    // affine.py:59
-            const float *ra = prm + 2 * D + 4;
-#pragma unroll
-            for (int i = 0; i < EPL / 4; ++i) {
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * i + k;
+                    a[e] = al_a[k] * a[e] + be_a[k];
+                    b[e] = al_b[k] * b[e] + be_b[k];
+                }
+            } else {                                                // affine.py:59
                 const float4 r0 = *reinterpret_cast<const float4 *>(ra + EPL * q + 4 * i);
                 const float4 r1 = *reinterpret_cast<const float4 *>(ra + HALF + EPL * q + 4 * i);
                 const float ra_a[4] = {r0.x, r0.y, r0.z, r0.w}, ra_b[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int e = 4 * i + k;
-                    const float na = a[e] - be_a[e], nb = b[e] - be_b[e];
+                    const float na = a[e] - be_a[k], nb = b[e] - be_b[k];
                     const float qa = na * ra_a[k], qb = nb * ra_b[k];
-                    a[e] = fmaf(fmaf(-al_a[e], qa, na), ra_a[k], qa);
-                    b[e] = fmaf(fmaf(-al_b[e], qb, nb), ra_b[k], qb);
+                    a[e] = fmaf(fmaf(-al_a[k], qa, na), ra_a[k], qa);
+                    b[e] = fmaf(fmaf(-al_b[k], qb, nb), ra_b[k], qb);
                 }
             }
         }
@@ -218,18 +216,26 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
     }
     // (src_plane 1: plane B conditions plane A)
     switch (op.kind * 2 + op.src_plane) {
-    case TFK_OP_AFFINE_FWD * 2: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, a, b, ld); break;
-    case TFK_OP_AFFINE_FWD * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, b, a, ld); break;
-    case TFK_OP_AFFINE_INV * 2: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, a, b, ld); break;
-    case TFK_OP_AFFINE_INV * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, b, a, ld); break;
-    case TFK_OP_SHIFT_FWD * 2: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, a, b, ld); break;
-    case TFK_OP_SHIFT_FWD * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, b, a, ld); break;
-    case TFK_OP_SHIFT_INV * 2: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, a, b, ld); break;
-    case TFK_OP_SHIFT_INV * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); break;
-    case TFK_OP_RQS_FWD * 2: couple_rqs_m<EPL, false>(op, prm, lane, q, a, b, ld); break;
-    case TFK_OP_RQS_FWD * 2 + 1: couple_rqs_m<EPL, false>(op, prm, lane, q, b, a, ld); break;
-    case TFK_OP_RQS_INV * 2: couple_rqs_m<EPL, true>(op, prm, lane, q, a, b, ld); break;
-    default: couple_rqs_m<EPL, true>(op, prm, lane, q, b, a, ld); break;
+    case TFK_OP_AFFINE_FWD * 2: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_AFFINE_FWD * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_AFFINE_INV * 2: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_AFFINE_INV * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_SHIFT_FWD * 2: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_SHIFT_FWD * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_SHIFT_INV * 2: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_SHIFT_INV * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); return;
+    default: break;
+    }
+    // the spline op exists for D <= 128 only: at D = 256 one coupling's parameters (209 KB) exceed
+    // the LDS anyway, and its 24-register record beside 64 row registers would live in scratch
+    if constexpr (EPL <= kMaxEplRqs) {
+        switch (op.kind * 2 + op.src_plane) {
+        case TFK_OP_RQS_FWD * 2: couple_rqs_m<EPL, false>(op, prm, lane, q, a, b, ld); return;
+        case TFK_OP_RQS_FWD * 2 + 1: couple_rqs_m<EPL, false>(op, prm, lane, q, b, a, ld); return;
+        case TFK_OP_RQS_INV * 2: couple_rqs_m<EPL, true>(op, prm, lane, q, a, b, ld); return;
+        case TFK_OP_RQS_INV * 2 + 1: couple_rqs_m<EPL, true>(op, prm, lane, q, b, a, ld); return;
+        default: break;
+        }
     }
 }
 
@@ -406,6 +412,7 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
         } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
             if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
             if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            if (EPL > kMaxEplRqs) return fail(TFK_EINVAL, "%s: op %d: RQS couplings need D <= %d on the MFMA path", fn, i, 8 * kMaxEplRqs);
             if (o.K != 8) return fail(TFK_EINVAL, "%s: op %d: fused RQS supports n_bins = 8, got %d", fn, i, o.K);
             if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
             const int T2 = EPL * 6;

@@ -225,7 +225,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
     if mfma:
-        if H > 16:
+        if H > 16 or (kind == "rqs" and D > 128):
             return None
         head, block = _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
         if kind == "rqs":
