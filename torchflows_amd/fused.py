@@ -42,6 +42,10 @@ MAX_PARAM_BYTES = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS", 40 * 1024))
 # the matrix-core layout stores MFMA A-operands per lane (zero-padded to 16 hidden units):
 # RealNVP(64, n_layers=8) is 49 KB; its kernel runs 512-thread workgroups, 3 per CU
 MAX_PARAM_BYTES_MFMA = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS_MFMA", 52 * 1024))
+# wider rows hold more registers per lane, so fewer workgroups fit a CU whatever the LDS use:
+# D = 128 (120 VGPRs) runs 2 x 512 threads per CU, D = 256 (179 VGPRs) one -- their launches may
+# stage more of the program (each extra launch re-reads and re-writes all the rows)
+MFMA_BUDGET_WIDE = {128: 76 * 1024, 256: 150 * 1024}
 MAX_OPS = 96
 
 
@@ -313,7 +317,8 @@ def compile_chain(composition, direction: int, device: torch.device,
         # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
         # gets a launch of its own, and the small elementwise ops around it ride along
         small = kind in (OP_EW_MULADD, OP_EW_SUBDIV)
-        over = (used + n) * 4 > (MAX_PARAM_BYTES_MFMA if mfma else MAX_PARAM_BYTES)
+        budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(D, 0)) if mfma else MAX_PARAM_BYTES
+        over = (used + n) * 4 > budget
         if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
             segments.append(Segment(ops, torch.cat(blocks).contiguous(), mfma))
             ops, blocks, used = [], [], 0
