@@ -34,6 +34,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4     # wave64 instructions / s (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak (= fp32-input MFMA peak), same guide
 WORKLOADS = {
@@ -223,6 +224,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true",
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
+    ap.add_argument("--no-sample", action="store_true", help="skip the Flow.sample throughput leg")
     ap.add_argument("--no-mfma", action="store_true",
                     help="fused flow programs on the VALU interpreter (k_flow_run) instead of k_flow_run_mfma")
     args = ap.parse_args()
@@ -300,16 +302,35 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         if dom_name.startswith("flow_run"):
-            # conditioner fused in-kernel: h never reaches HBM, the kernel is fp32-VALU-bound
-            # (report against the fp32 vector peak, and say so)
-            roofline = {"bound": "valu", "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+            # conditioner fused in-kernel: h never reaches HBM.  SURVEY.md 8(d): report the fused
+            # kernel against the fp32 matrix / vector peak (the same 157.3 TFLOP/s) and say so.
+            # The GEMMs of flow_run_mfma run on the matrix cores ("mfma"); what actually limits
+            # both kernels is vector-ALU issue of the transform's exp / log / divide ("limiter").
+            valu = None
+            try:
+                valu = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(
+                    dom_name + ":valu_insts")
+                if valu is not None and rows != WORKLOADS[args.workload][3]:
+                    valu = None
+            except (OSError, KeyError, ValueError):
+                pass
+            roofline = {"bound": "mfma" if dom_name == "flow_run_mfma" else "valu",
+                        "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
+                        "limiter": "valu-issue",
                         "note": "fused flow program (conditioner in-kernel" +
                                 (", GEMMs as v_mfma_f32_16x16x4_f32" if dom_name == "flow_run_mfma" else "") +
-                                "): fp32 vector-ALU bound; achieved = algorithmic conditioner FLOPs "
-                                "2*(S*H+H*T*P) per row-layer / launch time, transcendentals of the "
-                                "transform not counted; peak = fp32 vector = fp32-input MFMA peak",
+                                "); achieved = algorithmic conditioner FLOPs 2*(S*H+H*T*P) per row-layer "
+                                "/ launch time (the transform's transcendentals are not counted); peak = "
+                                "dense fp32 matrix peak; the kernel is limited by vector-ALU issue, see "
+                                "valu_issue_frac",
                         "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
+            if valu is not None:
+                # wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / live duration
+                # against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz
+                rate = valu / (dom["avg_us"] * 1e-6)
+                roofline["valu_insts_per_launch"] = valu
+                roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
         else:
             roofline = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
@@ -373,6 +394,22 @@ def main():
                 "bytes_per_launch": lw[lw_name]["bytes_per_launch"], "avg_us": lw[lw_name]["avg_us"],
                 "launches": lw[lw_name]["launches"], "evals_per_s": rows * 3 / lw_elapsed,
                 "note": "same workload with TORCHFLOWS_AMD_FUSED=0 (bench.py --no-fused), 3 steps"}
+        if world == 1 and not args.no_sample:
+            # sample throughput next to log_prob (Flow.sample = base draw +
+            # bijection.inverse with log-det, flows.py:117-146), same rows, not part of `value`
+            srows = step_rows
+            with torch.no_grad():
+                flow.sample((srows,), return_log_prob=True)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(3):
+                    xs, lps = flow.sample((srows,), return_log_prob=True)
+                torch.cuda.synchronize()
+                s_elapsed = time.perf_counter() - t2
+            result["sample"] = {"value": srows * 3 / s_elapsed, "unit": "samples/s", "rows": srows,
+                                "note": "Flow.sample((rows,), return_log_prob=True): torch.randn base "
+                                        "draw + inverse flow program, 3 calls"}
+            del xs, lps
         if world == 1 and not args.no_cpu_baseline and not isinstance(D, tuple):
             base, ref = cpu_baseline(arch, D, n_layers, flow_host)
             result["cpu_baseline"] = base

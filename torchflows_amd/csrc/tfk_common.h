@@ -11,6 +11,11 @@ namespace tfk {
 constexpr int kWave = 64;         // CDNA4 wavefront
 constexpr int kBlock = 256;       // 4 waves, one per SIMD
 constexpr int kCUs = 256;         // MI355X
+// Grid of the compute-bound flow-program kernels, in resident sets of workgroups.  With exactly
+// one resident set every CU gets the same share and the launch ends with the slowest CU; measured
+// on MI355X (RealNVP D=64, 2^20 rows): 1 set 557 us, 1.5 sets 543, 2 sets 531, 4 sets 511,
+// 8 sets 504, 16 sets 511 (each workgroup re-stages its parameter block from L2).
+constexpr int kGridOversubscribe = 4;
 constexpr int kMaxGrid = kCUs * 8;  // memory-bound kernels: <= 8 resident blocks per CU, grid-stride the rest
 
 // affine.py:19-23 -- python doubles rounded once to fp32, as ATen does when a python

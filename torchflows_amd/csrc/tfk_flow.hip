@@ -388,7 +388,7 @@ static int launch_flow_b(const float *x, float *z, float *logdet, const float *l
     if (per_cu < 1) per_cu = 1;
     constexpr int rows_per_block = R * (BLOCK / G);
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu;
+    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((k_flow_run<G, BLOCK, R>), dim3(grid), dim3(BLOCK), lds, s,
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(z), logdet,

@@ -339,12 +339,17 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
             return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
         }
     }
-    int per_cu = 2048 / BLOCK;                       // 32 waves per CU
-    if ((int)((160 * 1024) / lds) < per_cu) per_cu = (int)((160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
+    // resident workgroups per CU as the runtime computes them (registers, LDS, wave slots); the
+    // grid is a few resident sets, grid-strided over the rows (kGridOversubscribe, tfk_common.h)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK>, BLOCK, lds) != hipSuccess
+        || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu;
+    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
                        log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
