@@ -409,6 +409,203 @@ void orc_rqs_inv(const float *z, const float *h, float *x, float *logdet,
                 bin_idx ? bin_idx + n * T : NULL, T, K, boundary, 1);
 }
 
+/* ---- reverse mode ------------------------------------------
+ * The reference has no backward code of its own: its gradients are what torch.autograd
+ * derives from the forward graphs restated above.  The functions below are the
+ * hand-derived reverse mode of exactly those graphs (same masks, same clip
+ * sub-gradients, same constant knots), pinned to the reference's autograd outputs in
+ * tests/golden/grads*.npz.  Upstream: gz (N,T) = dL/d out, gld (N,) = dL/d logdet.
+ * Outputs: gx (N,T) = dL/d x, gh (N,T,P) = dL/d h (both OVERWRITTEN). */
+
+void orc_affine_bwd(const float *x, const float *h, const float *gz, const float *gld,
+                    float *gx, float *gh, int64_t N, int T, int inverse)
+{
+    for (int64_t n = 0; n < N; ++n)
+        for (int t = 0; t < T; ++t) {
+            const int64_t i = n * T + t;
+            const float e = expf(h[2 * i] / 2.0f + aff_c0());   /* affine.py:33-34 */
+            const float alpha = e + AFF_MIN_SCALE;
+            const float beta = h[2 * i + 1];
+            float galpha;
+            if (!inverse) {               /* out = alpha x + beta, ld = +sum log alpha */
+                gx[i] = gz[i] * alpha;
+                gh[2 * i + 1] = gz[i];
+                galpha = gz[i] * x[i] + gld[n] / alpha;
+            } else {                      /* out = (x - beta) / alpha, ld = -sum log alpha */
+                const float r = gz[i] / alpha;
+                gx[i] = r;
+                gh[2 * i + 1] = -r;
+                galpha = -r * ((x[i] - beta) / alpha) - gld[n] / alpha;
+            }
+            gh[2 * i] = galpha * e * 0.5f;      /* d alpha / d u = exp(c + u/2) / 2 */
+        }
+}
+
+/* softmax weights of compute_bins (same arithmetic as rqs_bins) */
+static void rqs_softmax(const float *u, int K, float *sm)
+{
+    float mx = u[0];
+    for (int j = 1; j < K; ++j) mx = u[j] > mx ? u[j] : mx;
+    float sum = 0.0f;
+    for (int j = 0; j < K; ++j) {
+        sm[j] = expf(u[j] - mx);
+        sum += sm[j];
+    }
+    const float rsum = 1.0f / sum;
+    for (int j = 0; j < K; ++j) sm[j] = sm[j] * rsum;
+}
+
+/* F.softplus'(t), beta = 1, threshold = 20 (ATen: z = exp(t); z / (z + 1)) */
+static inline float softplus_grad(float t)
+{
+    if (t > 20.0f) return 1.0f;
+    const float z = expf(t);
+    return z / (z + 1.0f);
+}
+
+/* One in-box element.  F(x, theta) = rqs_forward_1d output, L(x, theta) = its log-det.
+ * forward direction:  out = F(v),  ld = L(v):        upstream (A, B) on (out, ld).
+ * inverse direction:  out = X with F(X) = v,  ld = -L(X)  (rational_quadratic.py:130-182
+ *   solves the same rational quadratic in closed form); by implicit differentiation
+ *   dX/dv = 1/F_x,  dX/dtheta = -F_theta/F_x,  so with G = A - B L_x the gradients are
+ *   those of the forward direction for the upstream pair (-G/F_x, -B) at x = X, and
+ *   gv = G/F_x. */
+static void rqs_element_bwd(float v, const float *h, int K, float boundary, int inverse,
+                            float A, float B, float *gv, float *gh)
+{
+    const int P = 3 * K - 1;
+    const float c = (float)rqs_boundary_u_delta();
+    const float scale = (float)(1.0 - 1e-3 * (double)K);
+    const float span = (float)((double)boundary + (double)boundary);
+    rqs_knots kn;
+    rqs_build(h, K, boundary, &kn);
+    for (int j = 0; j < P; ++j) gh[j] = 0.0f;
+
+    float xin = v;
+    int k;
+    if (!inverse) {
+        int cnt = 0;
+        for (int j = 0; j <= K; ++j) cnt += (kn.bin_x[j] < v);
+        k = cnt - 1;
+    } else {
+        float o, l;
+        int32_t kk;
+        rqs_element(v, h, K, boundary, 1, &o, &l, &kk);
+        k = kk;
+        xin = o;                                   /* X = F^-1(v) */
+    }
+    const float bx = kn.bin_x[k];
+    const float wk = kn.bin_w[k], hk = kn.bin_h[k];
+    const float dk = kn.delta[k], dk1 = kn.delta[k + 1];
+    const float s = hk / wk;
+    const float term1 = dk1 + dk - 2.0f * s;
+    const float xi_raw = (xin - bx) / wk;
+    const float xi = clipf(xi_raw, 0.0f, 1.0f);
+    const int pass = (xi_raw >= 0.0f && xi_raw <= 1.0f);   /* torch.clip sub-gradient */
+    const float omx = 1.0f - xi;
+    const float q = xi * omx;
+    const float inner2 = s * (xi * xi) + dk * q;
+    const float num0 = hk * inner2;
+    const float den0 = s + term1 * q;
+    const float inner = dk1 * (xi * xi) + (2.0f * s) * q + dk * (omx * omx);
+
+    /* d F / d xi and d L / d xi (everything else held fixed) */
+    const float dq = 1.0f - 2.0f * xi;
+    const float F_xi = (hk * (2.0f * s * xi + dk * dq)) / den0 - (num0 / (den0 * den0)) * (term1 * dq);
+    const float L_xi = (2.0f * dk1 * xi + 2.0f * s * dq - 2.0f * dk * omx) / inner
+                       - 2.0f * (term1 * dq) / den0;
+    const float F_x = pass ? F_xi / wk : 0.0f;
+    const float L_x = pass ? L_xi / wk : 0.0f;
+    if (inverse) {
+        const float G = A - B * L_x;               /* d loss / d X, with ld_inv = -L(X) */
+        *gv = G / F_x;
+        A = -(G / F_x);
+        B = -B;
+    } else {
+        *gv = A * F_x + B * L_x;
+    }
+
+    /* reverse sweep of the forward graph for upstream (A, B) */
+    float g_s = 0.0f, g_q = 0.0f, g_xi = 0.0f, g_d0 = 0.0f, g_d1 = 0.0f;
+    float g_hk = 0.0f, g_wk = 0.0f, g_by = A;
+    const float g_num0 = A / den0;
+    float g_den0 = -A * num0 / (den0 * den0);
+    g_s += B * 2.0f / s;
+    const float g_inner = B / inner;
+    g_den0 += -2.0f * B / den0;
+    g_d1 += g_inner * (xi * xi);
+    g_s += g_inner * 2.0f * q;
+    g_q += g_inner * 2.0f * s;
+    g_d0 += g_inner * (omx * omx);
+    g_xi += g_inner * (2.0f * dk1 * xi - 2.0f * dk * omx);
+    g_s += g_den0;
+    const float g_t1 = g_den0 * q;
+    g_q += g_den0 * term1;
+    g_hk += g_num0 * inner2;
+    const float g_in2 = g_num0 * hk;
+    g_s += g_in2 * (xi * xi);
+    g_xi += g_in2 * 2.0f * s * xi;
+    g_d0 += g_in2 * q;
+    g_q += g_in2 * dk;
+    g_d1 += g_t1;
+    g_d0 += g_t1;
+    g_s -= 2.0f * g_t1;
+    g_xi += g_q * dq;
+    float g_bx = 0.0f;
+    if (pass) {                                    /* xi = (x - bx) / wk */
+        g_bx -= g_xi / wk;
+        g_wk -= g_xi * xi_raw / wk;
+    }
+    g_hk += g_s / wk;                              /* s = hk / wk */
+    g_wk -= g_s * s / wk;
+    /* wk = bin_x[k+1] - bin_x[k], hk = bin_y[k+1] - bin_y[k]; knots 0 and K are constants */
+    const float g_x0 = g_bx - g_wk, g_x1 = g_wk;
+    const float g_y0 = g_by - g_hk, g_y1 = g_hk;
+    const float gcx0 = (k >= 1) ? span * g_x0 : 0.0f, gcx1 = (k + 1 <= K - 1) ? span * g_x1 : 0.0f;
+    const float gcy0 = (k >= 1) ? span * g_y0 : 0.0f, gcy1 = (k + 1 <= K - 1) ? span * g_y1 : 0.0f;
+    float ux[ORC_MAX_BINS], uy[ORC_MAX_BINS], smx[ORC_MAX_BINS], smy[ORC_MAX_BINS];
+    for (int j = 0; j < K; ++j) {
+        ux[j] = h[j];
+        uy[j] = h[j] + h[K + j] / 1000.0f;
+    }
+    rqs_softmax(ux, K, smx);
+    rqs_softmax(uy, K, smy);
+    float gwx[ORC_MAX_BINS], gwy[ORC_MAX_BINS], dotx = 0.0f, doty = 0.0f;
+    for (int i = 0; i < K; ++i) {                  /* cumsum: knot j sums bins i < j */
+        gwx[i] = scale * ((i < k ? gcx0 : 0.0f) + (i < k + 1 ? gcx1 : 0.0f));
+        gwy[i] = scale * ((i < k ? gcy0 : 0.0f) + (i < k + 1 ? gcy1 : 0.0f));
+        dotx += smx[i] * gwx[i];
+        doty += smy[i] * gwy[i];
+    }
+    for (int i = 0; i < K; ++i) {                  /* softmax backward */
+        const float gux = smx[i] * (gwx[i] - dotx);
+        const float guy = smy[i] * (gwy[i] - doty);
+        gh[i] = gux + guy;                         /* u_y enters as u_x + u_y / 1000 */
+        gh[K + i] = guy / 1000.0f;
+    }
+    if (k >= 1)
+        gh[2 * K + k - 1] = g_d0 * softplus_grad(c + h[2 * K + k - 1] / 1000.0f) / 1000.0f;
+    if (k <= K - 2)
+        gh[2 * K + k] = g_d1 * softplus_grad(c + h[2 * K + k] / 1000.0f) / 1000.0f;
+}
+
+void orc_rqs_bwd(const float *x, const float *h, const float *gz, const float *gld,
+                 float *gx, float *gh, int64_t N, int T, int K, float boundary, int inverse)
+{
+    const int P = 3 * K - 1;
+    for (int64_t n = 0; n < N; ++n)
+        for (int t = 0; t < T; ++t) {
+            const int64_t i = n * T + t;
+            const float v = x[i];
+            if (v > -boundary && v < boundary) {
+                rqs_element_bwd(v, h + i * P, K, boundary, inverse, gz[i], gld[n], gx + i, gh + i * P);
+            } else {                               /* identity outside the box, base.py:54-55 */
+                gx[i] = gz[i];
+                for (int j = 0; j < P; ++j) gh[i * P + j] = 0.0f;
+            }
+        }
+}
+
 /* ---- base distribution --------------------------------------------------- */
 
 static float gauss_row(const float *z, const float *loc, const float *log_scale, int D)

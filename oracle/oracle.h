@@ -73,6 +73,15 @@ void orc_rqs_inv(const float *z, const float *h, float *x, float *logdet,
                  float *logdet_el, int32_t *bin_idx,
                  int64_t N, int T, int K, float boundary);
 
+/* Reverse mode of the two transformers above (what torch.autograd derives from
+ * affine.py:33-59 and rational_quadratic.py:45-200; the reference has no backward code).
+ * gz (N,T) = dL/d out, gld (N,) = dL/d logdet; gx (N,T), gh (N,T,P) OVERWRITTEN.
+ * inverse != 0: gradients of the inverse-direction maps (x = first argument of *_inv). */
+void orc_affine_bwd(const float *x, const float *h, const float *gz, const float *gld,
+                    float *gx, float *gh, int64_t N, int T, int inverse);
+void orc_rqs_bwd(const float *x, const float *h, const float *gz, const float *gld,
+                 float *gx, float *gh, int64_t N, int T, int K, float boundary, int inverse);
+
 /* Invertible1x1ConvolutionTransformer + LUTransformer
  * (transformers/linear/convolution.py:33-70, transformers/linear/matrix.py:20-82) on
  * x (N, n, HW) channel-major with h (N, n + n(n-1)); logdet (N,) OVERWRITTEN with

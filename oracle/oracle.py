@@ -88,6 +88,9 @@ def lib() -> C.CDLL:
         for name in ("orc_rqs_fwd", "orc_rqs_inv"):
             getattr(L, name).argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _i32p,
                                          C.c_int64, C.c_int, C.c_int, C.c_float]
+        L.orc_affine_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int]
+        L.orc_rqs_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int,
+                                  C.c_int, C.c_float, C.c_int]
         L.orc_rqs_knots.argtypes = [_f32p, C.c_int64, C.c_int, C.c_float, _f32p, _f32p, _f32p]
         L.orc_diag_gauss_logprob.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int]
         L.orc_composition_forward.argtypes = [C.POINTER(_OrcLayer), C.c_int, _f32p, _f32p,
@@ -206,6 +209,29 @@ def rqs(x, h, n_bins: int = 8, boundary: float = 50.0, inverse: bool = False):
     fn = lib().orc_rqs_inv if inverse else lib().orc_rqs_fwd
     fn(_fp(x), _fp(h), _fp(out), _fp(ld), _fp(ld_el), _ip(k), N, T, n_bins, boundary)
     return out, ld, ld_el, k
+
+
+def affine_bwd(x, h, gz, gld, inverse: bool = False):
+    """Reverse mode of ``affine``: (gx (N,T), gh (N,T,2)) for upstream gz (N,T), gld (N,)."""
+    x, h, gz, gld = _f32(x), _f32(h), _f32(gz), _f32(gld)
+    N, T = x.shape
+    assert h.shape == (N, T, 2) and gz.shape == (N, T) and gld.shape == (N,)
+    gx = np.empty_like(x)
+    gh = np.empty_like(h)
+    lib().orc_affine_bwd(_fp(x), _fp(h), _fp(gz), _fp(gld), _fp(gx), _fp(gh), N, T, int(inverse))
+    return gx, gh
+
+
+def rqs_bwd(x, h, gz, gld, n_bins: int = 8, boundary: float = 50.0, inverse: bool = False):
+    """Reverse mode of ``rqs``: (gx (N,T), gh (N,T,3K-1))."""
+    x, h, gz, gld = _f32(x), _f32(h), _f32(gz), _f32(gld)
+    N, T = x.shape
+    assert h.shape == (N, T, 3 * n_bins - 1) and gz.shape == (N, T) and gld.shape == (N,)
+    gx = np.empty_like(x)
+    gh = np.empty_like(h)
+    lib().orc_rqs_bwd(_fp(x), _fp(h), _fp(gz), _fp(gld), _fp(gx), _fp(gh), N, T, n_bins,
+                      boundary, int(inverse))
+    return gx, gh
 
 
 def rqs_knots(h, n_bins: int = 8, boundary: float = 50.0):
@@ -352,6 +378,61 @@ class OracleFlow:
         lib().orc_flow_log_prob(self._arr, len(self.layers), _fp(self.loc), _fp(self.log_scale),
                                 _fp(x), _fp(ctx), self.C, _fp(z), _fp(lp), N, self.D)
         return (z, lp) if return_z else lp
+
+    def log_prob_grad(self, x, g_lp=None):
+        """Reverse mode of ``log_prob`` (flows.py:628-658 as torch.autograd differentiates it):
+        returns ``(gx (N,D), grads)`` for the upstream ``g_lp`` (N,) = d loss / d log_prob
+        (default: ones).  ``grads[i]`` is a dict for layer i with ``value`` (D,2) and / or
+        ``weights`` / ``biases`` lists.  Conditioners without a context only."""
+        assert self.C == 0
+        x = _f32(x).reshape(-1, self.D)
+        N, D = x.shape
+        g = np.ones(N, np.float32) if g_lp is None else _f32(g_lp).reshape(N)
+        z, _, tz, _ = self.forward(x, trace=True)
+        scale2 = np.exp(self.log_scale).astype(np.float32) ** 2
+        g_rows = (-(z - self.loc) / scale2 * g[:, None]).astype(np.float32)   # gaussian.py:46-54
+        g_ld = g.copy()                                                       # flows.py:647-648
+        grads = [dict() for _ in self.layers]
+        for i in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[i]
+            x_in = x if i == 0 else tz[i - 1]
+            if L.kind in (ELEMENTWISE_AFFINE, ELEMENTWISE_INVERSE_AFFINE):
+                h = np.broadcast_to(L.value[None], (N, D, 2))
+                g_rows, gh = affine_bwd(x_in, h, g_rows, g_ld,
+                                        inverse=(L.kind == ELEMENTWISE_INVERSE_AFFINE))
+                grads[i]["value"] = gh.sum(axis=0, dtype=np.float32)
+            elif L.kind == PERMUTATION:
+                g_rows = np.ascontiguousarray(g_rows[:, L.perm_inv])          # z_j = x[perm_fwd[j]]
+            else:
+                xa = x_in[:, L.src_idx]
+                acts = [xa]                                   # conditioner forward, transforms.py:293-307
+                for li, (W, b) in enumerate(zip(L.weights, L.biases)):
+                    pre = acts[-1] @ W.T + b
+                    acts.append(pre if li == len(L.weights) - 1 else np.tanh(pre).astype(np.float32))
+                hflat = _f32(acts[-1])
+                T = L.tgt_idx.size
+                xb = _f32(x_in[:, L.tgt_idx])
+                gzb = _f32(g_rows[:, L.tgt_idx])
+                if L.kind == AFFINE_COUPLING:
+                    gxb, gh = affine_bwd(xb, hflat.reshape(N, T, 2), gzb, g_ld)
+                elif L.kind == RQS_COUPLING:
+                    gxb, gh = rqs_bwd(xb, hflat.reshape(N, T, -1), gzb, g_ld, L.n_bins, L.boundary)
+                else:                                         # Shift: z = x + h, log-det 0
+                    gxb, gh = gzb, gzb
+                gcur = _f32(gh).reshape(N, -1)
+                gW, gb = [None] * len(L.weights), [None] * len(L.weights)
+                for li in range(len(L.weights) - 1, -1, -1):
+                    gW[li] = (gcur.T @ acts[li]).astype(np.float32)
+                    gb[li] = gcur.sum(axis=0, dtype=np.float32)
+                    gcur = gcur @ L.weights[li]
+                    if li > 0:
+                        gcur = (gcur * (1.0 - acts[li] ** 2)).astype(np.float32)   # tanh'
+                grads[i]["weights"], grads[i]["biases"] = gW, gb
+                g_new = g_rows.copy()
+                g_new[:, L.tgt_idx] = gxb
+                g_new[:, L.src_idx] += gcur
+                g_rows = g_new
+        return g_rows, grads
 
     def sample_log_prob(self, z, context=None):
         """Flow.sample(return_log_prob=True) on a given base draw z:

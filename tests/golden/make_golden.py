@@ -370,6 +370,88 @@ def gen_image():
     save("flow_glow_3x8x8.npz", **out)
 
 
+# ---------------------------------------------------------------- F8 gradients
+def _tr_grads(tr, x, h, gz, gld, inverse, dtype):
+    x = x.to(dtype).clone().requires_grad_(True)
+    h = h.to(dtype).clone().requires_grad_(True)
+    out, ld = (tr.inverse if inverse else tr.forward)(x, h)
+    loss = (out * gz.to(dtype)).sum() + (ld * gld.to(dtype)).sum()
+    gx, gh = torch.autograd.grad(loss, (x, h))
+    return np32(gx), np32(gh)
+
+
+def gen_grads():
+    """Reverse-mode gradients of the reference (its autograd graph), transformer level and
+    whole-flow level, fp32 and fp64 (the fp64 run is the noise floor)."""
+    out = {}
+    torch.manual_seed(7)
+    for T in (2, 32):
+        tr = Affine((T,))
+        x = torch.randn(48, T) * 2
+        h = torch.randn(48, T, 2)
+        h[0] = 0.0
+        h[1, :, 0] = 12.0
+        h[2, :, 0] = -12.0
+        gz, gld = torch.randn(48, T), torch.randn(48)
+        out.update({f"affine_T{T}_x": np32(x), f"affine_T{T}_h": np32(h),
+                    f"affine_T{T}_gz": np32(gz), f"affine_T{T}_gld": np32(gld)})
+        for inverse in (False, True):
+            for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+                gx, gh = _tr_grads(tr, x, h, gz, gld, inverse, dt)
+                d = "inv" if inverse else "fwd"
+                out[f"affine_T{T}_{d}_gx{tag}"] = gx
+                out[f"affine_T{T}_{d}_gh{tag}"] = gh
+    rq = np.load(os.path.join(OUT, "rqs.npz"))
+    cases = []
+    for tag, boundary, n_bins in (("B50_K8", 50.0, 8), ("B5_K8", 5.0, 8), ("B5_K4", 5.0, 4)):
+        x = torch.from_numpy(rq[f"{tag}_x"])
+        h = torch.from_numpy(rq[f"{tag}_h"])
+        T = x.shape[1]
+        tr = RationalQuadratic((T,), boundary=boundary, n_bins=n_bins)
+        gz, gld = torch.randn(*x.shape), torch.randn(x.shape[0])
+        out[f"rqs_{tag}_gz"] = np32(gz)
+        out[f"rqs_{tag}_gld"] = np32(gld)
+        for inverse in (False, True):
+            for dt, t2 in ((torch.float32, ""), (torch.float64, "64")):
+                gx, gh = _tr_grads(tr, x, h, gz, gld, inverse, dt)
+                d = "inv" if inverse else "fwd"
+                out[f"rqs_{tag}_{d}_gx{t2}"] = gx
+                out[f"rqs_{tag}_{d}_gh{t2}"] = gh
+        cases.append(tag)
+    out["rqs_cases"] = np.array(cases)
+    save("grads.npz", **out)
+
+    # whole flows: weights and x of the existing flow fixtures ("init" variant)
+    flows = [("flow_realnvp3.npz", RealNVP, 3, {}),
+             ("flow_realnvp64.npz", RealNVP, 64, dict(n_layers=8)),
+             ("flow_nsf64.npz", CouplingRQNSF, 64, dict(n_layers=8)),
+             ("flow_nice7.npz", NICE, 7, {}),
+             ("flow_realnvp_7x11.npz", RealNVP, (7, 11), {})]
+    for fname, ctor, es, kw in flows:
+        fx = np.load(os.path.join(OUT, fname))
+        sd = {k[len("sd_init/"):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd_init/")}
+        x = torch.from_numpy(fx["x"])
+        g = torch.Generator().manual_seed(99)
+        w = torch.rand(x.shape[0], generator=g) + 0.5          # per-row upstream gradient
+        o = {"w": np32(w)}
+        for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+            flow = Flow(ctor(es, **kw)).to(dt)
+            flow.load_state_dict({k: v.to(dt) for k, v in sd.items()})
+            flow.eval()
+            xx = x.to(dt).clone().requires_grad_(True)
+            lp = flow.log_prob(xx)
+            loss = (lp * w.to(dt)).sum()
+            names = [n for n, p_ in flow.named_parameters() if p_.requires_grad]
+            params = [p_ for n, p_ in flow.named_parameters() if p_.requires_grad]
+            grads = torch.autograd.grad(loss, [xx] + params, allow_unused=True)
+            o[f"gx{tag}"] = np32(grads[0])
+            for n, gr in zip(names, grads[1:]):
+                o[f"g{tag}/{n}"] = np32(gr if gr is not None else torch.zeros(()))
+        # ActNorm values carry no gradient in the reference (requires_grad False, layers.py:49)
+        o["trainable"] = np.array(names)
+        save("grads_" + fname, **o)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows", "image"]
     for w in which:
