@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 4
+#define TFK_ABI_VERSION 5
 
 enum {
     TFK_OK = 0,
@@ -210,6 +210,37 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                       const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
                       int32_t accumulate, void *stream);
+
+/* ---- reverse mode of the layer kernels ------------------------------------
+ * The reference has no backward code; these replace what torch.autograd derives from
+ * affine.py:36-59, spline/base.py:53-72 + rational_quadratic.py:45-200, layers_base.py:237-318
+ * and gaussian.py:46-54.  Recompute, not store: the kernels take the layer INPUT rows x and the
+ * conditioner output h of the forward call, nothing else is kept between the two launches.
+ *   g   (N, D) in/out: the gradient row buffer of the composition.  On entry its target columns
+ *       hold dL/d(out rows), on exit dL/d(x target); pass-through columns are untouched (the
+ *       conditioner's contribution to them is the caller's GEMM backward).
+ *   gld (N,)   dL/d(log-det of this layer) = dL/d(total log-det)
+ *   gh  (N, T, P) out: dL/dh, same layout as h.
+ * inverse != 0: backward of the *_inv entry point (x = the rows that call received). */
+int tfk_affine_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                            int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t inverse,
+                            void *stream);
+int tfk_shift_coupling_bwd(const float *g, float *gh, int64_t N, int32_t D, const int32_t *tgt_idx,
+                           int32_t T, int32_t inverse, void *stream);
+int tfk_rqs_coupling_bwd_supported(int32_t n_bins);             /* 4, 8, 16 */
+int tfk_rqs_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                         int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t n_bins,
+                         float boundary, int32_t inverse, void *stream);
+/* ElementwiseAffine / ActNorm with batch-constant value (D, 2): g updated in place over all D
+ * columns; gvalue (D, 2) = sum over rows of dL/dvalue (deterministic two-stage sum), or NULL to
+ * skip it (ActNorm's value does not train, layers.py:49) -- then x, gld, workspace may be NULL. */
+int64_t tfk_elementwise_affine_bwd_workspace_bytes(int64_t N, int32_t D);
+int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, const float *gld,
+                               float *gvalue, float *workspace, int64_t N, int32_t D,
+                               int32_t inverse, void *stream);
+/* g (N, D) out = glp[row] * d log N(z; loc, exp(log_scale)) / dz */
+int tfk_diag_gauss_logprob_bwd(const float *z, const float *loc, const float *log_scale,
+                               const float *glp, float *g, int64_t N, int32_t D, void *stream);
 
 #ifdef __cplusplus
 }

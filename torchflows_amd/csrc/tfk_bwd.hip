@@ -1,0 +1,577 @@
+// tfk_bwd.hip -- reverse mode of the layer kernels (training on the HIP path).
+//
+// The reference has no backward code: its gradients are what torch.autograd derives from
+//   Affine.forward / inverse                 transformers/linear/affine.py:36-59
+//   MonotonicSpline + RationalQuadratic      transformers/spline/base.py:53-72,
+//                                            transformers/spline/rational_quadratic.py:45-200
+//   ElementwiseBijection (ElementwiseAffine, ActNorm)     layers_base.py:237-318
+//   DiagonalGaussian.log_prob                base_distributions/gaussian.py:46-54
+// The kernels below are the hand-derived reverse mode of exactly those graphs (same clip
+// sub-gradients, same constant boundary knots, identity outside the spline box), checked
+// against oracle/oracle.c:orc_*_bwd, which is pinned to the reference's autograd outputs
+// (tests/golden/grads*.npz).
+//
+// Recompute, not store: a backward kernel receives the layer INPUT rows x and the conditioner
+// output h and rebuilds alpha / knots / bins itself; nothing from the forward launch is kept.
+// Data movement: `g` is the (N, D) gradient row buffer of the whole composition, updated IN
+// PLACE -- on entry the target columns hold dL/d(out), on exit dL/d(x_target); the pass-through
+// columns are not touched (their conditioner contribution is added by the caller).  gh (N, T, P)
+// is written once, coalesced.  All kernels are HBM-bound streams.
+#include "tfk_common.h"
+#include "tfk_spline.h"
+
+namespace tfk {
+
+// ---------------------------------------------------------------------------------------------
+// affine / shift coupling: one lane per target element
+//   bytes per element: x 4 + h 8 + g 4 (+4 written) + gh 8 written (+ gld, shared per row)
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(kBlock) void k_affine_coupling_bwd(
+    const float *__restrict__ x, const float *__restrict__ h, float *g, const float *__restrict__ gld,
+    float *__restrict__ gh, long long N, int D, const int *__restrict__ tgt_idx, int T)
+{
+    const long long total = N * (long long)T;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const long long row = e / T;
+        const int t = (int)(e - row * T);
+        const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
+        const float2 hh = reinterpret_cast<const float2 *>(h)[e];
+        const float ex = exp_noovf(hh.x * 0.5f + kAffC0);           // affine.py:33-34
+        const float alpha = ex + kAffMinScale;
+        const float ra = __builtin_amdgcn_rcpf(alpha);
+        const float gz = g[row * D + idx];
+        const float xv = x[row * D + idx];
+        const float gl = gld[row];
+        float gx, gbeta, galpha;
+        if (!INVERSE) {                 // out = alpha x + beta, ld = +sum log alpha
+            gx = gz * alpha;
+            gbeta = gz;
+            galpha = gz * xv + gl * ra;
+        } else {                        // out = (x - beta) / alpha, ld = -sum log alpha
+            const float r = gz * ra;
+            gx = r;
+            gbeta = -r;
+            galpha = -r * ((xv - hh.y) * ra) - gl * ra;
+        }
+        g[row * D + idx] = gx;
+        reinterpret_cast<float2 *>(gh)[e] = make_float2(galpha * ex * 0.5f, gbeta);
+    }
+}
+
+// shift coupling (affine.py:137-159): out = x +/- h, log-det 0: gh = +/- g[:, target]
+__global__ __launch_bounds__(kBlock) void k_shift_coupling_bwd(
+    const float *__restrict__ g, float *__restrict__ gh, long long N, int D,
+    const int *__restrict__ tgt_idx, int T, float sign)
+{
+    const long long total = N * (long long)T;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const long long row = e / T;
+        const int t = (int)(e - row * T);
+        const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
+        gh[e] = sign * g[row * D + idx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RQ-spline coupling.  F(x, theta) = rqs_forward_1d, L(x, theta) = its log-det.
+//   forward direction: out = F(v), ld = L(v); upstream (A, B) on (out, ld).
+//   inverse direction: out = X with F(X) = v, ld = -L(X).  Implicit differentiation:
+//     dX/dv = 1/F_x, dX/dtheta = -F_theta/F_x, so with G = A - B L_x the parameter gradients
+//     are those of the forward graph at x = X for the upstream pair (-G/F_x, -B), gv = G/F_x.
+//     (If the root was clipped the reference's graph has xi constant: gv = 0 and A reaches
+//     only the knots through out = xi w + x_k.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus20_grad(float t) {        // ATen: z = exp(t); z / (z + 1)
+    if (t > 20.0f) return 1.0f;
+    const float z = exp_noovf(t);
+    return z * __builtin_amdgcn_rcpf(z + 1.0f);
+}
+
+// p: the element's P = 3K-1 parameters on entry, its parameter gradients on exit.
+template <int KT, bool INVERSE>
+__device__ __forceinline__ void rqs_bwd_eval(float (&p)[3 * KT - 1], float v, const RqsConst &C,
+                                             float A, float B, float &gv)
+{
+    float smx[KT], smy[KT];
+    float mx = 0.0f, my = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const float ux = p[j];
+        const float uy = ux + div_1000(p[KT + j]);                  // rational_quadratic.py:76
+        smx[j] = ux;
+        smy[j] = uy;
+        mx = j ? fmaxf(mx, ux) : ux;
+        my = j ? fmaxf(my, uy) : uy;
+    }
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        smx[j] = exp_noovf(smx[j] - mx);
+        smy[j] = exp_noovf(smy[j] - my);
+        sx += smx[j];
+        sy += smy[j];
+    }
+    const float rx = div_fast(1.0f, sx), ry = div_fast(1.0f, sy);
+    int k = 0;
+    float bxk = C.minimum, bxk1 = C.maximum, byk = C.minimum, byk1 = C.maximum;
+    float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+    bool prev_below = true;
+#pragma unroll
+    for (int j = 1; j <= KT; ++j) {
+        smx[j - 1] = smx[j - 1] * rx;                               // softmax, :46
+        smy[j - 1] = smy[j - 1] * ry;
+        runx = runx + (kRqsMinBin + C.scale * smx[j - 1]);          // :47-48
+        runy = runy + (kRqsMinBin + C.scale * smy[j - 1]);
+        const float kx = (j == KT) ? C.maximum : C.span * runx + C.minimum;
+        const float ky = (j == KT) ? C.maximum : C.span * runy + C.minimum;
+        const bool below = (INVERSE ? ky : kx) < v;                 // searchsorted left, :82 / :147
+        const bool sel = prev_below && !below;
+        k = sel ? j - 1 : k;
+        bxk = sel ? prevx : bxk;
+        bxk1 = sel ? kx : bxk1;
+        byk = sel ? prevy : byk;
+        byk1 = sel ? ky : byk1;
+        prev_below = below;
+        prevx = kx;
+        prevy = ky;
+    }
+    const float wk = bxk1 - bxk, hk = byk1 - byk;
+    float udk = C.c, udk1 = C.c;
+#pragma unroll
+    for (int j = 0; j < KT - 1; ++j) {
+        udk = (k == j + 1) ? p[2 * KT + j] : udk;
+        udk1 = (k == j) ? p[2 * KT + j] : udk1;
+    }
+    const float tdk = C.c + div_1000(udk), tdk1 = C.c + div_1000(udk1);
+    const float dk = kRqsMinDelta + softplus20(tdk);                // :77
+    const float dk1 = kRqsMinDelta + softplus20(tdk1);
+    const float rw = __builtin_amdgcn_rcpf(wk);
+    const float s = div_fast(hk, wk);
+    const float term1 = dk1 + dk - 2.0f * s;
+
+    float xi_raw;
+    if (!INVERSE) {
+        xi_raw = div_fast(v - bxk, wk);                             // :99
+    } else {                                                        // :164-173
+        const float term0 = v - byk;
+        const float term2 = hk * dk;
+        const float a = (hk * s - term2) + term0 * term1;
+        const float b = term2 - term0 * term1;
+        const float c = (-s) * term0;
+        float r = sqrtf(b * b - (4.0f * a) * c);
+        r = r < 0.0f ? 0.0f : r;
+        xi_raw = div_fast(2.0f * c, (-b) - r);
+    }
+    const bool pass = (xi_raw >= 0.0f) && (xi_raw <= 1.0f);         // torch.clip sub-gradient
+    const float xi = clip01(xi_raw);
+    const float omx = 1.0f - xi;
+    const float q = xi * omx;
+    const float inner2 = s * (xi * xi) + dk * q;
+    const float num0 = hk * inner2;
+    const float den0 = s + term1 * q;
+    const float rden = __builtin_amdgcn_rcpf(den0);
+    const float inner = dk1 * (xi * xi) + (2.0f * s) * q + dk * (omx * omx);
+    const float rinner = __builtin_amdgcn_rcpf(inner);
+    const float dq = 1.0f - 2.0f * xi;
+
+    float g_wk = 0.0f, g_bx = 0.0f;
+    if (!INVERSE) {
+        // gv = A F_x + B L_x falls out of the sweep below (through g_xi)
+    } else {
+        const float F_xi = (hk * (2.0f * s * xi + dk * dq)) * rden - (num0 * rden * rden) * (term1 * dq);
+        const float L_xi = (2.0f * dk1 * xi + 2.0f * s * dq - 2.0f * dk * omx) * rinner
+                           - 2.0f * (term1 * dq) * rden;
+        if (pass) {
+            const float F_x = F_xi * rw, L_x = L_xi * rw;
+            const float G = A - B * L_x;                            // d loss / d X (ld_inv = -L(X))
+            gv = div_fast(G, F_x);
+            A = -gv;
+        } else {                                                    // xi is a constant of the graph
+            gv = 0.0f;
+            g_wk = A * xi;                                          // out = xi w + x_k, :178
+            g_bx = A;
+            A = 0.0f;
+        }
+        B = -B;
+    }
+
+    // reverse sweep of the forward graph (:94-109, :56-63) for upstream (A, B)
+    float g_s = 0.0f, g_q = 0.0f, g_xi = 0.0f, g_d0 = 0.0f, g_d1 = 0.0f, g_hk = 0.0f;
+    const float g_by = A;
+    const float g_num0 = A * rden;
+    float g_den0 = -A * num0 * rden * rden;
+    g_s += B * 2.0f * __builtin_amdgcn_rcpf(s);
+    const float g_inner = B * rinner;
+    g_den0 += -2.0f * B * rden;
+    g_d1 += g_inner * (xi * xi);
+    g_s += g_inner * 2.0f * q;
+    g_q += g_inner * 2.0f * s;
+    g_d0 += g_inner * (omx * omx);
+    g_xi += g_inner * (2.0f * dk1 * xi - 2.0f * dk * omx);
+    g_s += g_den0;
+    const float g_t1 = g_den0 * q;
+    g_q += g_den0 * term1;
+    g_hk += g_num0 * inner2;
+    const float g_in2 = g_num0 * hk;
+    g_s += g_in2 * (xi * xi);
+    g_xi += g_in2 * 2.0f * s * xi;
+    g_d0 += g_in2 * q;
+    g_q += g_in2 * dk;
+    g_d1 += g_t1;
+    g_d0 += g_t1;
+    g_s -= 2.0f * g_t1;
+    g_xi += g_q * dq;
+    if (pass) {                                               // xi = (x - x_k) / w
+        if (!INVERSE) gv = g_xi * rw;
+        g_bx -= g_xi * rw;
+        g_wk -= g_xi * xi_raw * rw;
+    } else if (!INVERSE) {
+        gv = 0.0f;
+    }
+    g_hk += g_s * rw;                                               // s = h / w
+    g_wk -= g_s * s * rw;
+    // w = x_{k+1} - x_k, h = y_{k+1} - y_k; knots 0 and K are constants (:51-52)
+    const float g_x0 = g_bx - g_wk, g_x1 = g_wk;
+    const float g_y0 = g_by - g_hk, g_y1 = g_hk;
+    const float sc = C.scale * C.span;
+    const float gcx0 = (k >= 1) ? sc * g_x0 : 0.0f, gcx1 = (k + 1 <= KT - 1) ? sc * g_x1 : 0.0f;
+    const float gcy0 = (k >= 1) ? sc * g_y0 : 0.0f, gcy1 = (k + 1 <= KT - 1) ? sc * g_y1 : 0.0f;
+    float dotx = 0.0f, doty = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {                                  // cumsum: knot j sums bins i < j
+        const float gwx = (i < k ? gcx0 : 0.0f) + (i < k + 1 ? gcx1 : 0.0f);
+        const float gwy = (i < k ? gcy0 : 0.0f) + (i < k + 1 ? gcy1 : 0.0f);
+        dotx += smx[i] * gwx;
+        doty += smy[i] * gwy;
+    }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {                                  // softmax backward
+        const float gwx = (i < k ? gcx0 : 0.0f) + (i < k + 1 ? gcx1 : 0.0f);
+        const float gwy = (i < k ? gcy0 : 0.0f) + (i < k + 1 ? gcy1 : 0.0f);
+        const float gux = smx[i] * (gwx - dotx);
+        const float guy = smy[i] * (gwy - doty);
+        p[i] = gux + guy;                                           // u_y enters as u_x + u_y / 1000
+        p[KT + i] = div_1000(guy);
+    }
+    const float gud0 = div_1000(g_d0 * softplus20_grad(tdk));
+    const float gud1 = div_1000(g_d1 * softplus20_grad(tdk1));
+#pragma unroll
+    for (int j = 0; j < KT - 1; ++j)
+        p[2 * KT + j] = (k == j + 1) ? gud0 : ((k == j) ? gud1 : 0.0f);
+}
+
+// Flat map over the N*T spline elements; a workgroup takes 256 consecutive elements, i.e. 256
+// consecutive parameter records (256*P floats, 16-byte aligned): coalesced float4 loads into
+// LDS, each lane reads its own record at a P-dword stride (conflict-free for odd P), the
+// gradient record goes back through the same LDS slot and out with coalesced float4 stores.
+//   bytes per element: h 4P + gh 4P + x 4 + g 8 (+ gld per row)   (K = 8: 196 B)
+template <int KT, bool INVERSE>
+__global__ __launch_bounds__(kBlock) void k_rqs_coupling_bwd(
+    const float *__restrict__ x, const float *__restrict__ h, float *g, const float *__restrict__ gld,
+    float *__restrict__ gh, long long N, int D, const int *__restrict__ tgt_idx, int T, RqsConst C)
+{
+    constexpr int P = 3 * KT - 1;
+    __shared__ __attribute__((aligned(16))) float rec[kBlock * P];
+    const int tid = threadIdx.x;
+    const long long total = N * (long long)T;
+    const long long n_tiles = (total + kBlock - 1) / kBlock;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long e0 = tile * kBlock;
+        const int E = (int)((total - e0) < (long long)kBlock ? (total - e0) : (long long)kBlock);
+        const int nv = (E * P) >> 2, nfl = E * P;
+        const float4 *src = reinterpret_cast<const float4 *>(h + e0 * P);
+        float4 *dst = reinterpret_cast<float4 *>(rec);
+        __syncthreads();                       // previous tile's stores have read rec
+        for (int i = tid; i < nv; i += kBlock) dst[i] = src[i];
+        for (int i = (nv << 2) + tid; i < nfl; i += kBlock) rec[i] = h[e0 * P + i];
+        __syncthreads();
+        if (tid < E) {
+            const long long e = e0 + tid;
+            const long long row = e / T;
+            const int t = (int)(e - row * T);
+            const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
+            const float v = x[row * D + idx];
+            const float A = g[row * D + idx];
+            float p[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) p[j] = rec[tid * P + j];
+            float gv = A;                      // identity outside the box, spline/base.py:54-55
+            if (v > C.minimum && v < C.maximum) {
+                rqs_bwd_eval<KT, INVERSE>(p, v, C, A, gld[row], gv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < P; ++j) p[j] = 0.0f;
+            }
+            g[row * D + idx] = gv;
+#pragma unroll
+            for (int j = 0; j < P; ++j) rec[tid * P + j] = p[j];
+        }
+        __syncthreads();
+        float4 *out = reinterpret_cast<float4 *>(gh + e0 * P);
+        for (int i = tid; i < nv; i += kBlock) out[i] = dst[i];
+        for (int i = (nv << 2) + tid; i < nfl; i += kBlock) gh[e0 * P + i] = rec[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ElementwiseAffine / ActNorm with batch-constant parameters value (D, 2):
+//   g <- g * alpha (forward form) or g / alpha (inverse form), in place;
+//   gvalue[d] = sum over rows of (d loss / d u_alpha, d loss / d beta)  -- two-stage, deterministic:
+//   a workgroup owns a contiguous slab of rows, thread (ty, tx) walks rows ty, ty + RY, ... of
+//   the slab at columns tx, tx + CW, ...; partials are reduced over ty through LDS and written to
+//   part[block][2 D]; k_colsum_final adds the blocks in index order.
+//   bytes per row: g 8 D (+ x 4 D when the parameter gradient is wanted)
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE, bool WANT_PARAM>
+__global__ __launch_bounds__(kBlock) void k_elementwise_affine_bwd(
+    const float *__restrict__ x, const float *__restrict__ value, float *g,
+    const float *__restrict__ gld, float *__restrict__ part, long long N, int D, int CW,
+    long long rows_per_block)
+{
+    __shared__ float red[2 * kBlock];
+    const int tid = threadIdx.x;
+    const int tx = tid % CW, ty = tid / CW, RY = kBlock / CW;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int c0 = 0; c0 < D; c0 += CW) {
+        const int c = c0 + tx;
+        float sa = 0.0f, sb = 0.0f;
+        if (c < D) {
+            const float u = value[2 * c], beta = value[2 * c + 1];
+            const float ex = exp_noovf(u * 0.5f + kAffC0);
+            const float alpha = ex + kAffMinScale;
+            const float ra = __builtin_amdgcn_rcpf(alpha);
+            for (long long row = r0 + ty; row < r1; row += RY) {
+                const float gz = g[row * D + c];
+                float gx, gb = 0.0f, ga = 0.0f;
+                if (!INVERSE) {
+                    gx = gz * alpha;
+                    if (WANT_PARAM) {
+                        gb = gz;
+                        ga = gz * x[row * D + c] + gld[row] * ra;
+                    }
+                } else {
+                    const float r = gz * ra;
+                    gx = r;
+                    if (WANT_PARAM) {
+                        gb = -r;
+                        ga = -r * ((x[row * D + c] - beta) * ra) - gld[row] * ra;
+                    }
+                }
+                g[row * D + c] = gx;
+                if (WANT_PARAM) {
+                    sa += ga;
+                    sb += gb;
+                }
+            }
+            sa = sa * ex * 0.5f;                                    // d alpha / d u
+        }
+        if (WANT_PARAM) {
+            __syncthreads();
+            red[tid] = sa;
+            red[kBlock + tid] = sb;
+            __syncthreads();
+            if (ty == 0 && c < D) {
+                float ta = 0.0f, tb = 0.0f;
+                for (int j = 0; j < RY; ++j) {
+                    ta += red[j * CW + tx];
+                    tb += red[kBlock + j * CW + tx];
+                }
+                part[(long long)blockIdx.x * 2 * D + 2 * c] = ta;
+                part[(long long)blockIdx.x * 2 * D + 2 * c + 1] = tb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_colsum_final(const float *__restrict__ part,
+                                                         float *__restrict__ out, int n_blocks, int M)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= M) return;
+    float s = 0.0f;
+    for (int b = 0; b < n_blocks; ++b) s += part[(long long)b * M + c];
+    out[c] = s;
+}
+
+// DiagonalGaussian.log_prob backward (gaussian.py:46-54): g[row, d] = -glp[row] (z - loc) / scale^2
+__global__ __launch_bounds__(kBlock) void k_diag_gauss_bwd(
+    const float *__restrict__ z, const float *__restrict__ loc, const float *__restrict__ log_scale,
+    const float *__restrict__ glp, float *__restrict__ g, long long N, int D)
+{
+    const long long total = N * (long long)D;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const long long row = e / D;
+        const int d = (int)(e - row * D);
+        const float sc = exp_noovf(log_scale[d]);
+        const float t = div_fast(z[e] - loc[d], sc);
+        g[e] = -glp[row] * div_fast(t, sc);
+    }
+}
+
+static int check_common(const char *fn, int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T)
+{
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D < 1) return fail(TFK_EINVAL, "%s: D = %d < 1", fn, D);
+    if (T < 1 || T > D) return fail(TFK_EINVAL, "%s: T = %d must be in [1, D = %d]", fn, T, D);
+    (void)tgt_idx;
+    return TFK_OK;
+}
+
+template <int KT>
+static int launch_rqs_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                          int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, RqsConst C,
+                          int inverse, hipStream_t s, const char *fn)
+{
+    const int64_t tiles = (N * (int64_t)T + kBlock - 1) / kBlock;
+    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    if (inverse)
+        hipLaunchKernelGGL((k_rqs_coupling_bwd<KT, true>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld,
+                           gh, (long long)N, D, tgt_idx, T, C);
+    else
+        hipLaunchKernelGGL((k_rqs_coupling_bwd<KT, false>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld,
+                           gh, (long long)N, D, tgt_idx, T, C);
+    return check_launch(fn);
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+extern "C" {
+
+int tfk_affine_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                            int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t inverse,
+                            void *stream)
+{
+    const char *fn = "tfk_affine_coupling_bwd";
+    if (int rc = check_common(fn, N, D, tgt_idx, T)) return rc;
+    if (N == 0) return TFK_OK;
+    if (!x || !h || !g || !gld || !gh) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if ((reinterpret_cast<uintptr_t>(h) & 7u) || (reinterpret_cast<uintptr_t>(gh) & 7u))
+        return fail(TFK_EINVAL, "%s: h and gh must be 8-byte aligned", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(N * (int64_t)T, kBlock);
+    if (inverse)
+        hipLaunchKernelGGL((k_affine_coupling_bwd<true>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld, gh,
+                           (long long)N, D, tgt_idx, T);
+    else
+        hipLaunchKernelGGL((k_affine_coupling_bwd<false>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld, gh,
+                           (long long)N, D, tgt_idx, T);
+    return check_launch(fn);
+}
+
+int tfk_shift_coupling_bwd(const float *g, float *gh, int64_t N, int32_t D, const int32_t *tgt_idx,
+                           int32_t T, int32_t inverse, void *stream)
+{
+    const char *fn = "tfk_shift_coupling_bwd";
+    if (int rc = check_common(fn, N, D, tgt_idx, T)) return rc;
+    if (N == 0) return TFK_OK;
+    if (!g || !gh) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_shift_coupling_bwd, dim3(grid_for(N * (int64_t)T, kBlock)), dim3(kBlock), 0, s, g,
+                       gh, (long long)N, D, tgt_idx, T, inverse ? -1.0f : 1.0f);
+    return check_launch(fn);
+}
+
+int tfk_rqs_coupling_bwd_supported(int32_t n_bins) { return (n_bins == 4 || n_bins == 8 || n_bins == 16) ? 1 : 0; }
+
+int tfk_rqs_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                         int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t n_bins,
+                         float boundary, int32_t inverse, void *stream)
+{
+    const char *fn = "tfk_rqs_coupling_bwd";
+    if (int rc = check_common(fn, N, D, tgt_idx, T)) return rc;
+    if (!tfk_rqs_coupling_bwd_supported(n_bins))
+        return fail(TFK_EINVAL, "%s: n_bins = %d (backward kernels exist for 4, 8, 16)", fn, n_bins);
+    if (!(boundary > 0.0f)) return fail(TFK_EINVAL, "%s: boundary must be positive", fn);
+    if (N == 0) return TFK_OK;
+    if (!x || !h || !g || !gld || !gh) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(h) || !aligned16(gh)) return fail(TFK_EINVAL, "%s: h and gh must be 16-byte aligned", fn);
+    RqsConst C;
+    C.minimum = -boundary;
+    C.maximum = boundary;
+    C.span = (float)((double)boundary + (double)boundary);
+    C.scale = (float)(1.0 - 1e-3 * (double)n_bins);
+    C.c = (float)log(expm1(1.0 - 1e-5));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_bins == 8) return launch_rqs_bwd<8>(x, h, g, gld, gh, N, D, tgt_idx, T, C, inverse, s, fn);
+    if (n_bins == 4) return launch_rqs_bwd<4>(x, h, g, gld, gh, N, D, tgt_idx, T, C, inverse, s, fn);
+    return launch_rqs_bwd<16>(x, h, g, gld, gh, N, D, tgt_idx, T, C, inverse, s, fn);
+}
+
+int64_t tfk_elementwise_affine_bwd_workspace_bytes(int64_t N, int32_t D)
+{
+    if (N <= 0 || D <= 0) return 0;
+    return (int64_t)kMaxGrid * 2 * D * (int64_t)sizeof(float);
+}
+
+int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, const float *gld,
+                               float *gvalue, float *workspace, int64_t N, int32_t D,
+                               int32_t inverse, void *stream)
+{
+    const char *fn = "tfk_elementwise_affine_bwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D < 1) return fail(TFK_EINVAL, "%s: D = %d < 1", fn, D);
+    if (!value || (N > 0 && !g)) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (gvalue && N > 0 && (!x || !gld || !workspace))
+        return fail(TFK_EINVAL, "%s: the parameter gradient needs x, gld and a workspace", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        if (gvalue) {
+            hipError_t e = hipMemsetAsync(gvalue, 0, (size_t)2 * D * sizeof(float), s);
+            if (e != hipSuccess) return fail(TFK_ELAUNCH, "%s: memset: %s", fn, hipGetErrorString(e));
+        }
+        return TFK_OK;
+    }
+    int CW = pow2_ceil(D);
+    if (CW > kBlock) CW = kBlock;
+    const int RY = kBlock / CW;
+    // slabs of rows: enough workgroups to fill the chip, at least RY * 8 rows each
+    int64_t blocks = kMaxGrid;
+    int64_t rpb = (N + blocks - 1) / blocks;
+    const int64_t min_rows = (int64_t)RY * 8;
+    if (rpb < min_rows) rpb = min_rows;
+    blocks = (N + rpb - 1) / rpb;
+    const int grid = (int)blocks;
+    if (gvalue) {
+        if (inverse)
+            hipLaunchKernelGGL((k_elementwise_affine_bwd<true, true>), dim3(grid), dim3(kBlock), 0, s, x, value,
+                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+        else
+            hipLaunchKernelGGL((k_elementwise_affine_bwd<false, true>), dim3(grid), dim3(kBlock), 0, s, x, value,
+                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+        if (int rc = check_launch(fn)) return rc;
+        hipLaunchKernelGGL(k_colsum_final, dim3((2 * D + kBlock - 1) / kBlock), dim3(kBlock), 0, s, workspace,
+                           gvalue, grid, 2 * D);
+    } else {
+        if (inverse)
+            hipLaunchKernelGGL((k_elementwise_affine_bwd<true, false>), dim3(grid), dim3(kBlock), 0, s, x, value,
+                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+        else
+            hipLaunchKernelGGL((k_elementwise_affine_bwd<false, false>), dim3(grid), dim3(kBlock), 0, s, x, value,
+                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+    }
+    return check_launch(fn);
+}
+
+int tfk_diag_gauss_logprob_bwd(const float *z, const float *loc, const float *log_scale,
+                               const float *glp, float *g, int64_t N, int32_t D, void *stream)
+{
+    const char *fn = "tfk_diag_gauss_logprob_bwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D < 1) return fail(TFK_EINVAL, "%s: D = %d < 1", fn, D);
+    if (N == 0) return TFK_OK;
+    if (!z || !loc || !log_scale || !glp || !g) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_diag_gauss_bwd, dim3(grid_for(N * (int64_t)D, kBlock)), dim3(kBlock), 0, s, z, loc,
+                       log_scale, glp, g, (long long)N, D);
+    return check_launch(fn);
+}
+
+}  // extern "C"

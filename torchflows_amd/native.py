@@ -33,9 +33,13 @@ SYMBOLS = (
     "tfk_sum_workspace_bytes", "tfk_sum_f32",
     "tfk_flow_supported", "tfk_flow_run",
     "tfk_flow_mfma_supported", "tfk_flow_run_mfma",
+    "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
+    "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd",
+    "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
+    "tfk_diag_gauss_logprob_bwd",
 )
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NativeError(RuntimeError):
@@ -83,6 +87,15 @@ def _bind(L: C.CDLL) -> None:
                                _vp, _i64, _i32, _vp]
     L.tfk_flow_mfma_supported.argtypes = [_i32]
     L.tfk_flow_run_mfma.argtypes = L.tfk_flow_run.argtypes
+    L.tfk_affine_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
+    L.tfk_shift_coupling_bwd.argtypes = [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
+    L.tfk_rqs_coupling_bwd_supported.argtypes = [_i32]
+    L.tfk_rqs_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32,
+                                       C.c_float, _i32, _vp]
+    L.tfk_elementwise_affine_bwd_workspace_bytes.argtypes = [_i64, _i32]
+    L.tfk_elementwise_affine_bwd_workspace_bytes.restype = _i64
+    L.tfk_elementwise_affine_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]
+    L.tfk_diag_gauss_logprob_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -269,6 +282,98 @@ def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
             _f32(out, name), N, D)
     with torch.cuda.device(z.device):
         rc = lib().tfk_diag_gauss_logprob(*args, _stream(z))
+    calls += 1
+    _check(rc, name)
+
+
+# ---- reverse mode (csrc/tfk_bwd.hip) ------------------------------------------------------
+def _bwd_common(name, x, g, gld, tgt_idx, T):
+    N, D = _rows(g, name)
+    if x is not None and x.shape != g.shape:
+        raise NativeError(f"{name}: x shape {tuple(x.shape)} != g shape {tuple(g.shape)}")
+    if gld is not None and gld.numel() != N:
+        raise NativeError(f"{name}: gld has {gld.numel()} elements, expected {N}")
+    if tgt_idx is not None and tgt_idx.numel() != T:
+        raise NativeError(f"{name}: tgt_idx has {tgt_idx.numel()} entries, expected T = {T}")
+    return N, D
+
+
+def affine_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, inverse=False):
+    """In place on g (N, D): target columns dL/d out -> dL/d x; gh (N, T, 2) written."""
+    global calls
+    name = "tfk_affine_coupling_bwd"
+    N, D = _bwd_common(name, x, g, gld, tgt_idx, T)
+    if h.numel() != N * T * 2 or gh.numel() != N * T * 2:
+        raise NativeError(f"{name}: h / gh must hold N*T*2 = {N * T * 2} elements")
+    args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
+            _idx(tgt_idx, name), T, 1 if inverse else 0)
+    with torch.cuda.device(g.device):
+        rc = lib().tfk_affine_coupling_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def shift_coupling_bwd(g, gh, tgt_idx, T, inverse=False):
+    global calls
+    name = "tfk_shift_coupling_bwd"
+    N, D = _bwd_common(name, None, g, None, tgt_idx, T)
+    if gh.numel() != N * T:
+        raise NativeError(f"{name}: gh must hold N*T = {N * T} elements")
+    args = (_f32(g, name), _f32(gh, name), N, D, _idx(tgt_idx, name), T, 1 if inverse else 0)
+    with torch.cuda.device(g.device):
+        rc = lib().tfk_shift_coupling_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def rqs_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_bins, boundary, inverse=False):
+    global calls
+    name = "tfk_rqs_coupling_bwd"
+    N, D = _bwd_common(name, x, g, gld, tgt_idx, T)
+    P = 3 * int(n_bins) - 1
+    if h.numel() != N * T * P or gh.numel() != N * T * P:
+        raise NativeError(f"{name}: h / gh must hold N*T*P = {N * T * P} elements")
+    args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
+            _idx(tgt_idx, name), T, int(n_bins), C.c_float(float(boundary)), 1 if inverse else 0)
+    with torch.cuda.device(g.device):
+        rc = lib().tfk_rqs_coupling_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def elementwise_affine_bwd(x, value, g, gld, want_param, inverse=False):
+    """In place on g (all D columns).  Returns dL/dvalue (D, 2) when ``want_param``."""
+    global calls
+    name = "tfk_elementwise_affine_bwd"
+    N, D = _rows(g, name)
+    if value.numel() != 2 * D:
+        raise NativeError(f"{name}: value has {value.numel()} elements, expected 2*D = {2 * D}")
+    gvalue = ws = None
+    if want_param:
+        if x is None or x.shape != g.shape or gld is None or gld.numel() != N:
+            raise NativeError(f"{name}: the parameter gradient needs x (N, D) and gld (N,)")
+        gvalue = torch.empty(D, 2, dtype=torch.float32, device=g.device)
+        nbytes = int(lib().tfk_elementwise_affine_bwd_workspace_bytes(N, D))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g.device)
+    args = (_f32(x if want_param else None, name), _f32(value, name), _f32(g, name),
+            _f32(gld if want_param else None, name), _f32(gvalue, name), _f32(ws, name), N, D,
+            1 if inverse else 0)
+    with torch.cuda.device(g.device):
+        rc = lib().tfk_elementwise_affine_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+    return gvalue
+
+
+def diag_gauss_logprob_bwd(z, loc, log_scale, glp, g):
+    global calls
+    name = "tfk_diag_gauss_logprob_bwd"
+    N, D = _rows(z, name)
+    if loc.numel() != D or log_scale.numel() != D or glp.numel() != N or g.shape != z.shape:
+        raise NativeError(f"{name}: bad parameter / gradient shape")
+    args = (_f32(z, name), _f32(loc, name), _f32(log_scale, name), _f32(glp, name), _f32(g, name), N, D)
+    with torch.cuda.device(z.device):
+        rc = lib().tfk_diag_gauss_logprob_bwd(*args, _stream(z))
     calls += 1
     _check(rc, name)
 
