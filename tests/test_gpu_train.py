@@ -1,0 +1,205 @@
+"""Training on the HIP path (torchflows_amd/autograd.py + csrc/tfk_bwd.hip): whole-flow
+gradients against the reference's autograd outputs (tests/golden/grads_flow_*.npz), against the
+oracle's hand-derived backward on seeded batches, and ``Flow.fit`` on the device.
+
+Bars as in tests/test_grads_cpu.py: norm-wise per tensor ``max(1e-5, 3 x floor)`` where the floor
+is the reference's own fp32-vs-fp64 distance (spline flows: ~5e-4; affine flows: ~5e-7)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_of
+from test_grads_cpu import FLOWS, _mirror_flow, _param_of, normwise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from torchflows_amd import native as nat
+    nat.lib()
+    return nat
+
+
+def graph_nodes(t, depth=6):
+    seen, frontier = set(), [t.grad_fn]
+    for _ in range(depth):
+        nxt = []
+        for fn in frontier:
+            if fn is None:
+                continue
+            seen.add(type(fn).__name__)
+            nxt.extend(f for f, _ in fn.next_functions)
+        frontier = nxt
+    return seen
+
+
+def hip_grads(flow, x, w):
+    x = x.clone().requires_grad_(True)
+    lp = flow.log_prob(x)
+    named = [(n, p) for n, p in flow.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad((lp * w).sum(), [x] + [p for _, p in named], allow_unused=True)
+    return lp, grads[0], {n: g for (n, _), g in zip(named, grads[1:])}
+
+
+@pytest.mark.parametrize("fname,arch,es,n_layers", FLOWS)
+def test_flow_grads_golden_on_hip(native, fname, arch, es, n_layers):
+    fx, gr = load_golden(fname), load_golden("grads_" + fname)
+    flow = _mirror_flow(arch, es, n_layers, state_dict_of(fx, "init")).cuda()
+    before = native.calls
+    lp, gx, grads = hip_grads(flow, torch.tensor(fx["x"]).cuda(), torch.tensor(gr["w"]).cuda())
+    n_layers_total = len(flow.bijection.layers)
+    assert native.calls - before >= 2 * n_layers_total, "the reverse-mode kernels did not run"
+    assert {"GaussLogProbFunctionBackward", "ChainFunctionBackward"} <= graph_nodes(lp)
+    e, floor = normwise(gx.cpu().numpy(), gr["gx64"]), normwise(gr["gx"], gr["gx64"])
+    print(f"{fname}: gx {e:.2e} (floor {floor:.2e})")
+    assert e < max(1e-5, 3 * floor)
+    worst = 0.0
+    for name in gr["trainable"]:
+        g = grads[str(name)]
+        if g is None:
+            continue
+        r32, r64 = gr["g/" + name], gr["g64/" + name]
+        e, floor = normwise(g.cpu().numpy(), r64), normwise(r32, r64)
+        worst = max(worst, e)
+        assert e < max(1e-5, 3 * floor), (name, e, floor)
+    print(f"{fname}: worst parameter gradient {worst:.2e}")
+
+
+@pytest.mark.parametrize("arch,D,n_layers", [("RealNVP", 64, 8), ("NICE", 64, 8), ("CouplingRQNSF", 64, 8),
+                                             ("RealNVP", 256, 8)])
+def test_flow_grads_vs_oracle_large_batch(native, oracle, arch, D, n_layers):
+    """4 096 seeded rows, data-initialised weights.  The exact gradient is fp64 autograd through
+    the ATen composite path on the host; the HIP gradient must be as close to it as the oracle's
+    hand-derived fp32 backward is (3x), or within 1e-5."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    torch.manual_seed(3)
+    flow = Flow(getattr(A, arch)(D, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(4096, D))                      # ActNorm data-dependent init (CPU)
+    flow.eval()
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    oflow = oracle.preset_from_state_dict(arch, D, n_layers, sd)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4096, D, generator=g)
+    w = torch.rand(4096, generator=g) + 0.5
+    gx_o, grads_o = oflow.log_prob_grad(x.numpy(), w.numpy())
+    _, gx_t, grads_t = hip_grads(copy.deepcopy(flow).double(), x.double(), w.double())   # host fp64
+    lp, gx, grads = hip_grads(flow.cuda(), x.cuda(), w.cuda())
+    lp_o = oflow.log_prob(x.numpy())
+    assert np.max(np.abs(lp.detach().cpu().numpy() - lp_o) / np.maximum(1, np.abs(lp_o))) < (4e-5 if "RQ" in arch else 1e-5)
+    e, o = normwise(gx.cpu().numpy(), gx_t.numpy()), normwise(gx_o, gx_t.numpy())
+    assert e < max(1e-5, 3 * o), (e, o)
+    worst = worst_o = 0.0
+    for name, gr in grads.items():
+        if gr is None or "global_theta_flat" in name:
+            continue
+        truth = grads_t[name].numpy()
+        eh = normwise(gr.cpu().numpy(), truth)
+        eo = normwise(_param_of(grads_o, name).reshape(truth.shape), truth)
+        worst, worst_o = max(worst, eh), max(worst_o, eo)
+        assert eh < max(1e-5, 3 * eo), (name, eh, eo)
+    print(f"{arch}({D}) vs fp64: gx HIP {e:.2e} / oracle {o:.2e}; worst parameter gradient HIP {worst:.2e} / oracle {worst_o:.2e}")
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("CouplingRQNSF", 16), ("NICE", 7)])
+def test_inverse_direction_grads_vs_fp64(native, arch, D):
+    """Flow.sample-style gradients (bijection.inverse, log p(z) + log|dx/dz|) vs fp64 autograd
+    through the ATen composite path on the host."""
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    torch.manual_seed(5)
+    flow = Flow(getattr(A, arch)(D, n_layers=3)).eval()
+    z = torch.randn(512, D)
+    w = torch.rand(512) + 0.5
+
+    def run(f, zz, ww):
+        zz = zz.clone().requires_grad_(True)
+        x, ld = f.bijection.inverse(zz)
+        loss = ((x ** 2).sum(dim=-1) * ww).sum() + (ld * ww).sum()
+        named = [(n, p) for n, p in f.named_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, [zz] + [p for _, p in named], allow_unused=True)
+        return x, grads[0], {n: g for (n, _), g in zip(named, grads[1:])}
+
+    import copy
+    f64 = copy.deepcopy(flow).double()
+    x64, gz64, g64 = run(f64, z.double(), w.double())
+    x32, gz32, g32 = run(copy.deepcopy(flow), z, w)                       # ATen fp32 on the host: the floor
+    before = native.calls
+    xh, gzh, gh = run(copy.deepcopy(flow).cuda(), z.cuda(), w.cuda())
+    assert native.calls > before
+    e, floor = normwise(gzh.cpu().numpy(), gz64.numpy()), normwise(gz32.numpy(), gz64.numpy())
+    print(f"{arch}({D}) inverse: gz {e:.2e} (ATen fp32 floor {floor:.2e})")
+    assert e < max(1e-5, 3 * floor)
+    for n in g64:
+        if g64[n] is None:
+            continue
+        e, floor = normwise(gh[n].cpu().numpy(), g64[n].numpy()), normwise(g32[n].numpy(), g64[n].numpy())
+        assert e < max(1e-5, 3 * floor), (n, e, floor)
+
+
+def test_actnorm_initialises_inside_the_chain(native):
+    """First training-mode pass: ActNorm takes mean / std of ITS input batch (layers.py:51-69);
+    the HIP chain and the host ATen path must agree on the resulting values."""
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive.architectures import RealNVP
+    import copy
+    torch.manual_seed(1)
+    flow = Flow(RealNVP(16, n_layers=3))
+    x = torch.randn(2048, 16) * 2 + 1
+    host, dev = copy.deepcopy(flow), copy.deepcopy(flow).cuda()
+    host.train(), dev.train()
+    lp_h = host.log_prob(x)
+    lp_d = dev.log_prob(x.cuda())
+    assert lp_d.requires_grad
+    for (k, a), (_, b) in zip(host.state_dict().items(), dev.state_dict().items()):
+        assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=2e-5), k
+    assert torch.allclose(lp_h.detach(), lp_d.detach().cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_fit_on_device_recovers_diagonal_gaussian(native):
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive.layers import ElementwiseAffine
+    torch.manual_seed(0)
+    sigma = torch.tensor([[0.1, 1.0, 10.0]])
+    x = torch.randn(10_000, 3) * sigma
+    flow = Flow(ElementwiseAffine(event_shape=(3,))).cuda()
+    before = native.calls
+    flow.fit(x, n_epochs=100)
+    assert native.calls - before > 1000          # 10 batches x 100 epochs x (fwd + bwd) on libtfk
+    std = torch.std(flow.sample(100_000).detach(), dim=0).cpu()
+    assert float(((std - sigma.ravel()).abs() / sigma.ravel()).max()) < 0.1
+
+
+@pytest.mark.parametrize("arch,lr", [("RealNVP", 0.01), ("CouplingRQNSF", 0.01)])
+def test_fit_on_device_follows_the_host_trajectory(native, arch, lr):
+    """Same data, same batches (shuffle off), same AdamW: fitting on the HIP path must land where
+    fitting on the host ATen path lands, and improve the likelihood."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    torch.manual_seed(0)
+    mix = torch.randn(8192, 8)
+    x = torch.cat([mix[:, :4] * 0.3 + 2.0, torch.tanh(mix[:, 4:]) + 0.1 * mix[:, :4]], dim=1)
+    flow = Flow(getattr(A, arch)(8, n_layers=2))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x)                          # data-dependent init
+    flow.eval()
+    with torch.no_grad():
+        before = float(flow.log_prob(x).mean())
+    host, dev = copy.deepcopy(flow), copy.deepcopy(flow).cuda()
+    host.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
+    calls = native.calls
+    dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
+    assert native.calls - calls > 5 * 8 * 2 * len(flow.bijection.layers) // 2
+    with torch.no_grad():
+        after_h = float(host.log_prob(x).mean())
+        after_d = float(dev.log_prob(x.cuda()).mean())
+    print(f"{arch}: mean log-likelihood {before:.4f} -> host {after_h:.4f}, device {after_d:.4f}")
+    assert after_d > before
+    assert abs(after_d - after_h) < 5e-3 * max(1.0, abs(after_h))

@@ -1,0 +1,266 @@
+"""Training on the HIP path: one autograd node per composition.
+
+The reference trains through ``torch.autograd`` over its per-layer ATen graphs
+(``Flow.fit`` flows.py:226-455 -> ``log_prob`` :628-658 -> ``BijectiveComposition.forward``
+bijections/base.py:203-224).  Here a whole composition is ONE ``torch.autograd.Function``:
+
+* forward: the same libtfk layer kernels as inference, out of place, keeping only the
+  (N, D) rows that entered each coupling / trainable elementwise layer.  The conditioner
+  output ``h`` (2.9 KB per row per RQ-spline layer) is NOT kept.
+* backward: walk the layers in reverse over one gradient row buffer ``g`` (N, D) and the
+  per-row log-det gradient; per layer one reverse-mode kernel of csrc/tfk_bwd.hip, which
+  recomputes alpha / knots / bins from the saved input rows and a re-evaluated ``h``
+  ("recompute, not store").  The conditioner MLP's own backward (two skinny GEMMs) is
+  ``torch.autograd.grad`` on PyTorch-ROCm, fed with the kernel's ``dL/dh``.
+
+Only what the kernels cover takes this route (affine / inverse-affine / shift / RQ-spline
+couplings with 4, 8 or 16 bins, ElementwiseAffine / ActNorm, permutations, no context);
+anything else keeps the ATen composite graph.  ``TORCHFLOWS_AMD_TRAIN=0`` forces the latter.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+from torchflows_amd import native
+
+FORWARD, INVERSE = 0, 1
+
+
+def enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_TRAIN", "1") != "0"
+
+
+def _flatten(layers, attr: str):
+    from torchflows_amd.fused import _flatten as flat
+    return flat(layers, attr)
+
+
+def _step_kind(layer) -> Optional[str]:
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import (
+        CouplingBijection, ElementwiseBijection)
+    from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
+    if isinstance(layer, PermutationMatrix):
+        return "perm"
+    if isinstance(layer, ElementwiseBijection):
+        ok = layer.use_global_parameters and layer.transformer.native_kind in ("affine", "inverse_affine")
+        return "elementwise" if ok else None
+    if isinstance(layer, CouplingBijection):
+        if layer.context_shape is not None:
+            return None
+        kind = layer.transformer.native_kind
+        if kind in ("affine", "inverse_affine", "shift"):
+            return "coupling"
+        if kind == "rqs" and native.lib().tfk_rqs_coupling_bwd_supported(int(layer.transformer.n_bins)):
+            return "coupling"
+    return None
+
+
+def training_plan(composition, direction: int):
+    """[(layer, direction, kind)] if every layer has forward and reverse-mode kernels, else None."""
+    order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
+    flat = _flatten(order, "forward" if direction == FORWARD else "inverse")
+    if flat is None:
+        return None
+    plan = []
+    for layer, d in flat:
+        kind = _step_kind(layer)
+        if kind is None:
+            return None
+        plan.append((layer, d, kind))
+    return plan
+
+
+def applicable(composition, x: torch.Tensor, context) -> bool:
+    """Autograd is on, something needs a gradient, and everything is fp32 on one HIP device."""
+    if not enabled() or context is not None or not torch.is_grad_enabled():
+        return False
+    if x.device.type != "cuda" or x.dtype != torch.float32:
+        return False
+    needs = x.requires_grad
+    for p in composition.parameters():
+        if p.device != x.device or p.dtype != torch.float32:
+            return False
+        needs = needs or p.requires_grad
+    for b in composition.buffers():
+        if b.is_floating_point() and (b.device != x.device or b.dtype != torch.float32):
+            return False
+    return needs
+
+
+def _layer_params(layer, kind: str) -> List[torch.Tensor]:
+    if kind == "elementwise":
+        return [layer.value]
+    if kind == "coupling":
+        return list(layer.conditioner_transform.parameters())
+    return []
+
+
+def _conditioner(layer, x_in: torch.Tensor) -> torch.Tensor:
+    """h (N, T*P) from the rows that enter the coupling (layers_base.py:117-143)."""
+    N = x_in.shape[0]
+    S = layer.coupling.source_event_size
+    x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
+    return layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape), context=None)
+
+
+def _affine_form_is_inverse(layer, d: int) -> bool:
+    """Does this step evaluate (x - beta) / alpha (True) or alpha x + beta (False)?"""
+    return (d == INVERSE) != (layer.transformer.native_kind == "inverse_affine")
+
+
+class ChainFunction(torch.autograd.Function):
+    """rows (N, D) -> (rows (N, D), log-det (N,)) through a whole plan."""
+
+    @staticmethod
+    def forward(ctx, plan, rows: torch.Tensor, *params: torch.Tensor):
+        from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
+        N, D = rows.shape
+        logdet = torch.empty(N, dtype=torch.float32, device=rows.device)
+        started = False
+        cur = rows
+        cur_is_saved = True          # never write into the caller's tensor
+        saved: List[Optional[torch.Tensor]] = []
+        for layer, d, kind in plan:
+            if kind == "perm":
+                out = torch.empty_like(cur)
+                perm = None if layer._is_reversal else (layer._fwd_index32 if d == FORWARD else layer._inv_index32)
+                native.permute(cur, perm, out)
+                saved.append(None)
+                cur, cur_is_saved = out, False
+            elif kind == "elementwise":
+                if isinstance(layer, ActNorm) and d == FORWARD and layer.training and layer.first_training_batch_pass:
+                    layer._data_dependent_init(cur.view(N, *layer.event_shape))
+                keep_input = layer.value.requires_grad
+                out = cur if (not cur_is_saved and not keep_input) else torch.empty_like(cur)
+                native.elementwise_affine(cur, layer.value.detach().reshape(D, 2).contiguous(), out, logdet,
+                                          layer.transformer.native_kind == "inverse_affine",
+                                          accumulate=started, inverse=(d == INVERSE))
+                started = True
+                saved.append(cur if keep_input else None)
+                cur, cur_is_saved = out, False
+            else:
+                h = _conditioner(layer, cur).reshape(N, -1).contiguous()
+                out = torch.empty_like(cur)
+                T = layer.coupling.target_event_size
+                tgt = None if layer._target_is_tail else layer._target_index32
+                tk = layer.transformer.native_kind
+                if tk in ("affine", "inverse_affine"):
+                    native.affine_coupling(cur, h, out, logdet, tgt, T, accumulate=started,
+                                           inverse=_affine_form_is_inverse(layer, d))
+                elif tk == "rqs":
+                    native.rqs_coupling(cur, h, out, logdet, tgt, T, layer.transformer.n_bins,
+                                        layer.transformer.boundary, accumulate=started, inverse=(d == INVERSE))
+                else:
+                    native.shift_coupling(cur, h, out, logdet, tgt, T, accumulate=started, inverse=(d == INVERSE))
+                started = True
+                saved.append(cur)
+                cur, cur_is_saved = out, False
+        if not started:
+            logdet.zero_()
+        if cur is rows:
+            cur = rows.clone()
+        ctx.plan = plan
+        ctx.saved_rows = saved
+        ctx.n_params = len(params)
+        return cur, logdet
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rows: Optional[torch.Tensor], g_logdet: Optional[torch.Tensor]):
+        plan, saved = ctx.plan, ctx.saved_rows
+        first = next(s for s in saved if s is not None) if any(s is not None for s in saved) else None
+        ref = g_rows if g_rows is not None else (g_logdet if g_logdet is not None else first)
+        device = ref.device
+        N = g_logdet.shape[0] if g_logdet is not None else g_rows.shape[0]
+        D = plan[0][0].n_dim
+        g = (torch.zeros(N, D, dtype=torch.float32, device=device) if g_rows is None
+             else g_rows.contiguous().clone())
+        gld = (torch.zeros(N, dtype=torch.float32, device=device) if g_logdet is None
+               else g_logdet.contiguous())
+        grads_per_step: List[List[Optional[torch.Tensor]]] = [[] for _ in plan]
+        for i in range(len(plan) - 1, -1, -1):
+            layer, d, kind = plan[i]
+            x_in = saved[i]
+            if kind == "perm":
+                out = torch.empty_like(g)
+                perm = None if layer._is_reversal else (layer._inv_index32 if d == FORWARD else layer._fwd_index32)
+                native.permute(g, perm, out)
+                g = out
+            elif kind == "elementwise":
+                want = layer.value.requires_grad
+                gv = native.elementwise_affine_bwd(x_in, layer.value.detach().reshape(D, 2).contiguous(), g,
+                                                   gld, want, inverse=_affine_form_is_inverse(layer, d))
+                grads_per_step[i] = [gv.view_as(layer.value) if want else None]
+            else:
+                T = layer.coupling.target_event_size
+                S = layer.coupling.source_event_size
+                tgt = None if layer._target_is_tail else layer._target_index32
+                tk = layer.transformer.native_kind
+                cparams = list(layer.conditioner_transform.parameters())
+                x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
+                x_a = x_a.detach().requires_grad_(True)
+                with torch.enable_grad():          # re-evaluate h with a graph: conditioner backward
+                    h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
+                                                     context=None).reshape(N, -1)
+                hc = h2.detach().contiguous()
+                gh = torch.empty_like(hc)
+                if tk in ("affine", "inverse_affine"):
+                    native.affine_coupling_bwd(x_in, hc, g, gld, gh, tgt, T,
+                                               inverse=_affine_form_is_inverse(layer, d))
+                elif tk == "rqs":
+                    native.rqs_coupling_bwd(x_in, hc, g, gld, gh, tgt, T, layer.transformer.n_bins,
+                                            layer.transformer.boundary, inverse=(d == INVERSE))
+                else:
+                    native.shift_coupling_bwd(g, gh, tgt, T, inverse=(d == INVERSE))
+                wanted = [p for p in cparams if p.requires_grad]
+                outs = torch.autograd.grad(h2, [x_a] + wanted, gh, allow_unused=True)
+                g_xa = outs[0].reshape(N, S)
+                if layer._source_is_head:
+                    g[:, :S].add_(g_xa)
+                else:
+                    g.index_add_(1, layer._source_index, g_xa)
+                it = iter(outs[1:])
+                grads_per_step[i] = [next(it) if p.requires_grad else None for p in cparams]
+        flat: List[Optional[torch.Tensor]] = []
+        for gs in grads_per_step:
+            flat.extend(gs)
+        assert len(flat) == ctx.n_params
+        g_in = g if ctx.needs_input_grad[1] else None
+        return (None, g_in, *flat)
+
+
+class GaussLogProbFunction(torch.autograd.Function):
+    """``DiagonalGaussian.log_prob(rows) [+ log_det]`` (gaussian.py:46-54, flows.py:647-648) with
+    fixed loc / scale: one forward and one reverse-mode launch."""
+
+    @staticmethod
+    def forward(ctx, rows, loc, log_scale, log_det):
+        out = torch.empty(rows.shape[0], dtype=torch.float32, device=rows.device)
+        native.diag_gauss_logprob(rows, loc, log_scale, log_det, out)
+        ctx.save_for_backward(rows, loc, log_scale)
+        ctx.has_ld = log_det is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, glp):
+        rows, loc, log_scale = ctx.saved_tensors
+        glp = glp.contiguous()
+        g = None
+        if ctx.needs_input_grad[0]:
+            g = torch.empty_like(rows)
+            native.diag_gauss_logprob_bwd(rows, loc, log_scale, glp, g)
+        return g, None, None, (glp if ctx.has_ld and ctx.needs_input_grad[3] else None)
+
+
+def run(composition, plan, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    from torchflows_amd.utils import as_rows
+    rows, batch = as_rows(x, composition.event_shape)
+    params: List[torch.Tensor] = []
+    for layer, _, kind in plan:
+        params.extend(_layer_params(layer, kind))
+    out, ld = ChainFunction.apply(plan, rows, *params)
+    return out.view(x.shape), ld.view(batch)

@@ -42,6 +42,18 @@ class DiagonalGaussian(torch.distributions.Distribution, nn.Module):
         return (native.eligible(value, self.loc, self.log_scale) and len(self.event_shape) == 1
                 and value.dim() >= 2)
 
+    def _trainable_ok(self, value: torch.Tensor, log_det) -> bool:
+        """Autograd on the HIP path: fp32 rows on the device, loc / scale fixed."""
+        from torchflows_amd import autograd as hip_autograd
+        if not (hip_autograd.enabled() and torch.is_grad_enabled() and len(self.event_shape) == 1
+                and value.dim() >= 2 and value.device.type == "cuda" and value.dtype == torch.float32):
+            return False
+        if self.loc.requires_grad or self.log_scale.requires_grad or self.loc.device != value.device:
+            return False
+        if log_det is not None and (log_det.device != value.device or log_det.dtype != torch.float32):
+            return False
+        return value.requires_grad or (log_det is not None and log_det.requires_grad)
+
     def log_prob_plus(self, value: torch.Tensor, log_det: torch.Tensor = None) -> torch.Tensor:
         """``log_prob(value) + log_det`` -- fused on the HIP path (flows.py:647-648)."""
         if value.dim() <= len(self.event_shape):
@@ -52,6 +64,12 @@ class DiagonalGaussian(torch.distributions.Distribution, nn.Module):
             out = torch.empty(rows.shape[0], dtype=torch.float32, device=rows.device)
             ld = None if log_det is None else log_det.reshape(-1).contiguous()
             native.diag_gauss_logprob(rows, self.loc.detach(), self.log_scale.detach(), ld, out)
+            return out.view(value.shape[:-1])
+        if self._trainable_ok(value, log_det):
+            from torchflows_amd.autograd import GaussLogProbFunction
+            rows = value.reshape(-1, self.event_shape[0]).contiguous()
+            ld = None if log_det is None else log_det.reshape(-1).contiguous()
+            out = GaussLogProbFunction.apply(rows, self.loc.detach(), self.log_scale.detach(), ld)
             return out.view(value.shape[:-1])
         t = (value - self.loc) / self.scale
         elementwise = -(0.5 * t ** 2 + 0.5 * self.log_2_pi + self.log_scale)

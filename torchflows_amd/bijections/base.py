@@ -180,8 +180,22 @@ class BijectiveComposition(Bijection):
         return out.view(x.shape), state.logdet.view(batch)
 
     # -- public maps -----------------------------------------------------------
+    def _run_trainable(self, x: torch.Tensor, context, d: int):
+        """Autograd on the HIP path: the whole chain as one autograd node (autograd.py)."""
+        from torchflows_amd import autograd as hip_autograd
+        if not hip_autograd.applicable(self, x, context):
+            return None
+        plan = hip_autograd.training_plan(self, d)
+        if plan is None:
+            return None
+        return hip_autograd.run(self, plan, x)
+
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):
+        if not kwargs and torch.is_grad_enabled():
+            trained = self._run_trainable(x, context, FORWARD)
+            if trained is not None:
+                return trained
         if not kwargs and native.eligible(x, context) and _params_ok(self):
             if context is None:
                 fused_out = self._run_fused(x, FORWARD)
@@ -199,6 +213,10 @@ class BijectiveComposition(Bijection):
     @inverse_method
     def inverse(self, z: torch.Tensor, context: torch.Tensor = None, **kwargs):
         order = list(self.layers)[::-1]
+        if not kwargs and torch.is_grad_enabled():
+            trained = self._run_trainable(z, context, INVERSE)
+            if trained is not None:
+                return trained
         if not kwargs and native.eligible(z, context) and _params_ok(self):
             if context is None:
                 fused_out = self._run_fused(z, INVERSE)

@@ -10,11 +10,14 @@ The callers of the hot path, with the reference's signatures and conventions
 
 On an MI355X the whole of ``log_prob`` is a chain of libtfk launches on one stream with a
 single running log-det buffer; the base log-density kernel also performs the final add.
-Training loops (``fit`` / ``variational_fit``) are not part of this package's scope.
+``fit`` (reference :226-455) is here too: same arguments, loss and bookkeeping, but the data set
+lives on the device and the gradient runs through the reverse-mode kernels (autograd.py).
 """
 from __future__ import annotations
 
-from typing import Tuple, Union
+import time
+import warnings
+from typing import Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -106,6 +109,153 @@ class Flow(BaseFlow):
         if isinstance(self.base, DiagonalGaussian):
             return z, self.base.log_prob_plus(zf, log_det)      # fused base density + add
         return z, self.base.log_prob(zf) + log_det
+
+    def regularization(self, *args, **kwargs):
+        return self.bijection.regularization(*args, **kwargs)
+
+    # -- maximum-likelihood training (reference flows.py:199-224, :226-455) ----------------
+    def _base_batch_loss(self, batch, reduction=torch.mean, use_regularization: bool = True) -> torch.Tensor:
+        """``-reduction(log_prob(x) * w) / event_size [+ regularization]`` (reference :199-224)."""
+        x, weights = batch[:2]
+        context = batch[2] if len(batch) == 3 else None
+        dev = self.get_device()
+        lp = self.log_prob(x.to(dev), context=context)
+        loss = -reduction(lp * weights.to(dev)) / self.event_size
+        if use_regularization:
+            loss = loss + self.regularization()
+        return loss
+
+    def fit(self,
+            x_train: torch.Tensor,
+            n_epochs: int = 500,
+            lr: float = 0.05,
+            batch_size: Union[int, str, None] = 1024,
+            shuffle: bool = True,
+            show_progress: bool = False,
+            w_train: torch.Tensor = None,
+            context_train: torch.Tensor = None,
+            x_val: torch.Tensor = None,
+            w_val: torch.Tensor = None,
+            context_val: torch.Tensor = None,
+            keep_best_weights: bool = True,
+            early_stopping: bool = False,
+            early_stopping_threshold: int = 50,
+            max_batch_size_mb: int = None,
+            time_limit_seconds: Union[float, int] = None,
+            reset_optimizer: bool = True):
+        """Maximum-likelihood fit with AdamW; arguments and bookkeeping as the reference's
+        ``Flow.fit`` (:226-455): per-batch loss ``-mean(log_prob * w) / event_size +
+        regularization``, best weights by validation (else training) loss per epoch, early
+        stopping, roll-back on a non-finite loss, ``batch_size="adaptive"`` doubling every
+        10 epochs.  What differs is where the data lives: the training and validation sets
+        are moved to the flow's device ONCE and batches are index views of them (a device
+        ``randperm`` per epoch) -- no host DataLoader, no per-batch host-to-device copies --
+        and on an MI355X the gradient runs through the reverse-mode kernels (autograd.py)."""
+        t0 = time.time()
+        self.train()
+        if not any(p.requires_grad for p in self.parameters()):
+            self.eval()                      # nothing to fit (also: no parameters at all)
+            return
+        dev = self.get_device()
+
+        def resident(x, w, c, label):
+            n = len(x)
+            if w is None:
+                w = torch.ones(size=tuple(get_batch_shape(x, self.event_shape)))
+            if len(w) != n:
+                raise ValueError(f"Expected same number of {label} data and {label} weights, "
+                                 f"but found {n} and {len(w)}")
+            if c is not None and len(c) != n:
+                raise ValueError(f"Expected same number of {label} data and {label} contexts, "
+                                 f"but found {n} and {len(c)}")
+            return x.to(dev), w.to(dev), (None if c is None else c.to(dev))
+
+        def batches(data, size, permute):
+            x, w, c = data
+            n = len(x)
+            order = torch.randperm(n, device=dev) if (permute and n > 1) else None
+            for lo in range(0, n, size):
+                idx = slice(lo, lo + size) if order is None else order[lo:lo + size]
+                yield (x[idx], w[idx]) if c is None else (x[idx], w[idx], c[idx])
+
+        train = resident(x_train, w_train, context_train, "training")
+        val = None if x_val is None else resident(x_val, w_val, context_val, "validation")
+        n_train = len(x_train)
+
+        adaptive, max_batch_size = False, None
+        if batch_size is None:
+            batch_size = n_train
+        elif isinstance(batch_size, str):
+            if batch_size != "adaptive":
+                raise ValueError(f"Unknown batch size rule: {batch_size}")
+            adaptive = True
+            max_batch_size = min(4096, n_train // 10)
+            if max_batch_size_mb is not None:
+                max_batch_size = max(1, min(max_batch_size, int(max_batch_size_mb / (self.event_size / 2 ** 20))))
+            batch_size = max(32, min(1024, n_train // 100))
+
+        if self._optimizer is None or reset_optimizer:
+            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
+
+        def snapshot():
+            return {k: v.detach().clone() for k, v in self.state_dict().items()}
+
+        best_weights = snapshot()
+        best_val, best_train = float("inf"), float("inf")
+        best_val_epoch = best_train_epoch = 0
+        val_loss: Optional[float] = None
+        diverged = False
+        epochs = range(n_epochs)
+        pbar = None
+        if show_progress:
+            from tqdm import tqdm
+            epochs = pbar = tqdm(epochs, desc="Fitting NF")
+        for epoch in epochs:
+            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                print("Training time limit exceeded")
+                break
+            if adaptive and epoch % 10 == 9 and batch_size < max_batch_size:
+                batch_size = min(2 * batch_size, max_batch_size)
+            total, count = 0.0, 0
+            for batch in batches(train, batch_size, shuffle):
+                self._optimizer.zero_grad()
+                loss = self._base_batch_loss(batch, reduction=torch.mean, use_regularization=True)
+                value = float(loss.detach())
+                if value != value or value in (float("inf"), float("-inf")):
+                    self.load_state_dict(best_weights)     # the last kept (else the initial) weights
+                    diverged = True
+                    warnings.warn("Flow training diverged. Reverting to previous weights.")
+                    break
+                total += value
+                count += 1
+                loss.backward()
+                self._optimizer.step()
+                if pbar is not None:
+                    text = f"Training loss (batch): {value:.4f} [{best_train:.4f} @ {best_train_epoch}]"
+                    if val_loss is not None:
+                        text += f" , Validation loss (batch): {val_loss:.4f} [{best_val:.4f} @ {best_val_epoch}]"
+                    pbar.set_postfix_str(text)
+            if diverged:
+                break
+            average = total / count
+            if average < best_train:
+                best_train, best_train_epoch = average, epoch
+            if val is not None:
+                acc = 0.0
+                with torch.no_grad():
+                    for batch in batches(val, batch_size, False):
+                        acc += float(self._base_batch_loss(batch, reduction=torch.sum, use_regularization=False))
+                val_loss = acc / len(x_val)
+                if val_loss < best_val:
+                    best_val, best_val_epoch = val_loss, epoch
+            mark = best_val_epoch if val is not None else best_train_epoch
+            if keep_best_weights and mark == epoch:
+                best_weights = snapshot()
+            if early_stopping and epoch - mark > early_stopping_threshold:
+                break
+        if keep_best_weights:
+            self.load_state_dict(best_weights)
+        self.eval()
 
     def log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
         if context is None:
