@@ -64,7 +64,14 @@ class KernelTimer:
                             ("conv1x1_coupling", self._conv1x1_bytes),
                             ("permute", lambda a, k: 8 * a[0].numel()),
                             ("diag_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0]),
-                            ("flow_run", self._flow_bytes), ("flow_run_mfma", self._flow_bytes)):
+                            ("flow_run", self._flow_bytes), ("flow_run_mfma", self._flow_bytes),
+                            # reverse mode (csrc/tfk_bwd.hip): args (x, h, g, gld, gh, tgt, T, ...)
+                            ("affine_coupling_bwd", lambda a, k: a[2].shape[0] * (a[6] * (4 + 8 + 8 + 8) + 4)),
+                            ("rqs_coupling_bwd", lambda a, k: a[2].shape[0] * (a[6] * (4 + 8 + 8 * (3 * a[7] - 1)) + 4)),
+                            ("shift_coupling_bwd", lambda a, k: a[0].shape[0] * a[3] * 8),
+                            ("elementwise_affine_bwd",
+                             lambda a, k: a[2].numel() * (12 if a[4] else 8) + (4 * a[2].shape[0] if a[4] else 0)),
+                            ("diag_gauss_logprob_bwd", lambda a, k: 8 * a[0].numel() + 4 * a[0].shape[0])):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -122,7 +129,7 @@ class KernelTimer:
             r = inner(*a, **k)
             e.record()
             variant = name
-            if name.endswith("coupling") and name != "conv1x1_coupling":
+            if name.endswith("_coupling") and name != "conv1x1_coupling":
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
             flops = self._flow_flops(a, name == "flow_run_mfma") if name.startswith("flow_run") else 0
             self.records.append((variant, byte_fn(a, k), s, e, flops))
@@ -225,6 +232,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
     ap.add_argument("--no-sample", action="store_true", help="skip the Flow.sample throughput leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd + bwd + AdamW) leg")
     ap.add_argument("--no-mfma", action="store_true",
                     help="fused flow programs on the VALU interpreter (k_flow_run) instead of k_flow_run_mfma")
     args = ap.parse_args()
@@ -410,6 +418,49 @@ def main():
                                 "note": "Flow.sample((rows,), return_log_prob=True): torch.randn base "
                                         "draw + inverse flow program, 3 calls"}
             del xs, lps
+        if world == 1 and not args.no_train and not isinstance(D, tuple):
+            # one maximum-likelihood step on the HIP path = Flow.log_prob with
+            # autograd (layer kernels, out of place) + reverse-mode kernels + conditioner GEMM
+            # backward on PyTorch-ROCm + AdamW.  Not part of `value`.
+            trows = min(rows, chunk or rows, 1 << 18)
+            xt = x[:trows]
+            flow.train()
+            opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+
+            def train_step():
+                opt.zero_grad(set_to_none=True)
+                loss = -flow.log_prob(xt).mean() / flow.event_size + flow.regularization()
+                loss.backward()
+                opt.step()
+                return loss
+
+            train_step()
+            torch.cuda.synchronize()
+            timer.records = []
+            timer.active = True
+            t3 = time.perf_counter()
+            for _ in range(5):
+                loss = train_step()
+            torch.cuda.synchronize()
+            t_elapsed = time.perf_counter() - t3
+            timer.active = False
+            flow.eval()
+            tk = timer.summary()
+            bwd = {k: v for k, v in tk.items() if k.endswith("_bwd")}
+            top = max(bwd, key=lambda k: bwd[k]["ms"]) if bwd else None
+            result["train"] = {
+                "value": trows * 5 / t_elapsed, "unit": "samples/s", "rows": trows, "steps": 5,
+                "ms_per_step": 1e3 * t_elapsed / 5, "loss": float(loss.detach()),
+                "libtfk_ms_per_step": sum(v["ms"] for v in tk.values()) / 5,
+                "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                                "GBps": round(v["GBps"], 1)} for k, v in tk.items()},
+                "note": "fwd + reverse-mode libtfk kernels + hipBLASLt conditioner GEMMs (fwd, recompute, "
+                        "bwd) + AdamW; libtfk_ms_per_step is the share spent in libtfk kernels"}
+            if top is not None:
+                result["train"]["roofline_bwd"] = {
+                    "bound": "hbm", "kernel": top, "achieved": bwd[top]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": bwd[top]["GBps"] / HBM_PEAK_GBS,
+                    "bytes_per_launch": bwd[top]["bytes_per_launch"], "avg_us": bwd[top]["avg_us"]}
         if world == 1 and not args.no_cpu_baseline and not isinstance(D, tuple):
             base, ref = cpu_baseline(arch, D, n_layers, flow_host)
             result["cpu_baseline"] = base

@@ -58,7 +58,7 @@ def test_flow_grads_golden_on_hip(native, fname, arch, es, n_layers):
     worst = 0.0
     for name in gr["trainable"]:
         g = grads[str(name)]
-        if g is None:
+        if g is None or g.numel() == 0:               # global_theta_flat is empty for these presets
             continue
         r32, r64 = gr["g/" + name], gr["g64/" + name]
         e, floor = normwise(g.cpu().numpy(), r64), normwise(r32, r64)
@@ -96,7 +96,7 @@ def test_flow_grads_vs_oracle_large_batch(native, oracle, arch, D, n_layers):
     assert e < max(1e-5, 3 * o), (e, o)
     worst = worst_o = 0.0
     for name, gr in grads.items():
-        if gr is None or "global_theta_flat" in name:
+        if gr is None or gr.numel() == 0:
             continue
         truth = grads_t[name].numpy()
         eh = normwise(gr.cpu().numpy(), truth)
@@ -136,7 +136,7 @@ def test_inverse_direction_grads_vs_fp64(native, arch, D):
     print(f"{arch}({D}) inverse: gz {e:.2e} (ATen fp32 floor {floor:.2e})")
     assert e < max(1e-5, 3 * floor)
     for n in g64:
-        if g64[n] is None:
+        if g64[n] is None or g64[n].numel() == 0:
             continue
         e, floor = normwise(gh[n].cpu().numpy(), g64[n].numpy()), normwise(g32[n].numpy(), g64[n].numpy())
         assert e < max(1e-5, 3 * floor), (n, e, floor)

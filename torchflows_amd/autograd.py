@@ -106,6 +106,58 @@ def _conditioner(layer, x_in: torch.Tensor) -> torch.Tensor:
     return layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape), context=None)
 
 
+def _plain_mlp(layer):
+    """(Linear, Linear) when the conditioner is the default FeedForward: Linear, Tanh, Linear on
+    x_A alone (transforms.py:274-307), no global parameters, unbounded output -- the case whose
+    backward is written out below instead of being left to torch.autograd."""
+    import math
+    import torch.nn as nn
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
+    ct = layer.conditioner_transform
+    if type(ct) is not FeedForward or ct.n_global_parameters != 0 or ct.context_shape is not None:
+        return None
+    if ct.output_lower_bound != -math.inf or ct.output_upper_bound != math.inf:
+        return None
+    mods = list(ct.sequential)
+    if (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
+        return mods[0], mods[2]
+    return None
+
+
+SPLIT_K_ROWS = 1024
+
+
+def _outer_sum(a: torch.Tensor, b_aug: torch.Tensor) -> torch.Tensor:
+    """``a^T @ b_aug`` for tall operands (N x m, N x k, N >> m, k): the contraction runs over the
+    batch rows, so a plain GEMM has one tiny output tile and no parallelism (hipBLASLt: ~450 us at
+    N = 2^18).  Split the rows into slabs of 1024, one batched GEMM over the slabs, then add the
+    slab results (fixed order: deterministic)."""
+    N, m = a.shape
+    C = SPLIT_K_ROWS
+    S = N // C
+    out = None
+    if S >= 2:
+        head = torch.bmm(a[:S * C].view(S, C, m).transpose(1, 2), b_aug[:S * C].view(S, C, -1)).sum(dim=0)
+        out = head
+        if S * C < N:
+            out = out + a[S * C:].t() @ b_aug[S * C:]
+        return out
+    return a.t() @ b_aug
+
+
+def _mlp_backward(lin1, lin2, x_a: torch.Tensor, a1: torch.Tensor, gh: torch.Tensor):
+    """Reverse mode of h = W2 tanh(W1 x_a + b1) + b2 given a1 = tanh(.) and gh = dL/dh.
+    Returns (g_xa, dW1, db1, dW2, db2); the bias gradients ride along as a column of ones."""
+    N = gh.shape[0]
+    ones = torch.ones(N, 1, dtype=gh.dtype, device=gh.device)
+    dW2b = _outer_sum(gh, torch.cat([a1, ones], dim=1))             # (TP, H + 1)
+    g_pre = (gh @ lin2.weight) * (1.0 - a1 * a1)                     # tanh'
+    dW1b = _outer_sum(g_pre, torch.cat([x_a, ones], dim=1))          # (H, S + 1)
+    g_xa = g_pre @ lin1.weight
+    return g_xa, dW1b[:, :-1], dW1b[:, -1], dW2b[:, :-1], dW2b[:, -1]
+
+
 def _affine_form_is_inverse(layer, d: int) -> bool:
     """Does this step evaluate (x - beta) / alpha (True) or alpha x + beta (False)?"""
     return (d == INVERSE) != (layer.transformer.native_kind == "inverse_affine")
@@ -201,11 +253,17 @@ class ChainFunction(torch.autograd.Function):
                 tk = layer.transformer.native_kind
                 cparams = list(layer.conditioner_transform.parameters())
                 x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
-                x_a = x_a.detach().requires_grad_(True)
-                with torch.enable_grad():          # re-evaluate h with a graph: conditioner backward
-                    h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
-                                                     context=None).reshape(N, -1)
-                hc = h2.detach().contiguous()
+                mlp = _plain_mlp(layer)
+                if mlp is not None:            # re-evaluate h; keep the hidden activations
+                    lin1, lin2 = mlp
+                    a1 = torch.tanh(torch.addmm(lin1.bias, x_a, lin1.weight.t()))
+                    hc = torch.addmm(lin2.bias, a1, lin2.weight.t())
+                else:                          # any other conditioner: re-evaluate with a graph
+                    x_a = x_a.detach().requires_grad_(True)
+                    with torch.enable_grad():
+                        h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
+                                                         context=None).reshape(N, -1)
+                    hc = h2.detach().contiguous()
                 gh = torch.empty_like(hc)
                 if tk in ("affine", "inverse_affine"):
                     native.affine_coupling_bwd(x_in, hc, g, gld, gh, tgt, T,
@@ -215,15 +273,23 @@ class ChainFunction(torch.autograd.Function):
                                             layer.transformer.boundary, inverse=(d == INVERSE))
                 else:
                     native.shift_coupling_bwd(g, gh, tgt, T, inverse=(d == INVERSE))
-                wanted = [p for p in cparams if p.requires_grad]
-                outs = torch.autograd.grad(h2, [x_a] + wanted, gh, allow_unused=True)
-                g_xa = outs[0].reshape(N, S)
+                if mlp is not None:
+                    g_xa, dW1, db1, dW2, db2 = _mlp_backward(lin1, lin2, x_a, a1, gh)
+                    by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
+                    grads_per_step[i] = [by_param.get(id(p)) if p.requires_grad else None for p in cparams]
+                    # (global_theta_flat is empty here: its gradient is an empty tensor)
+                    grads_per_step[i] = [torch.zeros_like(p) if (gp is None and p.requires_grad) else gp
+                                         for gp, p in zip(grads_per_step[i], cparams)]
+                else:
+                    wanted = [p for p in cparams if p.requires_grad]
+                    outs = torch.autograd.grad(h2, [x_a] + wanted, gh, allow_unused=True)
+                    g_xa = outs[0].reshape(N, S)
+                    it = iter(outs[1:])
+                    grads_per_step[i] = [next(it) if p.requires_grad else None for p in cparams]
                 if layer._source_is_head:
                     g[:, :S].add_(g_xa)
                 else:
                     g.index_add_(1, layer._source_index, g_xa)
-                it = iter(outs[1:])
-                grads_per_step[i] = [next(it) if p.requires_grad else None for p in cparams]
         flat: List[Optional[torch.Tensor]] = []
         for gs in grads_per_step:
             flat.extend(gs)

@@ -325,77 +325,118 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling_bwd(
 //   part[block][2 D]; k_colsum_final adds the blocks in index order.
 //   bytes per row: g 8 D (+ x 4 D when the parameter gradient is wanted)
 // ---------------------------------------------------------------------------------------------
-template <bool INVERSE, bool WANT_PARAM>
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<4> { typedef float4 type; };
+__device__ __forceinline__ void unpack(float v, float (&a)[1]) { a[0] = v; }
+__device__ __forceinline__ void unpack(float4 v, float (&a)[4]) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+__device__ __forceinline__ float pack(const float (&a)[1]) { return a[0]; }
+__device__ __forceinline__ float4 pack(const float (&a)[4]) { return make_float4(a[0], a[1], a[2], a[3]); }
+
+// V = 4: a thread owns four consecutive columns (16-byte loads / stores, 1 KiB per
+// wave-instruction; D % 4 == 0); V = 1: any D.  CW = column groups walked side by side
+// (a power of two <= 256), RY = 256 / CW rows in flight per workgroup.
+template <bool INVERSE, bool WANT_PARAM, int V>
 __global__ __launch_bounds__(kBlock) void k_elementwise_affine_bwd(
     const float *__restrict__ x, const float *__restrict__ value, float *g,
     const float *__restrict__ gld, float *__restrict__ part, long long N, int D, int CW,
     long long rows_per_block)
 {
-    __shared__ float red[2 * kBlock];
+    typedef typename VecT<V>::type vec;
+    __shared__ float red[WANT_PARAM ? 2 * V * kBlock : 1];
     const int tid = threadIdx.x;
     const int tx = tid % CW, ty = tid / CW, RY = kBlock / CW;
+    const int G = D / V;                                            // column groups per row
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
-    for (int c0 = 0; c0 < D; c0 += CW) {
-        const int c = c0 + tx;
-        float sa = 0.0f, sb = 0.0f;
-        if (c < D) {
-            const float u = value[2 * c], beta = value[2 * c + 1];
-            const float ex = exp_noovf(u * 0.5f + kAffC0);
-            const float alpha = ex + kAffMinScale;
-            const float ra = __builtin_amdgcn_rcpf(alpha);
-            for (long long row = r0 + ty; row < r1; row += RY) {
-                const float gz = g[row * D + c];
-                float gx, gb = 0.0f, ga = 0.0f;
-                if (!INVERSE) {
-                    gx = gz * alpha;
-                    if (WANT_PARAM) {
-                        gb = gz;
-                        ga = gz * x[row * D + c] + gld[row] * ra;
-                    }
-                } else {
-                    const float r = gz * ra;
-                    gx = r;
-                    if (WANT_PARAM) {
-                        gb = -r;
-                        ga = -r * ((x[row * D + c] - beta) * ra) - gld[row] * ra;
-                    }
-                }
-                g[row * D + c] = gx;
-                if (WANT_PARAM) {
-                    sa += ga;
-                    sb += gb;
-                }
+    for (int c0 = 0; c0 < G; c0 += CW) {
+        const int cg = c0 + tx;
+        float sa[V], sb[V], ex[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) sa[i] = sb[i] = ex[i] = 0.0f;
+        if (cg < G) {
+            float alpha[V], ra[V], beta[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int c = cg * V + i;
+                beta[i] = value[2 * c + 1];
+                ex[i] = exp_noovf(value[2 * c] * 0.5f + kAffC0);
+                alpha[i] = ex[i] + kAffMinScale;
+                ra[i] = __builtin_amdgcn_rcpf(alpha[i]);
             }
-            sa = sa * ex * 0.5f;                                    // d alpha / d u
+            vec *gp = reinterpret_cast<vec *>(g);
+            const vec *xp = reinterpret_cast<const vec *>(x);
+#pragma unroll 4
+            for (long long row = r0 + ty; row < r1; row += RY) {
+                float gz[V], xv[V];
+                unpack(gp[row * G + cg], gz);
+                float gl = 0.0f;
+                if (WANT_PARAM) {
+                    unpack(xp[row * G + cg], xv);
+                    gl = gld[row];
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    if (!INVERSE) {
+                        if (WANT_PARAM) {
+                            sb[i] += gz[i];
+                            sa[i] += gz[i] * xv[i] + gl * ra[i];
+                        }
+                        gz[i] = gz[i] * alpha[i];
+                    } else {
+                        const float r = gz[i] * ra[i];
+                        if (WANT_PARAM) {
+                            sb[i] += -r;
+                            sa[i] += -r * ((xv[i] - beta[i]) * ra[i]) - gl * ra[i];
+                        }
+                        gz[i] = r;
+                    }
+                }
+                gp[row * G + cg] = pack(gz);
+            }
         }
         if (WANT_PARAM) {
             __syncthreads();
-            red[tid] = sa;
-            red[kBlock + tid] = sb;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                red[(2 * i) * kBlock + tid] = sa[i] * ex[i] * 0.5f;     // d alpha / d u
+                red[(2 * i + 1) * kBlock + tid] = sb[i];
+            }
             __syncthreads();
-            if (ty == 0 && c < D) {
-                float ta = 0.0f, tb = 0.0f;
-                for (int j = 0; j < RY; ++j) {
-                    ta += red[j * CW + tx];
-                    tb += red[kBlock + j * CW + tx];
+            if (ty == 0 && cg < G) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float ta = 0.0f, tb = 0.0f;
+                    for (int j = 0; j < RY; ++j) {
+                        ta += red[(2 * i) * kBlock + j * CW + tx];
+                        tb += red[(2 * i + 1) * kBlock + j * CW + tx];
+                    }
+                    const int c = cg * V + i;
+                    part[(long long)blockIdx.x * 2 * D + 2 * c] = ta;
+                    part[(long long)blockIdx.x * 2 * D + 2 * c + 1] = tb;
                 }
-                part[(long long)blockIdx.x * 2 * D + 2 * c] = ta;
-                part[(long long)blockIdx.x * 2 * D + 2 * c + 1] = tb;
             }
         }
     }
 }
 
+// one workgroup per column: threads stride over the per-block partials, then a fixed-order
+// LDS tree (deterministic)
 __global__ __launch_bounds__(kBlock) void k_colsum_final(const float *__restrict__ part,
                                                          float *__restrict__ out, int n_blocks, int M)
 {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= M) return;
+    __shared__ float red[kBlock];
+    const int c = blockIdx.x;
     float s = 0.0f;
-    for (int b = 0; b < n_blocks; ++b) s += part[(long long)b * M + c];
-    out[c] = s;
+    for (int b = threadIdx.x; b < n_blocks; b += kBlock) s += part[(long long)b * M + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
 }
 
 // DiagonalGaussian.log_prob backward (gaussian.py:46-54): g[row, d] = -glp[row] (z - loc) / scale^2
@@ -529,7 +570,9 @@ int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, con
         }
         return TFK_OK;
     }
-    int CW = pow2_ceil(D);
+    const bool vec4 = (D % 4 == 0) && aligned16(g) && (!gvalue || aligned16(x));
+    const int G = vec4 ? D / 4 : D;
+    int CW = pow2_ceil(G);
     if (CW > kBlock) CW = kBlock;
     const int RY = kBlock / CW;
     // slabs of rows: enough workgroups to fill the chip, at least RY * 8 rows each
@@ -539,24 +582,20 @@ int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, con
     if (rpb < min_rows) rpb = min_rows;
     blocks = (N + rpb - 1) / rpb;
     const int grid = (int)blocks;
+#define TFK_EW_BWD(INV, WANT, V)                                                                          \
+    hipLaunchKernelGGL((k_elementwise_affine_bwd<INV, WANT, V>), dim3(grid), dim3(kBlock), 0, s, x, value, g, \
+                       gld, workspace, (long long)N, D, CW, (long long)rpb)
     if (gvalue) {
-        if (inverse)
-            hipLaunchKernelGGL((k_elementwise_affine_bwd<true, true>), dim3(grid), dim3(kBlock), 0, s, x, value,
-                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
-        else
-            hipLaunchKernelGGL((k_elementwise_affine_bwd<false, true>), dim3(grid), dim3(kBlock), 0, s, x, value,
-                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+        if (vec4) { if (inverse) TFK_EW_BWD(true, true, 4); else TFK_EW_BWD(false, true, 4); }
+        else      { if (inverse) TFK_EW_BWD(true, true, 1); else TFK_EW_BWD(false, true, 1); }
         if (int rc = check_launch(fn)) return rc;
-        hipLaunchKernelGGL(k_colsum_final, dim3((2 * D + kBlock - 1) / kBlock), dim3(kBlock), 0, s, workspace,
+        hipLaunchKernelGGL(k_colsum_final, dim3(2 * D), dim3(kBlock), 0, s, workspace,
                            gvalue, grid, 2 * D);
     } else {
-        if (inverse)
-            hipLaunchKernelGGL((k_elementwise_affine_bwd<true, false>), dim3(grid), dim3(kBlock), 0, s, x, value,
-                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
-        else
-            hipLaunchKernelGGL((k_elementwise_affine_bwd<false, false>), dim3(grid), dim3(kBlock), 0, s, x, value,
-                               g, gld, workspace, (long long)N, D, CW, (long long)rpb);
+        if (vec4) { if (inverse) TFK_EW_BWD(true, false, 4); else TFK_EW_BWD(false, false, 4); }
+        else      { if (inverse) TFK_EW_BWD(true, false, 1); else TFK_EW_BWD(false, false, 1); }
     }
+#undef TFK_EW_BWD
     return check_launch(fn);
 }
 
