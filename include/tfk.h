@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 5
+#define TFK_ABI_VERSION 6
 
 enum {
     TFK_OK = 0,
@@ -241,6 +241,23 @@ int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, con
 /* g (N, D) out = glp[row] * d log N(z; loc, exp(log_scale)) / dz */
 int tfk_diag_gauss_logprob_bwd(const float *z, const float *loc, const float *log_scale,
                                const float *glp, float *g, int64_t N, int32_t D, void *stream);
+
+/* Fused training backward of ONE affine coupling layer on the HalfSplit mask (source = first half
+ * of the row, target = second half) with the default FeedForward(Linear, Tanh, Linear) conditioner,
+ * hidden width <= 15, D = 64 or 128: conditioner re-evaluation, transform backward, MLP backward
+ * and the weight-gradient sums over the N rows in one launch (h, dL/dh never exist in HBM).
+ *   x (N, D) the rows that entered the layer; g (N, D) in/out: dL/d(out rows) -> dL/d(x rows), all
+ *   D columns; gld (N,); inverse_form != 0: the layer evaluates (x - beta) / alpha (ActNorm-style).
+ *   params: the weights as MFMA operands (layout in csrc/tfk_bwd.hip, packed by
+ *   torchflows_amd/autograd.py:_TrainPack); out: tfk_coupling_train_bwd_out_floats(D) floats holding
+ *   dW2 | dW1 | db1 in accumulator layout (db2 = hidden unit 15 of dW2); workspace:
+ *   tfk_coupling_train_bwd_workspace_bytes(D).  The sums are deterministic. */
+int tfk_coupling_train_bwd_supported(int32_t D);
+int64_t tfk_coupling_train_bwd_out_floats(int32_t D);
+int64_t tfk_coupling_train_bwd_workspace_bytes(int32_t D);
+int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
+                                  int64_t n_params, int32_t gemm2_steps, float *out, float *workspace,
+                                  int64_t N, int32_t D, int32_t inverse_form, void *stream);
 
 #ifdef __cplusplus
 }

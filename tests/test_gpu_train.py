@@ -203,3 +203,45 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, lr):
     print(f"{arch}: mean log-likelihood {before:.4f} -> host {after_h:.4f}, device {after_d:.4f}")
     assert after_d > before
     assert abs(after_d - after_h) < 5e-3 * max(1.0, abs(after_h))
+
+
+@pytest.mark.parametrize("D,N", [(64, 4099), (64, 17), (64, 1), (128, 2050)])
+@pytest.mark.parametrize("layer_cls", ["AffineCoupling", "InverseAffineCoupling"])
+def test_fused_training_backward_matches_layerwise(native, monkeypatch, D, N, layer_cls):
+    """tfk_affine_coupling_train_bwd (conditioner + transform + MLP backward + weight-gradient sums
+    in one launch) against the layer-by-layer reverse-mode route and fp64 autograd on the host."""
+    import copy
+    from torchflows_amd.bijections.base import BijectiveComposition
+    from torchflows_amd.bijections.finite.autoregressive import layers as L
+    from torchflows_amd.bijections.finite.matrix.permutation import ReversePermutationMatrix
+    torch.manual_seed(D + N)
+    comp = BijectiveComposition([getattr(L, layer_cls)((D,)), ReversePermutationMatrix((D,)),
+                                 getattr(L, layer_cls)((D,))])
+    for p in comp.parameters():
+        p.data.mul_(3.0)                                  # leave the near-identity initialisation
+    x = torch.randn(N, D)
+    wz, wl = torch.randn(N, D), torch.randn(N)
+
+    def grads(c, xx, a, b):
+        xx = xx.clone().requires_grad_(True)
+        z, ld = c.forward(xx)
+        ps = [p for p in c.parameters() if p.requires_grad and p.numel()]
+        out = torch.autograd.grad((z * a).sum() + (ld * b).sum(), [xx] + ps)
+        return [o.detach().double().cpu().numpy() for o in out]
+
+    truth = grads(copy.deepcopy(comp).double(), x.double(), wz.double(), wl.double())
+    dev = copy.deepcopy(comp).cuda()
+    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_FUSED", "0")
+    before = native.calls
+    split = grads(dev, x.cuda(), wz.cuda(), wl.cuda())
+    n_split = native.calls - before
+    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_FUSED", "1")
+    before = native.calls
+    fused = grads(dev, x.cuda(), wz.cuda(), wl.cuda())
+    assert native.calls - before == n_split               # same number of libtfk entry points ...
+    worst_f = worst_s = 0.0
+    for t, s_, f in zip(truth, split, fused):
+        worst_s = max(worst_s, normwise(s_, t))
+        worst_f = max(worst_f, normwise(f, t))
+    print(f"{layer_cls}({D}), N={N}: vs fp64 -- fused {worst_f:.2e}, layer-by-layer {worst_s:.2e}")
+    assert worst_f < max(1e-5, 3 * worst_s)

@@ -125,6 +125,102 @@ def _plain_mlp(layer):
     return None
 
 
+class _TrainPack:
+    """Index maps between a coupling layer's (W1, b1, W2, b2) and the operand / accumulator layouts
+    of tfk_affine_coupling_train_bwd (csrc/tfk_bwd.hip), built once per (D, H, device).
+    Lane l = (q = l >> 4, i = l & 15); hidden unit of D-row i: u(i) = 4 (i & 3) + (i >> 2)."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, D: int, H: int, device) -> "_TrainPack":
+        key = (D, H, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(D, H, device)
+        return cls._cache[key]
+
+    def __init__(self, D: int, H: int, device):
+        half, EPL = D // 2, D // 8
+        T2, T1 = EPL // 2, EPL // 4
+        self.steps2 = (H + 3) // 4
+        TP = 2 * half
+        off_b1 = H * half
+        off_W2 = off_b1 + H
+        off_b2 = off_W2 + TP * H
+        Z = off_b2 + TP                                   # index of the appended zero
+        ar = torch.arange
+        W1idx = torch.full((16, half), Z, dtype=torch.long)
+        W1idx[:H] = (ar(H)[:, None] * half + ar(half)[None, :])
+        b1idx = torch.full((16,), Z, dtype=torch.long)
+        b1idx[:H] = off_b1 + ar(H)
+        W2idx = torch.full((half, 2, 16), Z, dtype=torch.long)
+        W2idx[:, :, :H] = off_W2 + ((ar(half)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
+        b2idx = off_b2 + (ar(half)[:, None] * 2 + ar(2)[None, :])
+        lane = ar(64)
+        ql, il = lane >> 4, lane & 15
+        unit = 4 * (il & 3) + (il >> 2)
+        q2, r2 = il >> 2, il & 3
+        qq, rr = torch.meshgrid(ar(4), ar(4), indexing="ij")
+        parts = [torch.stack([W1idx[unit, EPL * ql + s] for s in range(EPL)]).reshape(-1),        # A1
+                 b1idx[4 * rr + qq].reshape(-1)]                                                  # b1[q][r]
+        A2, b2m, A2T, A1T = [], [], [], []
+        for t in range(T2):
+            for r1 in range(self.steps2):
+                A2.append(W2idx[EPL * q2 + 2 * t + (r2 >> 1), r2 & 1, 4 * r1 + ql])
+            b2m.append(b2idx[EPL * qq + 2 * t + (rr >> 1), rr & 1].reshape(-1))
+            for r in range(4):
+                A2T.append(W2idx[EPL * ql + 2 * t + (r >> 1), r & 1, unit])
+        for t in range(T1):
+            for r in range(4):
+                A1T.append(W1idx[4 * r + ql, EPL * (il >> 2) + 4 * t + (il & 3)])
+        parts += [torch.stack(A2).reshape(-1), torch.stack(b2m).reshape(-1),
+                  torch.stack(A2T).reshape(-1), torch.stack(A1T).reshape(-1)]
+        self.param_index = torch.cat(parts).to(device)
+        self.n_flat = Z + 1
+        # accumulator layout -> [dW1 (H, half) | db1 (H) | dW2 (TP, H) | db2 (TP)]
+        u = ar(H)
+        e = ar(half)
+        off1 = T2 * 256
+        dW1 = off1 + (((e // 16)[None, :] * 64 + 16 * ((e % 16) // 4)[None, :] + u[:, None]) * 4 + (e % 4)[None, :])
+        db1 = off1 + T1 * 256 + 4 * (u % 4) + (u // 4)
+        m = ar(half)[:, None].expand(half, 2).reshape(-1)
+        pbit = ar(2)[None, :].expand(half, 2).reshape(-1)
+        q_m, rem = m // EPL, m % EPL
+        T_m, r_m = rem // 2, 2 * (rem % 2) + pbit
+        dW2 = ((T_m * 64 + 16 * q_m)[:, None] + u[None, :]) * 4 + r_m[:, None]
+        db2 = (T_m * 64 + 16 * q_m + 15) * 4 + r_m
+        self.grad_index = torch.cat([dW1.reshape(-1), db1, dW2.reshape(-1), db2]).to(device)
+        self.sizes = (H * half, H, TP * H, TP)
+        self.shapes = ((H, half), (H,), (TP, H), (TP,))
+        self.zero = torch.zeros(1, dtype=torch.float32, device=device)
+        n_out = int(native.lib().tfk_coupling_train_bwd_out_floats(D))
+        self.n_out = n_out
+        self.workspace = torch.empty(int(native.lib().tfk_coupling_train_bwd_workspace_bytes(D)) // 4,
+                                     dtype=torch.float32, device=device)
+
+
+def fused_train_enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_TRAIN_FUSED", "1") != "0"
+
+
+def _fused_bwd_layer(layer, D: int):
+    """(lin1, lin2) when the layer's whole backward can run as tfk_affine_coupling_train_bwd."""
+    if not fused_train_enabled() or not native.lib().tfk_coupling_train_bwd_supported(D):
+        return None
+    if layer.transformer.native_kind not in ("affine", "inverse_affine"):
+        return None
+    c = layer.coupling
+    if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
+            and c.target_event_size == D // 2):
+        return None
+    mlp = _plain_mlp(layer)
+    if mlp is None or mlp[0].out_features > 15:
+        return None
+    if not all(p.dtype == torch.float32 for p in (mlp[0].weight, mlp[0].bias, mlp[1].weight, mlp[1].bias)):
+        return None
+    return mlp
+
+
 SPLIT_K_ROWS = 1024
 
 
@@ -252,6 +348,22 @@ class ChainFunction(torch.autograd.Function):
                 tgt = None if layer._target_is_tail else layer._target_index32
                 tk = layer.transformer.native_kind
                 cparams = list(layer.conditioner_transform.parameters())
+                fused = _fused_bwd_layer(layer, D)
+                if fused is not None:       # one launch: conditioner, transform and MLP backward
+                    lin1, lin2 = fused
+                    pack = _TrainPack.get(D, lin1.out_features, g.device)
+                    flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
+                                      lin2.weight.detach().reshape(-1), lin2.bias.detach(), pack.zero])
+                    out = torch.empty(pack.n_out, dtype=torch.float32, device=g.device)
+                    native.affine_coupling_train_bwd(x_in, g, gld, flat[pack.param_index], pack.steps2, out,
+                                                     pack.workspace, inverse_form=_affine_form_is_inverse(layer, d))
+                    dW1, db1, dW2, db2 = (t.view(shp) for t, shp in
+                                          zip(out[pack.grad_index].split(pack.sizes), pack.shapes))
+                    by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
+                    grads_per_step[i] = [(by_param.get(id(p), None) if p.requires_grad else None) for p in cparams]
+                    grads_per_step[i] = [torch.zeros_like(p) if (gp is None and p.requires_grad) else gp
+                                         for gp, p in zip(grads_per_step[i], cparams)]
+                    continue
                 x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
                 mlp = _plain_mlp(layer)
                 if mlp is not None:            # re-evaluate h; keep the hidden activations

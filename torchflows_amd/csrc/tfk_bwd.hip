@@ -614,3 +614,338 @@ int tfk_diag_gauss_logprob_bwd(const float *z, const float *loc, const float *lo
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Fused training backward of one affine coupling layer (HalfSplit: source = first half of the
+// row, target = second half; FeedForward(Linear, Tanh, Linear) conditioner, hidden width <= 15).
+// ONE launch does what the layer-by-layer route does in ~15: re-evaluate the conditioner, reverse
+// the transform, reverse the MLP (dL/dx_A) and reduce the weight gradients over the batch rows --
+// h, dL/dh and the hidden activations never exist in HBM.
+//   bytes per row: x 4D + g 8D + 4 (gld)            (D = 64: 772 B; the split route moves ~3 KB)
+// Register layout = the forward flow program's (tfk_flow_mfma.hip): a wave owns 16 rows, lane
+// (q, j) holds elements [EPL q, EPL (q+1)) of the source half and of the target half of row j.
+//   1. GEMM 1 + tanh, GEMM 2 -> (u, beta) of this lane's target elements       (as the forward)
+//   2. transform backward in registers -> dL/dx_B, dL/dh (same D-layout as h)
+//   3. dL/dhidden = W2^T dL/dh  : MFMA, A-operand = W2 packed so the result lands on the lane /
+//      register that holds the matching hidden unit; times tanh'
+//   4. dL/dx_A   = W1^T dL/dpre : MFMA, result lands on the lane that holds the element
+//   5. dW2 += dL/dh^T hidden, dW1 += dL/dpre^T x_A: the contraction runs over the 16 ROWS of the
+//      wave, i.e. over the lane index that MFMA never contracts -- both operands take one trip
+//      through a wave-private LDS tile (written row-major, read transposed), accumulators stay
+//      in registers for the whole row loop; db2 rides along as hidden unit 15 == 1.
+//   6. per-workgroup partial sums -> part[block][M]; tfk reduces them with k_colsum2d.
+// Parameter block (floats, packed by torchflows_amd/autograd.py:_TrainPack):
+//   A1[EPL][64] | b1[16] | A2[T2][steps2][64] | b2[T2][16] | A2T[T2][4][64] | A1T[EPL/4][4][64]
+// Partial layout (M floats): dW2[T2][64][4] | dW1[EPL/4][64][4] | db1[16]
+// =============================================================================================
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int EPL, bool INVFORM>
+__global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
+    const float *__restrict__ x, float *g, const float *__restrict__ gld,
+    const float *__restrict__ params, int n_params, int steps2, float *__restrict__ part, long long N)
+{
+    constexpr int D = 8 * EPL, HALF = 4 * EPL, T2 = EPL / 2, T1 = EPL / 4;
+    constexpr int SCR = 512 + 192 * EPL;                 // floats of scratch per wave
+    constexpr int M = T2 * 256 + T1 * 256 + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(params);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < (n_params >> 2); i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *A1 = lds;
+    const float *b1 = A1 + EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + T2 * steps2 * 64;
+    const float *A2T = b2 + T2 * 16;
+    const float *A1T = A2T + T2 * 4 * 64;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    float *scr = lds + n_params + wave * SCR;
+    float *scr_h = scr;                                  // [q][row][r]   hidden (unit 4r+q)
+    float *scr_p = scr + 256;                            // [q][row][r]   dL/dpre
+    float *scr_g = scr + 512;                            // [t][q][row][r] dL/dh
+    float *scr_x = scr + 512 + 128 * EPL;                // [row][HALF]   x_A
+
+    f32x4_t accW2[T2], accW1[T1];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) accW2[t] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < T1; ++t) accW1[t] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+    float sb1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    constexpr int rows_per_block = (kBlock / 64) * 16;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * 16; row0 < N; row0 += stride) {
+        const long long row = row0 + j;
+        const bool valid = row < N;
+        const long long rr = valid ? row : N - 1;
+        float xa[EPL], xb[EPL], ga[EPL], gb[EPL];
+        {
+            const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+            const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+            const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + EPL * q);
+            const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF + EPL * q);
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const float4 va = pa[i], vb = pb[i], wa = qa[i], wb = qb[i];
+                xa[4 * i] = va.x; xa[4 * i + 1] = va.y; xa[4 * i + 2] = va.z; xa[4 * i + 3] = va.w;
+                xb[4 * i] = vb.x; xb[4 * i + 1] = vb.y; xb[4 * i + 2] = vb.z; xb[4 * i + 3] = vb.w;
+                ga[4 * i] = wa.x; ga[4 * i + 1] = wa.y; ga[4 * i + 2] = wa.z; ga[4 * i + 3] = wa.w;
+                gb[4 * i] = wb.x; gb[4 * i + 1] = wb.y; gb[4 * i + 2] = wb.z; gb[4 * i + 3] = wb.w;
+            }
+        }
+        float gl = gld[rr];
+        if (!valid) {                       // padding rows of the last tile contribute nothing
+            gl = 0.0f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) ga[e] = gb[e] = 0.0f;
+        }
+
+        // 1. conditioner forward (transforms.py:293-304)
+        f32x4_t acc = *reinterpret_cast<const f32x4_t *>(b1 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], xa[s], acc, 0, 0, 0);
+        float hid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[r] = tanh_fast(acc[r]);
+
+        // 2. h tile by tile, transform backward (affine.py:36-59)
+        f32x4_t ghv[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            f32x4_t o = *reinterpret_cast<const f32x4_t *>(b2 + (t * 4 + q) * 4);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+            if (steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
+            if (steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
+            if (steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                const float beta = o[2 * i + 1];
+                const float ex = exp_noovf(o[2 * i] * 0.5f + kAffC0);
+                const float alpha = ex + kAffMinScale;
+                const float ra = __builtin_amdgcn_rcpf(alpha);
+                const float gz = gb[e];
+                float gx, gbeta, galpha;
+                if (!INVFORM) {
+                    gx = gz * alpha;
+                    gbeta = gz;
+                    galpha = gz * xb[e] + gl * ra;
+                } else {
+                    const float r_ = gz * ra;
+                    gx = r_;
+                    gbeta = -r_;
+                    galpha = -r_ * ((xb[e] - beta) * ra) - gl * ra;
+                }
+                gb[e] = gx;
+                ghv[t][2 * i] = galpha * ex * 0.5f;
+                ghv[t][2 * i + 1] = gbeta;
+            }
+        }
+
+        // 3. dL/dhidden (unit 4r+q lands in register r), times tanh'
+        f32x4_t gha = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gha = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[(t * 4 + r) * 64 + lane], ghv[t][r], gha, 0, 0, 0);
+        float gpre[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gpre[r] = gha[r] * (1.0f - hid[r] * hid[r]);
+            sb1[r] += gpre[r];
+        }
+
+        // 4. dL/dx_A: element EPL q + 4 t + r' lands in register r' of tile t
+#pragma unroll
+        for (int t = 0; t < T1; ++t) {
+            f32x4_t d = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(A1T[(t * 4 + r) * 64 + lane], gpre[r], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[4 * t + r] += d[r];
+        }
+        if (valid) {
+            float4 *qa = reinterpret_cast<float4 *>(g + row * D + EPL * q);
+            float4 *qb = reinterpret_cast<float4 *>(g + row * D + HALF + EPL * q);
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                qa[i] = make_float4(ga[4 * i], ga[4 * i + 1], ga[4 * i + 2], ga[4 * i + 3]);
+                qb[i] = make_float4(gb[4 * i], gb[4 * i + 1], gb[4 * i + 2], gb[4 * i + 3]);
+            }
+        }
+
+        // 5. weight gradients: both operands through the wave-private LDS tile (row-major in,
+        //    transposed out); hidden unit 15 (r = 3 of lane-group q = 3) is the constant 1 -> db2
+        wave_lds_sync();                    // the previous iteration's reads are done
+        *reinterpret_cast<float4 *>(scr_h + (q * 16 + j) * 4) =
+            make_float4(hid[0], hid[1], hid[2], q == 3 ? 1.0f : hid[3]);
+        *reinterpret_cast<float4 *>(scr_p + (q * 16 + j) * 4) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+            *reinterpret_cast<float4 *>(scr_g + ((t * 4 + q) * 16 + j) * 4) =
+                make_float4(ghv[t][0], ghv[t][1], ghv[t][2], ghv[t][3]);
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i)
+            *reinterpret_cast<float4 *>(scr_x + j * HALF + EPL * q + 4 * i) =
+                make_float4(xa[4 * i], xa[4 * i + 1], xa[4 * i + 2], xa[4 * i + 3]);
+        wave_lds_sync();
+        float bh[4], bp[4];                 // B-operands: [k = row 4s+q][column = unit j]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bh[s] = scr_h[((j & 3) * 16 + 4 * s + q) * 4 + (j >> 2)];
+            bp[s] = scr_p[((j & 3) * 16 + 4 * s + q) * 4 + (j >> 2)];
+        }
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)     // A-operand: [D-row j of tile t][k = row 4s+q]
+                accW2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    scr_g[((t * 4 + (j >> 2)) * 16 + 4 * s + q) * 4 + (j & 3)], bh[s], accW2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)     // A-operand: [input 16 t + j][k = row 4s+q]
+                accW1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(scr_x[(4 * s + q) * HALF + 16 * t + j], bp[s],
+                                                                accW1[t], 0, 0, 0);
+    }
+
+    // 6. wave results -> LDS, summed over the workgroup's waves -> part[block][M]
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+        *reinterpret_cast<float4 *>(scr + (t * 64 + lane) * 4) =
+            make_float4(accW2[t][0], accW2[t][1], accW2[t][2], accW2[t][3]);
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+        *reinterpret_cast<float4 *>(scr + T2 * 256 + (t * 64 + lane) * 4) =
+            make_float4(accW1[t][0], accW1[t][1], accW1[t][2], accW1[t][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = sb1[r];
+        v += __shfl_xor(v, 1, kWave);
+        v += __shfl_xor(v, 2, kWave);
+        v += __shfl_xor(v, 4, kWave);
+        v += __shfl_xor(v, 8, kWave);
+        if (j == 0) scr[T2 * 256 + T1 * 256 + 4 * q + r] = v;
+    }
+    __syncthreads();
+    const float *all = lds + n_params;
+    for (int c = threadIdx.x; c < M; c += kBlock) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += all[w * SCR + c];
+        part[(long long)blockIdx.x * M + c] = s;
+    }
+}
+
+// column sums of part[n_blocks][M] -> out[M]: 64 columns x 4 row slices per workgroup, coalesced
+// along the columns, fixed-order combination (deterministic)
+__global__ __launch_bounds__(kBlock) void k_colsum2d(const float *__restrict__ part, float *__restrict__ out,
+                                                     int n_blocks, int M)
+{
+    __shared__ float red[kBlock];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < M)
+        for (int b = slice; b < n_blocks; b += 4) s += part[(long long)b * M + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slice == 0 && c < M) out[c] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+}
+
+template <int EPL>
+static int launch_train_bwd(const float *x, float *g, const float *gld, const float *params, int n_params,
+                            int steps2, float *out, float *workspace, int64_t N, int inverse_form,
+                            hipStream_t s, const char *fn)
+{
+    constexpr int SCR = 512 + 192 * EPL;
+    constexpr int M = (EPL / 2) * 256 + (EPL / 4) * 256 + 16;
+    const size_t lds = ((size_t)n_params + (kBlock / 64) * SCR) * sizeof(float);
+    if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: %zu bytes of LDS needed", fn, lds);
+    const void *kern = inverse_form ? reinterpret_cast<const void *>(&k_affine_coupling_train_bwd<EPL, true>)
+                                    : reinterpret_cast<const void *>(&k_affine_coupling_train_bwd<EPL, false>);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
+    }
+    int per_cu = 0;
+    hipError_t e = inverse_form
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_affine_coupling_train_bwd<EPL, true>, kBlock, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_affine_coupling_train_bwd<EPL, false>, kBlock, lds);
+    if (e != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    constexpr int rows_per_block = (kBlock / 64) * 16;
+    int64_t grid = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * per_cu;          // one resident set: few partial rows to add
+    if (grid > cap) grid = cap;
+    if (inverse_form)
+        hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, true>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
+                           gld, params, n_params, steps2, workspace, (long long)N);
+    else
+        hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, false>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
+                           gld, params, n_params, steps2, workspace, (long long)N);
+    if (int rc = check_launch(fn)) return rc;
+    hipLaunchKernelGGL(k_colsum2d, dim3((M + 63) / 64), dim3(kBlock), 0, s, workspace, out, (int)grid, M);
+    return check_launch(fn);
+}
+
+extern "C" {
+
+int tfk_coupling_train_bwd_supported(int32_t D) { return (D == 64 || D == 128) ? 1 : 0; }
+
+int64_t tfk_coupling_train_bwd_out_floats(int32_t D)
+{
+    if (!tfk_coupling_train_bwd_supported(D)) return 0;
+    const int EPL = D / 8;
+    return (int64_t)(EPL / 2) * 256 + (EPL / 4) * 256 + 16;
+}
+
+int64_t tfk_coupling_train_bwd_workspace_bytes(int32_t D)
+{
+    return tfk_coupling_train_bwd_out_floats(D) * (int64_t)kCUs * 8 * (int64_t)sizeof(float);
+}
+
+int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
+                                  int64_t n_params, int32_t gemm2_steps, float *out, float *workspace,
+                                  int64_t N, int32_t D, int32_t inverse_form, void *stream)
+{
+    const char *fn = "tfk_affine_coupling_train_bwd";
+    if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
+    if (!tfk_coupling_train_bwd_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64 or 128", fn, D);
+    if (gemm2_steps < 1 || gemm2_steps > 4) return fail(TFK_EINVAL, "%s: GEMM-2 steps %d not in [1, 4]", fn, gemm2_steps);
+    const int EPL = D / 8, T2 = EPL / 2, T1 = EPL / 4;
+    const int64_t need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * gemm2_steps * 64 + T2 * 16 + T2 * 4 * 64 + T1 * 4 * 64;
+    if (n_params != need) return fail(TFK_EINVAL, "%s: parameter block has %lld floats, expected %lld", fn,
+                                      (long long)n_params, (long long)need);
+    if (!x || !g || !gld || !params || !out || !workspace) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(x) || !aligned16(g) || !aligned16(params))
+        return fail(TFK_EINVAL, "%s: x, g and params must be 16-byte aligned", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (EPL == 8)
+        return launch_train_bwd<8>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form, s, fn);
+    return launch_train_bwd<16>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form, s, fn);
+}
+
+}  // extern "C"

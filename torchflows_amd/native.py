@@ -37,9 +37,11 @@ SYMBOLS = (
     "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd",
     "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
     "tfk_diag_gauss_logprob_bwd",
+    "tfk_coupling_train_bwd_supported", "tfk_coupling_train_bwd_out_floats",
+    "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
 )
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NativeError(RuntimeError):
@@ -96,6 +98,12 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_elementwise_affine_bwd_workspace_bytes.restype = _i64
     L.tfk_elementwise_affine_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]
     L.tfk_diag_gauss_logprob_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
+    L.tfk_coupling_train_bwd_supported.argtypes = [_i32]
+    L.tfk_coupling_train_bwd_out_floats.argtypes = [_i32]
+    L.tfk_coupling_train_bwd_out_floats.restype = _i64
+    L.tfk_coupling_train_bwd_workspace_bytes.argtypes = [_i32]
+    L.tfk_coupling_train_bwd_workspace_bytes.restype = _i64
+    L.tfk_affine_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -374,6 +382,26 @@ def diag_gauss_logprob_bwd(z, loc, log_scale, glp, g):
     args = (_f32(z, name), _f32(loc, name), _f32(log_scale, name), _f32(glp, name), _f32(g, name), N, D)
     with torch.cuda.device(z.device):
         rc = lib().tfk_diag_gauss_logprob_bwd(*args, _stream(z))
+    calls += 1
+    _check(rc, name)
+
+
+def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, inverse_form=False):
+    """Fused conditioner + transform + MLP backward of one HalfSplit affine coupling (in place on
+    g, accumulator-layout weight gradients into ``out``)."""
+    global calls
+    name = "tfk_affine_coupling_train_bwd"
+    N, D = _rows(g, name)
+    if x.shape != g.shape or gld.numel() != N:
+        raise NativeError(f"{name}: bad x / gld shape")
+    if out.numel() != int(lib().tfk_coupling_train_bwd_out_floats(D)):
+        raise NativeError(f"{name}: out must hold tfk_coupling_train_bwd_out_floats(D) floats")
+    if workspace.numel() * 4 < int(lib().tfk_coupling_train_bwd_workspace_bytes(D)):
+        raise NativeError(f"{name}: workspace too small")
+    args = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
+            int(gemm2_steps), _f32(out, name), _f32(workspace, name), N, D, 1 if inverse_form else 0)
+    with torch.cuda.device(g.device):
+        rc = lib().tfk_affine_coupling_train_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
 
