@@ -221,6 +221,58 @@ def _fused_bwd_layer(layer, D: int):
     return mlp
 
 
+class _PlanPacks:
+    """All fusable coupling layers of one plan: ONE concatenation + ONE gather packs every layer's
+    weights into MFMA-operand order per step, and ONE gather maps all accumulator-layout gradient
+    blocks back -- instead of three small launches per layer."""
+
+    def __init__(self, plan, D: int, device):
+        self.layers = []                      # (plan index, lin1, lin2, pack)
+        pidx, gidx, off_flat, off_out = [], [], 0, 0
+        for i, (layer, d, kind) in enumerate(plan):
+            if kind != "coupling":
+                continue
+            mlp = _fused_bwd_layer(layer, D)
+            if mlp is None:
+                continue
+            pack = _TrainPack.get(D, mlp[0].out_features, device)
+            self.layers.append((i, mlp[0], mlp[1], pack))
+            pidx.append(pack.param_index + off_flat)
+            gidx.append(pack.grad_index + off_out)
+            off_flat += pack.n_flat
+            off_out += pack.n_out
+        self.slot = {i: k for k, (i, _, _, _) in enumerate(self.layers)}
+        if self.layers:
+            self.param_index = torch.cat(pidx)
+            self.grad_index = torch.cat(gidx)
+            self.n_out_total = off_out
+            self.zero = self.layers[0][3].zero
+
+    def pack(self):
+        """[packed operand block of layer k] for the current weights."""
+        pieces = []
+        for _, lin1, lin2, pack in self.layers:
+            pieces += [lin1.weight.detach().reshape(-1), lin1.bias.detach(),
+                       lin2.weight.detach().reshape(-1), lin2.bias.detach(), self.zero]
+        packed = torch.cat(pieces)[self.param_index]
+        out, lo = [], 0
+        for _, _, _, pack in self.layers:
+            n = pack.param_index.numel()
+            out.append(packed[lo:lo + n])
+            lo += n
+        return out
+
+
+def _plan_packs(plan, D: int, device) -> _PlanPacks:
+    owner = plan[0][0]
+    key = (tuple(id(l) for l, _, _ in plan), tuple(d for _, d, _ in plan), str(device), fused_train_enabled())
+    cache = owner.__dict__.setdefault("_tfk_plan_packs", {})
+    if key not in cache:
+        cache.clear()
+        cache[key] = _PlanPacks(plan, D, device)
+    return cache[key]
+
+
 SPLIT_K_ROWS = 1024
 
 
@@ -271,7 +323,9 @@ class ChainFunction(torch.autograd.Function):
         cur = rows
         cur_is_saved = True          # never write into the caller's tensor
         saved: List[Optional[torch.Tensor]] = []
-        for layer, d, kind in plan:
+        packs = _plan_packs(plan, D, rows.device)
+        packed = packs.pack() if packs.layers else []
+        for step, (layer, d, kind) in enumerate(plan):
             if kind == "perm":
                 out = torch.empty_like(cur)
                 perm = None if layer._is_reversal else (layer._fwd_index32 if d == FORWARD else layer._inv_index32)
@@ -288,6 +342,19 @@ class ChainFunction(torch.autograd.Function):
                                           accumulate=started, inverse=(d == INVERSE))
                 started = True
                 saved.append(cur if keep_input else None)
+                cur, cur_is_saved = out, False
+            elif step in packs.slot:
+                # conditioner + transform in one launch (single-op flow program on the matrix
+                # cores; the operand block is the head of the layer's training pack)
+                k = packs.slot[step]
+                pack = packs.layers[k][3]
+                n_fwd = (D // 8) * 64 + 16 + (D // 16) * pack.steps2 * 64 + (D // 16) * 16
+                op = 3 if _affine_form_is_inverse(layer, d) else 2          # TFK_OP_AFFINE_INV / _FWD
+                out = torch.empty_like(cur)
+                native.flow_run_mfma(cur, out, logdet, None, None, None, [(op, 0, pack.steps2, 0)],
+                                     packed[k][:n_fwd], accumulate=started)
+                started = True
+                saved.append(cur)
                 cur, cur_is_saved = out, False
             else:
                 h = _conditioner(layer, cur).reshape(N, -1).contiguous()
@@ -313,6 +380,7 @@ class ChainFunction(torch.autograd.Function):
         ctx.plan = plan
         ctx.saved_rows = saved
         ctx.n_params = len(params)
+        ctx.packs, ctx.packed = packs, packed
         return cur, logdet
 
     @staticmethod
@@ -329,6 +397,9 @@ class ChainFunction(torch.autograd.Function):
         gld = (torch.zeros(N, dtype=torch.float32, device=device) if g_logdet is None
                else g_logdet.contiguous())
         grads_per_step: List[List[Optional[torch.Tensor]]] = [[] for _ in plan]
+        packs = ctx.packs
+        out_all = (torch.empty(packs.n_out_total, dtype=torch.float32, device=device)
+                   if packs.layers else None)
         for i in range(len(plan) - 1, -1, -1):
             layer, d, kind = plan[i]
             x_in = saved[i]
@@ -348,21 +419,12 @@ class ChainFunction(torch.autograd.Function):
                 tgt = None if layer._target_is_tail else layer._target_index32
                 tk = layer.transformer.native_kind
                 cparams = list(layer.conditioner_transform.parameters())
-                fused = _fused_bwd_layer(layer, D)
-                if fused is not None:       # one launch: conditioner, transform and MLP backward
-                    lin1, lin2 = fused
-                    pack = _TrainPack.get(D, lin1.out_features, g.device)
-                    flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
-                                      lin2.weight.detach().reshape(-1), lin2.bias.detach(), pack.zero])
-                    out = torch.empty(pack.n_out, dtype=torch.float32, device=g.device)
-                    native.affine_coupling_train_bwd(x_in, g, gld, flat[pack.param_index], pack.steps2, out,
-                                                     pack.workspace, inverse_form=_affine_form_is_inverse(layer, d))
-                    dW1, db1, dW2, db2 = (t.view(shp) for t, shp in
-                                          zip(out[pack.grad_index].split(pack.sizes), pack.shapes))
-                    by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
-                    grads_per_step[i] = [(by_param.get(id(p), None) if p.requires_grad else None) for p in cparams]
-                    grads_per_step[i] = [torch.zeros_like(p) if (gp is None and p.requires_grad) else gp
-                                         for gp, p in zip(grads_per_step[i], cparams)]
+                if i in packs.slot:         # one launch: conditioner, transform and MLP backward
+                    k = packs.slot[i]
+                    pack = packs.layers[k][3]
+                    native.affine_coupling_train_bwd(x_in, g, gld, ctx.packed[k], pack.steps2,
+                                                     out_all[k * pack.n_out:(k + 1) * pack.n_out], pack.workspace,
+                                                     inverse_form=_affine_form_is_inverse(layer, d))
                     continue
                 x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
                 mlp = _plain_mlp(layer)
@@ -402,6 +464,18 @@ class ChainFunction(torch.autograd.Function):
                     g[:, :S].add_(g_xa)
                 else:
                     g.index_add_(1, layer._source_index, g_xa)
+        if packs.layers:                    # accumulator layout -> parameter layout, all layers at once
+            pieces = out_all[packs.grad_index]
+            lo = 0
+            for i, lin1, lin2, pack in packs.layers:
+                dW1, db1, dW2, db2 = (t.view(shp) for t, shp in
+                                      zip(pieces[lo:lo + sum(pack.sizes)].split(pack.sizes), pack.shapes))
+                lo += sum(pack.sizes)
+                by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
+                cparams = list(plan[i][0].conditioner_transform.parameters())
+                grads_per_step[i] = [
+                    (by_param[id(p)] if id(p) in by_param else torch.zeros_like(p)) if p.requires_grad else None
+                    for p in cparams]
         flat: List[Optional[torch.Tensor]] = []
         for gs in grads_per_step:
             flat.extend(gs)

@@ -232,9 +232,24 @@ class BijectiveComposition(Bijection):
         return z, log_det
 
     def regularization(self, *aux):
+        """Sum of the layers' regularisation terms (reference :234-243).  The L2 terms of the
+        coupling layers -- ``l2_coef * sum_p ||p||^2`` per layer, layers_base.py:38-48 -- are
+        evaluated together per coefficient (one concatenation and one reduction instead of two
+        tiny launches per parameter tensor, forward and backward)."""
         total = torch.tensor(0.0)
+        by_coef = {}
         for layer in self.layers:
-            total = total + layer.regularization()
+            terms = getattr(layer, "_l2_terms", None)
+            got = terms() if terms is not None else None
+            if got is None:
+                total = total + layer.regularization()
+            else:
+                coef, params = got
+                by_coef.setdefault(coef, []).extend(params)
+        for coef, params in by_coef.items():
+            if params:
+                flat = torch.cat([p.reshape(-1) for p in params])
+                total = total + torch.dot(flat, flat) * coef
         return total
 
     # a composition nested in a composition is itself a native step

@@ -49,6 +49,16 @@ class AutoregressiveBijection(Bijection):
             return self.sq_norm_param() * self.l2_coef
         return torch.tensor(0.0)
 
+    def _l2_terms(self):
+        """(coefficient, parameters) of this layer's L2 term when ``regularization`` is the plain
+        rule above, so that a composition can evaluate all of them in one reduction; None if a
+        subclass overrides ``regularization``."""
+        if type(self).regularization is not AutoregressiveBijection.regularization:
+            return None
+        if self.l2_regularization and self.l2_coef > 0:
+            return float(self.l2_coef), [p for p in self.parameters() if p.requires_grad]
+        return 0.0, []
+
     # run a single layer natively when it is called on its own (outside a composition)
     def _native_standalone(self, x: torch.Tensor, context, d: int):
         rows, batch = as_rows(x, self.event_shape)
