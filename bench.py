@@ -71,7 +71,9 @@ class KernelTimer:
                             ("shift_coupling_bwd", lambda a, k: a[0].shape[0] * a[3] * 8),
                             ("elementwise_affine_bwd",
                              lambda a, k: a[2].numel() * (12 if a[4] else 8) + (4 * a[2].shape[0] if a[4] else 0)),
-                            ("diag_gauss_logprob_bwd", lambda a, k: 8 * a[0].numel() + 4 * a[0].shape[0])):
+                            ("diag_gauss_logprob_bwd", lambda a, k: 8 * a[0].numel() + 4 * a[0].shape[0]),
+                            # fused training backward: x read, g read + written, gld
+                            ("affine_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + 4 * a[1].shape[0])):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -449,7 +451,7 @@ def main():
             timer.active = False
             flow.eval()
             tk = timer.summary()
-            bwd = {k: v for k, v in tk.items() if k.endswith("_bwd")}
+            bwd = {k: v for k, v in tk.items() if k.endswith("_bwd") and k != "affine_coupling_train_bwd"}
             top = max(bwd, key=lambda k: bwd[k]["ms"]) if bwd else None
             result["train"] = {
                 "value": trows * 5 / t_elapsed, "unit": "samples/s", "rows": trows, "steps": 5,
@@ -457,9 +459,12 @@ def main():
                 "libtfk_ms_per_step": sum(v["ms"] for v in tk.values()) / 2,
                 "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                                 "GBps": round(v["GBps"], 1)} for k, v in tk.items()},
-                "note": "fwd + reverse-mode libtfk kernels + hipBLASLt conditioner GEMMs (fwd, recompute, "
-                        "bwd) + AdamW; libtfk_ms_per_step is the share spent in libtfk kernels (HIP events "
-                        "over two extra steps); the eager step is bound by launch / Python overhead"}
+                "note": "Flow.log_prob with autograd + backward + AdamW: libtfk layer kernels, single-op MFMA "
+                        "flow programs for the coupling forward, fused coupling backward (conditioner, "
+                        "transform, MLP and weight-gradient sums in one launch) where supported, else "
+                        "reverse-mode kernels + PyTorch-ROCm GEMMs; libtfk_ms_per_step is the share spent in "
+                        "libtfk kernels (HIP events over two extra steps); the eager step is bound by "
+                        "launch / Python overhead"}
             if top is not None:
                 result["train"]["roofline_bwd"] = {
                     "bound": "hbm", "kernel": top, "achieved": bwd[top]["GBps"], "peak": HBM_PEAK_GBS,

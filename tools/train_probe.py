@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Profiling probe for the training step (used under rocprofv3, see profiles/README.md):
+RealNVP / NSF on 2^18 resident rows, N maximum-likelihood steps, prints ms per step."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import bench  # noqa: E402
+
+arch = sys.argv[1] if len(sys.argv) > 1 else "RealNVP"
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+flow = bench.make_flow(arch, D, 8).cuda()
+x = torch.randn(1 << 18, D, device="cuda")
+flow.train()
+opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = -flow.log_prob(x).mean() / flow.event_size + flow.regularization()
+    loss.backward()
+    opt.step()
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+print(f"{arch}({D}): {1e3 * (time.perf_counter() - t0) / steps:.3f} ms per step")

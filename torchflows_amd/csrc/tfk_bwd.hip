@@ -657,8 +657,13 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
     const float *__restrict__ params, int n_params, int steps2, float *__restrict__ part, long long N)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL, T2 = EPL / 2, T1 = EPL / 4;
-    constexpr int SCR = 512 + 192 * EPL;                 // floats of scratch per wave
+    // wave-private transpose tiles.  Strides are padded so that the transposed ds_read_b32 of a
+    // half-wave touch 32 different banks: blocks of 16 rows x 4 floats every 72 floats (bank =
+    // 8*block + 4*q + r), x rows every HALF + 16 floats (bank = 16*q + column).
+    constexpr int BLK = 72, XROW = HALF + 16;
+    constexpr int SCR_H = 4 * BLK, SCR_G = T2 * 4 * BLK, SCR_X = 16 * XROW;
     constexpr int M = T2 * 256 + T1 * 256 + 16;
+    constexpr int SCR = (2 * SCR_H + SCR_G + SCR_X) > M ? (2 * SCR_H + SCR_G + SCR_X) : M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float4 *src = reinterpret_cast<const float4 *>(params);
@@ -677,9 +682,9 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
     const int q = lane >> 4, j = lane & 15;
     float *scr = lds + n_params + wave * SCR;
     float *scr_h = scr;                                  // [q][row][r]   hidden (unit 4r+q)
-    float *scr_p = scr + 256;                            // [q][row][r]   dL/dpre
-    float *scr_g = scr + 512;                            // [t][q][row][r] dL/dh
-    float *scr_x = scr + 512 + 128 * EPL;                // [row][HALF]   x_A
+    float *scr_p = scr + SCR_H;                          // [q][row][r]   dL/dpre
+    float *scr_g = scr + 2 * SCR_H;                      // [t][q][row][r] dL/dh
+    float *scr_x = scr + 2 * SCR_H + SCR_G;              // [row][HALF]   x_A
 
     f32x4_t accW2[T2], accW1[T1];
 #pragma unroll
@@ -796,35 +801,35 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
         // 5. weight gradients: both operands through the wave-private LDS tile (row-major in,
         //    transposed out); hidden unit 15 (r = 3 of lane-group q = 3) is the constant 1 -> db2
         wave_lds_sync();                    // the previous iteration's reads are done
-        *reinterpret_cast<float4 *>(scr_h + (q * 16 + j) * 4) =
+        *reinterpret_cast<float4 *>(scr_h + q * BLK + j * 4) =
             make_float4(hid[0], hid[1], hid[2], q == 3 ? 1.0f : hid[3]);
-        *reinterpret_cast<float4 *>(scr_p + (q * 16 + j) * 4) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
+        *reinterpret_cast<float4 *>(scr_p + q * BLK + j * 4) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
 #pragma unroll
         for (int t = 0; t < T2; ++t)
-            *reinterpret_cast<float4 *>(scr_g + ((t * 4 + q) * 16 + j) * 4) =
+            *reinterpret_cast<float4 *>(scr_g + (t * 4 + q) * BLK + j * 4) =
                 make_float4(ghv[t][0], ghv[t][1], ghv[t][2], ghv[t][3]);
 #pragma unroll
         for (int i = 0; i < EPL / 4; ++i)
-            *reinterpret_cast<float4 *>(scr_x + j * HALF + EPL * q + 4 * i) =
+            *reinterpret_cast<float4 *>(scr_x + j * XROW + EPL * q + 4 * i) =
                 make_float4(xa[4 * i], xa[4 * i + 1], xa[4 * i + 2], xa[4 * i + 3]);
         wave_lds_sync();
         float bh[4], bp[4];                 // B-operands: [k = row 4s+q][column = unit j]
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bh[s] = scr_h[((j & 3) * 16 + 4 * s + q) * 4 + (j >> 2)];
-            bp[s] = scr_p[((j & 3) * 16 + 4 * s + q) * 4 + (j >> 2)];
+            bh[s] = scr_h[(j & 3) * BLK + (4 * s + q) * 4 + (j >> 2)];
+            bp[s] = scr_p[(j & 3) * BLK + (4 * s + q) * 4 + (j >> 2)];
         }
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
             for (int s = 0; s < 4; ++s)     // A-operand: [D-row j of tile t][k = row 4s+q]
                 accW2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                    scr_g[((t * 4 + (j >> 2)) * 16 + 4 * s + q) * 4 + (j & 3)], bh[s], accW2[t], 0, 0, 0);
+                    scr_g[(t * 4 + (j >> 2)) * BLK + (4 * s + q) * 4 + (j & 3)], bh[s], accW2[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int s = 0; s < 4; ++s)     // A-operand: [input 16 t + j][k = row 4s+q]
-                accW1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(scr_x[(4 * s + q) * HALF + 16 * t + j], bp[s],
+                accW1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(scr_x[(4 * s + q) * XROW + 16 * t + j], bp[s],
                                                                 accW1[t], 0, 0, 0);
     }
 
@@ -857,19 +862,25 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
     }
 }
 
-// column sums of part[n_blocks][M] -> out[M]: 64 columns x 4 row slices per workgroup, coalesced
-// along the columns, fixed-order combination (deterministic)
-__global__ __launch_bounds__(kBlock) void k_colsum2d(const float *__restrict__ part, float *__restrict__ out,
-                                                     int n_blocks, int M)
+// column sums of part[n_blocks][M] -> out[M]: 64 columns x 16 row slices per 1024-thread
+// workgroup, coalesced along the columns, fixed-order tree (deterministic)
+__global__ __launch_bounds__(1024) void k_colsum2d(const float *__restrict__ part, float *__restrict__ out,
+                                                   int n_blocks, int M)
 {
-    __shared__ float red[kBlock];
+    __shared__ float red[1024];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float s = 0.0f;
-    if (c < M)
-        for (int b = slice; b < n_blocks; b += 4) s += part[(long long)b * M + c];
+    if (c < M) {
+#pragma unroll 4
+        for (int b = slice; b < n_blocks; b += 16) s += part[(long long)b * M + c];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
-    if (slice == 0 && c < M) out[c] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    for (int o = 512; o >= 64; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (slice == 0 && c < M) out[c] = red[threadIdx.x];
 }
 
 template <int EPL>
@@ -877,8 +888,9 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
                             int steps2, float *out, float *workspace, int64_t N, int inverse_form,
                             hipStream_t s, const char *fn)
 {
-    constexpr int SCR = 512 + 192 * EPL;
     constexpr int M = (EPL / 2) * 256 + (EPL / 4) * 256 + 16;
+    constexpr int TILES = 2 * 4 * 72 + (EPL / 2) * 4 * 72 + 16 * (4 * EPL + 16);
+    constexpr int SCR = TILES > M ? TILES : M;                    // as in the kernel
     const size_t lds = ((size_t)n_params + (kBlock / 64) * SCR) * sizeof(float);
     if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: %zu bytes of LDS needed", fn, lds);
     const void *kern = inverse_form ? reinterpret_cast<const void *>(&k_affine_coupling_train_bwd<EPL, true>)
@@ -907,7 +919,7 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
         hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, false>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
                            gld, params, n_params, steps2, workspace, (long long)N);
     if (int rc = check_launch(fn)) return rc;
-    hipLaunchKernelGGL(k_colsum2d, dim3((M + 63) / 64), dim3(kBlock), 0, s, workspace, out, (int)grid, M);
+    hipLaunchKernelGGL(k_colsum2d, dim3((M + 63) / 64), dim3(1024), 0, s, workspace, out, (int)grid, M);
     return check_launch(fn);
 }
 

@@ -180,6 +180,26 @@ def _idx(t: Optional[torch.Tensor], what: str) -> Optional[int]:
     return _ptr(t, what)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(t: torch.Tensor):
+    """Make the tensor's device current for the launch -- a no-op (and no context-manager cost on
+    the launch path) when it already is."""
+    idx = t.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -204,7 +224,7 @@ def _coupling(name, x, h, out, logdet, tgt_idx, T, P, accumulate, extra=()):
     fn = getattr(lib(), name)
     args = (_f32(x, name), _f32(h, name), _f32(out, name), _f32(logdet, name), N, D,
             _idx(tgt_idx, name), T, *extra, 1 if accumulate else 0)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = fn(*args, _stream(x))
     calls += 1
     _check(rc, name)
@@ -242,7 +262,7 @@ def conv1x1_coupling(x, h, out, logdet, tgt_idx, T, n_channels, accumulate=False
         raise NativeError(f"{name}: tgt_idx has {tgt_idx.numel()} entries, expected T = {T}")
     args = (_f32(x, name), _f32(h, name), _f32(out, name), _f32(logdet, name), N, D,
             _idx(tgt_idx, name), T, n, 1 if accumulate else 0)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = getattr(lib(), name)(*args, _stream(x))
     calls += 1
     _check(rc, name)
@@ -259,7 +279,7 @@ def elementwise_affine(x, value, out, logdet, inverse_affine, accumulate=False, 
         raise NativeError(f"{name}: bad out/logdet shape")
     args = (_f32(x, name), _f32(value, name), _f32(out, name), _f32(logdet, name), N, D,
             1 if inverse_affine else 0, 1 if accumulate else 0)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = getattr(lib(), name)(*args, _stream(x))
     calls += 1
     _check(rc, name)
@@ -274,7 +294,7 @@ def permute(x, perm, out):
     if perm is not None and perm.numel() != D:
         raise NativeError(f"tfk_permute: perm has {perm.numel()} entries, expected D = {D}")
     args = (_f32(x, "tfk_permute"), _idx(perm, "tfk_permute"), _f32(out, "tfk_permute"), N, D)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = lib().tfk_permute(*args, _stream(x))
     calls += 1
     _check(rc, "tfk_permute")
@@ -288,7 +308,7 @@ def diag_gauss_logprob(z, loc, log_scale, logdet_in, out):
         raise NativeError(f"{name}: bad parameter/out shape")
     args = (_f32(z, name), _f32(loc, name), _f32(log_scale, name), _f32(logdet_in, name),
             _f32(out, name), N, D)
-    with torch.cuda.device(z.device):
+    with _device_guard(z):
         rc = lib().tfk_diag_gauss_logprob(*args, _stream(z))
     calls += 1
     _check(rc, name)
@@ -315,7 +335,7 @@ def affine_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, inverse=False):
         raise NativeError(f"{name}: h / gh must hold N*T*2 = {N * T * 2} elements")
     args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
             _idx(tgt_idx, name), T, 1 if inverse else 0)
-    with torch.cuda.device(g.device):
+    with _device_guard(g):
         rc = lib().tfk_affine_coupling_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
@@ -328,7 +348,7 @@ def shift_coupling_bwd(g, gh, tgt_idx, T, inverse=False):
     if gh.numel() != N * T:
         raise NativeError(f"{name}: gh must hold N*T = {N * T} elements")
     args = (_f32(g, name), _f32(gh, name), N, D, _idx(tgt_idx, name), T, 1 if inverse else 0)
-    with torch.cuda.device(g.device):
+    with _device_guard(g):
         rc = lib().tfk_shift_coupling_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
@@ -343,7 +363,7 @@ def rqs_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_bins, boundary, inverse=Fal
         raise NativeError(f"{name}: h / gh must hold N*T*P = {N * T * P} elements")
     args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
             _idx(tgt_idx, name), T, int(n_bins), C.c_float(float(boundary)), 1 if inverse else 0)
-    with torch.cuda.device(g.device):
+    with _device_guard(g):
         rc = lib().tfk_rqs_coupling_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
@@ -366,7 +386,7 @@ def elementwise_affine_bwd(x, value, g, gld, want_param, inverse=False):
     args = (_f32(x if want_param else None, name), _f32(value, name), _f32(g, name),
             _f32(gld if want_param else None, name), _f32(gvalue, name), _f32(ws, name), N, D,
             1 if inverse else 0)
-    with torch.cuda.device(g.device):
+    with _device_guard(g):
         rc = lib().tfk_elementwise_affine_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
@@ -380,7 +400,7 @@ def diag_gauss_logprob_bwd(z, loc, log_scale, glp, g):
     if loc.numel() != D or log_scale.numel() != D or glp.numel() != N or g.shape != z.shape:
         raise NativeError(f"{name}: bad parameter / gradient shape")
     args = (_f32(z, name), _f32(loc, name), _f32(log_scale, name), _f32(glp, name), _f32(g, name), N, D)
-    with torch.cuda.device(z.device):
+    with _device_guard(z):
         rc = lib().tfk_diag_gauss_logprob_bwd(*args, _stream(z))
     calls += 1
     _check(rc, name)
@@ -400,7 +420,7 @@ def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, in
         raise NativeError(f"{name}: workspace too small")
     args = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
             int(gemm2_steps), _f32(out, name), _f32(workspace, name), N, D, 1 if inverse_form else 0)
-    with torch.cuda.device(g.device):
+    with _device_guard(g):
         rc = lib().tfk_affine_coupling_train_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
@@ -433,7 +453,7 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
             _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
             _f32(params, name), params.numel(), 1 if accumulate else 0)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = lib().tfk_flow_run(*args, _stream(x))
     calls += 1
     _check(rc, name)
@@ -452,7 +472,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
             _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
             _f32(params, name), params.numel(), 1 if accumulate else 0)
-    with torch.cuda.device(x.device):
+    with _device_guard(x):
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
     _check(rc, name)
@@ -466,7 +486,7 @@ def sum_f32(values: torch.Tensor) -> torch.Tensor:
     _f32(v, "tfk_sum_f32")
     out = torch.empty(1, dtype=torch.float64, device=v.device)
     ws = torch.empty(int(lib().tfk_sum_workspace_bytes(N)), dtype=torch.uint8, device=v.device)
-    with torch.cuda.device(v.device):
+    with _device_guard(v):
         rc = lib().tfk_sum_f32(_f32(v, "tfk_sum_f32"), out.data_ptr(), ws.data_ptr(), N, _stream(v))
     calls += 1
     _check(rc, "tfk_sum_f32")
