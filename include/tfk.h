@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 6
+#define TFK_ABI_VERSION 7
 
 enum {
     TFK_OK = 0,
@@ -202,6 +202,8 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * Elementwise ops use the parameter layout of tfk_flow_run; a coupling op holds
  *   A1[D/8][64] | b1[4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],
  *   T2 = D/16 (affine), D/32 (shift), 6*D/8 (RQS, n_bins = 8: 6 tiles of 4 parameters per element)
+ * accumulate: bit 0 = add to logdet instead of overwriting it; bit 1 = store the rows reversed
+ *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store).
  * i.e. the MFMA A-operands per lane, with the row / column permutations that make the
  * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
  * packed by torchflows_amd/fused.py:_pack_mfma). */
@@ -248,6 +250,10 @@ int tfk_diag_gauss_logprob_bwd(const float *z, const float *loc, const float *lo
  * and the weight-gradient sums over the N rows in one launch (h, dL/dh never exist in HBM).
  *   x (N, D) the rows that entered the layer; g (N, D) in/out: dL/d(out rows) -> dL/d(x rows), all
  *   D columns; gld (N,); inverse_form != 0: the layer evaluates (x - beta) / alpha (ActNorm-style).
+ *   g_reversed != 0: g arrives as dL/d(rows AFTER a following reversal), i.e. column c is read from
+ *   g[n, D-1-c]; gscale (D floats or NULL): column factors applied to g as it is read -- the reverse
+ *   mode of an ActNorm / ElementwiseAffine with fixed parameters that follows the coupling
+ *   (1/alpha for the inverse-affine form, alpha for the affine form).
  *   params: the weights as MFMA operands (layout in csrc/tfk_bwd.hip, packed by
  *   torchflows_amd/autograd.py:_TrainPack); out: tfk_coupling_train_bwd_out_floats(D) floats holding
  *   dW2 | dW1 | db1 in accumulator layout (db2 = hidden unit 15 of dW2); workspace:
@@ -257,7 +263,8 @@ int64_t tfk_coupling_train_bwd_out_floats(int32_t D);
 int64_t tfk_coupling_train_bwd_workspace_bytes(int32_t D);
 int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
                                   int64_t n_params, int32_t gemm2_steps, float *out, float *workspace,
-                                  int64_t N, int32_t D, int32_t inverse_form, void *stream);
+                                  int64_t N, int32_t D, int32_t inverse_form, const float *gscale,
+                                  int32_t g_reversed, void *stream);
 
 #ifdef __cplusplus
 }

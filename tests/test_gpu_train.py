@@ -49,8 +49,10 @@ def test_flow_grads_golden_on_hip(native, fname, arch, es, n_layers):
     flow = _mirror_flow(arch, es, n_layers, state_dict_of(fx, "init")).cuda()
     before = native.calls
     lp, gx, grads = hip_grads(flow, torch.tensor(fx["x"]).cuda(), torch.tensor(gr["w"]).cuda())
-    n_layers_total = len(flow.bijection.layers)
-    assert native.calls - before >= 2 * n_layers_total, "the reverse-mode kernels did not run"
+    n_couplings = sum(1 for l in flow.bijection.layers if hasattr(l, "coupling"))
+    # at least one forward and one reverse-mode libtfk launch per coupling layer (layers that ride
+    # along in a fused launch do not add calls)
+    assert native.calls - before >= 2 * n_couplings, "the reverse-mode kernels did not run"
     assert {"GaussLogProbFunctionBackward", "ChainFunctionBackward"} <= graph_nodes(lp)
     e, floor = normwise(gx.cpu().numpy(), gr["gx64"]), normwise(gr["gx"], gr["gx64"])
     print(f"{fname}: gx {e:.2e} (floor {floor:.2e})")
@@ -238,7 +240,7 @@ def test_fused_training_backward_matches_layerwise(native, monkeypatch, D, N, la
     monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_FUSED", "1")
     before = native.calls
     fused = grads(dev, x.cuda(), wz.cuda(), wl.cuda())
-    assert native.calls - before == n_split               # same number of libtfk entry points ...
+    assert 0 < native.calls - before <= n_split           # fewer launches: the reversal rides along
     worst_f = worst_s = 0.0
     for t, s_, f in zip(truth, split, fused):
         worst_s = max(worst_s, normwise(s_, t))

@@ -221,13 +221,41 @@ def _fused_bwd_layer(layer, D: int):
     return mlp
 
 
+def _ew_block(layer, d: int, D: int) -> torch.Tensor:
+    """Parameter block of a fixed ElementwiseAffine / ActNorm op as tfk_flow_run reads it
+    (alpha[D] | beta[D] | sum log alpha, pad[3] | 1/alpha[D] for the dividing form), cached on the
+    layer until its value changes (ActNorm: once, at its data-dependent initialisation)."""
+    key = (layer.value._version, layer.value.data_ptr(), d)
+    hit = layer.__dict__.get("_tfk_ew_block")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    v = layer.value.detach().reshape(D, 2)
+    alpha = layer.transformer.constrain_scale(v[:, 0])                     # affine.py:33-34
+    ldc = torch.log(alpha).sum().reshape(1)
+    inverse_form = _affine_form_is_inverse(layer, d)
+    pad = torch.zeros(3, dtype=torch.float32, device=v.device)
+    parts = [alpha, v[:, 1].contiguous(), -ldc if inverse_form else ldc, pad]
+    if inverse_form:
+        parts.append(1.0 / alpha)
+    block = torch.cat(parts).float().contiguous()
+    layer.__dict__["_tfk_ew_block"] = (key, block)
+    return block
+
+
 class _PlanPacks:
     """All fusable coupling layers of one plan: ONE concatenation + ONE gather packs every layer's
     weights into MFMA-operand order per step, and ONE gather maps all accumulator-layout gradient
-    blocks back -- instead of three small launches per layer."""
+    blocks back -- instead of three small launches per layer.
 
-    def __init__(self, plan, D: int, device):
+    With ``fold`` the fixed elementwise layer (ActNorm) and the reversal that FOLLOW a fusable
+    coupling ride along: forward = one flow program [coupling, elementwise] with a reversed store,
+    backward = the reversed / scaled load of tfk_affine_coupling_train_bwd."""
+
+    def __init__(self, plan, D: int, device, fold: bool):
         self.layers = []                      # (plan index, lin1, lin2, pack)
+        self.fold = []                        # per fusable layer: (ew step or None, reversal step or None)
+        self.folded_steps = set()
+        self.D = D
         pidx, gidx, off_flat, off_out = [], [], 0, 0
         for i, (layer, d, kind) in enumerate(plan):
             if kind != "coupling":
@@ -236,40 +264,57 @@ class _PlanPacks:
             if mlp is None:
                 continue
             pack = _TrainPack.get(D, mlp[0].out_features, device)
+            ew_step = rev_step = None
+            j = i + 1
+            if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
+                ew_step = j
+                j += 1
+            if fold and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
+                rev_step = j
             self.layers.append((i, mlp[0], mlp[1], pack))
-            pidx.append(pack.param_index + off_flat)
+            self.fold.append((ew_step, rev_step))
+            self.folded_steps.update(t for t in (ew_step, rev_step) if t is not None)
+            n_train = pack.param_index.numel()
+            idx = [pack.param_index + off_flat]
+            n_ew = 0
+            if ew_step is not None:           # the elementwise block follows the operand block
+                n_ew = (3 * D + 4) if _affine_form_is_inverse(plan[ew_step][0], plan[ew_step][1]) else (2 * D + 4)
+                idx.append(torch.arange(n_ew, device=device) + (off_flat + pack.n_flat))
+            pidx.append(torch.cat(idx))
             gidx.append(pack.grad_index + off_out)
-            off_flat += pack.n_flat
+            off_flat += pack.n_flat + n_ew
             off_out += pack.n_out
         self.slot = {i: k for k, (i, _, _, _) in enumerate(self.layers)}
+        self.plan = plan
         if self.layers:
+            self.block_sizes = [int(t.numel()) for t in pidx]
             self.param_index = torch.cat(pidx)
             self.grad_index = torch.cat(gidx)
             self.n_out_total = off_out
             self.zero = self.layers[0][3].zero
 
     def pack(self):
-        """[packed operand block of layer k] for the current weights."""
+        """[packed block of layer k: operands (+ the folded elementwise parameters)] for the
+        current weights."""
         pieces = []
-        for _, lin1, lin2, pack in self.layers:
+        for (_, lin1, lin2, pack), (ew_step, _) in zip(self.layers, self.fold):
             pieces += [lin1.weight.detach().reshape(-1), lin1.bias.detach(),
                        lin2.weight.detach().reshape(-1), lin2.bias.detach(), self.zero]
+            if ew_step is not None:
+                pieces.append(_ew_block(self.plan[ew_step][0], self.plan[ew_step][1], self.D))
         packed = torch.cat(pieces)[self.param_index]
-        out, lo = [], 0
-        for _, _, _, pack in self.layers:
-            n = pack.param_index.numel()
-            out.append(packed[lo:lo + n])
-            lo += n
-        return out
+        return list(packed.split(self.block_sizes))
 
 
-def _plan_packs(plan, D: int, device) -> _PlanPacks:
+def _plan_packs(plan, D: int, device, fold: bool) -> _PlanPacks:
     owner = plan[0][0]
-    key = (tuple(id(l) for l, _, _ in plan), tuple(d for _, d, _ in plan), str(device), fused_train_enabled())
+    key = (tuple(id(l) for l, _, _ in plan), tuple(d for _, d, _ in plan), str(device),
+           fused_train_enabled(), fold)
     cache = owner.__dict__.setdefault("_tfk_plan_packs", {})
     if key not in cache:
-        cache.clear()
-        cache[key] = _PlanPacks(plan, D, device)
+        if len(cache) > 4:
+            cache.clear()
+        cache[key] = _PlanPacks(plan, D, device, fold)
     return cache[key]
 
 
@@ -323,9 +368,15 @@ class ChainFunction(torch.autograd.Function):
         cur = rows
         cur_is_saved = True          # never write into the caller's tensor
         saved: List[Optional[torch.Tensor]] = []
-        packs = _plan_packs(plan, D, rows.device)
+        # an ActNorm that still has to take its statistics from this batch cannot ride along
+        needs_init = any(kind == "elementwise" and isinstance(layer, ActNorm) and d == FORWARD
+                         and layer.training and layer.first_training_batch_pass for layer, d, kind in plan)
+        packs = _plan_packs(plan, D, rows.device, fold=not needs_init)
         packed = packs.pack() if packs.layers else []
         for step, (layer, d, kind) in enumerate(plan):
+            if step in packs.folded_steps:
+                saved.append(None)          # ran inside the preceding coupling's flow program
+                continue
             if kind == "perm":
                 out = torch.empty_like(cur)
                 perm = None if layer._is_reversal else (layer._fwd_index32 if d == FORWARD else layer._inv_index32)
@@ -344,15 +395,20 @@ class ChainFunction(torch.autograd.Function):
                 saved.append(cur if keep_input else None)
                 cur, cur_is_saved = out, False
             elif step in packs.slot:
-                # conditioner + transform in one launch (single-op flow program on the matrix
-                # cores; the operand block is the head of the layer's training pack)
+                # conditioner + transform (+ the fixed elementwise layer and the reversal that
+                # follow) in one launch: a flow program on the matrix cores whose operand block is
+                # the head of the layer's training pack
                 k = packs.slot[step]
                 pack = packs.layers[k][3]
-                n_fwd = (D // 8) * 64 + 16 + (D // 16) * pack.steps2 * 64 + (D // 16) * 16
-                op = 3 if _affine_form_is_inverse(layer, d) else 2          # TFK_OP_AFFINE_INV / _FWD
+                ew_step, rev_step = packs.fold[k]
+                ops = [(3 if _affine_form_is_inverse(layer, d) else 2, 0, pack.steps2, 0)]   # TFK_OP_AFFINE_*
+                if ew_step is not None:
+                    ew_layer, ew_d, _ = plan[ew_step]
+                    ops.append((1 if _affine_form_is_inverse(ew_layer, ew_d) else 0, 0, 0,
+                                pack.param_index.numel()))                                # TFK_OP_EW_*
                 out = torch.empty_like(cur)
-                native.flow_run_mfma(cur, out, logdet, None, None, None, [(op, 0, pack.steps2, 0)],
-                                     packed[k][:n_fwd], accumulate=started)
+                native.flow_run_mfma(cur, out, logdet, None, None, None, ops, packed[k], accumulate=started,
+                                     reverse_out=rev_step is not None)
                 started = True
                 saved.append(cur)
                 cur, cur_is_saved = out, False
@@ -403,6 +459,9 @@ class ChainFunction(torch.autograd.Function):
         for i in range(len(plan) - 1, -1, -1):
             layer, d, kind = plan[i]
             x_in = saved[i]
+            if i in packs.folded_steps:     # handled by the load of the coupling's backward kernel
+                grads_per_step[i] = [None] * len(_layer_params(layer, kind))
+                continue
             if kind == "perm":
                 out = torch.empty_like(g)
                 perm = None if layer._is_reversal else (layer._inv_index32 if d == FORWARD else layer._fwd_index32)
@@ -422,9 +481,17 @@ class ChainFunction(torch.autograd.Function):
                 if i in packs.slot:         # one launch: conditioner, transform and MLP backward
                     k = packs.slot[i]
                     pack = packs.layers[k][3]
-                    native.affine_coupling_train_bwd(x_in, g, gld, ctx.packed[k], pack.steps2,
+                    n_train = pack.param_index.numel()
+                    ew_step, rev_step = packs.fold[k]
+                    gscale = None
+                    if ew_step is not None:     # d(alpha x + beta)/dx = alpha, d((x - beta)/alpha)/dx = 1/alpha
+                        ew_layer, ew_d, _ = plan[ew_step]
+                        lo = n_train + ((2 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0)
+                        gscale = ctx.packed[k][lo:lo + D]
+                    native.affine_coupling_train_bwd(x_in, g, gld, ctx.packed[k][:n_train], pack.steps2,
                                                      out_all[k * pack.n_out:(k + 1) * pack.n_out], pack.workspace,
-                                                     inverse_form=_affine_form_is_inverse(layer, d))
+                                                     inverse_form=_affine_form_is_inverse(layer, d),
+                                                     gscale=gscale, g_reversed=rev_step is not None)
                     continue
                 x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
                 mlp = _plain_mlp(layer)

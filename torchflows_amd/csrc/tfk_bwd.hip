@@ -654,7 +654,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int EPL, bool INVFORM>
 __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
     const float *__restrict__ x, float *g, const float *__restrict__ gld,
-    const float *__restrict__ params, int n_params, int steps2, float *__restrict__ part, long long N)
+    const float *__restrict__ params, int n_params, int steps2, float *__restrict__ part, long long N,
+    const float *__restrict__ gscale, int g_reversed)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL, T2 = EPL / 2, T1 = EPL / 4;
     // wave-private transpose tiles.  Strides are padded so that the transposed ds_read_b32 of a
@@ -703,15 +704,40 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
         {
             const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
             const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
-            const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + EPL * q);
-            const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF + EPL * q);
 #pragma unroll
             for (int i = 0; i < EPL / 4; ++i) {
-                const float4 va = pa[i], vb = pb[i], wa = qa[i], wb = qb[i];
+                const float4 va = pa[i], vb = pb[i];
                 xa[4 * i] = va.x; xa[4 * i + 1] = va.y; xa[4 * i + 2] = va.z; xa[4 * i + 3] = va.w;
                 xb[4 * i] = vb.x; xb[4 * i + 1] = vb.y; xb[4 * i + 2] = vb.z; xb[4 * i + 3] = vb.w;
-                ga[4 * i] = wa.x; ga[4 * i + 1] = wa.y; ga[4 * i + 2] = wa.z; ga[4 * i + 3] = wa.w;
-                gb[4 * i] = wb.x; gb[4 * i + 1] = wb.y; gb[4 * i + 2] = wb.z; gb[4 * i + 3] = wb.w;
+            }
+            if (!g_reversed) {
+                const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + EPL * q);
+                const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 wa = qa[i], wb = qb[i];
+                    ga[4 * i] = wa.x; ga[4 * i + 1] = wa.y; ga[4 * i + 2] = wa.z; ga[4 * i + 3] = wa.w;
+                    gb[4 * i] = wb.x; gb[4 * i + 1] = wb.y; gb[4 * i + 2] = wb.z; gb[4 * i + 3] = wb.w;
+                }
+            } else {        // column c of the logical row sits at D-1-c (a reversal followed the layer)
+                const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + D - EPL * (q + 1));
+                const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF - EPL * (q + 1));
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 wa = qa[i], wb = qb[i];
+                    ga[EPL - 1 - 4 * i] = wa.x; ga[EPL - 2 - 4 * i] = wa.y; ga[EPL - 3 - 4 * i] = wa.z; ga[EPL - 4 - 4 * i] = wa.w;
+                    gb[EPL - 1 - 4 * i] = wb.x; gb[EPL - 2 - 4 * i] = wb.y; gb[EPL - 3 - 4 * i] = wb.z; gb[EPL - 4 - 4 * i] = wb.w;
+                }
+            }
+            if (gscale) {   // reverse mode of a fixed elementwise scale that followed the layer
+                const float4 *sa = reinterpret_cast<const float4 *>(gscale + EPL * q);
+                const float4 *sb = reinterpret_cast<const float4 *>(gscale + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 ua = sa[i], ub = sb[i];
+                    ga[4 * i] *= ua.x; ga[4 * i + 1] *= ua.y; ga[4 * i + 2] *= ua.z; ga[4 * i + 3] *= ua.w;
+                    gb[4 * i] *= ub.x; gb[4 * i + 1] *= ub.y; gb[4 * i + 2] *= ub.z; gb[4 * i + 3] *= ub.w;
+                }
             }
         }
         float gl = gld[rr];
@@ -886,7 +912,7 @@ __global__ __launch_bounds__(1024) void k_colsum2d(const float *__restrict__ par
 template <int EPL>
 static int launch_train_bwd(const float *x, float *g, const float *gld, const float *params, int n_params,
                             int steps2, float *out, float *workspace, int64_t N, int inverse_form,
-                            hipStream_t s, const char *fn)
+                            const float *gscale, int g_reversed, hipStream_t s, const char *fn)
 {
     constexpr int M = (EPL / 2) * 256 + (EPL / 4) * 256 + 16;
     constexpr int TILES = 2 * 4 * 72 + (EPL / 2) * 4 * 72 + 16 * (4 * EPL + 16);
@@ -914,10 +940,10 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
     if (grid > cap) grid = cap;
     if (inverse_form)
         hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, true>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
-                           gld, params, n_params, steps2, workspace, (long long)N);
+                           gld, params, n_params, steps2, workspace, (long long)N, gscale, g_reversed);
     else
         hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, false>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
-                           gld, params, n_params, steps2, workspace, (long long)N);
+                           gld, params, n_params, steps2, workspace, (long long)N, gscale, g_reversed);
     if (int rc = check_launch(fn)) return rc;
     hipLaunchKernelGGL(k_colsum2d, dim3((M + 63) / 64), dim3(1024), 0, s, workspace, out, (int)grid, M);
     return check_launch(fn);
@@ -941,7 +967,8 @@ int64_t tfk_coupling_train_bwd_workspace_bytes(int32_t D)
 
 int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
                                   int64_t n_params, int32_t gemm2_steps, float *out, float *workspace,
-                                  int64_t N, int32_t D, int32_t inverse_form, void *stream)
+                                  int64_t N, int32_t D, int32_t inverse_form, const float *gscale,
+                                  int32_t g_reversed, void *stream)
 {
     const char *fn = "tfk_affine_coupling_train_bwd";
     if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
@@ -952,12 +979,14 @@ int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, co
     if (n_params != need) return fail(TFK_EINVAL, "%s: parameter block has %lld floats, expected %lld", fn,
                                       (long long)n_params, (long long)need);
     if (!x || !g || !gld || !params || !out || !workspace) return fail(TFK_EINVAL, "%s: null pointer", fn);
-    if (!aligned16(x) || !aligned16(g) || !aligned16(params))
-        return fail(TFK_EINVAL, "%s: x, g and params must be 16-byte aligned", fn);
+    if (!aligned16(x) || !aligned16(g) || !aligned16(params) || (gscale && !aligned16(gscale)))
+        return fail(TFK_EINVAL, "%s: x, g, params and gscale must be 16-byte aligned", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (EPL == 8)
-        return launch_train_bwd<8>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form, s, fn);
-    return launch_train_bwd<16>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form, s, fn);
+        return launch_train_bwd<8>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form,
+                                   gscale, g_reversed ? 1 : 0, s, fn);
+    return launch_train_bwd<16>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form,
+                                gscale, g_reversed ? 1 : 0, s, fn);
 }
 
 }  // extern "C"

@@ -244,10 +244,12 @@ template <int EPL, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
-    const float *__restrict__ params, int n_params, MProgram prog, int accumulate)
+    const float *__restrict__ params, int n_params, MProgram prog, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    const int accumulate = flags & 1;
+    const bool reverse_out = (flags & 2) != 0;          // store z[row, D-1-c] = value of column c
     {
         const float4 *src = reinterpret_cast<const float4 *>(params);
         float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -305,13 +307,23 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
             lp += __shfl_xor(lp, 32, kWave);
         }
         if (row < N) {
-            if (z) {
+            if (z && !reverse_out) {
                 float4 *qa = reinterpret_cast<float4 *>(z + row * D + EPL * q);
                 float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF + EPL * q);
 #pragma unroll
                 for (int i = 0; i < EPL / 4; ++i) {
                     qa[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
                     qb[i] = make_float4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+                }
+            } else if (z) {
+                // a ReversePermutationMatrix after the program (matrix/permutation.py:34-37) folded
+                // into the store: plane A lands mirrored in the second half, plane B in the first
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + D - EPL * (q + 1));
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF - EPL * (q + 1));
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[EPL - 1 - 4 * i], a[EPL - 2 - 4 * i], a[EPL - 3 - 4 * i], a[EPL - 4 - 4 * i]);
+                    qb[i] = make_float4(b[EPL - 1 - 4 * i], b[EPL - 2 - 4 * i], b[EPL - 3 - 4 * i], b[EPL - 4 - 4 * i]);
                 }
             }
             if (q == 0) {

@@ -41,7 +41,7 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
 )
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NativeError(RuntimeError):
@@ -103,7 +103,8 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_coupling_train_bwd_out_floats.restype = _i64
     L.tfk_coupling_train_bwd_workspace_bytes.argtypes = [_i32]
     L.tfk_coupling_train_bwd_workspace_bytes.restype = _i64
-    L.tfk_affine_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp]
+    L.tfk_affine_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
+                                                _vp, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -406,7 +407,8 @@ def diag_gauss_logprob_bwd(z, loc, log_scale, glp, g):
     _check(rc, name)
 
 
-def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, inverse_form=False):
+def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, inverse_form=False,
+                              gscale=None, g_reversed=False):
     """Fused conditioner + transform + MLP backward of one HalfSplit affine coupling (in place on
     g, accumulator-layout weight gradients into ``out``)."""
     global calls
@@ -419,7 +421,10 @@ def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, in
     if workspace.numel() * 4 < int(lib().tfk_coupling_train_bwd_workspace_bytes(D)):
         raise NativeError(f"{name}: workspace too small")
     args = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
-            int(gemm2_steps), _f32(out, name), _f32(workspace, name), N, D, 1 if inverse_form else 0)
+            int(gemm2_steps), _f32(out, name), _f32(workspace, name), N, D, 1 if inverse_form else 0,
+            _f32(gscale, name), 1 if g_reversed else 0)
+    if gscale is not None and gscale.numel() != D:
+        raise NativeError(f"{name}: gscale must hold D = {D} floats")
     with _device_guard(g):
         rc = lib().tfk_affine_coupling_train_bwd(*args, _stream(g))
     calls += 1
@@ -459,7 +464,8 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
     _check(rc, name)
 
 
-def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
+def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False,
+                  reverse_out=False):
     """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
     ops: list of (kind, src_plane, gemm2_steps, offset); params packed by fused._pack_mfma."""
     global calls
@@ -471,7 +477,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
             _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
-            _f32(params, name), params.numel(), 1 if accumulate else 0)
+            _f32(params, name), params.numel(), (1 if accumulate else 0) | (2 if reverse_out else 0))
     with _device_guard(x):
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
