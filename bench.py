@@ -465,6 +465,26 @@ def main():
                         "reverse-mode kernels + PyTorch-ROCm GEMMs; libtfk_ms_per_step is the share spent in "
                         "libtfk kernels (HIP events over two extra steps); the eager step is bound by "
                         "launch / Python overhead"}
+            if args.workload == "realnvp64":
+                # the same step captured once into a hipGraph and replayed (TORCHFLOWS_AMD_GRAPH=1 in
+                # Flow.fit).  Measured in a child process: an invalidated capture crashes the process
+                # on this stack instead of raising, and must not take the bench line with it.
+                import subprocess
+                try:
+                    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_probe.py"), "full"],
+                                          capture_output=True, text=True, timeout=240)
+                    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("full:")]
+                    if proc.returncode == 0 and line:
+                        ms = float(line[-1].split()[1])
+                        result["train"]["hipgraph"] = {"ms_per_step": ms, "value": trows / (ms * 1e-3),
+                                                       "unit": "samples/s", "steps": 20,
+                                                       "note": "tools/graph_probe.py: one captured step "
+                                                               "(fwd + bwd + AdamW) replayed 20 times"}
+                    else:
+                        result["train"]["hipgraph"] = {"error": f"exit code {proc.returncode}: "
+                                                                + proc.stderr.strip()[-200:]}
+                except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
+                    result["train"]["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
             if top is not None:
                 result["train"]["roofline_bwd"] = {
                     "bound": "hbm", "kernel": top, "achieved": bwd[top]["GBps"], "peak": HBM_PEAK_GBS,

@@ -177,17 +177,18 @@ def test_fit_on_device_recovers_diagonal_gaussian(native):
     assert float(((std - sigma.ravel()).abs() / sigma.ravel()).max()) < 0.1
 
 
-@pytest.mark.parametrize("arch,lr", [("RealNVP", 0.01), ("CouplingRQNSF", 0.01)])
-def test_fit_on_device_follows_the_host_trajectory(native, arch, lr):
+@pytest.mark.parametrize("arch,D,lr", [("RealNVP", 8, 0.01), ("CouplingRQNSF", 8, 0.01), ("RealNVP", 64, 0.01)])
+def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     """Same data, same batches (shuffle off), same AdamW: fitting on the HIP path must land where
     fitting on the host ATen path lands, and improve the likelihood."""
     import copy
     from torchflows_amd.flows import Flow
     from torchflows_amd.bijections.finite.autoregressive import architectures as A
     torch.manual_seed(0)
-    mix = torch.randn(8192, 8)
-    x = torch.cat([mix[:, :4] * 0.3 + 2.0, torch.tanh(mix[:, 4:]) + 0.1 * mix[:, :4]], dim=1)
-    flow = Flow(getattr(A, arch)(8, n_layers=2))
+    mix = torch.randn(8192, D)
+    h = D // 2
+    x = torch.cat([mix[:, :h] * 0.3 + 2.0, torch.tanh(mix[:, h:]) + 0.1 * mix[:, :h]], dim=1)
+    flow = Flow(getattr(A, arch)(D, n_layers=2))
     flow.train()
     with torch.no_grad():
         flow.log_prob(x)                          # data-dependent init
@@ -198,13 +199,32 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, lr):
     host.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     calls = native.calls
     dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
-    assert native.calls - calls > 5 * 8 * 2 * len(flow.bijection.layers) // 2
+    assert native.calls > calls
+    assert dev._fit_stats == {"eager_steps": 40, "graph_replays": 0, "graph_captures": 0}
     with torch.no_grad():
         after_h = float(host.log_prob(x).mean())
         after_d = float(dev.log_prob(x.cuda()).mean())
-    print(f"{arch}: mean log-likelihood {before:.4f} -> host {after_h:.4f}, device {after_d:.4f}")
+    print(f"{arch}({D}): mean log-likelihood {before:.4f} -> host {after_h:.4f}, device {after_d:.4f}")
     assert after_d > before
     assert abs(after_d - after_h) < 5e-3 * max(1.0, abs(after_h))
+
+
+def test_fit_with_hipgraph_replay_in_a_subprocess(native):
+    """TORCHFLOWS_AMD_GRAPH=1: the fully fused training step is captured once and replayed.  Run in
+    a child process: an invalidated capture crashes the process on this stack instead of raising."""
+    import json
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_fit_worker.py")
+    proc = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = json.loads(proc.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out["graph_stats"] == {"eager_steps": 2, "graph_replays": 38, "graph_captures": 1}
+    assert out["eager_stats"]["graph_replays"] == 0 and out["eager_stats"]["eager_steps"] == 40
+    assert out["after_graph"] > out["before"]
+    assert abs(out["after_graph"] - out["after_eager"]) < 1e-3 * max(1.0, abs(out["after_eager"]))
 
 
 @pytest.mark.parametrize("D,N", [(64, 4099), (64, 17), (64, 1), (128, 2050)])

@@ -318,6 +318,14 @@ def _plan_packs(plan, D: int, device, fold: bool) -> _PlanPacks:
     return cache[key]
 
 
+def fully_fused(plan, D: int) -> bool:
+    """Every coupling of the plan runs as the fused launches (flow program forward, fused training
+    backward): the step then consists of libtfk kernels and elementwise ATen ops only -- no GEMM
+    library calls -- which is the configuration verified to survive hipGraph capture."""
+    couplings = [layer for layer, _, kind in plan if kind == "coupling"]
+    return bool(couplings) and all(_fused_bwd_layer(layer, D) is not None for layer in couplings)
+
+
 SPLIT_K_ROWS = 1024
 
 

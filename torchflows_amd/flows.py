@@ -15,6 +15,8 @@ lives on the device and the gradient runs through the reverse-mode kernels (auto
 """
 from __future__ import annotations
 
+import contextlib
+import os
 import time
 import warnings
 from typing import Optional, Tuple, Union
@@ -125,6 +127,21 @@ class Flow(BaseFlow):
             loss = loss + self.regularization()
         return loss
 
+    def _graph_safe(self) -> bool:
+        from torchflows_amd import autograd as hip_autograd
+        from torchflows_amd.bijections.base import BijectiveComposition, method_direction
+        b = self.bijection
+        if not (hip_autograd.enabled() and isinstance(b, BijectiveComposition)
+                and isinstance(self.base, DiagonalGaussian)):
+            return False
+        if self.base.loc.requires_grad or self.base.log_scale.requires_grad or len(self.base.event_shape) != 1:
+            return False
+        if any(p.dtype != torch.float32 or p.device.type != "cuda" for p in self.parameters()):
+            return False
+        d = method_direction(b.forward)
+        plan = None if d is None else hip_autograd.training_plan(b, d)
+        return plan is not None and hip_autograd.fully_fused(plan, b.n_dim)
+
     def fit(self,
             x_train: torch.Tensor,
             n_epochs: int = 500,
@@ -194,8 +211,40 @@ class Flow(BaseFlow):
                 max_batch_size = max(1, min(max_batch_size, int(max_batch_size_mb / (self.event_size / 2 ** 20))))
             batch_size = max(32, min(1024, n_train // 100))
 
+        # On the device the step is launch-bound (~120 launches of 5-50 us): after two eager steps
+        # (lazy initialisation, ActNorm statistics) a full-size batch step is captured ONCE into a
+        # hipGraph -- forward, backward and the AdamW update -- and replayed on static buffers.
+        # Only the route that is known to be capture-safe qualifies: a composition whose couplings
+        # all run as the fused launches (libtfk kernels + elementwise ATen ops on fixed shapes, no
+        # GEMM-library calls, no host synchronisation) and a fixed diagonal Gaussian base.  Steps
+        # with hipBLASLt GEMMs invalidated the capture on this stack, and an invalidated capture
+        # does not raise here, it crashes the process -- so no speculative tries.
+        # Opt-in (TORCHFLOWS_AMD_GRAPH=1) for that reason.  The whole loop then runs on a side
+        # stream: autograd state created on the legacy default stream would invalidate the capture.
+        use_graph = (dev.type == "cuda" and os.environ.get("TORCHFLOWS_AMD_GRAPH", "0") == "1"
+                     and context_train is None and self._graph_safe())
         if self._optimizer is None or reset_optimizer:
-            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
+            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr, capturable=use_graph)
+        graphed = None               # (batch size, graph, static x, static w, static loss)
+        stats = {"eager_steps": 0, "graph_replays": 0, "graph_captures": 0}
+        self._fit_stats = stats
+
+        side = main_stream = None
+        if use_graph:
+            main_stream = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(main_stream)
+
+        def capture(xb, wb):
+            xs, ws = xb.clone(), wb.clone()
+            graph = torch.cuda.CUDAGraph()
+            self._optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = self._base_batch_loss((xs, ws), reduction=torch.mean, use_regularization=True)
+                static_loss.backward()
+                self._optimizer.step()
+            stats["graph_captures"] += 1
+            return len(xb), graph, xs, ws, static_loss
 
         def snapshot():
             return {k: v.detach().clone() for k, v in self.state_dict().items()}
@@ -210,49 +259,77 @@ class Flow(BaseFlow):
         if show_progress:
             from tqdm import tqdm
             epochs = pbar = tqdm(epochs, desc="Fitting NF")
-        for epoch in epochs:
-            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
-                print("Training time limit exceeded")
-                break
-            if adaptive and epoch % 10 == 9 and batch_size < max_batch_size:
-                batch_size = min(2 * batch_size, max_batch_size)
-            total, count = 0.0, 0
-            for batch in batches(train, batch_size, shuffle):
-                self._optimizer.zero_grad()
-                loss = self._base_batch_loss(batch, reduction=torch.mean, use_regularization=True)
-                value = float(loss.detach())
-                if value != value or value in (float("inf"), float("-inf")):
-                    self.load_state_dict(best_weights)     # the last kept (else the initial) weights
-                    diverged = True
-                    warnings.warn("Flow training diverged. Reverting to previous weights.")
+        with (torch.cuda.stream(side) if use_graph else contextlib.nullcontext()):
+            for epoch in epochs:
+                if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                    print("Training time limit exceeded")
                     break
-                total += value
-                count += 1
-                loss.backward()
-                self._optimizer.step()
-                if pbar is not None:
-                    text = f"Training loss (batch): {value:.4f} [{best_train:.4f} @ {best_train_epoch}]"
-                    if val_loss is not None:
-                        text += f" , Validation loss (batch): {val_loss:.4f} [{best_val:.4f} @ {best_val_epoch}]"
-                    pbar.set_postfix_str(text)
-            if diverged:
-                break
-            average = total / count
-            if average < best_train:
-                best_train, best_train_epoch = average, epoch
-            if val is not None:
-                acc = 0.0
-                with torch.no_grad():
-                    for batch in batches(val, batch_size, False):
-                        acc += float(self._base_batch_loss(batch, reduction=torch.sum, use_regularization=False))
-                val_loss = acc / len(x_val)
-                if val_loss < best_val:
-                    best_val, best_val_epoch = val_loss, epoch
-            mark = best_val_epoch if val is not None else best_train_epoch
-            if keep_best_weights and mark == epoch:
-                best_weights = snapshot()
-            if early_stopping and epoch - mark > early_stopping_threshold:
-                break
+                if adaptive and epoch % 10 == 9 and batch_size < max_batch_size:
+                    batch_size = min(2 * batch_size, max_batch_size)
+                total, count = 0.0, 0
+                for batch in batches(train, batch_size, shuffle):
+                    replay = use_graph and stats["eager_steps"] >= 2 and len(batch[0]) == batch_size
+                    if replay and (graphed is None or graphed[0] != batch_size):
+                        loss = None                   # no autograd graph of an eager step may be alive
+                        try:
+                            graphed = capture(batch[0], batch[1])
+                        except Exception as exc:      # capture is an optimisation: fall back, say so once
+                            warnings.warn(f"hipGraph capture of the training step failed ({exc}); running eagerly")
+                            use_graph, replay, graphed = False, False, None
+                            torch.cuda.synchronize()
+                            self._optimizer.zero_grad(set_to_none=True)
+                    if replay:
+                        # (a non-finite loss is noticed after the captured update has run; the
+                        # roll-back below restores the kept weights either way)
+                        graphed[2].copy_(batch[0])
+                        graphed[3].copy_(batch[1])
+                        graphed[1].replay()
+                        value = float(graphed[4].detach())
+                        stats["graph_replays"] += 1
+                    else:
+                        self._optimizer.zero_grad()
+                        loss = self._base_batch_loss(batch, reduction=torch.mean, use_regularization=True)
+                        value = float(loss.detach())
+                    if value != value or value in (float("inf"), float("-inf")):
+                        self.load_state_dict(best_weights)     # the last kept (else the initial) weights
+                        diverged = True
+                        warnings.warn("Flow training diverged. Reverting to previous weights.")
+                        break
+                    total += value
+                    count += 1
+                    if not replay:
+                        loss.backward()
+                        self._optimizer.step()
+                        stats["eager_steps"] += 1
+                    if pbar is not None:
+                        text = f"Training loss (batch): {value:.4f} [{best_train:.4f} @ {best_train_epoch}]"
+                        if val_loss is not None:
+                            text += f" , Validation loss (batch): {val_loss:.4f} [{best_val:.4f} @ {best_val_epoch}]"
+                        pbar.set_postfix_str(text)
+                if graphed is not None:       # replays move the weights, not their version counters
+                    from torchflows_amd import fused
+                    fused.invalidate(self)
+                if diverged:
+                    break
+                average = total / count
+                if average < best_train:
+                    best_train, best_train_epoch = average, epoch
+                if val is not None:
+                    acc = 0.0
+                    with torch.no_grad():
+                        for batch in batches(val, batch_size, False):
+                            acc += float(self._base_batch_loss(batch, reduction=torch.sum, use_regularization=False))
+                    val_loss = acc / len(x_val)
+                    if val_loss < best_val:
+                        best_val, best_val_epoch = val_loss, epoch
+                mark = best_val_epoch if val is not None else best_train_epoch
+                if keep_best_weights and mark == epoch:
+                    best_weights = snapshot()
+                if early_stopping and epoch - mark > early_stopping_threshold:
+                    break
+        if side is not None:
+            main_stream.wait_stream(side)
+        graphed = None
         if keep_best_weights:
             self.load_state_dict(best_weights)
         self.eval()

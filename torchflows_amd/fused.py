@@ -331,6 +331,13 @@ def compile_chain(composition, direction: int, device: torch.device,
     return CompiledChain(D, segments, pos, identity, _params_version(composition))
 
 
+def invalidate(module: nn.Module) -> None:
+    """Drop cached flow programs below ``module``.  Needed after parameters were changed behind
+    autograd's back (a replayed hipGraph updates them without moving their version counters)."""
+    for m in module.modules():
+        m.__dict__.pop("_tfk_compiled", None)
+
+
 def get_compiled(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
     """Cached ``compile_chain``; recompiles when a parameter / buffer was modified in place."""
     cache = composition.__dict__.setdefault("_tfk_compiled", {})
