@@ -134,6 +134,12 @@ class KernelTimer:
             if name.endswith("_coupling") and name != "conv1x1_coupling":
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
             flops = self._flow_flops(a, name == "flow_run_mfma") if name.startswith("flow_run") else 0
+            if name == "affine_coupling_train_bwd":
+                # conditioner re-evaluation + MLP backward + weight gradients: 3 x the forward's
+                # 2*(S*H + H*T*P) per row, true (unpadded) hidden width
+                n_rows, d_ = a[1].shape
+                h_ = KernelTimer.true_hidden.get(d_, 16)
+                flops = n_rows * 6 * h_ * (d_ // 2 + d_)
             self.records.append((variant, byte_fn(a, k), s, e, flops))
             return r
         setattr(self.native, name, timed)
@@ -485,6 +491,15 @@ def main():
                                                                 + proc.stderr.strip()[-200:]}
                 except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
                     result["train"]["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            fb = tk.get("affine_coupling_train_bwd")
+            if fb is not None:
+                result["train"]["roofline_fused_bwd"] = {
+                    "bound": "mfma", "kernel": "affine_coupling_train_bwd", "achieved": fb["TFLOPs"],
+                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fb["TFLOPs"] / FP32_PEAK_TFLOPS,
+                    "avg_us": fb["avg_us"], "hbm_GBps": fb["GBps"], "hbm_frac": fb["GBps"] / HBM_PEAK_GBS,
+                    "note": "algorithmic FLOPs 6*H*(S + T*P) per row (conditioner re-evaluation, MLP backward, "
+                            "weight gradients; v_mfma_f32_16x16x4_f32), launch time includes the column-sum "
+                            "kernel that follows"}
             if top is not None:
                 result["train"]["roofline_bwd"] = {
                     "bound": "hbm", "kernel": top, "achieved": bwd[top]["GBps"], "peak": HBM_PEAK_GBS,
