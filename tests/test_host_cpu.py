@@ -318,3 +318,15 @@ def test_sharded_log_likelihood_two_ranks_gloo():
                           script], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_OK" in out.stdout
+
+
+def test_sharded_fit_two_ranks_gloo():
+    """Data-parallel training on CPU: per-rank shards, one all-reduce of the flat gradient per step,
+    ActNorm statistics of the global first batch; must reproduce the one-process run."""
+    script = os.path.join(ROOT, "tests", "dist_fit_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29655",
+                          script], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "DIST_FIT_OK" in out.stdout

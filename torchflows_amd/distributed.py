@@ -53,3 +53,113 @@ def sharded_log_likelihood(flow, x_local: torch.Tensor, context: Optional[torch.
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return lp, total
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel maximum-likelihood training (SURVEY.md 8(e) + 8(f)-2)
+# ---------------------------------------------------------------------------------------------
+def _world(group) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class _GlobalActNormInit:
+    """While active, ActNorm's data-dependent initialisation (layers.py:51-69) uses the statistics
+    of the GLOBAL first batch: one all-reduce of (count, sum x, sum x^2) per ActNorm layer, once."""
+
+    def __init__(self, flow, group):
+        from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
+        self.layers = [m for m in flow.modules() if isinstance(m, ActNorm)]
+        self.group = group
+
+    def __enter__(self):
+        group = self.group
+
+        def make(layer):
+            @torch.no_grad()
+            def init(x):
+                n_batch_dims = x.dim() - len(layer.event_shape)
+                flat = x.reshape(-1, *x.shape[n_batch_dims:]).double()
+                stats = torch.cat([flat.new_tensor([flat.shape[0]]), flat.sum(0).reshape(-1),
+                                   flat.square().sum(0).reshape(-1)])
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                n = stats[0]
+                d = flat[0].numel()
+                mean = stats[1:1 + d] / n
+                var = (stats[1 + d:] - n * mean * mean) / torch.clamp(n - 1, min=1.0)   # unbiased, as torch.std
+                scale = torch.sqrt(torch.clamp(var, min=0.0)) if float(n) > 1 else torch.ones_like(mean)
+                shape = tuple(layer.event_shape)
+                shift = mean.reshape(*shape, 1).to(layer.value)
+                scale = scale.reshape(*shape, 1).to(layer.value)
+                layer.value.copy_(torch.cat([layer.transformer.unconstrain_scale(scale), shift], dim=-1))
+                layer.first_training_batch_pass = False
+            return init
+
+        for layer in self.layers:
+            layer.__dict__["_data_dependent_init"] = make(layer)
+        return self
+
+    def __exit__(self, *exc):
+        for layer in self.layers:
+            layer.__dict__.pop("_data_dependent_init", None)
+        return False
+
+
+def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.05,
+                batch_size: int = 1024, shuffle: bool = True, w_local: Optional[torch.Tensor] = None,
+                seed: int = 0, group=None, optimizer=None):
+    """Data-parallel ``Flow.fit`` (flows.py:226-455 semantics for the loss: ``-mean(log_prob * w) /
+    event_size + regularization`` over the GLOBAL batch): every rank holds a replica and its own
+    shard of the training rows (already on its device), takes ``batch_size // world_size`` of them
+    per step, and the ranks exchange exactly one all-reduce(SUM) of the flat gradient (a few tens
+    of KB: latency-bound on xGMI) before the identical AdamW update -- replicas stay bit-identical.
+    ActNorm takes its initial statistics from the global first batch (one more all-reduce, once).
+    ``optimizer``: ``callable(parameters, lr)`` (default AdamW, as ``Flow.fit``).
+    Returns the list of global per-step training losses."""
+    rank, world = _world(group)
+    distributed = world > 1
+    dev = flow.get_device()
+    x_local = x_local.to(dev)
+    n_local = x_local.shape[0]
+    w_local = torch.ones(n_local, device=dev) if w_local is None else w_local.to(dev)
+    local_bs = max(1, batch_size // world)
+    params = [p for p in flow.parameters() if p.requires_grad]
+    if not params:
+        return []
+    opt = (optimizer or (lambda ps, lr_: torch.optim.AdamW(ps, lr=lr_)))(flow.parameters(), lr)
+    gen = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
+    flow.train()
+    losses = []
+    ctx = _GlobalActNormInit(flow, group) if distributed else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        for _ in range(n_epochs):
+            order = torch.randperm(n_local, generator=gen).to(dev) if shuffle and n_local > 1 else None
+            for lo in range(0, n_local, local_bs):
+                idx = slice(lo, lo + local_bs) if order is None else order[lo:lo + local_bs]
+                xb, wb = x_local[idx], w_local[idx]
+                count = torch.tensor([float(xb.shape[0])], dtype=torch.float64, device=dev)
+                if distributed:
+                    dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)     # global batch rows
+                opt.zero_grad(set_to_none=True)
+                lp = flow.log_prob(xb)
+                loss = -(lp * wb).sum() / (float(count) * flow.event_size) + flow.regularization() / world
+                loss.backward()
+                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                  for p in params] + [loss.detach().reshape(1)])
+                if distributed:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)     # THE exchange step
+                lo_f = 0
+                for p in params:
+                    n = p.numel()
+                    p.grad = flat[lo_f:lo_f + n].view_as(p)
+                    lo_f += n
+                losses.append(float(flat[-1]))
+                opt.step()
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    flow.eval()
+    return losses
