@@ -452,6 +452,42 @@ def gen_grads():
         save("grads_" + fname, **o)
 
 
+# ---------------------------------------------------------------- F9 sibling layers
+def gen_siblings():
+    from torchflows.bijections.finite.autoregressive.layers import (
+        ElementwiseScale, ElementwiseRQSpline, LinearAffineCoupling, LinearRQSCoupling, LinearShiftCoupling)
+    from torchflows.bijections.finite.autoregressive.conditioning.transforms import ResidualFeedForward
+    out = {}
+    cases = [("ElementwiseScale", lambda: ElementwiseScale((6,))),
+             ("ElementwiseRQSpline", lambda: ElementwiseRQSpline((6,))),
+             ("LinearAffineCoupling", lambda: LinearAffineCoupling((6,))),
+             ("LinearRQSCoupling", lambda: LinearRQSCoupling((6,))),
+             ("LinearShiftCoupling", lambda: LinearShiftCoupling((6,))),
+             ("AffineCoupling_ResidualFeedForward",
+              lambda: AffineCoupling((6,), conditioner_transform_class=ResidualFeedForward)),
+             ("RQSCoupling_ResidualFeedForward",
+              lambda: RQSCoupling((8,), conditioner_transform_class=ResidualFeedForward,
+                                  conditioner_kwargs=dict(n_layers=4, block_size=3)))]
+    for name, make in cases:
+        torch.manual_seed(0)
+        layer = make()
+        with torch.no_grad():
+            for p_ in layer.parameters():
+                p_.mul_(2.0)                      # leave the near-identity initialisation
+        g = torch.Generator().manual_seed(3)
+        D = int(np.prod(layer.event_shape))
+        x = torch.randn(40, D, generator=g) * 1.5
+        with torch.no_grad():
+            z, ld = layer.forward(x)
+            xi, ldi = layer.inverse(x)
+        for k, v in layer.state_dict().items():
+            out[f"{name}/sd/{k}"] = np32(v)
+        out.update({f"{name}/x": np32(x), f"{name}/z": np32(z), f"{name}/ld": np32(ld),
+                    f"{name}/xinv": np32(xi), f"{name}/ldinv": np32(ldi)})
+    out["cases"] = np.array([c[0] for c in cases])
+    save("siblings.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows", "image"]
     for w in which:

@@ -235,3 +235,28 @@ def test_full_size_properties(pkg, oracle, arch, D, N, chunk):
     assert e < tol
     total = native.sum_f32(lp).item()
     assert abs(total - float(lp.double().sum().item())) < 1e-6 * abs(total)
+
+
+@pytest.mark.parametrize("name", ["LinearAffineCoupling", "LinearRQSCoupling", "LinearShiftCoupling",
+                                  "AffineCoupling_ResidualFeedForward", "RQSCoupling_ResidualFeedForward"])
+def test_sibling_couplings_on_hip(name):
+    """SURVEY 8(f)-4 siblings: the coupling kernels consume h whatever predicted it
+    (ResidualFeedForward on PyTorch-ROCm); outputs vs the reference's (tests/golden/siblings.npz)."""
+    from test_host_cpu import _sibling
+    from torchflows_amd import native
+    fx = load_golden("siblings.npz")
+    torch.manual_seed(0)
+    layer = _sibling(name)
+    layer.load_state_dict({k[len(name) + 4:]: torch.tensor(fx[k]) for k in fx.files if k.startswith(name + "/sd/")})
+    layer = layer.cuda()
+    x = torch.tensor(fx[f"{name}/x"]).cuda()
+    before = native.calls
+    with torch.no_grad():
+        z, ld = layer.forward(x)
+        xi, ldi = layer.inverse(x)
+    assert native.calls - before == 2
+    tol = 4e-5 if "RQS" in name else 1e-5
+    for mine, key in ((z, "z"), (ld, "ld"), (xi, "xinv"), (ldi, "ldinv")):
+        ref = fx[f"{name}/{key}"]
+        err = np.max(np.abs(mine.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref)))
+        assert err < tol, (name, key, err)

@@ -330,3 +330,37 @@ def test_sharded_fit_two_ranks_gloo():
                           script], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_FIT_OK" in out.stdout
+
+
+# ------------------------------------------------------------------ sibling layers
+def _sibling(name):
+    from torchflows_amd.bijections.finite.autoregressive import layers as L
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import ResidualFeedForward
+    if name == "AffineCoupling_ResidualFeedForward":
+        return L.AffineCoupling((6,), conditioner_transform_class=ResidualFeedForward)
+    if name == "RQSCoupling_ResidualFeedForward":
+        return L.RQSCoupling((8,), conditioner_transform_class=ResidualFeedForward,
+                             conditioner_kwargs=dict(n_layers=4, block_size=3))
+    return getattr(L, name)((6,))
+
+
+@pytest.mark.parametrize("name", ["ElementwiseScale", "ElementwiseRQSpline", "LinearAffineCoupling",
+                                  "LinearRQSCoupling", "LinearShiftCoupling",
+                                  "AffineCoupling_ResidualFeedForward", "RQSCoupling_ResidualFeedForward"])
+def test_sibling_layers_match_reference(name):
+    """Same constructor + the reference's state dict => the reference's outputs (tests/golden/siblings.npz)."""
+    fx = load_golden("siblings.npz")
+    torch.manual_seed(0)
+    layer = _sibling(name)
+    sd = {k[len(name) + 4:]: torch.tensor(fx[k]) for k in fx.files if k.startswith(name + "/sd/")}
+    assert set(sd) == set(layer.state_dict()), (sorted(sd), sorted(layer.state_dict()))
+    layer.load_state_dict(sd)
+    x = torch.tensor(fx[f"{name}/x"])
+    with torch.no_grad():
+        z, ld = layer.forward(x)
+        xi, ldi = layer.inverse(x)
+    tol = 4e-5 if "RQS" in name else 1e-5
+    for mine, key in ((z, "z"), (ld, "ld"), (xi, "xinv"), (ldi, "ldinv")):
+        ref = fx[f"{name}/{key}"]
+        err = np.max(np.abs(mine.numpy() - ref) / np.maximum(1.0, np.abs(ref)))
+        assert err < tol, (name, key, err)

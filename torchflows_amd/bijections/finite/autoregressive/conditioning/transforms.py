@@ -142,3 +142,42 @@ class Linear(FeedForward):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs, n_layers=1)
+
+
+class ResidualFeedForward(TensorConditionerTransform):
+    """``Linear, act, (x + Linear-act-...-Linear(x))*, Linear`` (reference :315-362).  Works with
+    every coupling kernel (they consume ``h`` whatever predicted it); runs on PyTorch-ROCm."""
+
+    class ResidualBlock(nn.Module):
+        def __init__(self, event_size: int, hidden_size: int, block_size: int, nonlinearity: Type[nn.Module]):
+            super().__init__()
+            if block_size < 2:
+                raise ValueError(f"block_size must be at least 2 but found {block_size}. "
+                                 f"For block_size = 1, use the FeedForward class instead.")
+            mods = [nn.Linear(event_size, hidden_size), nonlinearity()]
+            for _ in range(block_size - 2):
+                mods += [nn.Linear(hidden_size, hidden_size), nonlinearity()]
+            mods.append(nn.Linear(hidden_size, event_size))
+            self.sequential = nn.Sequential(*mods)
+
+        def forward(self, x):
+            return x + self.sequential(x)
+
+    def __init__(self, input_event_shape, parameter_shape, context_shape=None, n_hidden: int = None,
+                 n_layers: int = 3, block_size: int = 2, nonlinearity: Type[nn.Module] = nn.ReLU, **kwargs):
+        super().__init__(input_event_shape=input_event_shape, context_shape=context_shape,
+                         parameter_shape=parameter_shape, **kwargs)
+        n_in, n_out = self.n_input_event_dims, self.n_predicted_parameters
+        if n_hidden is None:
+            n_hidden = max(int(5 * math.log10(max(n_in, n_out))), 4)
+        if n_layers <= 2:
+            raise ValueError(f"Number of layers in ResidualFeedForward must be at least 3, but found {n_layers}")
+        mods = [nn.Linear(n_in, n_hidden), nonlinearity()]
+        for _ in range(n_layers - 2):
+            mods.append(self.ResidualBlock(n_hidden, n_hidden, block_size, nonlinearity=nonlinearity))
+        mods.append(nn.Linear(n_hidden, n_out))
+        mods.append(nn.Unflatten(dim=-1, unflattened_size=(n_out,)))
+        self.sequential = nn.Sequential(*mods)
+
+    def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        return self.sequential(self.context_combiner(x, context))

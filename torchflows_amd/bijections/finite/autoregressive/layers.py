@@ -12,7 +12,7 @@ from torchflows_amd.bijections.base import RowState, forward_method
 from torchflows_amd.bijections.finite.autoregressive.layers_base import (
     CouplingBijection, ElementwiseBijection)
 from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import (
-    Affine, InverseAffine, Shift)
+    Affine, InverseAffine, Scale, Shift)
 from torchflows_amd.bijections.finite.autoregressive.transformers.spline.rational_quadratic import (
     RationalQuadratic)
 
@@ -25,6 +25,21 @@ class ElementwiseAffine(ElementwiseBijection):
 class ElementwiseInverseAffine(ElementwiseBijection):
     def __init__(self, event_shape: Sequence[int], **kwargs):
         super().__init__(event_shape, InverseAffine, **kwargs)
+
+
+class ElementwiseScale(ElementwiseBijection):
+    """Reference :72-79 (ATen composite path)."""
+
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, Scale, **kwargs)
+
+
+class ElementwiseRQSpline(ElementwiseBijection):
+    """One learned RQ spline per event element (reference :92-99; ATen composite path: the
+    parameters are batch constants, there is no per-row ``h`` stream to run the kernel on)."""
+
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, RationalQuadratic, **kwargs)
 
 
 class ElementwiseShift(ElementwiseBijection):
@@ -95,3 +110,21 @@ class ShiftCoupling(CouplingBijection):
 class RQSCoupling(CouplingBijection):
     def __init__(self, event_shape: Sequence[int], **kwargs):
         super().__init__(event_shape, RationalQuadratic, **kwargs)
+
+
+# The reference's "Linear*" couplings pass ``n_layers=1`` as a layer keyword (:298-335); it ends
+# in ``Bijection.__init__(**kwargs)`` and never reaches the conditioner, so they are the plain
+# couplings under another name.  Kept that way (state dicts must match).
+class LinearAffineCoupling(AffineCoupling):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, **kwargs, n_layers=1)
+
+
+class LinearRQSCoupling(RQSCoupling):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, **kwargs, n_layers=1)
+
+
+class LinearShiftCoupling(ShiftCoupling):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, **kwargs, n_layers=1)

@@ -98,3 +98,36 @@ class Shift(ScalarTransformer):
 
     def inverse(self, z: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         return z - h[..., 0], self._zero_logdet(z)
+
+
+class Scale(ScalarTransformer):
+    """``z = alpha * x`` with ``alpha = exp(log(1 - m) + u / 2) + m`` (reference :162-206).
+    ATen only (an elementwise scale with learned constants is an ``Affine`` with beta = 0)."""
+
+    def __init__(self, event_shape: Sequence[int], min_scale: float = 1e-10):
+        super().__init__(event_shape=event_shape)
+        self.m = min_scale
+        self.const = 2.0
+        self.u_alpha_1 = math.log(1 - self.m)
+
+    @property
+    def parameter_shape_per_element(self):
+        return (1,)
+
+    @property
+    def default_parameters(self) -> torch.Tensor:
+        return torch.zeros(self.parameter_shape)
+
+    def unconstrain_alpha(self, a: torch.Tensor) -> torch.Tensor:
+        return self.const * (torch.log(a - self.m) - self.u_alpha_1)
+
+    def constrain_alpha(self, u: torch.Tensor) -> torch.Tensor:
+        return torch.exp(self.u_alpha_1 + u / self.const) + self.m
+
+    def forward(self, x: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        alpha = self.constrain_alpha(h[..., 0])
+        return alpha * x, sum_except_batch(torch.log(alpha), self.event_shape)
+
+    def inverse(self, z: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        alpha = self.constrain_alpha(h[..., 0])
+        return z / alpha, -sum_except_batch(torch.log(alpha), self.event_shape)
