@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 7
+#define TFK_ABI_VERSION 8
 
 enum {
     TFK_OK = 0,
@@ -212,6 +212,17 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                       const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
                       int32_t accumulate, void *stream);
+
+/* Linear rational spline coupling: MonotonicSpline + LinearRational
+ * (spline/base.py:53-72, spline/linear_rational.py:9-182) inside CouplingBijection.forward / inverse.
+ * Same conventions as tfk_rqs_coupling_*; h is (N, T, 4*n_bins) = [u_x | u_y | u_lambda | u_d (K-1) |
+ * u_w0] per element, 16-byte aligned; n_bins 4 or 8. */
+int tfk_lrs_coupling_fwd(const float *x, const float *h, float *z, float *logdet, int64_t N, int32_t D,
+                         const int32_t *tgt_idx, int32_t T, int32_t n_bins, float boundary,
+                         int32_t accumulate, void *stream);
+int tfk_lrs_coupling_inv(const float *z, const float *h, float *x, float *logdet, int64_t N, int32_t D,
+                         const int32_t *tgt_idx, int32_t T, int32_t n_bins, float boundary,
+                         int32_t accumulate, void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

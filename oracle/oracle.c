@@ -409,6 +409,124 @@ void orc_rqs_inv(const float *z, const float *h, float *x, float *logdet,
                 bin_idx ? bin_idx + n * T : NULL, T, K, boundary, 1);
 }
 
+/* ---- linear rational spline ---------------------------------
+ * transformers/spline/linear_rational.py:9-182.  4K parameters per element:
+ * [u_x (K) | u_y (K) | u_lambda (K) | u_d (K-1) | u_w0]. */
+#define LRS_MIN_BIN ((float)1e-2)
+#define LRS_MIN_D ((float)1e-5)
+#define LRS_EPS ((float)5e-10)
+static inline double lrs_const(void) { return log(exp(1.0 - 1e-5) - 1.0); }   /* :23 */
+
+/* compute_bins :68-76 (softmax as ATen's CPU kernel, see rqs_bins) */
+static void lrs_bins(const float *u, int K, float minimum, float maximum, float *bins /* K+1 */)
+{
+    float mx = u[0];
+    for (int j = 1; j < K; ++j) mx = u[j] > mx ? u[j] : mx;
+    float e[ORC_MAX_BINS];
+    float sum = 0.0f;
+    for (int j = 0; j < K; ++j) {
+        e[j] = expf(u[j] - mx);
+        sum += e[j];
+    }
+    const float rsum = 1.0f / sum;
+    const float scale = (float)(1.0 - 1e-2 * (double)K);
+    const float span = (float)((double)maximum - (double)minimum);
+    float run = 0.0f;
+    bins[0] = 0.0f;
+    for (int j = 0; j < K; ++j) {
+        run = run + (LRS_MIN_BIN + scale * (e[j] * rsum));
+        bins[j + 1] = run;
+    }
+    for (int j = 0; j <= K; ++j) bins[j] = span * bins[j] + minimum;
+    bins[0] = minimum;
+    bins[K] = maximum;
+}
+
+static void lrs_element(float v, const float *h, int K, float boundary, int inverse,
+                        float *out, float *ld)
+{
+    float ux[ORC_MAX_BINS], uxy[ORC_MAX_BINS], kx[ORC_MAX_BINS + 1], ky[ORC_MAX_BINS + 1];
+    float kd[ORC_MAX_BINS + 1], w[ORC_MAX_BINS + 1];
+    const float c = (float)lrs_const();
+    for (int j = 0; j < K; ++j) {
+        ux[j] = h[j];
+        uxy[j] = h[j] + h[K + j] / 100.0f;                          /* :87 */
+    }
+    lrs_bins(ux, K, -boundary, boundary, kx);                       /* :86 */
+    lrs_bins(uxy, K, -boundary, boundary, ky);
+    kd[0] = 1.0f;                                                   /* pad value 1.0, :80 */
+    kd[K] = 1.0f;
+    for (int j = 1; j < K; ++j)
+        kd[j] = softplusf(c + h[3 * K + j - 1] / 100.0f) + LRS_MIN_D;   /* :79, :89 */
+    const float w0 = softplusf(h[4 * K - 1]);                       /* :41 */
+    for (int j = 0; j <= K; ++j) w[j] = w0 * sqrtf(kd[0] / kd[j]);  /* :42 */
+
+    const float *search = inverse ? ky : kx;                        /* searchsorted left :105 / :150 */
+    int cnt = 0;
+    for (int j = 0; j <= K; ++j) cnt += (search[j] < v);
+    const int k = cnt - 1;
+    const float lam = 1.0f / (1.0f + expf(-h[2 * K + k]));          /* torch.sigmoid :88 */
+    const float wk = w[k], wk1 = w[k + 1];
+    const float xk = kx[k], xk1 = kx[k + 1], yk = ky[k], yk1 = ky[k + 1];
+    const float dk = kd[k], dk1 = kd[k + 1];
+    const float one_m = 1.0f - lam;
+    const float ym = (one_m * wk * yk + lam * wk1 * yk1) / (one_m * wk + lam * wk1);        /* :58-61 */
+    const float wm = (lam * wk * dk + one_m * wk1 * dk1) * ((xk1 - xk) / (yk1 - yk));       /* :62-67 */
+    const float dx = xk1 - xk;
+    if (!inverse) {
+        const float phi = (v - xk) / dx;                            /* :110 */
+        if (!(phi > lam)) {                                         /* :113-121 */
+            const float den = wk * (lam - phi) + wm * phi;
+            *out = (wk * yk * (lam - phi) + wm * ym * phi) / den;
+            *ld = logf(lam * wk * wm * (ym - yk)) - logf(den * den + LRS_EPS) - logf(dx);
+        } else {                                                    /* :123-131 */
+            const float den = wm * (1.0f - phi) + wk1 * (phi - lam);
+            *out = (wm * ym * (1.0f - phi) + wk1 * yk1 * (phi - lam)) / den;
+            *ld = logf(one_m * wm * wk1 * (yk1 - ym)) - logf(den * den + LRS_EPS) - logf(dx);
+        }
+    } else {
+        if (!(v > ym)) {                                            /* :157-166 */
+            const float den = wk * (yk - v) + wm * (v - ym);
+            *out = (lam * wk * (yk - v)) / den * dx + xk;
+            *ld = logf(lam * wk * wm * (ym - yk)) - logf(den * den + LRS_EPS) + logf(dx);
+        } else {                                                    /* :168-176 */
+            const float den = wk1 * (yk1 - v) + wm * (v - ym);
+            *out = (lam * wk1 * (yk1 - v) + wm * (v - ym)) / den * dx + xk;
+            *ld = logf(one_m * wm * wk1 * (yk1 - ym)) - logf(den * den + LRS_EPS) + logf(dx);
+        }
+    }
+}
+
+static void lrs_row(const float *x, const float *h, float *out, float *ld, int T, int K,
+                    float boundary, int inverse)
+{
+    const int P = 4 * K;
+    float acc = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const float v = x[t];
+        float o = v, l = 0.0f;                  /* spline/base.py:54-55 */
+        if (v > -boundary && v < boundary)      /* strict, base.py:29-33 */
+            lrs_element(v, h + (int64_t)t * P, K, boundary, inverse, &o, &l);
+        out[t] = o;
+        acc += l;
+    }
+    *ld = acc;
+}
+
+void orc_lrs_fwd(const float *x, const float *h, float *z, float *logdet,
+                 int64_t N, int T, int K, float boundary)
+{
+    for (int64_t n = 0; n < N; ++n)
+        lrs_row(x + n * T, h + n * (int64_t)T * 4 * K, z + n * T, logdet + n, T, K, boundary, 0);
+}
+
+void orc_lrs_inv(const float *z, const float *h, float *x, float *logdet,
+                 int64_t N, int T, int K, float boundary)
+{
+    for (int64_t n = 0; n < N; ++n)
+        lrs_row(z + n * T, h + n * (int64_t)T * 4 * K, x + n * T, logdet + n, T, K, boundary, 1);
+}
+
 /* ---- reverse mode ------------------------------------------
  * The reference has no backward code of its own: its gradients are what torch.autograd
  * derives from the forward graphs restated above.  The functions below are the
@@ -678,6 +796,7 @@ static int layer_P(const orc_layer *L)
     switch (L->kind) {
     case ORC_AFFINE_COUPLING: return 2;
     case ORC_RQS_COUPLING: return 3 * L->K - 1;
+    case ORC_LRS_COUPLING: return 4 * L->K;
     case ORC_SHIFT_COUPLING: return 1;
     default: return 0;
     }
@@ -748,6 +867,7 @@ static float layer_row(const orc_layer *L, const float *in, const float *ctx, in
     }
     case ORC_AFFINE_COUPLING:
     case ORC_RQS_COUPLING:
+    case ORC_LRS_COUPLING:
     case ORC_SHIFT_COUPLING: {
         /* layers_base.py:145-163 */
         memcpy(out, in, sizeof(float) * (size_t)D);                  /* clone :146/:156 */
@@ -761,6 +881,8 @@ static float layer_row(const orc_layer *L, const float *in, const float *ctx, in
         } else if (L->kind == ORC_RQS_COUPLING) {
             rqs_row(w->xb, w->h, w->zb, &ld, NULL, NULL, L->T, L->K, L->boundary,
                     direction);
+        } else if (L->kind == ORC_LRS_COUPLING) {
+            lrs_row(w->xb, w->h, w->zb, &ld, L->T, L->K, L->boundary, direction);
         } else {
             /* Shift: affine.py:137-159, log-det 0 */
             for (int t = 0; t < L->T; ++t)

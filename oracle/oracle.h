@@ -82,6 +82,13 @@ void orc_affine_bwd(const float *x, const float *h, const float *gz, const float
 void orc_rqs_bwd(const float *x, const float *h, const float *gz, const float *gld,
                  float *gx, float *gh, int64_t N, int T, int K, float boundary, int inverse);
 
+/* MonotonicSpline + LinearRational on (N,T) with h (N,T,4K)
+ * (transformers/spline/linear_rational.py:9-182); logdet (N,) OVERWRITTEN. */
+void orc_lrs_fwd(const float *x, const float *h, float *z, float *logdet,
+                 int64_t N, int T, int K, float boundary);
+void orc_lrs_inv(const float *z, const float *h, float *x, float *logdet,
+                 int64_t N, int T, int K, float boundary);
+
 /* Invertible1x1ConvolutionTransformer + LUTransformer
  * (transformers/linear/convolution.py:33-70, transformers/linear/matrix.py:20-82) on
  * x (N, n, HW) channel-major with h (N, n + n(n-1)); logdet (N,) OVERWRITTEN with
@@ -119,7 +126,8 @@ enum {
     ORC_PERMUTATION = 2,                /* matrix/permutation.py:8-26       */
     ORC_AFFINE_COUPLING = 3,            /* layers.py:102-113                */
     ORC_RQS_COUPLING = 4,               /* layers.py:154-163                */
-    ORC_SHIFT_COUPLING = 5              /* layers.py:130-139 (NICE)         */
+    ORC_SHIFT_COUPLING = 5,             /* layers.py:130-139 (NICE)         */
+    ORC_LRS_COUPLING = 6                /* layers.py:142-151                */
 };
 
 typedef struct {

@@ -28,6 +28,7 @@ PERMUTATION = 2
 AFFINE_COUPLING = 3
 RQS_COUPLING = 4
 SHIFT_COUPLING = 5
+LRS_COUPLING = 6
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -91,6 +92,8 @@ def lib() -> C.CDLL:
         L.orc_affine_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int]
         L.orc_rqs_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int,
                                   C.c_int, C.c_float, C.c_int]
+        for name in ("orc_lrs_fwd", "orc_lrs_inv"):
+            getattr(L, name).argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_float]
         L.orc_rqs_knots.argtypes = [_f32p, C.c_int64, C.c_int, C.c_float, _f32p, _f32p, _f32p]
         L.orc_diag_gauss_logprob.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int]
         L.orc_composition_forward.argtypes = [C.POINTER(_OrcLayer), C.c_int, _f32p, _f32p,
@@ -209,6 +212,17 @@ def rqs(x, h, n_bins: int = 8, boundary: float = 50.0, inverse: bool = False):
     fn = lib().orc_rqs_inv if inverse else lib().orc_rqs_fwd
     fn(_fp(x), _fp(h), _fp(out), _fp(ld), _fp(ld_el), _ip(k), N, T, n_bins, boundary)
     return out, ld, ld_el, k
+
+
+def lrs(x, h, n_bins: int = 8, boundary: float = 50.0, inverse: bool = False):
+    """Linear rational spline on (N,T) with h (N,T,4K): (out, logdet (N,))."""
+    x, h = _f32(x), _f32(h)
+    N, T = x.shape
+    assert h.shape == (N, T, 4 * n_bins)
+    out = np.empty_like(x)
+    ld = np.empty(N, np.float32)
+    (lib().orc_lrs_inv if inverse else lib().orc_lrs_fwd)(_fp(x), _fp(h), _fp(out), _fp(ld), N, T, n_bins, boundary)
+    return out, ld
 
 
 def affine_bwd(x, h, gz, gld, inverse: bool = False):
@@ -442,7 +456,8 @@ class OracleFlow:
         return x, diag_gauss_logprob(z, self.loc, self.log_scale) + ld
 
 
-_COUPLING_KIND = {"RealNVP": AFFINE_COUPLING, "CouplingRQNSF": RQS_COUPLING, "NICE": SHIFT_COUPLING}
+_COUPLING_KIND = {"RealNVP": AFFINE_COUPLING, "CouplingRQNSF": RQS_COUPLING, "NICE": SHIFT_COUPLING,
+                  "CouplingLRS": LRS_COUPLING}
 
 
 def preset_from_state_dict(arch: str, D: int, n_layers: int, sd: Dict[str, np.ndarray],

@@ -488,6 +488,46 @@ def gen_siblings():
     save("siblings.npz", **out)
 
 
+# ---------------------------------------------------------------- F10 linear rational spline
+def gen_lrs():
+    from torchflows.bijections.finite.autoregressive.transformers.spline.linear_rational import LinearRational
+    from torchflows.bijections.finite.autoregressive.architectures import CouplingLRS
+    out = {}
+    torch.manual_seed(0)
+    T = 8
+    cases = []
+    for boundary in (50.0, 5.0):
+        for n_bins in (8, 4):
+            P = 4 * n_bins
+            rows_x, rows_h = [], []
+            for xs in (0.01, 1.0, 3.0, 30.0, 100.0):
+                for hs in (0.3, 1.0, 5.0):
+                    rows_x.append(torch.randn(6, T) * xs)
+                    rows_h.append(torch.randn(6, T, P) * hs)
+            hz = torch.zeros(2, T, P)
+            xz = torch.randn(2, T) * boundary / 3
+            xe = torch.tensor([[boundary, -boundary, boundary * 1.2, -boundary * 1.2,
+                                np.nextafter(np.float32(boundary), np.float32(0)),
+                                np.nextafter(np.float32(-boundary), np.float32(0)), 0.0, 1e-30]])
+            he = torch.randn(1, T, P)
+            x = torch.cat(rows_x + [xz, xe])
+            h = torch.cat(rows_h + [hz, he])
+            tr = LinearRational((T,), boundary=boundary, n_bins=n_bins)
+            tag = f"B{int(boundary)}_K{n_bins}"
+            with torch.no_grad():
+                z, ld = tr.forward(x, h)
+                xi, ldi = tr.inverse(x, h)
+                z64, ld64 = tr.forward(x.double(), h.double())
+                xi64, ldi64 = tr.inverse(x.double(), h.double())
+            out.update({f"{tag}_x": np32(x), f"{tag}_h": np32(h), f"{tag}_z": np32(z), f"{tag}_ld": np32(ld),
+                        f"{tag}_xinv": np32(xi), f"{tag}_ldinv": np32(ldi), f"{tag}_z64": np32(z64),
+                        f"{tag}_ld64": np32(ld64), f"{tag}_xinv64": np32(xi64), f"{tag}_ldinv64": np32(ldi64)})
+            cases.append(tag)
+    out["cases"] = np.array(cases)
+    save("lrs.npz", **out)
+    flow_fixture("flow_lrs16.npz", CouplingLRS, 16, 64, dict(n_layers=3))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows", "image"]
     for w in which:

@@ -37,7 +37,8 @@ def pkg():
 
 
 def build_flow(pkg, arch, event_shape, n_layers, context_shape=None):
-    ctor = {"RealNVP": pkg.RealNVP, "CouplingRQNSF": pkg.CouplingRQNSF, "NICE": pkg.NICE}[arch]
+    ctor = {"RealNVP": pkg.RealNVP, "CouplingRQNSF": pkg.CouplingRQNSF, "NICE": pkg.NICE,
+            "CouplingLRS": pkg.CouplingLRS}[arch]
     kw = dict(n_layers=n_layers)
     if context_shape is not None:
         kw["context_shape"] = context_shape
@@ -54,6 +55,7 @@ FLOWS = [
     ("flow_realnvp5_ctx3.npz", "RealNVP", 2, (3,), False),
     ("flow_nsf6_ctx2.npz", "CouplingRQNSF", 2, (2,), True),
     ("flow_nsf_3x5x2.npz", "CouplingRQNSF", 2, None, True),
+    ("flow_lrs16.npz", "CouplingLRS", 3, None, True),
 ]
 
 

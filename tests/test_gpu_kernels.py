@@ -291,3 +291,54 @@ def test_empty_and_errors(native):
         native.rqs_coupling(x, torch.zeros(4, 32, 3 * 40 - 1, device="cuda"), x.clone(), torch.zeros(4, device="cuda"), None, 32, 40, 50.0)
     with pytest.raises(native.NativeError):       # non-contiguous
         native.permute(torch.zeros(4, 128, device="cuda")[:, ::2], None, torch.zeros(4, 64, device="cuda"))
+
+
+# ------------------------------------------------------------------ linear rational spline (8f-4)
+@pytest.mark.parametrize("N,D,T", [(1000, 64, 32), (257, 3, 2), (100, 77, 39), (8, 1024, 512), (1, 8, 4)])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("n_bins", [8, 4])
+def test_lrs_coupling_vs_oracle(native, oracle, N, D, T, masked, inverse, n_bins):
+    """tfk_lrs_coupling_* vs orc_lrs_* on seeded inputs (box +-5, O(1) parameters): 2e-5 relative
+    (device expf / logf differ from glibc's in the last bit; 1/bin-width amplifies, as for RQS)."""
+    rng = np.random.default_rng(N + D + 3 * masked + inverse + n_bins)
+    x, tgt = full_row_case(rng, N, D, T, masked)
+    x[:3] *= 10                                          # leave the box
+    h = rng.standard_normal((N, T, 4 * n_bins)).astype(np.float32)
+    out = torch.empty(N, D, device="cuda")
+    ld = torch.empty(N, device="cuda")
+    native.lrs_coupling(dev(x), dev(h), out, ld, dev(tgt, torch.int32) if masked else None, T, n_bins, 5.0,
+                        inverse=inverse)
+    z_o, ld_o = oracle.lrs(x[:, tgt], h, n_bins, 5.0, inverse=inverse)
+    expect = x.copy()
+    expect[:, tgt] = z_o
+    e_z, e_l = rel(out.cpu().numpy(), expect), rel(ld.cpu().numpy(), ld_o)
+    assert e_z < 2e-5 and e_l < 2e-5 * max(1.0, T / 32), (e_z, e_l)
+    keep = np.ones(D, bool)
+    keep[tgt] = False
+    assert np.array_equal(out.cpu().numpy()[:, keep], x[:, keep])
+    # in place + accumulate
+    buf = dev(x).clone()
+    acc = torch.full((N,), 2.5, device="cuda")
+    native.lrs_coupling(buf, dev(h), buf, acc, dev(tgt, torch.int32) if masked else None, T, n_bins, 5.0,
+                        accumulate=True, inverse=inverse)
+    assert torch.equal(buf, out) and torch.allclose(acc, ld + 2.5, rtol=1e-6, atol=1e-5)
+
+
+def test_lrs_golden_on_hip(native):
+    fx = load_golden("lrs.npz")
+    for tag in fx["cases"]:
+        B = float(str(tag).split("_")[0][1:])
+        K = int(str(tag).split("K")[1])
+        x, h = fx[f"{tag}_x"], fx[f"{tag}_h"]
+        N, T = x.shape
+        for inverse, zk, lk in ((False, "z", "ld"), (True, "xinv", "ldinv")):
+            out = torch.empty(N, T, device="cuda")
+            ld = torch.empty(N, device="cuda")
+            native.lrs_coupling(dev(x), dev(h), out, ld, None, T, K, B, inverse=inverse)
+            e_z = rel(out.cpu().numpy(), fx[f"{tag}_{zk}64"])
+            e_l = rel(ld.cpu().numpy(), fx[f"{tag}_{lk}64"])
+            f_z = rel(fx[f"{tag}_{zk}"], fx[f"{tag}_{zk}64"])
+            f_l = rel(fx[f"{tag}_{lk}"], fx[f"{tag}_{lk}64"])
+            print(f"lrs {tag} inverse={inverse}: out {e_z:.2e} (floor {f_z:.2e}), log-det {e_l:.2e} (floor {f_l:.2e})")
+            assert e_z < max(1e-5, 3 * f_z) and e_l < max(1e-5, 3 * f_l)

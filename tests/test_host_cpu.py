@@ -123,6 +123,7 @@ FLOWS = [
     ("flow_realnvp5_ctx3.npz", tfa.RealNVP, {}, (3,)),
     ("flow_nsf6_ctx2.npz", tfa.CouplingRQNSF, {}, (2,)),
     ("flow_nsf_3x5x2.npz", tfa.CouplingRQNSF, {}, None),
+    ("flow_lrs16.npz", tfa.CouplingLRS, dict(n_layers=3), None),
 ]
 
 

@@ -166,6 +166,7 @@ FLOWS = [
     ("flow_realnvp5_ctx3.npz", "RealNVP", 2, 3, False),
     ("flow_nsf6_ctx2.npz", "CouplingRQNSF", 2, 2, True),
     ("flow_nsf_3x5x2.npz", "CouplingRQNSF", 2, 0, True),
+    ("flow_lrs16.npz", "CouplingLRS", 3, 0, True),
 ]
 
 
@@ -242,3 +243,22 @@ def test_conv1x1_golden(oracle):
     _, ld_img = oracle.conv1x1(x, h)
     _, ld_vec = oracle.conv1x1(x[:, :, 0, 0], h)
     assert np.array_equal(ld_img, ld_vec)
+
+
+# ------------------------------------------------------------------ linear rational spline (8f-4)
+def test_lrs_golden(oracle):
+    """orc_lrs_fwd / _inv against LinearRational.forward / inverse of the reference
+    (tests/golden/lrs.npz), at the reference's own fp32-vs-fp64 distance."""
+    fx = load_golden("lrs.npz")
+    for tag in fx["cases"]:
+        B = float(str(tag).split("_")[0][1:])
+        K = int(str(tag).split("K")[1])
+        x, h = fx[f"{tag}_x"], fx[f"{tag}_h"]
+        z, ld = oracle.lrs(x, h, K, B)
+        xi, ldi = oracle.lrs(x, h, K, B, inverse=True)
+        for mine, key in ((z, "z"), (ld, "ld"), (xi, "xinv"), (ldi, "ldinv")):
+            e = rel(mine, fx[f"{tag}_{key}64"])
+            floor = rel(fx[f"{tag}_{key}"], fx[f"{tag}_{key}64"])
+            assert e < max(1e-5, 2 * floor), (tag, key, e, floor)
+        outside = np.abs(x) >= B                       # strict box: identity, zero log-det
+        assert np.array_equal(z[outside], x[outside]) and np.array_equal(xi[outside], x[outside])

@@ -8,6 +8,6 @@ autograd / fp64 / host tensors.  Module paths mirror the reference
 """
 from torchflows_amd.flows import Flow, BaseFlow  # noqa: F401
 from torchflows_amd.bijections.finite.autoregressive.architectures import (  # noqa: F401
-    RealNVP, CouplingRQNSF, NICE)
+    RealNVP, CouplingRQNSF, CouplingLRS, NICE)
 
 __version__ = "0.1.0"

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Type, Union
 
 from torchflows_amd.bijections.base import Bijection, BijectiveComposition
 from torchflows_amd.bijections.finite.autoregressive.layers import (
-    ActNorm, AffineCoupling, ElementwiseAffine, InverseAffineCoupling, RQSCoupling, ShiftCoupling)
+    ActNorm, AffineCoupling, ElementwiseAffine, InverseAffineCoupling, LRSCoupling, RQSCoupling, ShiftCoupling)
 from torchflows_amd.bijections.finite.matrix.permutation import ReversePermutationMatrix
 from torchflows_amd.utils import event_size
 
@@ -62,3 +62,10 @@ class CouplingRQNSF(AutoregressiveArchitecture):
 
     def __init__(self, event_shape: Shape, **kwargs):
         super().__init__(event_shape, base_bijection=RQSCoupling, **kwargs)
+
+
+class CouplingLRS(AutoregressiveArchitecture):
+    """Dolatabadi et al. 2020 -- linear rational spline couplings (reference :166-178)."""
+
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=LRSCoupling, **kwargs)

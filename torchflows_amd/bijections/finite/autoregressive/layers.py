@@ -13,6 +13,8 @@ from torchflows_amd.bijections.finite.autoregressive.layers_base import (
     CouplingBijection, ElementwiseBijection)
 from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import (
     Affine, InverseAffine, Scale, Shift)
+from torchflows_amd.bijections.finite.autoregressive.transformers.spline.linear_rational import (
+    LinearRational)
 from torchflows_amd.bijections.finite.autoregressive.transformers.spline.rational_quadratic import (
     RationalQuadratic)
 
@@ -112,6 +114,13 @@ class RQSCoupling(CouplingBijection):
         super().__init__(event_shape, RationalQuadratic, **kwargs)
 
 
+class LRSCoupling(CouplingBijection):
+    """Linear rational spline coupling (reference :142-151)."""
+
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, LinearRational, **kwargs)
+
+
 # The reference's "Linear*" couplings pass ``n_layers=1`` as a layer keyword (:298-335); it ends
 # in ``Bijection.__init__(**kwargs)`` and never reaches the conditioner, so they are the plain
 # couplings under another name.  Kept that way (state dicts must match).
@@ -121,6 +130,11 @@ class LinearAffineCoupling(AffineCoupling):
 
 
 class LinearRQSCoupling(RQSCoupling):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, **kwargs, n_layers=1)
+
+
+class LinearLRSCoupling(LRSCoupling):
     def __init__(self, event_shape: Sequence[int], **kwargs):
         super().__init__(event_shape, **kwargs, n_layers=1)
 

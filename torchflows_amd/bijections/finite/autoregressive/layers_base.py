@@ -136,6 +136,8 @@ class CouplingBijection(AutoregressiveBijection):
             return self.transformer.n_channels <= 16     # channels are kept in registers
         if kind == "rqs":
             return 2 <= self.transformer.n_bins <= 32
+        if kind == "lrs":
+            return self.transformer.n_bins in (4, 8)
         return kind in ("affine", "inverse_affine", "shift")
 
     def _native_ok(self, x, context) -> bool:
@@ -162,6 +164,10 @@ class CouplingBijection(AutoregressiveBijection):
         elif kind == "rqs":
             tr = self.transformer
             native.rqs_coupling(rows, h, out, state.logdet, tgt, T, tr.n_bins, tr.boundary,
+                                accumulate=acc, inverse=(d == INVERSE))
+        elif kind == "lrs":
+            tr = self.transformer
+            native.lrs_coupling(rows, h, out, state.logdet, tgt, T, tr.n_bins, tr.boundary,
                                 accumulate=acc, inverse=(d == INVERSE))
         elif kind == "shift":
             native.shift_coupling(rows, h, out, state.logdet, tgt, T, accumulate=acc,

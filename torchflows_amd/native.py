@@ -27,6 +27,7 @@ SYMBOLS = (
     "tfk_affine_coupling_fwd", "tfk_affine_coupling_inv",
     "tfk_shift_coupling_fwd", "tfk_shift_coupling_inv",
     "tfk_rqs_coupling_fwd", "tfk_rqs_coupling_inv",
+    "tfk_lrs_coupling_fwd", "tfk_lrs_coupling_inv",
     "tfk_conv1x1_coupling_fwd", "tfk_conv1x1_coupling_inv",
     "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
     "tfk_permute", "tfk_diag_gauss_logprob",
@@ -41,7 +42,7 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
 )
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class NativeError(RuntimeError):
@@ -73,6 +74,8 @@ def _bind(L: C.CDLL) -> None:
     rqs = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, C.c_float, _i32, _vp]
     L.tfk_rqs_coupling_fwd.argtypes = rqs
     L.tfk_rqs_coupling_inv.argtypes = rqs
+    L.tfk_lrs_coupling_fwd.argtypes = rqs
+    L.tfk_lrs_coupling_inv.argtypes = rqs
     conv = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]
     L.tfk_conv1x1_coupling_fwd.argtypes = conv
     L.tfk_conv1x1_coupling_inv.argtypes = conv
@@ -247,6 +250,13 @@ def rqs_coupling(x, h, out, logdet, tgt_idx, T, n_bins, boundary, accumulate=Fal
     """h: (N, T, 3*n_bins - 1)."""
     _coupling("tfk_rqs_coupling_inv" if inverse else "tfk_rqs_coupling_fwd",
               x, h, out, logdet, tgt_idx, T, 3 * n_bins - 1, accumulate,
+              extra=(int(n_bins), C.c_float(float(boundary))))
+
+
+def lrs_coupling(x, h, out, logdet, tgt_idx, T, n_bins, boundary, accumulate=False, inverse=False):
+    """Linear rational spline coupling; h: (N, T, 4*n_bins)."""
+    _coupling("tfk_lrs_coupling_inv" if inverse else "tfk_lrs_coupling_fwd",
+              x, h, out, logdet, tgt_idx, T, 4 * n_bins, accumulate,
               extra=(int(n_bins), C.c_float(float(boundary))))
 
 
