@@ -869,6 +869,34 @@ static float layer_row(const orc_layer *L, const float *in, const float *ctx, in
     case ORC_RQS_COUPLING:
     case ORC_LRS_COUPLING:
     case ORC_SHIFT_COUPLING: {
+        if (L->autoregressive) {
+            /* MaskedAutoregressiveBijection (layers_base.py:166-225): the conditioner is MADE
+             * (masked weights arrive pre-multiplied), every element is transformed.  One map is a
+             * single parallel pass; the other walks the D elements in order, re-running the
+             * conditioner on the partially inverted row and keeping the LAST pass's log-det
+             * (:213-221).  autoregressive == 1: forward parallel / inverse sequential;
+             * == 2: exchanged (InverseMaskedAutoregressiveBijection :227-234).
+             * swap_transformer: the transformer's own maps are exchanged (InverseAffine). */
+            const int sequential = (L->autoregressive == 1) ? (direction == 1) : (direction == 0);
+            const int tdir = (sequential ? 1 : 0) ^ (L->swap_transformer ? 1 : 0);
+            memcpy(out, in, sizeof(float) * (size_t)D);
+            const int passes = sequential ? D : 1;
+            for (int i = 0; i < passes; ++i) {
+                for (int s = 0; s < D; ++s) w->cond_in[s] = out[s];
+                for (int c = 0; c < C; ++c) w->cond_in[D + c] = ctx[c];
+                orc_feedforward_row(w->cond_in, L->n_linear, L->dims, L->W, L->b, w->h, w->scratch);
+                for (int t = 0; t < D; ++t) w->xb[t] = out[t];
+                if (L->kind == ORC_AFFINE_COUPLING)
+                    affine_row(w->xb, w->h, w->zb, &ld, D, tdir);
+                else if (L->kind == ORC_RQS_COUPLING)
+                    rqs_row(w->xb, w->h, w->zb, &ld, NULL, NULL, D, L->K, L->boundary, tdir);
+                else
+                    lrs_row(w->xb, w->h, w->zb, &ld, D, L->K, L->boundary, tdir);
+                if (sequential) out[i] = w->zb[i];
+                else memcpy(out, w->zb, sizeof(float) * (size_t)D);
+            }
+            break;
+        }
         /* layers_base.py:145-163 */
         memcpy(out, in, sizeof(float) * (size_t)D);                  /* clone :146/:156 */
         for (int s = 0; s < L->S; ++s) w->cond_in[s] = in[L->src_idx[s]]; /* :119-121 */

@@ -150,6 +150,10 @@ typedef struct {
     /* spline */
     int32_t K;
     float boundary;
+    /* MADE-based layers (layers_base.py:166-234): 0 = coupling; 1 = forward parallel, inverse
+     * sequential; 2 = exchanged.  S = T = D, src_idx = tgt_idx = identity, W pre-masked. */
+    int32_t autoregressive;
+    int32_t swap_transformer;   /* the transformer's forward / inverse exchanged (InverseAffine) */
 } orc_layer;
 
 /* BijectiveComposition.forward (bijections/base.py:203-224): layers in order,

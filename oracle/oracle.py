@@ -51,6 +51,8 @@ class _OrcLayer(C.Structure):
         ("b", C.POINTER(_f32p)),
         ("K", C.c_int32),
         ("boundary", C.c_float),
+        ("autoregressive", C.c_int32),
+        ("swap_transformer", C.c_int32),
     ]
 
 
@@ -293,6 +295,8 @@ class Layer:
     biases: List[np.ndarray] = field(default_factory=list)
     n_bins: int = 8
     boundary: float = 50.0
+    autoregressive: int = 0        # 1: forward parallel / inverse sequential (MADE); 2: exchanged
+    swap_transformer: bool = False
 
 
 class OracleFlow:
@@ -351,6 +355,8 @@ class OracleFlow:
                 assert dims[0] == o.S + self.C, (dims[0], o.S, self.C)
             o.K = L.n_bins
             o.boundary = L.boundary
+            o.autoregressive = L.autoregressive
+            o.swap_transformer = 1 if L.swap_transformer else 0
         self._arr = arr
 
     # -- evaluation -------------------------------------------------------
@@ -457,7 +463,13 @@ class OracleFlow:
 
 
 _COUPLING_KIND = {"RealNVP": AFFINE_COUPLING, "CouplingRQNSF": RQS_COUPLING, "NICE": SHIFT_COUPLING,
-                  "CouplingLRS": LRS_COUPLING}
+                  "CouplingLRS": LRS_COUPLING,
+                  # MADE-based presets (architectures.py:106-223): (kind, autoregressive mode, swap)
+                  "MAF": (AFFINE_COUPLING, 1, False), "IAF": (AFFINE_COUPLING, 2, True),
+                  "MaskedAutoregressiveRQNSF": (RQS_COUPLING, 1, False),
+                  "InverseAutoregressiveRQNSF": (RQS_COUPLING, 2, False),
+                  "MaskedAutoregressiveLRS": (LRS_COUPLING, 1, False),
+                  "InverseAutoregressiveLRS": (LRS_COUPLING, 2, False)}
 
 
 def preset_from_state_dict(arch: str, D: int, n_layers: int, sd: Dict[str, np.ndarray],
@@ -470,15 +482,23 @@ def preset_from_state_dict(arch: str, D: int, n_layers: int, sd: Dict[str, np.nd
     ``permute=False`` reproduces the ``edge_list=`` quirk (no permutation layers).
     """
     kind = _COUPLING_KIND[arch]
+    ar_mode, swap = 0, False
+    if isinstance(kind, tuple):
+        kind, ar_mode, swap = kind
     src_mask, tgt_mask = halfsplit_mask(D)
     src, tgt = mask_to_index(src_mask), mask_to_index(tgt_mask)
+    if ar_mode:
+        src = tgt = np.arange(D, dtype=np.int32)
     fwd, inv = reverse_permutation(D)
     g = lambda k: np.asarray(sd[k], dtype=np.float32)
 
     def mlp(i):
         pre = f"bijection.layers.{i}.conditioner_transform.sequential."
         lin = sorted({int(k[len(pre):].split(".")[0]) for k in sd if k.startswith(pre)})
-        return [g(f"{pre}{j}.weight") for j in lin], [g(f"{pre}{j}.bias") for j in lin]
+        # MADE.MaskedLinear (transforms.py:192-198): the effective weight is weight * mask
+        W = [g(f"{pre}{j}.weight") * g(f"{pre}{j}.mask") if f"{pre}{j}.mask" in sd else g(f"{pre}{j}.weight")
+             for j in lin]
+        return W, [g(f"{pre}{j}.bias") for j in lin]
 
     def elementwise(i):
         # ElementwiseAffine takes the flow's context_shape (architectures.py:46, :53):
@@ -498,7 +518,7 @@ def preset_from_state_dict(arch: str, D: int, n_layers: int, sd: Dict[str, np.nd
             i += 1
         W, b = mlp(i)
         layers.append(Layer(kind, src_idx=src, tgt_idx=tgt, weights=W, biases=b,
-                            n_bins=n_bins, boundary=boundary))
+                            n_bins=n_bins, boundary=boundary, autoregressive=ar_mode, swap_transformer=swap))
         i += 1
         layers.append(Layer(ELEMENTWISE_INVERSE_AFFINE, value=g(f"bijection.layers.{i}.value")))
         i += 1

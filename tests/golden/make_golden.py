@@ -528,6 +528,17 @@ def gen_lrs():
     flow_fixture("flow_lrs16.npz", CouplingLRS, 16, 64, dict(n_layers=3))
 
 
+# ---------------------------------------------------------------- F11 MADE-based flows (8f-4)
+def gen_maf():
+    from torchflows.bijections.finite.autoregressive.architectures import (
+        MAF, IAF, MaskedAutoregressiveRQNSF, InverseAutoregressiveRQNSF, MaskedAutoregressiveLRS)
+    flow_fixture("flow_maf6.npz", MAF, 6, 32, dict(n_layers=2))
+    flow_fixture("flow_iaf6.npz", IAF, 6, 32, dict(n_layers=2))
+    flow_fixture("flow_marqnsf5.npz", MaskedAutoregressiveRQNSF, 5, 24, dict(n_layers=2))
+    flow_fixture("flow_iarqnsf5.npz", InverseAutoregressiveRQNSF, 5, 24, dict(n_layers=2))
+    flow_fixture("flow_malrs5.npz", MaskedAutoregressiveLRS, 5, 24, dict(n_layers=2))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["affine", "rqs", "masks", "gauss", "layers", "flows", "image"]
     for w in which:

@@ -37,8 +37,7 @@ def pkg():
 
 
 def build_flow(pkg, arch, event_shape, n_layers, context_shape=None):
-    ctor = {"RealNVP": pkg.RealNVP, "CouplingRQNSF": pkg.CouplingRQNSF, "NICE": pkg.NICE,
-            "CouplingLRS": pkg.CouplingLRS}[arch]
+    ctor = getattr(pkg, arch)
     kw = dict(n_layers=n_layers)
     if context_shape is not None:
         kw["context_shape"] = context_shape
@@ -56,6 +55,11 @@ FLOWS = [
     ("flow_nsf6_ctx2.npz", "CouplingRQNSF", 2, (2,), True),
     ("flow_nsf_3x5x2.npz", "CouplingRQNSF", 2, None, True),
     ("flow_lrs16.npz", "CouplingLRS", 3, None, True),
+    ("flow_maf6.npz", "MAF", 2, None, False),
+    ("flow_iaf6.npz", "IAF", 2, None, False),
+    ("flow_marqnsf5.npz", "MaskedAutoregressiveRQNSF", 2, None, True),
+    ("flow_iarqnsf5.npz", "InverseAutoregressiveRQNSF", 2, None, True),
+    ("flow_malrs5.npz", "MaskedAutoregressiveLRS", 2, None, True),
 ]
 
 

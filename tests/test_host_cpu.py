@@ -124,6 +124,11 @@ FLOWS = [
     ("flow_nsf6_ctx2.npz", tfa.CouplingRQNSF, {}, (2,)),
     ("flow_nsf_3x5x2.npz", tfa.CouplingRQNSF, {}, None),
     ("flow_lrs16.npz", tfa.CouplingLRS, dict(n_layers=3), None),
+    ("flow_maf6.npz", tfa.MAF, dict(n_layers=2), None),
+    ("flow_iaf6.npz", tfa.IAF, dict(n_layers=2), None),
+    ("flow_marqnsf5.npz", tfa.MaskedAutoregressiveRQNSF, dict(n_layers=2), None),
+    ("flow_iarqnsf5.npz", tfa.InverseAutoregressiveRQNSF, dict(n_layers=2), None),
+    ("flow_malrs5.npz", tfa.MaskedAutoregressiveLRS, dict(n_layers=2), None),
 ]
 
 

@@ -167,6 +167,11 @@ FLOWS = [
     ("flow_nsf6_ctx2.npz", "CouplingRQNSF", 2, 2, True),
     ("flow_nsf_3x5x2.npz", "CouplingRQNSF", 2, 0, True),
     ("flow_lrs16.npz", "CouplingLRS", 3, 0, True),
+    ("flow_maf6.npz", "MAF", 2, 0, False),
+    ("flow_iaf6.npz", "IAF", 2, 0, False),
+    ("flow_marqnsf5.npz", "MaskedAutoregressiveRQNSF", 2, 0, True),
+    ("flow_iarqnsf5.npz", "InverseAutoregressiveRQNSF", 2, 0, True),
+    ("flow_malrs5.npz", "MaskedAutoregressiveLRS", 2, 0, True),
 ]
 
 

@@ -8,6 +8,7 @@ autograd / fp64 / host tensors.  Module paths mirror the reference
 """
 from torchflows_amd.flows import Flow, BaseFlow  # noqa: F401
 from torchflows_amd.bijections.finite.autoregressive.architectures import (  # noqa: F401
-    RealNVP, CouplingRQNSF, CouplingLRS, NICE)
+    RealNVP, CouplingRQNSF, CouplingLRS, NICE, MAF, IAF, MaskedAutoregressiveRQNSF,
+    InverseAutoregressiveRQNSF, MaskedAutoregressiveLRS, InverseAutoregressiveLRS)
 
 __version__ = "0.1.0"

@@ -12,7 +12,10 @@ from typing import Optional, Sequence, Type, Union
 
 from torchflows_amd.bijections.base import Bijection, BijectiveComposition
 from torchflows_amd.bijections.finite.autoregressive.layers import (
-    ActNorm, AffineCoupling, ElementwiseAffine, InverseAffineCoupling, LRSCoupling, RQSCoupling, ShiftCoupling)
+    ActNorm, AffineCoupling, AffineForwardMaskedAutoregressive, AffineInverseMaskedAutoregressive,
+    ElementwiseAffine, InverseAffineCoupling, LRSCoupling, LRSForwardMaskedAutoregressive,
+    LRSInverseMaskedAutoregressive, RQSCoupling, RQSForwardMaskedAutoregressive,
+    RQSInverseMaskedAutoregressive, ShiftCoupling)
 from torchflows_amd.bijections.finite.matrix.permutation import ReversePermutationMatrix
 from torchflows_amd.utils import event_size
 
@@ -69,3 +72,37 @@ class CouplingLRS(AutoregressiveArchitecture):
 
     def __init__(self, event_shape: Shape, **kwargs):
         super().__init__(event_shape, base_bijection=LRSCoupling, **kwargs)
+
+
+class MAF(AutoregressiveArchitecture):
+    """Papamakarios et al. 2018 -- masked autoregressive flow (reference :106-118)."""
+
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=AffineForwardMaskedAutoregressive, **kwargs)
+
+
+class IAF(AutoregressiveArchitecture):
+    """Kingma et al. 2017 -- inverse autoregressive flow (reference :121-133)."""
+
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=AffineInverseMaskedAutoregressive, **kwargs)
+
+
+class MaskedAutoregressiveRQNSF(AutoregressiveArchitecture):
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=RQSForwardMaskedAutoregressive, **kwargs)
+
+
+class InverseAutoregressiveRQNSF(AutoregressiveArchitecture):
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=RQSInverseMaskedAutoregressive, **kwargs)
+
+
+class MaskedAutoregressiveLRS(AutoregressiveArchitecture):
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=LRSForwardMaskedAutoregressive, **kwargs)
+
+
+class InverseAutoregressiveLRS(AutoregressiveArchitecture):
+    def __init__(self, event_shape: Shape, **kwargs):
+        super().__init__(event_shape, base_bijection=LRSInverseMaskedAutoregressive, **kwargs)

@@ -181,3 +181,69 @@ class ResidualFeedForward(TensorConditionerTransform):
 
     def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
         return self.sequential(self.context_combiner(x, context))
+
+
+class ElementwiseConditionerTransform(ConditionerTransform):
+    """A parameter set per element of the transformed tensor (reference :120-137)."""
+
+    def __init__(self, input_event_shape, transformed_event_shape, parameter_shape_per_element,
+                 context_shape=None, **kwargs):
+        super().__init__(input_event_shape=input_event_shape,
+                         parameter_shape=(*transformed_event_shape, *parameter_shape_per_element),
+                         context_shape=context_shape, **kwargs)
+
+
+class MADE(ElementwiseConditionerTransform):
+    """Masked autoencoder for distribution estimation (reference :184-267): masked Linear / Tanh
+    stack whose output for element i depends on inputs < i only.  Degrees: inputs 1..n, hidden
+    units ``(j mod (n - 1)) + 1``, outputs 1..D; hidden masks ``>=``, output mask ``>``.
+    The masked GEMMs run on PyTorch-ROCm; the transform that consumes the parameters is a libtfk
+    kernel with every position a target."""
+
+    class MaskedLinear(nn.Linear):
+        def __init__(self, in_features: int, out_features: int, mask: torch.Tensor):
+            super().__init__(in_features=in_features, out_features=out_features)
+            self.register_buffer("mask", mask)
+
+        def forward(self, x):
+            return nn.functional.linear(x, self.weight * self.mask, self.bias)
+
+    def __init__(self, input_event_shape, transformed_event_shape, parameter_shape_per_element,
+                 context_shape=None, n_hidden: int = None, n_layers: int = 2, **kwargs):
+        super().__init__(input_event_shape=input_event_shape, transformed_event_shape=transformed_event_shape,
+                         parameter_shape_per_element=parameter_shape_per_element,
+                         context_shape=context_shape, **kwargs)
+        per_element = event_size(parameter_shape_per_element)
+        n_out = event_size(transformed_event_shape)
+        n_in = self.n_input_event_dims
+        if n_hidden is None:
+            n_hidden = max(int(3 * math.log10(n_in)), 4)
+        degrees = [torch.arange(n_in) + 1]
+        degrees += [(torch.arange(n_hidden) % (n_in - 1)) + 1 for _ in range(n_layers - 1)]
+        degrees.append(torch.arange(n_out) + 1)
+        masks = self.create_masks(n_layers, degrees)
+        mods = []
+        for mask in masks[:-1]:
+            mods += [self.MaskedLinear(mask.shape[1], mask.shape[0], mask), nn.Tanh()]
+        mods.append(self.MaskedLinear(masks[-1].shape[1], masks[-1].shape[0] * per_element,
+                                      torch.repeat_interleave(masks[-1], per_element, dim=0)))
+        self.sequential = nn.Sequential(*mods)
+
+    @staticmethod
+    def create_masks(n_layers: int, ms):
+        masks = []
+        for i in range(1, n_layers + 1):
+            cur, prev = torch.meshgrid(ms[i], ms[i - 1], indexing="ij")
+            masks.append(((cur > prev) if i == n_layers else (cur >= prev)).to(torch.float))
+        return masks
+
+    def predict_theta_flat(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        theta = self.sequential(self.context_combiner(x, context))
+        if self.global_parameter_mask is None:
+            return torch.flatten(theta, start_dim=theta.dim() - len(self.input_event_shape))
+        return theta[..., ~self.global_parameter_mask]
+
+
+class LinearMADE(MADE):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, n_layers=1, **kwargs)

@@ -10,7 +10,8 @@ import torch
 
 from torchflows_amd.bijections.base import RowState, forward_method
 from torchflows_amd.bijections.finite.autoregressive.layers_base import (
-    CouplingBijection, ElementwiseBijection)
+    CouplingBijection, ElementwiseBijection, InverseMaskedAutoregressiveBijection,
+    MaskedAutoregressiveBijection)
 from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import (
     Affine, InverseAffine, Scale, Shift)
 from torchflows_amd.bijections.finite.autoregressive.transformers.spline.linear_rational import (
@@ -142,3 +143,34 @@ class LinearLRSCoupling(LRSCoupling):
 class LinearShiftCoupling(ShiftCoupling):
     def __init__(self, event_shape: Sequence[int], **kwargs):
         super().__init__(event_shape, **kwargs, n_layers=1)
+
+
+# -- MADE-based autoregressive layers (reference :338-407) ------------------------------------
+class AffineForwardMaskedAutoregressive(MaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, Affine, **kwargs)
+
+
+class RQSForwardMaskedAutoregressive(MaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, RationalQuadratic, **kwargs)
+
+
+class LRSForwardMaskedAutoregressive(MaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, LinearRational, **kwargs)
+
+
+class AffineInverseMaskedAutoregressive(InverseMaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, InverseAffine, **kwargs)
+
+
+class RQSInverseMaskedAutoregressive(InverseMaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, RationalQuadratic, **kwargs)
+
+
+class LRSInverseMaskedAutoregressive(InverseMaskedAutoregressiveBijection):
+    def __init__(self, event_shape: Sequence[int], **kwargs):
+        super().__init__(event_shape, LinearRational, **kwargs)

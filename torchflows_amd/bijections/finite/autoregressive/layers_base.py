@@ -26,7 +26,7 @@ from torchflows_amd.bijections.base import (Bijection, FORWARD, INVERSE, RowStat
 from torchflows_amd.bijections.finite.autoregressive.conditioning.coupling_masks import (
     PartialCoupling, make_coupling)
 from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import (
-    ConditionerTransform, FeedForward, Linear)
+    ConditionerTransform, FeedForward, Linear, MADE)
 from torchflows_amd.bijections.finite.autoregressive.transformers.base import (
     ScalarTransformer, TensorTransformer)
 from torchflows_amd.utils import as_rows, get_batch_shape
@@ -192,6 +192,126 @@ class CouplingBijection(AutoregressiveBijection):
         if self._native_ok(z, context):
             return self._native_standalone(z, context, INVERSE)
         return self._aten_apply(z, context, self.transformer.inverse)
+
+
+class MaskedAutoregressiveBijection(AutoregressiveBijection):
+    """MADE conditioner + scalar transformer on every element (reference :166-225).
+    ``forward`` is one parallel pass.  ``inverse`` walks the D elements in order, re-running
+    the conditioner on the partially inverted row each time; as in the reference, the returned
+    log-det is the one of the LAST pass (every element evaluated at its current -- already
+    inverted -- value), which equals the exact log-det for affine transformers.
+    On the HIP path each pass is the masked GEMMs on PyTorch-ROCm + one libtfk coupling kernel
+    with all D positions as targets."""
+
+    _sequential_when = INVERSE          # which of the two maps is the sequential one
+
+    def __init__(self, event_shape: Sequence[int], transformer_class: Type[ScalarTransformer],
+                 context_shape: Optional[Sequence[int]] = None, transformer_kwargs: dict = None,
+                 conditioner_kwargs: dict = None, l2_regularization: bool = True, **kwargs):
+        transformer = transformer_class(event_shape=event_shape, **(transformer_kwargs or {}))
+        conditioner_transform = MADE(input_event_shape=event_shape, transformed_event_shape=event_shape,
+                                     parameter_shape_per_element=transformer.parameter_shape_per_element,
+                                     context_shape=context_shape, **(conditioner_kwargs or {}))
+        super().__init__(transformer.event_shape, transformer, conditioner_transform,
+                         context_shape=context_shape, l2_regularization=l2_regularization, **kwargs)
+
+    # -- ATen composite path ---------------------------------------------------------
+    def apply_conditioner_transformer(self, inputs, context, forward: bool = True):
+        h = self.conditioner_transform(inputs, context)
+        return self.transformer.forward(inputs, h) if forward else self.transformer.inverse(inputs, h)
+
+    def _parallel(self, x, context):
+        return self.apply_conditioner_transformer(x, context, True)
+
+    def _sequential(self, z, context):
+        batch = get_batch_shape(z, self.event_shape)
+        flat = z.reshape(*batch, -1).clone()
+        log_det = torch.zeros(batch, device=z.device)
+        for i in range(flat.shape[-1]):
+            tmp, log_det = self.apply_conditioner_transformer(flat.view(z.shape), context, False)
+            flat = flat.clone()
+            flat[..., i] = tmp.reshape(*batch, -1)[..., i]
+        return flat.view(z.shape), log_det
+
+    # -- HIP path ----------------------------------------------------------------------
+    def _native_supported(self) -> bool:
+        kind = self.transformer.native_kind
+        if kind == "rqs":
+            return 2 <= self.transformer.n_bins <= 32
+        if kind == "lrs":
+            return self.transformer.n_bins in (4, 8)
+        return kind in ("affine", "inverse_affine")
+
+    def _native_ok(self, x, context) -> bool:
+        return self._native_supported() and native.eligible(x, context) and _params_ok(self)
+
+    def _native_pass(self, rows, out, logdet, context, transformer_inverse: bool, accumulate: bool):
+        N, D = rows.shape
+        ctx = None if context is None else context.reshape(N, *self.context_shape)
+        h = self.conditioner_transform(rows.view(N, *self.event_shape), ctx).reshape(N, -1).contiguous()
+        kind, tr = self.transformer.native_kind, self.transformer
+        if kind in ("affine", "inverse_affine"):
+            native.affine_coupling(rows, h, out, logdet, None, D, accumulate=accumulate,
+                                   inverse=transformer_inverse != (kind == "inverse_affine"))
+        elif kind == "rqs":
+            native.rqs_coupling(rows, h, out, logdet, None, D, tr.n_bins, tr.boundary,
+                                accumulate=accumulate, inverse=transformer_inverse)
+        else:
+            native.lrs_coupling(rows, h, out, logdet, None, D, tr.n_bins, tr.boundary,
+                                accumulate=accumulate, inverse=transformer_inverse)
+
+    def _native_step(self, state: RowState, context, d: int) -> None:
+        rows = state.rows
+        N, D = rows.shape
+        if d != self._sequential_when:                       # one parallel pass
+            out = rows if state.owned else state.out_buffer()
+            self._native_pass(rows, out, state.logdet, context, False, state.started)
+            state.started = True
+            state.commit(out)
+            return
+        cur = rows.clone()
+        tmp = torch.empty_like(cur)
+        ld = torch.empty(N, dtype=torch.float32, device=rows.device)
+        for i in range(D):                                   # layers_base.py:213-221
+            self._native_pass(cur, tmp, ld, context, True, False)
+            cur[:, i] = tmp[:, i]
+        if state.started:
+            state.logdet.add_(ld)
+        else:
+            state.logdet.copy_(ld)
+            state.started = True
+        state.commit(cur)
+
+    # -- public maps ---------------------------------------------------------------------
+    @forward_method
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(x, context):
+            return self._native_standalone(x, context, FORWARD)
+        return self._parallel(x, context)
+
+    @inverse_method
+    def inverse(self, z: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(z, context):
+            return self._native_standalone(z, context, INVERSE)
+        return self._sequential(z, context)
+
+
+class InverseMaskedAutoregressiveBijection(MaskedAutoregressiveBijection):
+    """The two maps exchanged (reference :227-234): ``forward`` is the sequential one (IAF)."""
+
+    _sequential_when = FORWARD
+
+    @forward_method
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(x, context):
+            return self._native_standalone(x, context, FORWARD)
+        return self._sequential(x, context)
+
+    @inverse_method
+    def inverse(self, z: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_ok(z, context):
+            return self._native_standalone(z, context, INVERSE)
+        return self._parallel(z, context)
 
 
 class ElementwiseBijection(AutoregressiveBijection):
