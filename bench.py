@@ -154,6 +154,8 @@ class KernelTimer:
         N, D = x.shape
         half = D // 2
         per_row = 0
+        if not isinstance(ops, (list, tuple)):          # prepacked int32[8] records
+            ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         for op in ops:
             kind, H = op[0], op[2]
             if mfma and kind in (2, 3, 4, 5):

@@ -265,6 +265,9 @@ class BijectiveComposition(Bijection):
 def _params_ok(module: nn.Module) -> bool:
     """The kernels read parameters as fp32 on the same HIP device, without autograd."""
     grad = torch.is_grad_enabled()
+    if not grad:                        # nothing can ask for a gradient: a cached static check
+        from torchflows_amd import fused
+        return fused.static_ok(module)
     for p in module.parameters():
         if p.device.type != "cuda" or p.dtype != torch.float32 or (grad and p.requires_grad):
             return False

@@ -63,6 +63,13 @@ class Segment:
     params: torch.Tensor                      # fp32 device block, numel % 4 == 0
     mfma: bool = False                        # packed for tfk_flow_run_mfma (matrix-core conditioner)
 
+    def packed_ops(self):
+        """The op records as the ctypes array the C-ABI takes, built once per segment."""
+        arr = self.__dict__.get("_ops_c")
+        if arr is None:
+            arr = self.__dict__["_ops_c"] = native._pack_ops(self.ops)
+        return arr
+
 
 @dataclass
 class CompiledChain:
@@ -98,12 +105,47 @@ def _flatten(layers, attr: str):
     return out
 
 
+def _tensor_slots(module: nn.Module):
+    """[(owner dict, name, tensor)] for every parameter and buffer below ``module``."""
+    slots = []
+    for m in module.modules():
+        for owner in (m._parameters, m._buffers):
+            for k, t in owner.items():
+                if t is not None:
+                    slots.append((owner, k, t))
+    return slots
+
+
 def _params_version(module: nn.Module) -> int:
-    """Changes whenever a parameter / buffer is modified in place or replaced by another tensor."""
-    v = 0
-    for t in list(module.parameters()) + list(module.buffers()):
+    """Changes whenever a parameter / buffer below ``module`` is modified in place (version
+    counter), moved or converted (data pointer) or replaced by another tensor (slot identity).
+    The walk over the module tree is done once and cached: per call this is one pass over a flat
+    list (the ``module.parameters()`` traversal alone cost ~150 us per ``log_prob`` call)."""
+    slots = module.__dict__.get("_tfk_slots")
+    if slots is None:
+        slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
+    v = len(slots)
+    for owner, k, t in slots:
+        if owner.get(k) is not t:                     # a tensor was replaced: re-walk the tree
+            slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
+            v = len(slots)
+            for _, _, t2 in slots:
+                v = (v * 1000003 + t2._version + (t2.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
+            return v
         v = (v * 1000003 + t._version + (t.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
     return v
+
+
+def static_ok(module: nn.Module) -> bool:
+    """Every parameter below ``module`` is fp32 on a HIP device (cached per parameter version)."""
+    version = _params_version(module)
+    hit = module.__dict__.get("_tfk_static_ok")
+    if hit is not None and hit[0] == version:
+        return hit[1]
+    ok = all(t.device.type == "cuda" and t.dtype == torch.float32
+             for owner, _, t in module.__dict__["_tfk_slots"] if owner is not None and isinstance(t, nn.Parameter))
+    module.__dict__["_tfk_static_ok"] = (version, ok)
+    return ok
 
 
 def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
@@ -371,11 +413,16 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
             lp = logprob
         return out, ld, lp
     loc_p = ls_p = None
-    if base is not None:
-        loc_p = torch.empty_like(base[0])
-        ls_p = torch.empty_like(base[1])
-        loc_p[chain.pos] = base[0]
-        ls_p[chain.pos] = base[1]
+    if base is not None:                          # base parameters in physical order, cached
+        key = (base[0].data_ptr(), base[0]._version, base[1].data_ptr(), base[1]._version)
+        hit = chain.__dict__.get("_base_cache")
+        if hit is None or hit[0] != key:
+            loc_p = torch.empty_like(base[0])
+            ls_p = torch.empty_like(base[1])
+            loc_p[chain.pos] = base[0]
+            ls_p[chain.pos] = base[1]
+            chain.__dict__["_base_cache"] = hit = (key, loc_p, ls_p)
+        loc_p, ls_p = hit[1], hit[2]
     for i, seg in enumerate(chain.segments):
         last = i == n_seg - 1
         need_rows = (not last) or want_rows
@@ -387,7 +434,7 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         run = native.flow_run_mfma if seg.mfma else native.flow_run
         run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
             loc_p if last else None, ls_p if last else None,
-            logprob if last else None, seg.ops, seg.params, accumulate=(i > 0))
+            logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0))
         if need_rows:
             cur = out
     out_rows = None

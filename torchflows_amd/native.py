@@ -443,7 +443,10 @@ def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, in
 
 def _pack_ops(ops):
     """Host-side op records: int32[8] each = kind, src_plane, H (or GEMM-2 steps), offset, K and
-    the fp32 bit patterns of boundary, scale, c (spline ops only)."""
+    the fp32 bit patterns of boundary, scale, c (spline ops only).  An array that is already
+    packed (``fused.Segment.packed_ops``) passes through."""
+    if isinstance(ops, C.Array):
+        return ops
     flat = []
     for op in ops:
         kind, plane, H, off = (int(v) for v in op[:4])
@@ -452,6 +455,10 @@ def _pack_ops(ops):
         bits = struct.unpack("<3i", struct.pack("<3f", *fl))
         flat += [kind, plane, H, off, K, *bits]
     return (_i32 * max(len(flat), 1))(*flat)
+
+
+def _n_ops(ops) -> int:
+    return len(ops) // 8 if isinstance(ops, C.Array) else len(ops)
 
 
 def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False):
@@ -466,7 +473,7 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
         if t is not None and t.numel() != n:
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
-            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
+            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, _n_ops(ops),
             _f32(params, name), params.numel(), 1 if accumulate else 0)
     with _device_guard(x):
         rc = lib().tfk_flow_run(*args, _stream(x))
@@ -486,7 +493,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
         if t is not None and t.numel() != n:
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
-            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, len(ops),
+            _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, _n_ops(ops),
             _f32(params, name), params.numel(), (1 if accumulate else 0) | (2 if reverse_out else 0))
     with _device_guard(x):
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
