@@ -79,15 +79,13 @@ def applicable(composition, x: torch.Tensor, context) -> bool:
         return False
     if x.device.type != "cuda" or x.dtype != torch.float32:
         return False
-    needs = x.requires_grad
-    for p in composition.parameters():
-        if p.device != x.device or p.dtype != torch.float32:
-            return False
-        needs = needs or p.requires_grad
-    for b in composition.buffers():
-        if b.is_floating_point() and (b.device != x.device or b.dtype != torch.float32):
-            return False
-    return needs
+    from torchflows_amd import fused
+    if not fused.static_ok(composition):
+        return False
+    first = next(composition.parameters(), None)
+    if first is not None and first.device != x.device:
+        return False
+    return x.requires_grad or fused.any_requires_grad(composition)
 
 
 def _layer_params(layer, kind: str) -> List[torch.Tensor]:

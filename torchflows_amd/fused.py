@@ -136,16 +136,45 @@ def _params_version(module: nn.Module) -> int:
     return v
 
 
+def _layout_version(module: nn.Module) -> int:
+    """Like ``_params_version`` without the in-place version counters: changes only when a tensor
+    is moved, converted or replaced (an optimizer step does not change it)."""
+    slots = module.__dict__.get("_tfk_slots")
+    if slots is None:
+        slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
+    v = len(slots)
+    for owner, k, t in slots:
+        if owner.get(k) is not t:
+            slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
+            return _layout_version(module)
+        v = (v * 1000003 + (t.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
+    return v
+
+
 def static_ok(module: nn.Module) -> bool:
-    """Every parameter below ``module`` is fp32 on a HIP device (cached per parameter version)."""
-    version = _params_version(module)
+    """Every floating-point parameter / buffer below ``module`` is fp32 on one HIP device (cached
+    until a tensor moves)."""
+    layout = _layout_version(module)
     hit = module.__dict__.get("_tfk_static_ok")
-    if hit is not None and hit[0] == version:
+    if hit is not None and hit[0] == layout:
         return hit[1]
-    ok = all(t.device.type == "cuda" and t.dtype == torch.float32
-             for owner, _, t in module.__dict__["_tfk_slots"] if owner is not None and isinstance(t, nn.Parameter))
-    module.__dict__["_tfk_static_ok"] = (version, ok)
+    devices = set()
+    ok = True
+    for _, _, t in module.__dict__["_tfk_slots"]:
+        if t.is_floating_point():
+            devices.add(t.device)
+            ok = ok and t.device.type == "cuda" and t.dtype == torch.float32
+    ok = ok and len(devices) <= 1
+    module.__dict__["_tfk_static_ok"] = (layout, ok)
     return ok
+
+
+def any_requires_grad(module: nn.Module) -> bool:
+    slots = module.__dict__.get("_tfk_slots")
+    if slots is None:
+        _layout_version(module)
+        slots = module.__dict__["_tfk_slots"]
+    return any(t.requires_grad for _, _, t in slots)
 
 
 def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
