@@ -196,11 +196,12 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * Same semantics and outputs as tfk_flow_run for chains of elementwise ops and affine / shift
  * couplings, with the two conditioner GEMMs issued as v_mfma_f32_16x16x4_f32 (fp32 in / fp32
  * accumulate: numerically an fmaf chain).  D must be 64, 128 or 256 (RQS ops: 64 or 128),
- * hidden width <= 16.
+ * hidden width <= 64 (RQS ops: <= 16).
  * ops (HOST pointer): n_ops x int32[8] = {kind, src_plane, gemm2_steps = ceil(H/4), param_offset,
  *   K, boundary, scale, c} (the last four as in tfk_flow_run, RQS ops only).
  * Elementwise ops use the parameter layout of tfk_flow_run; a coupling op holds
- *   A1[D/8][64] | b1[4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],
+ *   A1[D/8][HT][64] | b1[HT][4][4] | A2[T2][gemm2_steps][64] | b2[T2][4][4],  HT = 1 / 2 / 4 for
+ *   gemm2_steps <= 4 / 8 / 16,
  *   T2 = D/16 (affine), D/32 (shift), 6*D/8 (RQS, n_bins = 8: 6 tiles of 4 parameters per element)
  * accumulate: bit 0 = add to logdet instead of overwriting it; bit 1 = store the rows reversed
  *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store).

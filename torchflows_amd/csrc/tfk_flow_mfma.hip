@@ -61,36 +61,44 @@ __device__ __forceinline__ float tanh_act_m(float x) {       // see tanh_act in 
 // One coupling op with the kind and the roles of the planes fixed at compile time (src feeds
 // the conditioner, tgt is transformed): straight-line code, the scheduler is free to slide the
 // vector work of one tile under the MFMAs of the next.  apply_op_m dispatches once per op.
-template <int EPL, int KIND>
+// HT = 16-unit tiles of the hidden layer (hidden width <= 16 HT): GEMM 1 keeps HT accumulators,
+// GEMM 2 runs up to 4 HT k-steps (the unused ones are skipped uniformly).
+template <int EPL, int KIND, int HT>
 __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lane, int q,
                                          const float (&src)[EPL], float (&tgt)[EPL], float &ld)
 {
     constexpr bool affine = (KIND == TFK_OP_AFFINE_FWD || KIND == TFK_OP_AFFINE_INV);
     constexpr int T2 = affine ? EPL / 2 : EPL / 4;
     const float *A1 = prm;
-    const float *b1 = prm + EPL * 64;
-    const float *A2 = b1 + 16;
+    const float *b1 = prm + EPL * HT * 64;
+    const float *A2 = b1 + HT * 16;
     const float *b2 = A2 + T2 * op.steps2 * 64;
 
     // GEMM 1: hidden pre-activations of the 16 rows of this wave
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);      // bias of units 4r + q
+    f32x4 acc[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(b1 + t * 16 + 4 * q);   // units 16t + 4r + q
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src[s], acc, 0, 0, 0);
-    float hid[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);        // transforms.py:293-304
+        for (int t = 0; t < HT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(s * HT + t) * 64 + lane], src[s], acc[t], 0, 0, 0);
+    float hid[4 * HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[4 * t + r] = tanh_act_m(acc[t][r]);    // transforms.py:293-304
 
     // GEMM 2 + transform, two (affine) or four (shift) target elements per tile
     float part = 0.0f;
 #pragma unroll
     for (int t = 0; t < T2; ++t) {
         f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
-        // (hidden width <= 16: up to four k-steps; the unused ones are skipped uniformly)
         o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2) * 64 + lane], hid[0], o, 0, 0, 0);
-        if (op.steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
-        if (op.steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
-        if (op.steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < 4 * HT; ++k)
+            if (op.steps2 > k)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + k) * 64 + lane], hid[k], o, 0, 0, 0);
         if constexpr (affine) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -170,9 +178,23 @@ __device__ __forceinline__ void couple_rqs_m(const MOp op, const float *prm, int
 }
 
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
-//   A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4]
+//   A1[EPL][HT][64] | b1[HT][4][4] | A2[T2][steps2][64] | b2[T2][4][4],  HT = ceil(steps2 / 4) rounded
+//   up to 1, 2 or 4 (hidden width <= 64)
 // Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
-template <int EPL>
+template <int EPL, int KIND, int HTMAX>
+__device__ __forceinline__ void couple_any(const MOp op, const float *prm, int lane, int q,
+                                           const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+{
+    if constexpr (HTMAX == 1) {
+        couple_m<EPL, KIND, 1>(op, prm, lane, q, src, tgt, ld);
+    } else {
+        if (op.steps2 <= 4) couple_m<EPL, KIND, 1>(op, prm, lane, q, src, tgt, ld);
+        else if (op.steps2 <= 8) couple_m<EPL, KIND, 2>(op, prm, lane, q, src, tgt, ld);
+        else couple_m<EPL, KIND, 4>(op, prm, lane, q, src, tgt, ld);
+    }
+}
+
+template <int EPL, int HTMAX>
 __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int lane, int q,
                                            float (&a)[EPL], float (&b)[EPL], float &ld)
 {
@@ -216,14 +238,14 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
     }
     // (src_plane 1: plane B conditions plane A)
     switch (op.kind * 2 + op.src_plane) {
-    case TFK_OP_AFFINE_FWD * 2: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_AFFINE_FWD * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_FWD>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_AFFINE_INV * 2: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_AFFINE_INV * 2 + 1: couple_m<EPL, TFK_OP_AFFINE_INV>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_SHIFT_FWD * 2: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_SHIFT_FWD * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_FWD>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_SHIFT_INV * 2: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_SHIFT_INV * 2 + 1: couple_m<EPL, TFK_OP_SHIFT_INV>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_AFFINE_FWD * 2: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_AFFINE_FWD * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_AFFINE_INV * 2: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_AFFINE_INV * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_SHIFT_FWD * 2: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_SHIFT_FWD * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX>(op, prm, lane, q, b, a, ld); return;
+    case TFK_OP_SHIFT_INV * 2: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX>(op, prm, lane, q, a, b, ld); return;
+    case TFK_OP_SHIFT_INV * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX>(op, prm, lane, q, b, a, ld); return;
     default: break;
     }
     // the spline op exists for D <= 128 only: at D = 256 one coupling's parameters (209 KB) exceed
@@ -240,7 +262,10 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 }
 
 // Dynamic LDS: the parameter block [+ 3*D floats of base density].
-template <int EPL, int BLOCK>
+// HTMAX = 1: every coupling of the program has hidden width <= 16 (the presets: 96 VGPRs at
+// D = 64); HTMAX = 4: up to 64 (more registers: its own instantiation so that the narrow
+// programs keep their occupancy).
+template <int EPL, int BLOCK, int HTMAX>
 __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
         // per-lane share of the row's log-det; lane q == 0 carries the running value
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         for (int o = 0; o < prog.n_ops; ++o)
-            apply_op_m<EPL>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
+            apply_op_m<EPL, HTMAX>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
         float lp = 0.0f;
         if (logprob) {                                              // gaussian.py:46-54
 #pragma unroll
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
     }
 }
 
-template <int EPL, int BLOCK>
+template <int EPL, int BLOCK, int HTMAX>
 static int launch_mb(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, const float *params, int n_params,
                      const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
@@ -344,7 +369,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK, HTMAX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -354,7 +379,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     // resident workgroups per CU as the runtime computes them (registers, LDS, wave slots); the
     // grid is a few resident sets, grid-strided over the rows (kGridOversubscribe, tfk_common.h)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK>, BLOCK, lds) != hipSuccess
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK, HTMAX>, BLOCK, lds) != hipSuccess
         || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -363,7 +388,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
+    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
                        log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
     return check_launch(fn);
 }
@@ -375,9 +400,16 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
                     float *logprob, int64_t N, const float *params, int n_params,
                     const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
 {
-    if (N >= (int64_t)kCUs * 3 * 128)
-        return launch_mb<EPL, 512>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
-    return launch_mb<EPL, kBlock>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
+    bool wide = false;                     // a coupling with hidden width > 16 in the program?
+    for (int i = 0; i < prog.n_ops; ++i)
+        wide = wide || (prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV &&
+                        prog.op[i].steps2 > 4);
+    const bool big = N >= (int64_t)kCUs * 3 * 128;
+#define TFK_MB(BLOCK_, HT_) \
+    launch_mb<EPL, BLOCK_, HT_>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn)
+    if (wide) return big ? TFK_MB(512, 4) : TFK_MB(kBlock, 4);
+    return big ? TFK_MB(512, 1) : TFK_MB(kBlock, 1);
+#undef TFK_MB
 }
 
 }  // namespace tfk
@@ -422,10 +454,11 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
         if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
         else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
-            if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
+            if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
             if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             const int T2 = (o.kind <= TFK_OP_AFFINE_INV) ? EPL / 2 : EPL / 4;
-            need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
+            need = (int64_t)EPL * HT * 64 + HT * 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
         } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
             if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
             if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);

@@ -202,7 +202,8 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
 
 def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p):
     """Parameter block of one affine / shift coupling for tfk_flow_run_mfma
-    (csrc/tfk_flow_mfma.hip): A1[EPL][64] | b1[4][4] | A2[T2][steps2][64] | b2[T2][4][4].
+    (csrc/tfk_flow_mfma.hip): A1[EPL][HT][64] | b1[HT][4][4] | A2[T2][steps2][64] | b2[T2][4][4]
+    (HT = 1, 2 or 4 tiles of 16 hidden units; RQS: HT = 1).
     Lane l = (q = l >> 4, i = l & 15).  GEMM 1: D-row i <-> hidden unit 4*(i & 3) + (i >> 2),
     k-step s of lane-group q <-> physical source element EPL*q + s.  GEMM 2, tile t: D-row
     i = 4*q2 + r <-> parameter (r & 1) of target element EPL*q2 + 2t + (r >> 1) (affine) or
@@ -211,18 +212,20 @@ def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p)
     dev, dt = W1t.device, W1t.dtype
     P = W2p.shape[1]
     steps2 = (H + 3) // 4
-    W1pad = torch.zeros(16, half, dtype=dt, device=dev)
+    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)       # 16-unit tiles of the hidden layer
+    W1pad = torch.zeros(16 * HT, half, dtype=dt, device=dev)
     W1pad[:H] = W1t
-    b1pad = torch.zeros(16, dtype=dt, device=dev)
+    b1pad = torch.zeros(16 * HT, dtype=dt, device=dev)
     b1pad[:H] = b1
-    W2pad = torch.zeros(half, P, 16, dtype=dt, device=dev)
+    W2pad = torch.zeros(half, P, 16 * HT, dtype=dt, device=dev)
     W2pad[:, :, :H] = W2p
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
     unit1 = 4 * (il & 3) + (il >> 2)
-    A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)])            # (EPL, 64)
+    # A1[s][t][lane]: tile t holds hidden units 16t .. 16t+15 (D-row i <-> unit 16t + unit1(i))
+    A1 = torch.stack([W1pad[16 * t + unit1, EPL * ql + s] for s in range(EPL) for t in range(HT)])
     qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
-    b1m = b1pad[4 * rr + qq]                                                       # (4, 4): [q][r]
+    b1m = torch.stack([b1pad[16 * t + 4 * rr + qq] for t in range(HT)])           # [t][q][r]
     q2, r2 = il >> 2, il & 3
     if kind == "rqs":
         # 23 spline parameters per element padded to 24: tile 6e + c holds parameters 4c .. 4c+3
@@ -300,7 +303,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
     if mfma:
-        if H > 16 or (kind == "rqs" and D > 128):
+        if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and D > 128):
             return None
         head, block = _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
         if kind == "rqs":
