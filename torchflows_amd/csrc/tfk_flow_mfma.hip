@@ -394,7 +394,8 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
 }
 
 // the parameter block is per workgroup: with a whole program resident (~50 KB for RealNVP
-// D = 64, 8 layers) 512-thread workgroups keep 3 x 8 waves per CU, 256-thread ones only 3 x 4
+// D = 64, 8 layers; 96 VGPRs) two 512-thread workgroups = 16 waves fit a CU, 256-thread ones would
+// stop at 3 x 4 waves on LDS; small batches take the 256-thread variant (more workgroups)
 template <int EPL>
 static int launch_m(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                     float *logprob, int64_t N, const float *params, int n_params,

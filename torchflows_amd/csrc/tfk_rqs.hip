@@ -26,10 +26,6 @@
 #include "tfk_common.h"
 #include "tfk_spline.h"
 
-#ifndef TFK_ABLATE
-#define TFK_ABLATE 0
-#endif
-
 namespace tfk {
 
 // TILE = threads per workgroup = spline elements (parameter records) per LDS tile.
@@ -75,9 +71,6 @@ __global__ __launch_bounds__(TILE) void k_rqs_coupling(
             const int nfl = E * P;
 
             __syncthreads();   // previous tile's readers are done with rec / ld_s
-#if TFK_ABLATE == 2      /* timing experiment only: tile loaded once, then evaluated from stale LDS */
-            if (tile == (long long)blockIdx.x)
-#endif
             if (h_vec_ok && (hoff & 3) == 0) {
                 const float4 *src = reinterpret_cast<const float4 *>(h + hoff);
                 float4 *dst = reinterpret_cast<float4 *>(rec);
@@ -101,12 +94,8 @@ __global__ __launch_bounds__(TILE) void k_rqs_coupling(
                 const int idx = tgt_idx ? tgt_idx[t] : D - T + t;
                 const float v = x[row * D + idx];
                 float o = v;                                       // spline/base.py:54-55
-#if TFK_ABLATE == 1      /* timing experiment only: no spline evaluation */
-                o = v + rec[tid * P];
-#else
                 if (v > C.minimum && v < C.maximum)                // strict, base.py:29-33
                     rqs_eval<KT, INVERSE>(rec + tid * P, K, v, C, o, ld);
-#endif
                 z[row * D + idx] = o;
             }
 

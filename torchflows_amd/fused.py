@@ -40,7 +40,7 @@ FORWARD, INVERSE = 0, 1
 # the whole RealNVP(64, n_layers=8) program (35.8 KB)
 MAX_PARAM_BYTES = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS", 40 * 1024))
 # the matrix-core layout stores MFMA A-operands per lane (zero-padded to 16 hidden units):
-# RealNVP(64, n_layers=8) is 49 KB; its kernel runs 512-thread workgroups, 3 per CU
+# RealNVP(64, n_layers=8) is 49 KB; its kernel runs 512-thread workgroups, 2 per CU (register-bound)
 MAX_PARAM_BYTES_MFMA = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS_MFMA", 52 * 1024))
 # wider rows hold more registers per lane, so fewer workgroups fit a CU whatever the LDS use:
 # D = 128 (120 VGPRs) runs 2 x 512 threads per CU, D = 256 (179 VGPRs) one -- their launches may
