@@ -334,6 +334,87 @@ class Flow(BaseFlow):
             self.load_state_dict(best_weights)
         self.eval()
 
+    # -- stochastic variational inference (reference flows.py:457-603) ------------------------
+    def _variational_loss(self, target_log_prob, n_samples: int, use_regularization: bool = True,
+                          check_for_divergences: bool = False):
+        """``-mean(target_log_prob(x) + flow_log_prob)`` on ``n_samples`` draws of the flow, with the
+        reference's ``sample(return_log_prob=True)`` convention (reference :457-497).  Returns
+        (loss, flow log-prob, target log-prob, diverged)."""
+        flow_x, flow_lp = self.sample(n_samples, return_log_prob=True)
+        target_lp = target_log_prob(flow_x)
+        loss = -torch.mean(target_lp + flow_lp)
+        if use_regularization:
+            loss = loss + self.regularization()
+        diverged = False
+        if check_for_divergences:
+            with torch.no_grad():
+                diverged = bool((~torch.isfinite(loss)) | (flow_x.abs().max() > 1e8) | (flow_lp.abs().max() > 1e6)
+                                | (~torch.isfinite(flow_x)).any() | (~torch.isfinite(flow_lp)).any())
+        return loss, flow_lp, target_lp, diverged
+
+    def variational_fit(self, target_log_prob, n_epochs: int = 500, lr: float = 0.05, n_samples: int = 1,
+                        early_stopping: bool = False, early_stopping_threshold: int = 50,
+                        keep_best_weights: bool = True, show_progress: bool = False,
+                        check_for_divergences: bool = False, time_limit_seconds: Union[float, int] = None,
+                        reset_optimizer: bool = True):
+        """Fit to an unnormalised target log-density by stochastic variational inference (reference
+        :499-603; Rezende & Mohamed 2015).  One AdamW step per epoch on ``n_samples`` fresh draws; the
+        draws go through ``bijection.inverse`` with gradients -- on an MI355X the inverse-direction
+        reverse-mode kernels (autograd.py)."""
+        t0 = time.time()
+        if len(list(self.parameters())) == 0:
+            return
+        self.train()
+        if self._optimizer is None or reset_optimizer:
+            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
+
+        def snapshot():
+            return {k: v.detach().clone() for k, v in self.state_dict().items()}
+
+        initial, best = snapshot(), snapshot()
+        best_loss, best_epoch, n_div, gave_up = float("inf"), 0, 0, False
+        epochs = range(n_epochs)
+        pbar = None
+        if show_progress:
+            from tqdm import tqdm
+            epochs = pbar = tqdm(epochs, desc="Fitting with SVI")
+        for epoch in epochs:
+            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                print("Training time limit exceeded")
+                break
+            if check_for_divergences and not all(bool(torch.isfinite(p).all()) for p in self.parameters()):
+                gave_up = True
+                print("Flow training diverged")
+                print("Reverting to initial weights")
+                break
+            self._optimizer.zero_grad()
+            value = mean_flow = mean_target = float("nan")
+            try:
+                loss, flow_lp, target_lp, diverged = self._variational_loss(
+                    target_log_prob, n_samples, use_regularization=True, check_for_divergences=True)
+                if not diverged:
+                    loss.backward()
+                    self._optimizer.step()
+                    value = float(loss.detach())
+                    if value < best_loss:
+                        best_loss, best_epoch = value, epoch
+                        if keep_best_weights:
+                            best = snapshot()
+                    mean_flow, mean_target = float(flow_lp.detach().mean()), float(target_lp.detach().mean())
+            except ValueError:
+                diverged = True
+            n_div += int(diverged)
+            if pbar is not None:
+                pbar.set_postfix_str(f"Loss: {value:.4f} [best: {best_loss:.4f} @ {best_epoch}], divergences: {n_div}, "
+                                     f"flow log_prob: {mean_flow:.2f}, target log_prob: {mean_target:.2f}")
+            if early_stopping and epoch - best_epoch > early_stopping_threshold:
+                break
+        if gave_up:
+            self.load_state_dict(initial)
+        elif keep_best_weights:
+            self.load_state_dict(best)
+        self.eval()
+
     def log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
         if context is None:
             fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=False)
