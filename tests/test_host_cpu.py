@@ -370,3 +370,21 @@ def test_sibling_layers_match_reference(name):
         ref = fx[f"{name}/{key}"]
         err = np.max(np.abs(mine.numpy() - ref) / np.maximum(1.0, np.abs(ref)))
         assert err < tol, (name, key, err)
+
+
+def test_flow_mixture():
+    """Reference flows.py:716-829: log-sum-exp of the components, one component per sample."""
+    from torchflows_amd.flows import FlowMixture
+    torch.manual_seed(0)
+    flows = [tfa.Flow(tfa.RealNVP(3)).eval(), tfa.Flow(tfa.NICE(3)).eval()]
+    mix = FlowMixture(flows, weights=[0.25, 0.75])
+    x = torch.randn(11, 3)
+    with torch.no_grad():
+        lp = mix.log_prob(x)
+        parts = torch.stack([f.log_prob(x) for f in flows]) + torch.log(torch.tensor([0.25, 0.75]))[:, None]
+        assert torch.allclose(lp, torch.logsumexp(parts, dim=0), atol=1e-6)
+        s, slp = mix.sample(500, return_log_prob=True)
+    assert s.shape == (500, 3) and slp.shape == (500,) and torch.isfinite(s).all()
+    assert mix.n_components == 2 and abs(float(mix.weights.sum()) - 1.0) < 1e-6
+    with pytest.raises(AssertionError):
+        FlowMixture(flows, weights=[0.5, 0.6])

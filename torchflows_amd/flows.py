@@ -448,3 +448,64 @@ class Flow(BaseFlow):
         if return_log_prob:
             return x, self.base_log_prob(z) + log_det
         return x
+
+
+class FlowMixture(BaseFlow):
+    """Mixture of flows with categorical weights (reference flows.py:716-829).  ``log_prob`` is a
+    log-sum-exp over the components' ``Flow.log_prob`` -- each of them a flow program on an
+    MI355X; ``sample`` draws from every component and keeps one per row (the reference's scheme,
+    including its ``return_log_prob`` convention: the mixture of the components' sample log-probs)."""
+
+    def __init__(self, flows, weights=None, trainable_weights: bool = False, constrain_weights: bool = False):
+        super().__init__(event_shape=flows[0].event_shape)
+        if weights is None:
+            weights = [1.0 / len(flows)] * len(flows)
+        if len(weights) != len(flows) or not all(w > 0.0 for w in weights) or abs(sum(weights) - 1.0) > 1e-8:
+            raise AssertionError("weights must be positive, one per flow, and sum to 1")
+        self.constrain_weights = constrain_weights
+        self.flows = nn.ModuleList(flows)
+        logits = torch.log(torch.tensor(weights))
+        if trainable_weights:
+            self.logit_weights = nn.Parameter(logits)
+        else:
+            self.logit_weights = logits
+
+    @property
+    def n_components(self) -> int:
+        return len(self.flows)
+
+    @property
+    def weights(self) -> torch.Tensor:
+        u = self.logit_weights
+        if self.constrain_weights:
+            u = torch.sigmoid(u) * 10.0 - 5.0              # squashed into [-5, 5]
+        return torch.softmax(u, dim=0)
+
+    @property
+    def log_weights(self) -> torch.Tensor:
+        return self.weights.log()
+
+    def log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        per_flow = torch.stack([flow.log_prob(x, context=context) for flow in self.flows])
+        lw = self.log_weights.to(per_flow.device).view(-1, *([1] * (per_flow.dim() - 1)))
+        return torch.logsumexp(lw + per_flow, dim=0)
+
+    def sample(self, sample_shape, context: torch.Tensor = None, no_grad: bool = False,
+               return_log_prob: bool = False):
+        if isinstance(sample_shape, int):
+            sample_shape = (sample_shape,)
+        draws = [flow.sample(sample_shape, context=context, no_grad=no_grad, return_log_prob=True)
+                 for flow in self.flows]
+        xs = torch.stack([d[0] for d in draws])                       # (n_flows, *sample, *event)
+        which = torch.distributions.Categorical(probs=self.weights).sample(sample_shape=sample_shape)
+        pick = torch.nn.functional.one_hot(which, num_classes=len(draws)).movedim(-1, 0).to(xs.device)
+        pick = pick.view(*pick.shape, *([1] * len(self.event_shape)))
+        samples = torch.sum(pick * xs, dim=0)
+        if not return_log_prob:
+            return samples
+        lps = torch.stack([d[1] for d in draws])
+        lw = self.log_weights.to(lps.device).view(-1, *([1] * (lps.dim() - 1)))
+        return samples, torch.logsumexp(lw + lps, dim=0)
+
+    def regularization(self):
+        return sum(flow.regularization() for flow in self.flows)
