@@ -445,7 +445,7 @@ static void lrs_bins(const float *u, int K, float minimum, float maximum, float 
 static void lrs_element(float v, const float *h, int K, float boundary, int inverse,
                         float *out, float *ld)
 {
-    float ux[ORC_MAX_BINS], uxy[ORC_MAX_BINS], kx[ORC_MAX_BINS + 1], ky[ORC_MAX_BINS + 1];
+    float ux[ORC_MAX_BINS] = {0}, uxy[ORC_MAX_BINS] = {0}, kx[ORC_MAX_BINS + 1], ky[ORC_MAX_BINS + 1];
     float kd[ORC_MAX_BINS + 1], w[ORC_MAX_BINS + 1];
     const float c = (float)lrs_const();
     for (int j = 0; j < K; ++j) {
