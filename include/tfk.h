@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 8
+#define TFK_ABI_VERSION 9
 
 enum {
     TFK_OK = 0,
@@ -277,6 +277,20 @@ int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, co
                                   int64_t n_params, int32_t gemm2_steps, float *out, float *workspace,
                                   int64_t N, int32_t D, int32_t inverse_form, const float *gscale,
                                   int32_t g_reversed, void *stream);
+
+/* Training backward of ONE RQ-spline coupling layer (HalfSplit, FeedForward(Linear, Tanh, Linear)
+ * conditioner, hidden width <= 16, D = 64, 8 bins) with the conditioner re-evaluated in the kernel:
+ * h never exists in HBM, dL/dh is written once.  x, g, gld, inverse, gscale, g_reversed as in
+ * tfk_affine_coupling_train_bwd.  Outputs in accumulator order (the caller un-permutes):
+ *   gh_perm   (N, 768): column (6 e + c) * 16 + 4 q + r = dL/d(parameter 4c + r of target element 8q + e)
+ *   gpre_perm (N, 16):  column 4 q + r = dL/d(pre-activation of hidden unit 4 r + q)
+ * params: A1[8][64] | b1[16] | A2[48][gemm2_steps][64] | b2[48][16] | A2T[48][4][64] | A1T[2][4][64]
+ * (csrc/tfk_bwd.hip; packed by torchflows_amd/autograd.py:_RqsTrainPack). */
+int tfk_rqs_coupling_train_bwd_supported(int32_t D, int32_t n_bins);
+int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
+                               int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
+                               int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
+                               const float *gscale, int32_t g_reversed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -197,6 +197,87 @@ class _TrainPack:
                                      dtype=torch.float32, device=device)
 
 
+class _RqsTrainPack:
+    """Index maps for tfk_rqs_coupling_train_bwd (D = 64, 8 bins, hidden width H <= 16): operand
+    block from (W1, b1, W2, b2), and the un-permutations of its accumulator-order outputs."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, H: int, device) -> "_RqsTrainPack":
+        key = (H, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(H, device)
+        return cls._cache[key]
+
+    def __init__(self, H: int, device):
+        half, EPL, P = 32, 8, 23
+        self.H = H
+        self.steps2 = (H + 3) // 4
+        off_b1 = H * half
+        off_W2 = off_b1 + H
+        off_b2 = off_W2 + half * P * H
+        Z = off_b2 + half * P
+        ar = torch.arange
+        W1idx = torch.full((16, half), Z, dtype=torch.long)
+        W1idx[:H] = ar(H)[:, None] * half + ar(half)[None, :]
+        b1idx = torch.full((16,), Z, dtype=torch.long)
+        b1idx[:H] = off_b1 + ar(H)
+        W2idx = torch.full((half, 24, 16), Z, dtype=torch.long)
+        W2idx[:, :P, :H] = off_W2 + ((ar(half)[:, None, None] * P + ar(P)[None, :, None]) * H + ar(H)[None, None, :])
+        b2idx = torch.full((half, 24), Z, dtype=torch.long)
+        b2idx[:, :P] = off_b2 + ar(half)[:, None] * P + ar(P)[None, :]
+        lane = ar(64)
+        ql, il = lane >> 4, lane & 15
+        unit = 4 * (il & 3) + (il >> 2)
+        q2, r2 = il >> 2, il & 3
+        qq, rr = torch.meshgrid(ar(4), ar(4), indexing="ij")
+        A1 = torch.stack([W1idx[unit, EPL * ql + s] for s in range(EPL)])
+        b1m = b1idx[4 * rr + qq]
+        A2, b2m, A2T = [], [], []
+        for e in range(EPL):
+            for c in range(6):
+                for r1 in range(self.steps2):
+                    A2.append(W2idx[EPL * q2 + e, 4 * c + r2, 4 * r1 + ql])
+                b2m.append(b2idx[EPL * qq + e, 4 * c + rr].reshape(-1))
+                for r in range(4):
+                    A2T.append(W2idx[EPL * ql + e, 4 * c + r, unit])
+        A1T = [W1idx[4 * r + ql, EPL * (il >> 2) + 4 * t + (il & 3)] for t in range(2) for r in range(4)]
+        self.param_index = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1),
+                                      torch.stack(b2m).reshape(-1), torch.stack(A2T).reshape(-1),
+                                      torch.stack(A1T).reshape(-1)]).to(device)
+        self.n_fwd = EPL * 64 + 16 + 48 * self.steps2 * 64 + 48 * 16
+        # column of gh_perm that holds parameter p of target element m
+        m = ar(half)[:, None]
+        pp = ar(P)[None, :]
+        e_, q_ = m % EPL, m // EPL
+        self.gh_col = ((6 * e_ + pp // 4) * 16 + 4 * q_ + pp % 4).reshape(-1).to(device)     # (736,)
+        u = ar(H)
+        self.gpre_col = (4 * (u % 4) + u // 4).to(device)                                   # (H,)
+        self.zero = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def pack(self, lin1, lin2) -> torch.Tensor:
+        flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
+                          lin2.weight.detach().reshape(-1), lin2.bias.detach(), self.zero])
+        return flat[self.param_index]
+
+
+def _fused_rqs_layer(layer, D: int):
+    """(lin1, lin2) when the layer can use tfk_rqs_coupling_train_bwd (and the RQS flow-program op)."""
+    if not fused_train_enabled() or layer.transformer.native_kind != "rqs":
+        return None
+    if not native.lib().tfk_rqs_coupling_train_bwd_supported(D, int(layer.transformer.n_bins)):
+        return None
+    c = layer.coupling
+    if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
+            and c.target_event_size == D // 2):
+        return None
+    mlp = _plain_mlp(layer)
+    if mlp is None or mlp[0].out_features > 16:
+        return None
+    return mlp
+
+
 def fused_train_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_TRAIN_FUSED", "1") != "0"
 
@@ -379,6 +460,7 @@ class ChainFunction(torch.autograd.Function):
                          and layer.training and layer.first_training_batch_pass for layer, d, kind in plan)
         packs = _plan_packs(plan, D, rows.device, fold=not needs_init)
         packed = packs.pack() if packs.layers else []
+        rqs_blocks = {}
         for step, (layer, d, kind) in enumerate(plan):
             if step in packs.folded_steps:
                 saved.append(None)          # ran inside the preceding coupling's flow program
@@ -418,6 +500,22 @@ class ChainFunction(torch.autograd.Function):
                 started = True
                 saved.append(cur)
                 cur, cur_is_saved = out, False
+            elif kind == "coupling" and _fused_rqs_layer(layer, D) is not None:
+                # conditioner + spline in one launch (single-op flow program); the operand block is
+                # kept for the backward kernel
+                lin1, lin2 = _fused_rqs_layer(layer, D)
+                rp = _RqsTrainPack.get(lin1.out_features, cur.device)
+                block = rp.pack(lin1, lin2)
+                tr = layer.transformer
+                import math
+                op = (7 if d == INVERSE else 6, 0, rp.steps2, 0, 8, float(tr.boundary),
+                      float(1.0 - tr.min_bin_size * tr.n_bins), float(math.log(math.expm1(1 - tr.min_delta))))
+                out = torch.empty_like(cur)
+                native.flow_run_mfma(cur, out, logdet, None, None, None, [op], block[:rp.n_fwd], accumulate=started)
+                started = True
+                saved.append(cur)
+                rqs_blocks[step] = block
+                cur, cur_is_saved = out, False
             else:
                 h = _conditioner(layer, cur).reshape(N, -1).contiguous()
                 out = torch.empty_like(cur)
@@ -443,6 +541,7 @@ class ChainFunction(torch.autograd.Function):
         ctx.saved_rows = saved
         ctx.n_params = len(params)
         ctx.packs, ctx.packed = packs, packed
+        ctx.rqs_blocks = rqs_blocks
         return cur, logdet
 
     @staticmethod
@@ -498,6 +597,26 @@ class ChainFunction(torch.autograd.Function):
                                                      out_all[k * pack.n_out:(k + 1) * pack.n_out], pack.workspace,
                                                      inverse_form=_affine_form_is_inverse(layer, d),
                                                      gscale=gscale, g_reversed=rev_step is not None)
+                    continue
+                if i in ctx.rqs_blocks:     # conditioner re-evaluated in the kernel, dL/dh written once
+                    lin1, lin2 = _fused_rqs_layer(layer, D)
+                    rp = _RqsTrainPack.get(lin1.out_features, g.device)
+                    gh_perm = torch.empty(N, 768, dtype=torch.float32, device=g.device)
+                    gpre_perm = torch.empty(N, 16, dtype=torch.float32, device=g.device)
+                    native.rqs_coupling_train_bwd(x_in, g, gld, ctx.rqs_blocks[i], rp.steps2, gh_perm, gpre_perm,
+                                                  layer.transformer.n_bins, layer.transformer.boundary,
+                                                  inverse=(d == INVERSE))
+                    x_a = x_in[:, :S]
+                    a1 = torch.tanh(torch.addmm(lin1.bias, x_a, lin1.weight.t()))
+                    ones = torch.ones(N, 1, dtype=torch.float32, device=g.device)
+                    dW2b = _outer_sum(gh_perm, torch.cat([a1, ones], dim=1)).index_select(0, rp.gh_col)
+                    g_pre = gpre_perm.index_select(1, rp.gpre_col)
+                    dW1b = _outer_sum(g_pre, torch.cat([x_a, ones], dim=1))
+                    by_param = {id(lin1.weight): dW1b[:, :-1], id(lin1.bias): dW1b[:, -1],
+                                id(lin2.weight): dW2b[:, :-1], id(lin2.bias): dW2b[:, -1]}
+                    grads_per_step[i] = [
+                        (by_param[id(p)] if id(p) in by_param else torch.zeros_like(p)) if p.requires_grad else None
+                        for p in cparams]
                     continue
                 x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
                 mlp = _plain_mlp(layer)

@@ -990,3 +990,238 @@ int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, co
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Training backward of one RQ-spline coupling layer (HalfSplit, FeedForward(Linear, Tanh, Linear)
+// conditioner, hidden width <= 16, D = 64, 8 bins) with the conditioner re-evaluated in the
+// kernel.  The layer-by-layer route moves h (2.9 KB per row) through HBM five times (conditioner
+// re-evaluation, backward kernel, dL/dh for three GEMMs); here h never exists and dL/dh is written
+// once, for the one product that contracts over the batch rows (dW2 = dL/dh^T hidden, done as a
+// split-K batched GEMM by the caller):
+//   1. GEMM 1 + tanh                                  (as the forward flow program)
+//   2. per target element e of the lane (run-time loop): its 24 (23 + pad) spline parameters by
+//      6 MFMA tiles, rqs_bwd_eval in registers -> dL/dx_B[e] and the element's dL/dh record,
+//      24 MFMAs fold the record into dL/dhidden (A-operand = W2 packed so that the result lands
+//      on the register that holds the unit), and the record goes to HBM in ACCUMULATOR order:
+//      gh_perm[row][(6 e + c) * 16 + 4 q + r] = dL/d(parameter 4c + r of element 8q + e)
+//      (one float4 per tile and lane; the caller un-permutes the 768 rows of dW2 instead);
+//   3. dL/dpre = dL/dhidden * tanh', written as gpre_perm[row][4 q + r] (unit 4 r + q);
+//   4. dL/dx_A = W1^T dL/dpre by MFMA, added to the source half of g.
+// Parameter block (floats): A1[8][64] | b1[16] | A2[48][steps2][64] | b2[48][16] | A2T[48][4][64] |
+// A1T[2][4][64]  (tile index = 6 e + c) -- 105 KB for hidden 14: one 512-thread workgroup per CU.
+// =============================================================================================
+template <bool INVERSE>
+__global__ __launch_bounds__(512) void k_rqs_coupling_train_bwd(
+    const float *__restrict__ x, float *g, const float *__restrict__ gld, const float *__restrict__ params,
+    int n_params, int steps2, float *__restrict__ gh_perm, float *__restrict__ gpre_perm, long long N,
+    RqsConst C, const float *__restrict__ gscale, int g_reversed)
+{
+    constexpr int EPL = 8, D = 64, HALF = 32, T2 = 48, T1 = 2, BLOCK = 512;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(params);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *A1 = lds;
+    const float *b1 = A1 + EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + T2 * steps2 * 64;
+    const float *A2T = b2 + T2 * 16;
+    const float *A1T = A2T + T2 * 4 * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * 16; row0 < N; row0 += stride) {
+        const long long row = row0 + j;
+        const bool valid = row < N;
+        const long long rr = valid ? row : N - 1;
+        float xa[EPL], xb[EPL], ga[EPL], gb[EPL];
+        {
+            const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+            const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const float4 va = pa[i], vb = pb[i];
+                xa[4 * i] = va.x; xa[4 * i + 1] = va.y; xa[4 * i + 2] = va.z; xa[4 * i + 3] = va.w;
+                xb[4 * i] = vb.x; xb[4 * i + 1] = vb.y; xb[4 * i + 2] = vb.z; xb[4 * i + 3] = vb.w;
+            }
+            if (!g_reversed) {
+                const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + EPL * q);
+                const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 wa = qa[i], wb = qb[i];
+                    ga[4 * i] = wa.x; ga[4 * i + 1] = wa.y; ga[4 * i + 2] = wa.z; ga[4 * i + 3] = wa.w;
+                    gb[4 * i] = wb.x; gb[4 * i + 1] = wb.y; gb[4 * i + 2] = wb.z; gb[4 * i + 3] = wb.w;
+                }
+            } else {
+                const float4 *qa = reinterpret_cast<const float4 *>(g + rr * D + D - EPL * (q + 1));
+                const float4 *qb = reinterpret_cast<const float4 *>(g + rr * D + HALF - EPL * (q + 1));
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 wa = qa[i], wb = qb[i];
+                    ga[EPL - 1 - 4 * i] = wa.x; ga[EPL - 2 - 4 * i] = wa.y; ga[EPL - 3 - 4 * i] = wa.z; ga[EPL - 4 - 4 * i] = wa.w;
+                    gb[EPL - 1 - 4 * i] = wb.x; gb[EPL - 2 - 4 * i] = wb.y; gb[EPL - 3 - 4 * i] = wb.z; gb[EPL - 4 - 4 * i] = wb.w;
+                }
+            }
+            if (gscale) {
+                const float4 *sa = reinterpret_cast<const float4 *>(gscale + EPL * q);
+                const float4 *sb = reinterpret_cast<const float4 *>(gscale + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    const float4 ua = sa[i], ub = sb[i];
+                    ga[4 * i] *= ua.x; ga[4 * i + 1] *= ua.y; ga[4 * i + 2] *= ua.z; ga[4 * i + 3] *= ua.w;
+                    gb[4 * i] *= ub.x; gb[4 * i + 1] *= ub.y; gb[4 * i + 2] *= ub.z; gb[4 * i + 3] *= ub.w;
+                }
+            }
+        }
+        float gl = gld[rr];
+        if (!valid) {
+            gl = 0.0f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) ga[e] = gb[e] = 0.0f;
+        }
+
+        // 1. conditioner forward
+        f32x4_t acc = *reinterpret_cast<const f32x4_t *>(b1 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], xa[s], acc, 0, 0, 0);
+        float hid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[r] = tanh_fast(acc[r]);
+
+        // 2. element by element
+        f32x4_t gha = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+        float *out_row = gh_perm + rr * (long long)(T2 * 16) + 4 * q;
+        for (int e = 0; e < EPL; ++e) {
+            float p[24];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int t = e * 6 + c;
+                f32x4_t o = *reinterpret_cast<const f32x4_t *>(b2 + (t * 4 + q) * 4);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+                if (steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
+                if (steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
+                if (steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+                p[4 * c] = o[0]; p[4 * c + 1] = o[1]; p[4 * c + 2] = o[2]; p[4 * c + 3] = o[3];
+            }
+            float v = xb[0], A = gb[0];
+#pragma unroll
+            for (int i = 1; i < EPL; ++i) {
+                v = (e == i) ? xb[i] : v;
+                A = (e == i) ? gb[i] : A;
+            }
+            float p23[23];
+#pragma unroll
+            for (int i = 0; i < 23; ++i) p23[i] = p[i];
+            float gv = A;                                           // identity outside the box
+            if (v > C.minimum && v < C.maximum) {
+                rqs_bwd_eval<8, INVERSE>(p23, v, C, A, gl, gv);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 23; ++i) p23[i] = 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) gb[i] = (e == i) ? gv : gb[i];
+            // one accumulator per element (24 k-steps), combined afterwards: shorter fp32 chains
+            f32x4_t ghe = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int t = e * 6 + c;
+                const float r0 = p23[4 * c], r1 = p23[4 * c + 1], r2 = p23[4 * c + 2];
+                const float r3 = (c == 5) ? 0.0f : p23[c == 5 ? 0 : 4 * c + 3];
+                ghe = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[(t * 4 + 0) * 64 + lane], r0, ghe, 0, 0, 0);
+                ghe = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[(t * 4 + 1) * 64 + lane], r1, ghe, 0, 0, 0);
+                ghe = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[(t * 4 + 2) * 64 + lane], r2, ghe, 0, 0, 0);
+                ghe = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[(t * 4 + 3) * 64 + lane], r3, ghe, 0, 0, 0);
+                if (valid) *reinterpret_cast<float4 *>(out_row + t * 16) = make_float4(r0, r1, r2, r3);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gha[r] += ghe[r];
+        }
+
+        // 3. dL/dpre
+        float gpre[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gpre[r] = gha[r] * (1.0f - hid[r] * hid[r]);
+        if (valid)
+            *reinterpret_cast<float4 *>(gpre_perm + row * 16 + 4 * q) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
+
+        // 4. dL/dx_A
+#pragma unroll
+        for (int t = 0; t < T1; ++t) {
+            f32x4_t d = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(A1T[(t * 4 + r) * 64 + lane], gpre[r], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[4 * t + r] += d[r];
+        }
+        if (valid) {
+            float4 *qa = reinterpret_cast<float4 *>(g + row * D + EPL * q);
+            float4 *qb = reinterpret_cast<float4 *>(g + row * D + HALF + EPL * q);
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                qa[i] = make_float4(ga[4 * i], ga[4 * i + 1], ga[4 * i + 2], ga[4 * i + 3]);
+                qb[i] = make_float4(gb[4 * i], gb[4 * i + 1], gb[4 * i + 2], gb[4 * i + 3]);
+            }
+        }
+    }
+}
+
+extern "C" {
+
+int tfk_rqs_coupling_train_bwd_supported(int32_t D, int32_t n_bins) { return (D == 64 && n_bins == 8) ? 1 : 0; }
+
+int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
+                               int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
+                               int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
+                               const float *gscale, int32_t g_reversed, void *stream)
+{
+    const char *fn = "tfk_rqs_coupling_train_bwd";
+    if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
+    if (!tfk_rqs_coupling_train_bwd_supported(D, n_bins))
+        return fail(TFK_EINVAL, "%s: D = %d, n_bins = %d (the kernel exists for D = 64, 8 bins)", fn, D, n_bins);
+    if (gemm2_steps < 1 || gemm2_steps > 4) return fail(TFK_EINVAL, "%s: GEMM-2 steps %d not in [1, 4]", fn, gemm2_steps);
+    if (!(boundary > 0.0f)) return fail(TFK_EINVAL, "%s: boundary must be positive", fn);
+    const int64_t need = 8 * 64 + 16 + (int64_t)48 * gemm2_steps * 64 + 48 * 16 + 48 * 4 * 64 + 2 * 4 * 64;
+    if (n_params != need) return fail(TFK_EINVAL, "%s: parameter block has %lld floats, expected %lld", fn,
+                                      (long long)n_params, (long long)need);
+    if (!x || !g || !gld || !params || !gh_perm || !gpre_perm) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(x) || !aligned16(g) || !aligned16(params) || !aligned16(gh_perm) || !aligned16(gpre_perm) ||
+        (gscale && !aligned16(gscale)))
+        return fail(TFK_EINVAL, "%s: buffers must be 16-byte aligned", fn);
+    RqsConst C;
+    C.minimum = -boundary;
+    C.maximum = boundary;
+    C.span = (float)((double)boundary + (double)boundary);
+    C.scale = (float)(1.0 - 1e-3 * 8.0);
+    C.c = (float)log(expm1(1.0 - 1e-5));
+    const size_t lds = (size_t)n_params * sizeof(float);
+    if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: %zu bytes of LDS needed", fn, lds);
+    const void *kern = inverse ? reinterpret_cast<const void *>(&k_rqs_coupling_train_bwd<true>)
+                               : reinterpret_cast<const void *>(&k_rqs_coupling_train_bwd<false>);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
+    }
+    constexpr int rows_per_block = (512 / 64) * 16;
+    int64_t grid = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * kGridOversubscribe;      // one workgroup per CU resident
+    if (grid > cap) grid = cap;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (inverse)
+        hipLaunchKernelGGL((k_rqs_coupling_train_bwd<true>), dim3((int)grid), dim3(512), lds, s, x, g, gld, params,
+                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0);
+    else
+        hipLaunchKernelGGL((k_rqs_coupling_train_bwd<false>), dim3((int)grid), dim3(512), lds, s, x, g, gld, params,
+                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0);
+    return check_launch(fn);
+}
+
+}  // extern "C"

@@ -40,9 +40,10 @@ SYMBOLS = (
     "tfk_diag_gauss_logprob_bwd",
     "tfk_coupling_train_bwd_supported", "tfk_coupling_train_bwd_out_floats",
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
+    "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
 )
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class NativeError(RuntimeError):
@@ -108,6 +109,9 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_coupling_train_bwd_workspace_bytes.restype = _i64
     L.tfk_affine_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                                 _vp, _i32, _vp]
+    L.tfk_rqs_coupling_train_bwd_supported.argtypes = [_i32, _i32]
+    L.tfk_rqs_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
+                                             C.c_float, _i32, _vp, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -437,6 +441,26 @@ def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, in
         raise NativeError(f"{name}: gscale must hold D = {D} floats")
     with _device_guard(g):
         rc = lib().tfk_affine_coupling_train_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def rqs_coupling_train_bwd(x, g, gld, params, gemm2_steps, gh_perm, gpre_perm, n_bins, boundary,
+                           inverse=False, gscale=None, g_reversed=False):
+    """Conditioner re-evaluation + RQ-spline backward + dL/dhidden + dL/dx_A in one launch (in place on
+    g); gh_perm (N, 768) and gpre_perm (N, 16) in accumulator order."""
+    global calls
+    name = "tfk_rqs_coupling_train_bwd"
+    N, D = _rows(g, name)
+    if x.shape != g.shape or gld.numel() != N or gh_perm.shape != (N, 768) or gpre_perm.shape != (N, 16):
+        raise NativeError(f"{name}: bad x / gld / gh_perm / gpre_perm shape")
+    if gscale is not None and gscale.numel() != D:
+        raise NativeError(f"{name}: gscale must hold D = {D} floats")
+    args = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
+            int(gemm2_steps), _f32(gh_perm, name), _f32(gpre_perm, name), N, D, int(n_bins),
+            C.c_float(float(boundary)), 1 if inverse else 0, _f32(gscale, name), 1 if g_reversed else 0)
+    with _device_guard(g):
+        rc = lib().tfk_rqs_coupling_train_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
 
