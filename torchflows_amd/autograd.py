@@ -363,6 +363,20 @@ class _PlanPacks:
             gidx.append(pack.grad_index + off_out)
             off_flat += pack.n_flat + n_ew
             off_out += pack.n_out
+        # RQ-spline couplings with the in-kernel conditioner: the same ride-along pattern
+        self.rqs_fold = {}
+        for i, (layer, d, kind) in enumerate(plan):
+            if kind != "coupling" or _fused_rqs_layer(layer, D) is None:
+                continue
+            ew_step = rev_step = None
+            j = i + 1
+            if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
+                ew_step = j
+                j += 1
+            if fold and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
+                rev_step = j
+            self.rqs_fold[i] = (ew_step, rev_step)
+            self.folded_steps.update(t for t in (ew_step, rev_step) if t is not None)
         self.slot = {i: k for k, (i, _, _, _) in enumerate(self.layers)}
         self.plan = plan
         if self.layers:
@@ -510,8 +524,15 @@ class ChainFunction(torch.autograd.Function):
                 import math
                 op = (7 if d == INVERSE else 6, 0, rp.steps2, 0, 8, float(tr.boundary),
                       float(1.0 - tr.min_bin_size * tr.n_bins), float(math.log(math.expm1(1 - tr.min_delta))))
+                ew_step, rev_step = packs.rqs_fold.get(step, (None, None))
+                ops, prm = [op], block[:rp.n_fwd]
+                if ew_step is not None:      # the fixed elementwise layer that follows rides along
+                    ew_layer, ew_d, _ = plan[ew_step]
+                    ops.append((1 if _affine_form_is_inverse(ew_layer, ew_d) else 0, 0, 0, rp.n_fwd))
+                    prm = torch.cat([prm, _ew_block(ew_layer, ew_d, D)])
                 out = torch.empty_like(cur)
-                native.flow_run_mfma(cur, out, logdet, None, None, None, [op], block[:rp.n_fwd], accumulate=started)
+                native.flow_run_mfma(cur, out, logdet, None, None, None, ops, prm, accumulate=started,
+                                     reverse_out=rev_step is not None)
                 started = True
                 saved.append(cur)
                 rqs_blocks[step] = block
@@ -603,9 +624,17 @@ class ChainFunction(torch.autograd.Function):
                     rp = _RqsTrainPack.get(lin1.out_features, g.device)
                     gh_perm = torch.empty(N, 768, dtype=torch.float32, device=g.device)
                     gpre_perm = torch.empty(N, 16, dtype=torch.float32, device=g.device)
+                    ew_step, rev_step = packs.rqs_fold.get(i, (None, None))
+                    gscale = None
+                    if ew_step is not None:
+                        ew_layer, ew_d, _ = plan[ew_step]
+                        blk = _ew_block(ew_layer, ew_d, D)
+                        lo = (2 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0
+                        gscale = blk[lo:lo + D]
                     native.rqs_coupling_train_bwd(x_in, g, gld, ctx.rqs_blocks[i], rp.steps2, gh_perm, gpre_perm,
                                                   layer.transformer.n_bins, layer.transformer.boundary,
-                                                  inverse=(d == INVERSE))
+                                                  inverse=(d == INVERSE), gscale=gscale,
+                                                  g_reversed=rev_step is not None)
                     x_a = x_in[:, :S]
                     a1 = torch.tanh(torch.addmm(lin1.bias, x_a, lin1.weight.t()))
                     ones = torch.ones(N, 1, dtype=torch.float32, device=g.device)
