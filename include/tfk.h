@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 9
+#define TFK_ABI_VERSION 10
 
 enum {
     TFK_OK = 0,
@@ -224,6 +224,20 @@ int tfk_lrs_coupling_fwd(const float *x, const float *h, float *z, float *logdet
 int tfk_lrs_coupling_inv(const float *z, const float *h, float *x, float *logdet, int64_t N, int32_t D,
                          const int32_t *tgt_idx, int32_t T, int32_t n_bins, float boundary,
                          int32_t accumulate, void *stream);
+
+/* The SEQUENTIAL map of a MADE-based affine layer in one launch: MAF sampling
+ * (MaskedAutoregressiveBijection.inverse, layers_base.py:208-221) and IAF density
+ * (InverseMaskedAutoregressiveBijection.forward, :231-232), where the reference runs D conditioner
+ * passes.  MADE with two masked linear layers (transforms.py:184-267); weights arrive multiplied by
+ * their masks and zero-padded to hidden_padded (8, 16, 32 or 64) hidden units:
+ *   W1t (D, hidden_padded): W1t[i][k] = (W1 * mask1)[k][i];  b1 (hidden_padded)
+ *   W2  (D, 2, hidden_padded): W2[i][p][k] = (W2 * mask2)[2 i + p][k];  b2 (D, 2)
+ * divide != 0: x_i = (z_i - beta_i) / alpha_i, log-det -= log alpha_i (Affine.inverse);
+ * divide == 0: x_i = alpha_i z_i + beta_i, log-det += log alpha_i (InverseAffine.inverse).
+ * logdet (N,) overwritten or accumulated; x may alias z. */
+int tfk_made_affine_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
+                               const float *W1t, const float *b1, const float *W2, const float *b2,
+                               int32_t hidden_padded, int32_t divide, int32_t accumulate, void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

@@ -266,3 +266,37 @@ def test_sibling_couplings_on_hip(name):
         ref = fx[f"{name}/{key}"]
         err = np.max(np.abs(mine.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref)))
         assert err < tol, (name, key, err)
+
+
+@pytest.mark.parametrize("arch", ["MAF", "IAF"])
+@pytest.mark.parametrize("D,n_hidden", [(6, None), (64, None), (64, 24), (256, None), (256, 40), (7, 3)])
+def test_made_sequential_map_in_one_launch(pkg, oracle, arch, D, n_hidden):
+    """MAF.inverse / IAF.forward: the reference's D conditioner passes run as ONE libtfk launch per layer
+    (tfk_made_affine_sequential); parity with the oracle, which restates the D-pass loop."""
+    from torchflows_amd import native
+    torch.manual_seed(D + (n_hidden or 0))
+    kw = dict(n_layers=2)
+    if n_hidden is not None:
+        kw["conditioner_kwargs"] = dict(n_hidden=n_hidden)
+    flow = pkg.Flow(getattr(pkg, arch)(D, **kw))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(2048, D))                # ActNorm statistics
+    flow.eval()
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, 2, sd)
+    x = torch.randn(513, D)
+    flow = flow.cuda()
+    before = native.calls
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(x.cuda())
+        xr, ldi = flow.bijection.inverse(x.cuda())
+    launches = native.calls - before
+    if not (D == 256 and n_hidden == 40):        # (that one exceeds the LDS: D-pass loop, same results)
+        assert launches <= 2 * len(flow.bijection.layers), launches  # no D-pass loops
+    z_ref, ld_ref = ref.forward(x.numpy())
+    xr_ref, ldi_ref = ref.inverse(x.numpy())
+    e = dict(z=rel(z.cpu().numpy(), z_ref), ld=rel(ld.cpu().numpy(), ld_ref),
+             xr=rel(xr.cpu().numpy(), xr_ref), ldi=rel(ldi.cpu().numpy(), ldi_ref))
+    print(arch, D, n_hidden, launches, {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-5 * max(1.0, D / 64), e

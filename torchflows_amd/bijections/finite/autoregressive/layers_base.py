@@ -260,12 +260,61 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
             native.lrs_coupling(rows, h, out, logdet, None, D, tr.n_bins, tr.boundary,
                                 accumulate=accumulate, inverse=transformer_inverse)
 
+    def _made_pack(self):
+        """(W1t, b1, W2, b2) for tfk_made_affine_sequential -- masked, transposed, zero-padded to
+        8 / 16 / 32 / 64 hidden units -- when the layer qualifies (affine transformer, MADE with two
+        masked linear layers and no global parameters); cached until a weight changes."""
+        import os
+        import torch.nn as nn
+        from torchflows_amd import fused
+        if os.environ.get("TORCHFLOWS_AMD_MADE_FUSED", "1") == "0":      # (comparison runs)
+            return None
+        ct = self.conditioner_transform
+        if self.transformer.native_kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+            return None
+        mods = list(ct.sequential)
+        if not (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
+                and isinstance(mods[2], MADE.MaskedLinear)):
+            return None
+        lo, hi = ct.output_lower_bound, ct.output_upper_bound
+        H, D = mods[0].out_features, self.n_dim
+        if lo != float("-inf") or hi != float("inf") or H > 64 or mods[0].in_features != D:
+            return None
+        version = fused._params_version(ct)
+        hit = self.__dict__.get("_tfk_made_pack")
+        if hit is not None and hit[0] == version:
+            return hit[1]
+        HP = 8 if H <= 8 else (16 if H <= 16 else (32 if H <= 32 else 64))
+        if 4 * (3 * D * HP + HP + 2 * D) + 4 * 64 * (D + 1) > 160 * 1024:
+            return None                                  # weights + 64 staged rows do not fit the LDS
+        with torch.no_grad():
+            w1 = mods[0].weight * mods[0].mask                       # (H, D)
+            w2 = mods[2].weight * mods[2].mask                       # (2 D, H)
+            W1t = w1.new_zeros(D, HP)
+            W1t[:, :H] = w1.t()
+            b1 = w1.new_zeros(HP)
+            b1[:H] = mods[0].bias
+            W2 = w1.new_zeros(D, 2, HP)
+            W2[:, :, :H] = w2.view(D, 2, H)
+            b2 = mods[2].bias.detach().view(D, 2).contiguous()
+        packed = (W1t.contiguous(), b1, W2.contiguous(), b2)
+        self.__dict__["_tfk_made_pack"] = (version, packed)
+        return packed
+
     def _native_step(self, state: RowState, context, d: int) -> None:
         rows = state.rows
         N, D = rows.shape
         if d != self._sequential_when:                       # one parallel pass
             out = rows if state.owned else state.out_buffer()
             self._native_pass(rows, out, state.logdet, context, False, state.started)
+            state.started = True
+            state.commit(out)
+            return
+        packed = self._made_pack() if context is None else None
+        if packed is not None:                               # the D passes in ONE launch (tfk_made.hip)
+            out = rows if state.owned else state.out_buffer()
+            divide = self.transformer.native_kind == "affine"      # Affine.inverse divides
+            native.made_affine_sequential(rows, out, state.logdet, *packed, divide, accumulate=state.started)
             state.started = True
             state.commit(out)
             return

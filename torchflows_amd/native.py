@@ -41,9 +41,10 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_supported", "tfk_coupling_train_bwd_out_floats",
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
     "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
+    "tfk_made_affine_sequential",
 )
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class NativeError(RuntimeError):
@@ -112,6 +113,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_rqs_coupling_train_bwd_supported.argtypes = [_i32, _i32]
     L.tfk_rqs_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                              C.c_float, _i32, _vp, _i32, _vp]
+    L.tfk_made_affine_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -461,6 +463,24 @@ def rqs_coupling_train_bwd(x, g, gld, params, gemm2_steps, gh_perm, gpre_perm, n
             C.c_float(float(boundary)), 1 if inverse else 0, _f32(gscale, name), 1 if g_reversed else 0)
     with _device_guard(g):
         rc = lib().tfk_rqs_coupling_train_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def made_affine_sequential(z, out, logdet, W1t, b1, W2, b2, divide, accumulate=False):
+    """The sequential map of a MADE-based affine layer in one launch; W1t (D, HP), b1 (HP,),
+    W2 (D, 2, HP), b2 (D, 2) masked and zero-padded to HP hidden units."""
+    global calls
+    name = "tfk_made_affine_sequential"
+    N, D = _rows(z, name)
+    HP = b1.numel()
+    if out.shape != z.shape or logdet.numel() != N or W1t.numel() != D * HP or W2.numel() != 2 * D * HP \
+            or b2.numel() != 2 * D:
+        raise NativeError(f"{name}: bad tensor shapes")
+    args = (_f32(z, name), _f32(out, name), _f32(logdet, name), N, D, _f32(W1t, name), _f32(b1, name),
+            _f32(W2, name), _f32(b2, name), HP, 1 if divide else 0, 1 if accumulate else 0)
+    with _device_guard(z):
+        rc = lib().tfk_made_affine_sequential(*args, _stream(z))
     calls += 1
     _check(rc, name)
 
