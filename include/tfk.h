@@ -184,7 +184,9 @@ enum {
     TFK_OP_SHIFT_FWD = 4,
     TFK_OP_SHIFT_INV = 5,
     TFK_OP_RQS_FWD = 6,
-    TFK_OP_RQS_INV = 7
+    TFK_OP_RQS_INV = 7,
+    TFK_OP_MADE_FWD = 8,   /* MADE + Affine on the whole row, parallel map (tfk_flow_run_mfma only) */
+    TFK_OP_MADE_INV = 9    /* same with (x - beta) / alpha */
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,
@@ -205,6 +207,9 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  *   T2 = D/16 (affine), D/32 (shift), 6*D/8 (RQS, n_bins = 8: 6 tiles of 4 parameters per element)
  * accumulate: bit 0 = add to logdet instead of overwriting it; bit 1 = store the rows reversed
  *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store).
+ * A MADE op (TFK_OP_MADE_*: MaskedAutoregressiveBijection's parallel map, layers_base.py:201-206,
+ * affine transformer, weights pre-multiplied by the MADE masks) reads BOTH halves of the row and
+ * transforms both:  A1[2*D/8][HT][64] | b1[HT][4][4] | A2[2*D/16][gemm2_steps][64] | b2[2*D/16][4][4].
  * i.e. the MFMA A-operands per lane, with the row / column permutations that make the
  * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
  * packed by torchflows_amd/fused.py:_pack_mfma). */

@@ -122,6 +122,56 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
     else if constexpr (KIND == TFK_OP_AFFINE_INV) ld = ld + (-part);
 }
 
+// MADE-based affine layer, parallel map (MaskedAutoregressiveBijection.forward, layers_base.py:201-206;
+// MADE = two masked linear layers, transforms.py:184-267, masks folded into the packed weights): the
+// conditioner reads BOTH planes, every element of both planes is transformed with parameters that
+// depend on the preceding elements only -- all of them computed from the untouched row.
+template <int EPL, bool DIVIDE, int HT>
+__device__ __forceinline__ void made_m(const MOp op, const float *prm, int lane, int q,
+                                       float (&a)[EPL], float (&b)[EPL], float &ld)
+{
+    constexpr int T2 = EPL / 2;
+    const float *A1 = prm;
+    const float *b1 = prm + 2 * EPL * HT * 64;
+    const float *A2 = b1 + HT * 16;
+    const float *b2 = A2 + 2 * T2 * op.steps2 * 64;
+    f32x4 acc[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(b1 + t * 16 + 4 * q);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(s * HT + t) * 64 + lane], a[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[((EPL + s) * HT + t) * 64 + lane], b[s], acc[t], 0, 0, 0);
+        }
+    float hid[4 * HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[4 * t + r] = tanh_act_m(acc[t][r]);
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2 * T2; ++t) {
+        f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < 4 * HT; ++k)
+            if (op.steps2 > k)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + k) * 64 + lane], hid[k], o, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float al = aff_alpha(o[2 * i]);
+            const float be = o[2 * i + 1];
+            part += log_normal(al);
+            float &v = (t < T2) ? a[2 * t + i] : b[2 * (t - T2) + i];
+            if (!DIVIDE) v = al * v + be;
+            else v = div_fast(v - be, al);
+        }
+    }
+    ld = ld + (DIVIDE ? -part : part);
+}
+
 // RQ-spline coupling on the matrix cores (layers.py:154-163): GEMM 1 as above; GEMM 2 produces,
 // for each of this lane's EPL target elements, its 23 (+1 pad) spline parameters as 6 tiles of
 // 4 (D-row 4q+r of tile 6e+c <-> parameter 4c+r of target element EPL*q+e), i.e. the record
@@ -194,7 +244,7 @@ __device__ __forceinline__ void couple_any(const MOp op, const float *prm, int l
     }
 }
 
-template <int EPL, int HTMAX>
+template <int EPL, int HTMAX, bool MADE>
 __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int lane, int q,
                                            float (&a)[EPL], float (&b)[EPL], float &ld)
 {
@@ -248,6 +298,18 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
     case TFK_OP_SHIFT_INV * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX>(op, prm, lane, q, b, a, ld); return;
     default: break;
     }
+    if constexpr (MADE) if (op.kind == TFK_OP_MADE_FWD || op.kind == TFK_OP_MADE_INV) {
+        const bool div = (op.kind == TFK_OP_MADE_INV);
+        if constexpr (HTMAX == 1) {
+            if (div) made_m<EPL, true, 1>(op, prm, lane, q, a, b, ld);
+            else made_m<EPL, false, 1>(op, prm, lane, q, a, b, ld);
+        } else {
+            if (op.steps2 <= 4) { if (div) made_m<EPL, true, 1>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 1>(op, prm, lane, q, a, b, ld); }
+            else if (op.steps2 <= 8) { if (div) made_m<EPL, true, 2>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 2>(op, prm, lane, q, a, b, ld); }
+            else { if (div) made_m<EPL, true, 4>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 4>(op, prm, lane, q, a, b, ld); }
+        }
+        return;
+    }
     // the spline op exists for D <= 128 only: at D = 256 one coupling's parameters (209 KB) exceed
     // the LDS anyway, and its 24-register record beside 64 row registers would live in scratch
     if constexpr (EPL <= kMaxEplRqs) {
@@ -265,7 +327,8 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 // HTMAX = 1: every coupling of the program has hidden width <= 16 (the presets: 96 VGPRs at
 // D = 64); HTMAX = 4: up to 64 (more registers: its own instantiation so that the narrow
 // programs keep their occupancy).
-template <int EPL, int BLOCK, int HTMAX>
+// MADE: the program holds MADE ops (their own instantiation: they need more registers).
+template <int EPL, int BLOCK, int HTMAX, bool MADE>
 __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
         // per-lane share of the row's log-det; lane q == 0 carries the running value
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         for (int o = 0; o < prog.n_ops; ++o)
-            apply_op_m<EPL, HTMAX>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
+            apply_op_m<EPL, HTMAX, MADE>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
         float lp = 0.0f;
         if (logprob) {                                              // gaussian.py:46-54
 #pragma unroll
@@ -359,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
     }
 }
 
-template <int EPL, int BLOCK, int HTMAX>
+template <int EPL, int BLOCK, int HTMAX, bool MADE>
 static int launch_mb(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, const float *params, int n_params,
                      const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
@@ -369,7 +432,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK, HTMAX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -379,7 +442,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     // resident workgroups per CU as the runtime computes them (registers, LDS, wave slots); the
     // grid is a few resident sets, grid-strided over the rows (kGridOversubscribe, tfk_common.h)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK, HTMAX>, BLOCK, lds) != hipSuccess
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>, BLOCK, lds) != hipSuccess
         || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -388,7 +451,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
+    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
                        log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
     return check_launch(fn);
 }
@@ -403,13 +466,19 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
 {
     bool wide = false;                     // a coupling with hidden width > 16 in the program?
     for (int i = 0; i < prog.n_ops; ++i)
-        wide = wide || (prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV &&
-                        prog.op[i].steps2 > 4);
+        wide = wide || (((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||
+                         prog.op[i].kind >= TFK_OP_MADE_FWD) && prog.op[i].steps2 > 4);
     const bool big = N >= (int64_t)kCUs * 3 * 128;
-#define TFK_MB(BLOCK_, HT_) \
-    launch_mb<EPL, BLOCK_, HT_>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn)
-    if (wide) return big ? TFK_MB(512, 4) : TFK_MB(kBlock, 4);
-    return big ? TFK_MB(512, 1) : TFK_MB(kBlock, 1);
+    bool made = false;
+    for (int i = 0; i < prog.n_ops; ++i) made = made || prog.op[i].kind >= TFK_OP_MADE_FWD;
+#define TFK_MB(BLOCK_, HT_, MADE_) \
+    launch_mb<EPL, BLOCK_, HT_, MADE_>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn)
+    if (made) {
+        if (wide) return big ? TFK_MB(512, 4, true) : TFK_MB(kBlock, 4, true);
+        return big ? TFK_MB(512, 1, true) : TFK_MB(kBlock, 1, true);
+    }
+    if (wide) return big ? TFK_MB(512, 4, false) : TFK_MB(kBlock, 4, false);
+    return big ? TFK_MB(512, 1, false) : TFK_MB(kBlock, 1, false);
 #undef TFK_MB
 }
 
@@ -468,6 +537,10 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
             if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
             const int T2 = EPL * 6;
             need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+        } else if (o.kind == TFK_OP_MADE_FWD || o.kind == TFK_OP_MADE_INV) {
+            if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
+            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
+            need = (int64_t)2 * EPL * HT * 64 + HT * 16 + (int64_t)EPL * o.steps2 * 64 + (int64_t)EPL * 16;
         } else return fail(TFK_EINVAL, "%s: op %d: kind %d is not supported on the MFMA path", fn, i, o.kind);
         if (o.offset < 0 || (o.offset & 3) || o.offset + need > n_params)
             return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i,

@@ -31,7 +31,7 @@ import torch.nn as nn
 from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
-    OP_RQS_FWD, OP_RQS_INV = range(8)
+    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV = range(10)
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
 MAX_HIDDEN_RQS = 32
 FORWARD, INVERSE = 0, 1
@@ -340,13 +340,66 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     return (op, plane, H), block
 
 
+def _made_op(layer, d: int, pos: torch.Tensor, D: int):
+    """A MADE-based affine layer's PARALLEL map as one matrix-core op (tfk_flow_mfma.hip: made_m).
+    None for the sequential map, other transformers, deeper MADEs, a context."""
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import MADE
+    if d == layer._sequential_when or layer.context_shape is not None:
+        return None
+    kind = layer.transformer.native_kind
+    ct = layer.conditioner_transform
+    if kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+        return None
+    if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
+        return None
+    mods = list(ct.sequential)
+    if not (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], MADE.MaskedLinear)):
+        return None
+    H = mods[0].out_features
+    if mods[0].in_features != D or H > 64 or (D == 256 and H > 16):
+        return None
+    half, EPL = D // 2, D // 8
+    T2 = EPL // 2
+    steps2 = (H + 3) // 4
+    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
+    W1 = (mods[0].weight * mods[0].mask).detach()                       # (H, D) logical columns
+    W2 = (mods[2].weight * mods[2].mask).detach().view(D, 2, H)        # logical element, parameter, unit
+    dev, dt = W1.device, W1.dtype
+    W1p = torch.zeros(16 * HT, D, dtype=dt, device=dev)
+    W1p[:H, pos] = W1                                                   # physical columns
+    b1p = torch.zeros(16 * HT, dtype=dt, device=dev)
+    b1p[:H] = mods[0].bias.detach()
+    W2p = torch.zeros(D, 2, 16 * HT, dtype=dt, device=dev)
+    W2p[pos, :, :H] = W2                                                # physical elements
+    b2p = torch.empty(D, 2, dtype=dt, device=dev)
+    b2p[pos] = mods[2].bias.detach().view(D, 2)
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    q2, r2 = il >> 2, il & 3
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    A1 = torch.stack([W1p[16 * t + unit1, plane * half + EPL * ql + s]
+                      for plane in range(2) for s in range(EPL) for t in range(HT)])
+    b1m = torch.stack([b1p[16 * t + 4 * rr + qq] for t in range(HT)])
+    A2, b2m = [], []
+    for plane in range(2):
+        for t in range(T2):
+            for r1 in range(steps2):
+                A2.append(W2p[plane * half + EPL * q2 + 2 * t + (r2 >> 1), r2 & 1, 4 * r1 + ql])
+            b2m.append(b2p[plane * half + EPL * qq + 2 * t + (rr >> 1), rr & 1])
+    block = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1), torch.stack(b2m).reshape(-1)])
+    divide = (kind == "inverse_affine")                # the parallel map uses transformer.forward
+    return (OP_MADE_INV if divide else OP_MADE_FWD, 0, steps2), block
+
+
 def compile_chain(composition, direction: int, device: torch.device,
                   mfma: Optional[bool] = None) -> Optional[CompiledChain]:
     """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None.
     ``mfma`` None: use the matrix-core kernel when the chain qualifies (D in {64, 128}, affine /
     shift couplings, hidden width <= 16), else the vector-ALU one."""
     from torchflows_amd.bijections.finite.autoregressive.layers_base import (
-        CouplingBijection, ElementwiseBijection)
+        CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
 
     D = composition.n_dim
@@ -374,6 +427,8 @@ def compile_chain(composition, direction: int, device: torch.device,
                 item = _elementwise_op(layer, d, pos, D)
             elif isinstance(layer, CouplingBijection):
                 item = _coupling_op(layer, d, pos, D, mfma=mfma)
+            elif isinstance(layer, MaskedAutoregressiveBijection):
+                item = _made_op(layer, d, pos, D) if mfma else None
             else:
                 item = None
             if item is None:
