@@ -1,0 +1,14 @@
+// Instantiation of the matrix-core flow program for D = 128 (see tfk_flow_mfma.h): its own
+// translation unit so that the 16-element-per-lane kernels compile beside the others.
+#include "tfk_flow_mfma.h"
+
+namespace tfk {
+
+int flow_mfma_launch_16(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                        float *logprob, int64_t N, const float *params, int n_params, const MProgram &prog,
+                        int accumulate, hipStream_t s, const char *fn)
+{
+    return launch_m<16>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
+}
+
+}  // namespace tfk

@@ -62,7 +62,7 @@ calls = 0   # number of kernel entry points invoked (tests assert the HIP path r
 def build(verbose: bool = False) -> str:
     """Compile libtfk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.run(["make", "-C", CSRC, "-B"], check=True, stdout=out)
+    subprocess.run(["make", "-C", CSRC, "-B", "-j", str(min(os.cpu_count() or 1, 8))], check=True, stdout=out)
     global _lib
     _lib = None
     return LIB_PATH
