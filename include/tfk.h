@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 10
+#define TFK_ABI_VERSION 11
 
 enum {
     TFK_OK = 0,
@@ -243,6 +243,15 @@ int tfk_lrs_coupling_inv(const float *z, const float *h, float *x, float *logdet
 int tfk_made_affine_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
                                const float *W1t, const float *b1, const float *W2, const float *b2,
                                int32_t hidden_padded, int32_t divide, int32_t accumulate, void *stream);
+
+/* One block of the Glow ConvNet conditioner (multiscale/conditioning/classic.py, ConvNetBlock.forward) in
+ * one launch: conv3x3 (padding 1) -> ReLU -> MaxPool2d(2) -> inference BatchNorm2d given as per-channel
+ * scale / shift.  x (N, c_in, H, W) NCHW, weight (c_out, c_in, 3, 3), out (N, c_out, H/2, W/2);
+ * c_in, c_out in {4, 8}; H, W even. */
+int tfk_conv3x3_block_supported(int32_t c_in, int32_t c_out);
+int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const float *bias, const float *scale,
+                                 const float *shift, float *out, int64_t N, int32_t c_in, int32_t c_out,
+                                 int32_t H, int32_t W, void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

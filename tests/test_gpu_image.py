@@ -85,7 +85,8 @@ def test_image_layers_golden_on_hip(native):
         with torch.no_grad():
             z, ld = layer.forward(x)
             xi, ldi = layer.inverse(x)
-        assert native.calls - before == 2, tag            # one libtfk kernel per call
+        # one coupling kernel per call (+ the ConvNet conditioner's three fused block launches each)
+        assert native.calls - before in (2, 8), tag
         assert rel(z.cpu().numpy(), fx[f"{tag}_z"]) < 1e-5, tag
         assert rel(ld.cpu().numpy(), fx[f"{tag}_ld"]) < 1e-5, tag
         assert rel(xi.cpu().numpy(), fx[f"{tag}_xinv"]) < 1e-4, tag
@@ -132,3 +133,30 @@ def test_glow_hip_vs_host_config5(native, event_shape, n):
     assert lp_d.shape == (n,)
     assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 2e-5      # MIOpen vs host convolutions inside
     assert torch.allclose(xr.cpu(), x, atol=1e-3) and torch.allclose(ld, -ldr, atol=1e-3)
+
+
+@pytest.mark.parametrize("c_in,c_out,H,W,N", [(4, 8, 32, 32, 300), (8, 8, 16, 16, 513), (8, 4, 8, 8, 1000),
+                                                (4, 4, 2, 6, 7), (8, 8, 10, 4, 33)])
+def test_conv_block_kernel_vs_torch(c_in, c_out, H, W, N):
+    """tfk_conv3x3_relu_pool_affine = conv3x3(pad 1) -> ReLU -> MaxPool2d(2) -> inference BatchNorm of the
+    Glow ConvNet conditioner (classic.py: ConvNetBlock.forward), against the same ops in fp64 on the host."""
+    from torchflows_amd import native
+    torch.manual_seed(c_in * 100 + c_out + H)
+    conv = torch.nn.Conv2d(c_in, c_out, 3, padding=1)
+    bn = torch.nn.BatchNorm2d(c_out).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_()
+        bn.bias.normal_()
+    x = torch.randn(N, c_in, H, W)
+    with torch.no_grad():
+        ref = bn.double()(torch.nn.functional.max_pool2d(torch.relu(conv.double()(x.double())), 2))
+        conv, bn = conv.float().cuda(), bn.float().cuda()
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        before = native.calls
+        out = native.conv3x3_relu_pool_affine(x.cuda(), conv.weight, conv.bias, scale, shift)
+    assert native.calls == before + 1 and out.shape == ref.shape
+    err = float((out.cpu().double() - ref).abs().max() / max(1.0, float(ref.abs().max())))
+    assert err < 1e-5, err

@@ -68,9 +68,23 @@ class ConvNet(nn.Module):
             shrink = 2 if use_pooling else 1
             self.output_shape = (out_channels, input_height // shrink, input_width // shrink)
 
+        def _native_ok(self, x) -> bool:
+            from torchflows_amd import native
+            bn, conv = self.bn, self.conv
+            return (not bn.training and bn.track_running_stats and isinstance(self.pool, nn.MaxPool2d)
+                    and native.eligible(x, conv.weight, conv.bias, bn.weight, bn.bias)
+                    and x.dim() == 4 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                    and bool(native.lib().tfk_conv3x3_block_supported(conv.in_channels, conv.out_channels)))
+
         def forward(self, x):
-            y = self.pool(torch.relu(self.conv(x)))
             bn = self.bn
+            if self._native_ok(x):          # the whole block in one launch (csrc/tfk_convblock.hip)
+                from torchflows_amd import native
+                scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+                shift = (bn.bias - bn.running_mean * scale).detach()
+                return native.conv3x3_relu_pool_affine(x.contiguous(), self.conv.weight.detach().contiguous(),
+                                                       self.conv.bias.detach(), scale, shift)
+            y = self.pool(torch.relu(self.conv(x)))
             if bn.training or not bn.track_running_stats or y.device.type != "cuda":
                 return bn(y)
             # inference-mode BatchNorm is a per-channel scale and shift: one elementwise kernel at HBM

@@ -1,0 +1,128 @@
+// tfk_convblock.hip -- one block of the Glow ConvNet conditioner in one launch:
+//   conv3x3(padding 1) -> ReLU -> MaxPool2d(2) -> BatchNorm2d (inference: per-channel scale + shift)
+// (reference multiscale/conditioning/classic.py: ConvNetBlock.forward), for the tiny channel counts
+// of that network (4 -> 8 -> 8 -> 4).  The library route runs a Winograd convolution, a ReLU, a
+// pooling and a normalisation kernel and moves the full-resolution activation through HBM three
+// times (270 us + 55 us + 40 us + 50 us per block at 8192 x 4 x 32 x 32); here one lane computes one
+// POOLED pixel for all output channels -- the 2x2 window of convolution outputs never leaves
+// registers -- so HBM sees the input once and the pooled output once.
+//   FMAs per pooled pixel: 4 * 9 * CIN * COUT; weights are LDS broadcasts, [ci][co][12] (9 taps + pad)
+//   read as three ds_read_b128 per 36 FMAs.
+// Layout: NCHW, H and W even.  Accumulation order: bias, then input channels in order, taps row-major
+// (fp32 FMA chain; the reference's CPU convolution sums in a different order: a few ulp apart).
+#include "tfk_common.h"
+
+namespace tfk {
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+    long long N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) float ws[CIN * COUT * 12];
+    __shared__ float bs[3 * COUT];
+    for (int i = threadIdx.x; i < CIN * COUT * 12; i += kBlock) {
+        const int tap = i % 12, co = (i / 12) % COUT, ci = i / (12 * COUT);
+        ws[i] = tap < 9 ? w[(co * CIN + ci) * 9 + tap] : 0.0f;       // weight (COUT, CIN, 3, 3)
+    }
+    for (int i = threadIdx.x; i < COUT; i += kBlock) {
+        bs[i] = bias[i];
+        bs[COUT + i] = scale[i];
+        bs[2 * COUT + i] = shift[i];
+    }
+    __syncthreads();
+    const int PH = H >> 1, PW = W >> 1;
+    const long long total = N * (long long)PH * PW;
+    const long long plane = (long long)H * W;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const int pw = (int)(idx % PW);
+        const int ph = (int)((idx / PW) % PH);
+        const long long n = idx / ((long long)PW * PH);
+        float acc[COUT][4];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[co][k] = bs[co];
+        const int ih0 = 2 * ph - 1, iw0 = 2 * pw - 1;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *src = x + (n * CIN + ci) * plane;
+            float p[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ih = ih0 + r;
+                const bool rok = (ih >= 0) && (ih < H);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int iw = iw0 + c;
+                    p[r][c] = (rok && iw >= 0 && iw < W) ? src[(long long)ih * W + iw] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12);
+                const float4 w1 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12 + 4);
+                const float4 w2 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12 + 8);
+                const float k[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        float a = acc[co][2 * oy + ox];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a = fmaf(k[3 * ky + kx], p[oy + ky][ox + kx], a);
+                        acc[co][2 * oy + ox] = a;
+                    }
+            }
+        }
+        float *dst = out + (n * COUT) * (long long)PH * PW + (long long)ph * PW + pw;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = fmaxf(fmaxf(acc[co][0], acc[co][1]), fmaxf(acc[co][2], acc[co][3]));
+            v = fmaxf(v, 0.0f);                                      // relu and max commute
+            dst[(long long)co * PH * PW] = fmaf(v, bs[COUT + co], bs[2 * COUT + co]);
+        }
+    }
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+extern "C" {
+
+int tfk_conv3x3_block_supported(int32_t c_in, int32_t c_out)
+{
+    return ((c_in == 4 || c_in == 8) && (c_out == 4 || c_out == 8)) ? 1 : 0;
+}
+
+int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const float *bias, const float *scale,
+                                 const float *shift, float *out, int64_t N, int32_t c_in, int32_t c_out,
+                                 int32_t H, int32_t W, void *stream)
+{
+    const char *fn = "tfk_conv3x3_relu_pool_affine";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!tfk_conv3x3_block_supported(c_in, c_out))
+        return fail(TFK_EINVAL, "%s: channels %d -> %d (kernels exist for 4 / 8 -> 4 / 8)", fn, c_in, c_out);
+    if (H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(TFK_EINVAL, "%s: H = %d, W = %d must be even and >= 2", fn, H, W);
+    if (N == 0) return TFK_OK;
+    if (!x || !weight || !bias || !scale || !shift || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t total = N * (int64_t)(H / 2) * (W / 2);
+    const int grid = grid_for(total, kBlock);
+#define TFK_CB(CI, CO)                                                                                   \
+    hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO>), dim3(grid), dim3(kBlock), 0, s, x, weight, bias, \
+                       scale, shift, out, (long long)N, H, W)
+    if (c_in == 4 && c_out == 8) TFK_CB(4, 8);
+    else if (c_in == 8 && c_out == 8) TFK_CB(8, 8);
+    else if (c_in == 8 && c_out == 4) TFK_CB(8, 4);
+    else if (c_in == 4 && c_out == 4) TFK_CB(4, 4);
+#undef TFK_CB
+    return check_launch(fn);
+}
+
+}  // extern "C"

@@ -42,9 +42,10 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
     "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
     "tfk_made_affine_sequential",
+    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine",
 )
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class NativeError(RuntimeError):
@@ -114,6 +115,8 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_rqs_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                              C.c_float, _i32, _vp, _i32, _vp]
     L.tfk_made_affine_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    L.tfk_conv3x3_block_supported.argtypes = [_i32, _i32]
+    L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -483,6 +486,26 @@ def made_affine_sequential(z, out, logdet, W1t, b1, W2, b2, divide, accumulate=F
         rc = lib().tfk_made_affine_sequential(*args, _stream(z))
     calls += 1
     _check(rc, name)
+
+
+def conv3x3_relu_pool_affine(x, weight, bias, scale, shift):
+    """conv3x3(pad 1) -> ReLU -> MaxPool2d(2) -> per-channel scale / shift in one launch (NCHW)."""
+    global calls
+    name = "tfk_conv3x3_relu_pool_affine"
+    if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x.shape[1]:
+        raise NativeError(f"{name}: x (N, C, H, W) and weight (C_out, C, 3, 3) expected")
+    N, c_in, H, W = x.shape
+    c_out = weight.shape[0]
+    if bias.numel() != c_out or scale.numel() != c_out or shift.numel() != c_out:
+        raise NativeError(f"{name}: bias / scale / shift must hold c_out = {c_out} values")
+    out = torch.empty(N, c_out, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    args = (_f32(x, name), _f32(weight, name), _f32(bias, name), _f32(scale, name), _f32(shift, name),
+            _f32(out, name), N, c_in, c_out, H, W)
+    with _device_guard(x):
+        rc = lib().tfk_conv3x3_relu_pool_affine(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+    return out
 
 
 def _pack_ops(ops):
