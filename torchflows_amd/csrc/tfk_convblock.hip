@@ -14,7 +14,9 @@
 
 namespace tfk {
 
-template <int CIN, int COUT>
+// PX pooled pixels per lane along W (2 when the pooled width is even: the weights and the two shared
+// patch columns are reused).
+template <int CIN, int COUT, int PX>
 __global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
@@ -32,30 +34,33 @@ __global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
         bs[2 * COUT + i] = shift[i];
     }
     __syncthreads();
-    const int PH = H >> 1, PW = W >> 1;
-    const long long total = N * (long long)PH * PW;
+    const int PH = H >> 1, PW = W >> 1, PWX = PW / PX;
+    const long long total = N * (long long)PH * PWX;
     const long long plane = (long long)H * W;
+    constexpr int OW = 2 * PX, PC = OW + 2;              // conv outputs / patch columns per lane
     for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * kBlock) {
-        const int pw = (int)(idx % PW);
-        const int ph = (int)((idx / PW) % PH);
-        const long long n = idx / ((long long)PW * PH);
-        float acc[COUT][4];
+        const int pw = (int)(idx % PWX) * PX;
+        const int ph = (int)((idx / PWX) % PH);
+        const long long n = idx / ((long long)PWX * PH);
+        float acc[COUT][2][OW];
 #pragma unroll
         for (int co = 0; co < COUT; ++co)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[co][k] = bs[co];
-        const int ih0 = 2 * ph - 1, iw0 = 2 * pw - 1;
+            for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
+                for (int ox = 0; ox < OW; ++ox) acc[co][oy][ox] = bs[co];
+        const int ih0 = 2 * ph - 1, iw0 = 2 * pw - 1;
+#pragma unroll 1
+        for (int ci = 0; ci < CIN; ++ci) {   // rolled: one patch live at a time keeps the lane under 128 VGPRs
             const float *src = x + (n * CIN + ci) * plane;
-            float p[4][4];
+            float p[4][PC];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ih = ih0 + r;
                 const bool rok = (ih >= 0) && (ih < H);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < PC; ++c) {
                     const int iw = iw0 + c;
                     p[r][c] = (rok && iw >= 0 && iw < W) ? src[(long long)ih * W + iw] : 0.0f;
                 }
@@ -69,23 +74,26 @@ __global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
 #pragma unroll
                 for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
-                    for (int ox = 0; ox < 2; ++ox) {
-                        float a = acc[co][2 * oy + ox];
+                    for (int ox = 0; ox < OW; ++ox) {
+                        float a = acc[co][oy][ox];
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) a = fmaf(k[3 * ky + kx], p[oy + ky][ox + kx], a);
-                        acc[co][2 * oy + ox] = a;
+                        acc[co][oy][ox] = a;
                     }
             }
         }
         float *dst = out + (n * COUT) * (long long)PH * PW + (long long)ph * PW + pw;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-            float v = fmaxf(fmaxf(acc[co][0], acc[co][1]), fmaxf(acc[co][2], acc[co][3]));
-            v = fmaxf(v, 0.0f);                                      // relu and max commute
-            dst[(long long)co * PH * PW] = fmaf(v, bs[COUT + co], bs[2 * COUT + co]);
-        }
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int px = 0; px < PX; ++px) {
+                float v = fmaxf(fmaxf(acc[co][0][2 * px], acc[co][0][2 * px + 1]),
+                                fmaxf(acc[co][1][2 * px], acc[co][1][2 * px + 1]));
+                v = fmaxf(v, 0.0f);                                  // relu and max commute
+                dst[(long long)co * PH * PW + px] = fmaf(v, bs[COUT + co], bs[2 * COUT + co]);
+            }
     }
 }
 
@@ -112,11 +120,18 @@ int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const floa
     if (N == 0) return TFK_OK;
     if (!x || !weight || !bias || !scale || !shift || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t total = N * (int64_t)(H / 2) * (W / 2);
+    const int px = ((W / 2) % 2 == 0) ? 2 : 1;
+    const int64_t total = N * (int64_t)(H / 2) * ((W / 2) / px);
     const int grid = grid_for(total, kBlock);
-#define TFK_CB(CI, CO)                                                                                   \
-    hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO>), dim3(grid), dim3(kBlock), 0, s, x, weight, bias, \
-                       scale, shift, out, (long long)N, H, W)
+#define TFK_CB(CI, CO)                                                                                       \
+    do {                                                                                                     \
+        if (px == 2)                                                                                         \
+            hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO, 2>), dim3(grid), dim3(kBlock), 0, s, x,   \
+                               weight, bias, scale, shift, out, (long long)N, H, W);                         \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO, 1>), dim3(grid), dim3(kBlock), 0, s, x,   \
+                               weight, bias, scale, shift, out, (long long)N, H, W);                         \
+    } while (0)
     if (c_in == 4 && c_out == 8) TFK_CB(4, 8);
     else if (c_in == 8 && c_out == 8) TFK_CB(8, 8);
     else if (c_in == 8 && c_out == 4) TFK_CB(8, 4);
