@@ -8,7 +8,8 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torchflows_amd as tfa  # noqa: E402
-from torchflows_amd.distributed import shard_bounds, sharded_log_likelihood  # noqa: E402
+from torchflows_amd.distributed import (shard_bounds, sharded_log_likelihood,  # noqa: E402
+                                       sharded_log_likelihood_async)
 
 
 def main():
@@ -25,6 +26,12 @@ def main():
     assert torch.allclose(lp_local, full[lo:hi], atol=1e-5)
     expect = full.double().sum()
     assert abs(float(total) - float(expect)) < 1e-6 * abs(float(expect)), (float(total), float(expect))
+    # the in-flight variant (bench.py): three evaluations queued, sums valid after wait()
+    with torch.no_grad():
+        queued = [sharded_log_likelihood_async(flow, x[lo:hi], chunk_rows=300) for _ in range(3)]
+    for lp_a, total_a, work in queued:
+        work.wait()
+        assert torch.equal(lp_a, lp_local) and float(total_a) == float(total)
     gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(gathered, total)
     assert all(float(g) == float(total) for g in gathered)      # every rank holds the same sum
