@@ -192,6 +192,8 @@ class BijectiveComposition(Bijection):
 
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):
+        if x.numel() == 0:          # no rows: nothing to launch (the reference's reshapes reject this)
+            return x.clone(), x.new_zeros(get_batch_shape(x, self.event_shape))
         if not kwargs and torch.is_grad_enabled():
             trained = self._run_trainable(x, context, FORWARD)
             if trained is not None:
@@ -213,6 +215,8 @@ class BijectiveComposition(Bijection):
     @inverse_method
     def inverse(self, z: torch.Tensor, context: torch.Tensor = None, **kwargs):
         order = list(self.layers)[::-1]
+        if z.numel() == 0:
+            return z.clone(), z.new_zeros(get_batch_shape(z, self.event_shape))
         if not kwargs and torch.is_grad_enabled():
             trained = self._run_trainable(z, context, INVERSE)
             if trained is not None:

@@ -23,7 +23,7 @@ def get_batch_shape(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Size:
 
 def flatten_event(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tensor:
     """``(*batch, *event) -> (*batch, D)`` (utils.py:37-46)."""
-    return x.reshape(*get_batch_shape(x, event_shape), -1)
+    return x.reshape(*get_batch_shape(x, event_shape), event_size(event_shape))   # explicit: empty batches too
 
 
 def unflatten_event(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tensor:
@@ -40,4 +40,7 @@ def sum_except_batch(x: torch.Tensor, event_shape: Sequence[int]) -> torch.Tenso
 def as_rows(x: torch.Tensor, event_shape: Sequence[int]) -> Tuple[torch.Tensor, torch.Size]:
     """Contiguous ``(N, D)`` view/copy of ``x`` plus its batch shape -- what the kernels take."""
     batch = get_batch_shape(x, event_shape)
-    return x.reshape(-1, event_size(event_shape)).contiguous(), batch
+    rows = x.reshape(-1, event_size(event_shape)).contiguous()
+    if rows.device.type == "cuda" and rows.data_ptr() % 16:
+        rows = rows.clone()       # a view into the middle of a buffer: the kernels' float4 accesses need 16 B
+    return rows, batch
