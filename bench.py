@@ -187,7 +187,7 @@ def make_flow(arch, D, n_layers):
     """seed 0, data-initialised ActNorm (one train-mode forward on 4096 host rows), eval."""
     import torchflows_amd as tfa
     from torchflows_amd.bijections.finite.multiscale import AffineGlow
-    ctor = {"RealNVP": tfa.RealNVP, "CouplingRQNSF": tfa.CouplingRQNSF, "AffineGlow": AffineGlow}[arch]
+    ctor = AffineGlow if arch == "AffineGlow" else getattr(tfa, arch)
     torch.manual_seed(0)
     flow = tfa.Flow(ctor(D, n_layers=n_layers))
     shape = D if isinstance(D, tuple) else (D,)

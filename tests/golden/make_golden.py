@@ -428,28 +428,41 @@ def gen_grads():
              ("flow_nice7.npz", NICE, 7, {}),
              ("flow_realnvp_7x11.npz", RealNVP, (7, 11), {})]
     for fname, ctor, es, kw in flows:
-        fx = np.load(os.path.join(OUT, fname))
-        sd = {k[len("sd_init/"):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd_init/")}
-        x = torch.from_numpy(fx["x"])
-        g = torch.Generator().manual_seed(99)
-        w = torch.rand(x.shape[0], generator=g) + 0.5          # per-row upstream gradient
-        o = {"w": np32(w)}
-        for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
-            flow = Flow(ctor(es, **kw)).to(dt)
-            flow.load_state_dict({k: v.to(dt) for k, v in sd.items()})
-            flow.eval()
-            xx = x.to(dt).clone().requires_grad_(True)
-            lp = flow.log_prob(xx)
-            loss = (lp * w.to(dt)).sum()
-            names = [n for n, p_ in flow.named_parameters() if p_.requires_grad]
-            params = [p_ for n, p_ in flow.named_parameters() if p_.requires_grad]
-            grads = torch.autograd.grad(loss, [xx] + params, allow_unused=True)
-            o[f"gx{tag}"] = np32(grads[0])
-            for n, gr in zip(names, grads[1:]):
-                o[f"g{tag}/{n}"] = np32(gr if gr is not None else torch.zeros(()))
-        # ActNorm values carry no gradient in the reference (requires_grad False, layers.py:49)
-        o["trainable"] = np.array(names)
-        save("grads_" + fname, **o)
+        _flow_grads(fname, ctor, es, kw)
+
+
+def _flow_grads(fname, ctor, es, kw):
+    """d(sum_i w_i log_prob(x_i)) / d(x, parameters) of the reference's autograd, fp32 and fp64, on the
+    weights and inputs of an existing flow fixture."""
+    fx = np.load(os.path.join(OUT, fname))
+    sd = {k[len("sd_init/"):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd_init/")}
+    x = torch.from_numpy(fx["x"])
+    g = torch.Generator().manual_seed(99)
+    w = torch.rand(x.shape[0], generator=g) + 0.5          # per-row upstream gradient
+    o = {"w": np32(w)}
+    for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+        flow = Flow(ctor(es, **kw)).to(dt)
+        flow.load_state_dict({k: v.to(dt) for k, v in sd.items()})
+        flow.eval()
+        xx = x.to(dt).clone().requires_grad_(True)
+        lp = flow.log_prob(xx)
+        loss = (lp * w.to(dt)).sum()
+        names = [n for n, p_ in flow.named_parameters() if p_.requires_grad]
+        params = [p_ for n, p_ in flow.named_parameters() if p_.requires_grad]
+        grads = torch.autograd.grad(loss, [xx] + params, allow_unused=True)
+        o[f"gx{tag}"] = np32(grads[0])
+        for n, gr in zip(names, grads[1:]):
+            o[f"g{tag}/{n}"] = np32(gr if gr is not None else torch.zeros(()))
+    # ActNorm values carry no gradient in the reference (requires_grad False, layers.py:49)
+    o["trainable"] = np.array(names)
+    save("grads_" + fname, **o)
+
+
+def gen_grads_maf():
+    """MADE-based flows: the parallel (density) direction differentiated by the reference."""
+    from torchflows.bijections.finite.autoregressive.architectures import MAF, MaskedAutoregressiveRQNSF
+    _flow_grads("flow_maf6.npz", MAF, 6, dict(n_layers=2))
+    _flow_grads("flow_marqnsf5.npz", MaskedAutoregressiveRQNSF, 5, dict(n_layers=2))
 
 
 # ---------------------------------------------------------------- F9 sibling layers (SURVEY 8f-4)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden, state_dict_of
-from test_grads_cpu import FLOWS, _mirror_flow, _param_of, normwise
+from test_grads_cpu import FLOWS, MADE_FLOWS, _mirror_flow, _param_of, normwise
 
 pytestmark = pytest.mark.gpu
 
@@ -43,13 +43,14 @@ def hip_grads(flow, x, w):
     return lp, grads[0], {n: g for (n, _), g in zip(named, grads[1:])}
 
 
-@pytest.mark.parametrize("fname,arch,es,n_layers", FLOWS)
+@pytest.mark.parametrize("fname,arch,es,n_layers", FLOWS + MADE_FLOWS)
 def test_flow_grads_golden_on_hip(native, fname, arch, es, n_layers):
     fx, gr = load_golden(fname), load_golden("grads_" + fname)
     flow = _mirror_flow(arch, es, n_layers, state_dict_of(fx, "init")).cuda()
     before = native.calls
     lp, gx, grads = hip_grads(flow, torch.tensor(fx["x"]).cuda(), torch.tensor(gr["w"]).cuda())
-    n_couplings = sum(1 for l in flow.bijection.layers if hasattr(l, "coupling"))
+    n_couplings = sum(1 for l in flow.bijection.layers
+                      if hasattr(l, "coupling") or hasattr(l, "_sequential_when"))   # MADE layers count too
     # at least one forward and one reverse-mode libtfk launch per coupling layer (layers that ride
     # along in a fused launch do not add calls)
     assert native.calls - before >= 2 * n_couplings, "the reverse-mode kernels did not run"
@@ -112,6 +113,55 @@ def test_flow_grads_vs_oracle_large_batch(native, oracle, arch, D, n_layers):
     for name, (eh, eo) in errs.items():
         assert eh < max(1e-5, 3 * worst_o), (name, eh, eo, worst_o)
     print(f"{arch}({D}) vs fp64: gx HIP {e:.2e} / oracle {o:.2e}; worst parameter gradient HIP {worst:.2e} / oracle {worst_o:.2e}")
+
+
+@pytest.mark.parametrize("arch,D,direction", [("MAF", 64, "log_prob"), ("MaskedAutoregressiveRQNSF", 16, "log_prob"),
+                                              ("IAF", 64, "inverse")])
+def test_made_flow_grads_vs_fp64(native, arch, D, direction):
+    """MADE-based flows, parallel direction (MAF density, IAF sampling), 4 096 seeded rows: the HIP
+    gradient must be as close to fp64 autograd (ATen composite path on the host) as the host's own
+    fp32 autograd is (3x), or within 1e-5 norm-wise; the chain must be ONE autograd node."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    torch.manual_seed(4)
+    flow = Flow(getattr(A, arch)(D, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(4096, D))
+    flow.eval()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(4096, D, generator=g)
+    w = torch.rand(4096, generator=g) + 0.5
+
+    def run(f, xx, ww):
+        xx = xx.clone().requires_grad_(True)
+        if direction == "log_prob":
+            out = f.log_prob(xx)
+            loss = (out * ww).sum()
+        else:
+            out, ld = f.bijection.inverse(xx)
+            loss = ((out ** 2).sum(dim=-1) * ww).sum() + (ld * ww).sum()
+        named = [(n, p) for n, p in f.named_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, [xx] + [p for _, p in named], allow_unused=True)
+        return out, grads[0], {n: gr for (n, _), gr in zip(named, grads[1:])}
+
+    _, gx64, g64 = run(copy.deepcopy(flow).double(), x.double(), w.double())
+    _, gx32, g32 = run(copy.deepcopy(flow), x, w)
+    before = native.calls
+    out, gx, grads = run(flow.cuda(), x.cuda(), w.cuda())
+    assert native.calls - before >= 8, "forward and reverse-mode kernels of the 4 MADE layers did not run"
+    assert "ChainFunctionBackward" in graph_nodes(out)
+    e, floor = normwise(gx.cpu().numpy(), gx64.numpy()), normwise(gx32.numpy(), gx64.numpy())
+    assert e < max(1e-5, 3 * floor), (e, floor)
+    worst = worst_floor = 0.0
+    for name, gr in grads.items():
+        if gr is None or gr.numel() == 0:
+            continue
+        worst = max(worst, normwise(gr.cpu().numpy(), g64[name].numpy()))
+        worst_floor = max(worst_floor, normwise(g32[name].numpy(), g64[name].numpy()))
+    assert worst < max(1e-5, 3 * worst_floor), (worst, worst_floor)
+    print(f"{arch}({D}) {direction}: gx {e:.2e} (host fp32 {floor:.2e}); worst parameter {worst:.2e} ({worst_floor:.2e})")
 
 
 @pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("CouplingRQNSF", 16), ("NICE", 7)])

@@ -40,10 +40,21 @@ def _flatten(layers, attr: str):
 
 def _step_kind(layer) -> Optional[str]:
     from torchflows_amd.bijections.finite.autoregressive.layers_base import (
-        CouplingBijection, ElementwiseBijection)
+        CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
     if isinstance(layer, PermutationMatrix):
         return "perm"
+    if isinstance(layer, MaskedAutoregressiveBijection):
+        # the parallel pass (MAF density / IAF sampling): MADE on PyTorch-ROCm, the transformer's
+        # forward and reverse-mode kernels with every position a target
+        if layer.context_shape is not None:
+            return None
+        kind = layer.transformer.native_kind
+        if kind in ("affine", "inverse_affine"):
+            return "made"
+        if kind == "rqs" and native.lib().tfk_rqs_coupling_bwd_supported(int(layer.transformer.n_bins)):
+            return "made"
+        return None
     if isinstance(layer, ElementwiseBijection):
         ok = layer.use_global_parameters and layer.transformer.native_kind in ("affine", "inverse_affine")
         return "elementwise" if ok else None
@@ -67,8 +78,8 @@ def training_plan(composition, direction: int):
     plan = []
     for layer, d in flat:
         kind = _step_kind(layer)
-        if kind is None:
-            return None
+        if kind is None or (kind == "made" and d == layer._sequential_when):
+            return None         # (the element-by-element map is not differentiated on the HIP path)
         plan.append((layer, d, kind))
     return plan
 
@@ -91,7 +102,7 @@ def applicable(composition, x: torch.Tensor, context) -> bool:
 def _layer_params(layer, kind: str) -> List[torch.Tensor]:
     if kind == "elementwise":
         return [layer.value]
-    if kind == "coupling":
+    if kind in ("coupling", "made"):
         return list(layer.conditioner_transform.parameters())
     return []
 
@@ -440,16 +451,34 @@ def _outer_sum(a: torch.Tensor, b_aug: torch.Tensor) -> torch.Tensor:
     return a.t() @ b_aug
 
 
-def _mlp_backward(lin1, lin2, x_a: torch.Tensor, a1: torch.Tensor, gh: torch.Tensor):
+def _mlp_backward(W1: torch.Tensor, W2: torch.Tensor, x_a: torch.Tensor, a1: torch.Tensor, gh: torch.Tensor):
     """Reverse mode of h = W2 tanh(W1 x_a + b1) + b2 given a1 = tanh(.) and gh = dL/dh.
     Returns (g_xa, dW1, db1, dW2, db2); the bias gradients ride along as a column of ones."""
     N = gh.shape[0]
     ones = torch.ones(N, 1, dtype=gh.dtype, device=gh.device)
     dW2b = _outer_sum(gh, torch.cat([a1, ones], dim=1))             # (TP, H + 1)
-    g_pre = (gh @ lin2.weight) * (1.0 - a1 * a1)                     # tanh'
+    g_pre = (gh @ W2) * (1.0 - a1 * a1)                              # tanh'
     dW1b = _outer_sum(g_pre, torch.cat([x_a, ones], dim=1))          # (H, S + 1)
-    g_xa = g_pre @ lin1.weight
+    g_xa = g_pre @ W1
     return g_xa, dW1b[:, :-1], dW1b[:, -1], dW2b[:, :-1], dW2b[:, -1]
+
+
+def _made_mlp(layer):
+    """(MaskedLinear, MaskedLinear) when the conditioner is the default two-layer MADE (masked Linear,
+    Tanh, masked Linear; transforms.py:184-267) without global parameters or output bounds."""
+    import math
+    import torch.nn as nn
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import MADE
+    ct = layer.conditioner_transform
+    if not isinstance(ct, MADE) or ct.n_global_parameters != 0 or ct.context_shape is not None:
+        return None
+    if ct.output_lower_bound != -math.inf or ct.output_upper_bound != math.inf:
+        return None
+    mods = list(ct.sequential)
+    if (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], MADE.MaskedLinear) and mods[0].in_features == layer.n_dim):
+        return mods[0], mods[2]
+    return None
 
 
 def _affine_form_is_inverse(layer, d: int) -> bool:
@@ -495,6 +524,19 @@ class ChainFunction(torch.autograd.Function):
                                           accumulate=started, inverse=(d == INVERSE))
                 started = True
                 saved.append(cur if keep_input else None)
+                cur, cur_is_saved = out, False
+            elif kind == "made":
+                h = layer.conditioner_transform(cur.view(N, *layer.event_shape), None).reshape(N, -1).contiguous()
+                out = torch.empty_like(cur)
+                tk, tr = layer.transformer.native_kind, layer.transformer
+                if tk == "rqs":
+                    native.rqs_coupling(cur, h, out, logdet, None, D, tr.n_bins, tr.boundary,
+                                        accumulate=started, inverse=False)
+                else:       # the parallel pass always applies transformer.forward (layers_base.py:196-199)
+                    native.affine_coupling(cur, h, out, logdet, None, D, accumulate=started,
+                                           inverse=(tk == "inverse_affine"))
+                started = True
+                saved.append(cur)
                 cur, cur_is_saved = out, False
             elif step in packs.slot:
                 # conditioner + transform (+ the fixed elementwise layer and the reversal that
@@ -598,6 +640,43 @@ class ChainFunction(torch.autograd.Function):
                 gv = native.elementwise_affine_bwd(x_in, layer.value.detach().reshape(D, 2).contiguous(), g,
                                                    gld, want, inverse=_affine_form_is_inverse(layer, d))
                 grads_per_step[i] = [gv.view_as(layer.value) if want else None]
+            elif kind == "made":
+                # h depends on every input position (through the masks): re-evaluate MADE with a graph,
+                # the transformer's reverse-mode kernel gives dL/dh and the direct dL/dx, autograd the rest
+                cparams = list(layer.conditioner_transform.parameters())
+                tk, tr = layer.transformer.native_kind, layer.transformer
+                mlp = _made_mlp(layer)
+                if mlp is not None:             # masked MLP written out (weight-gradient GEMMs split over rows)
+                    lin1, lin2 = mlp
+                    W1, W2 = lin1.weight.detach() * lin1.mask, lin2.weight.detach() * lin2.mask
+                    a1 = torch.tanh(torch.addmm(lin1.bias.detach(), x_in, W1.t()))
+                    hc = torch.addmm(lin2.bias.detach(), a1, W2.t())
+                else:
+                    x_req = x_in.detach().requires_grad_(True)
+                    with torch.enable_grad():
+                        h2 = layer.conditioner_transform(x_req.view(N, *layer.event_shape), None).reshape(N, -1)
+                    hc = h2.detach().contiguous()
+                gh = torch.empty_like(hc)
+                if tk == "rqs":
+                    native.rqs_coupling_bwd(x_in, hc, g, gld, gh, None, D, tr.n_bins, tr.boundary, inverse=False)
+                else:
+                    native.affine_coupling_bwd(x_in, hc, g, gld, gh, None, D, inverse=(tk == "inverse_affine"))
+                if mlp is not None:
+                    g_x, dW1, db1, dW2, db2 = _mlp_backward(W1, W2, x_in, a1, gh)
+                    g.add_(g_x)
+                    by_param = {id(lin1.weight): dW1 * lin1.mask, id(lin1.bias): db1,
+                                id(lin2.weight): dW2 * lin2.mask, id(lin2.bias): db2}
+                    grads_per_step[i] = [
+                        (by_param[id(p)] if id(p) in by_param else torch.zeros_like(p)) if p.requires_grad else None
+                        for p in cparams]
+                    continue
+                wanted = [p for p in cparams if p.requires_grad]
+                outs = torch.autograd.grad(h2, [x_req] + wanted, gh, allow_unused=True)
+                g.add_(outs[0].reshape(N, D))
+                it = iter(outs[1:])
+                grads_per_step[i] = [next(it) if p.requires_grad else None for p in cparams]
+                grads_per_step[i] = [torch.zeros_like(p) if (gp is None and p.requires_grad) else gp
+                                     for gp, p in zip(grads_per_step[i], cparams)]
             else:
                 T = layer.coupling.target_event_size
                 S = layer.coupling.source_event_size
@@ -669,7 +748,7 @@ class ChainFunction(torch.autograd.Function):
                 else:
                     native.shift_coupling_bwd(g, gh, tgt, T, inverse=(d == INVERSE))
                 if mlp is not None:
-                    g_xa, dW1, db1, dW2, db2 = _mlp_backward(lin1, lin2, x_a, a1, gh)
+                    g_xa, dW1, db1, dW2, db2 = _mlp_backward(lin1.weight, lin2.weight, x_a, a1, gh)
                     by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
                     grads_per_step[i] = [by_param.get(id(p)) if p.requires_grad else None for p in cparams]
                     # (global_theta_flat is empty here: its gradient is an empty tensor)
