@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 11
+#define TFK_ABI_VERSION 12
 
 enum {
     TFK_OK = 0,
@@ -252,6 +252,14 @@ int tfk_conv3x3_block_supported(int32_t c_in, int32_t c_out);
 int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const float *bias, const float *scale,
                                  const float *shift, float *out, int64_t N, int32_t c_in, int32_t c_out,
                                  int32_t H, int32_t W, void *stream);
+
+/* ConvModifier with a 1x1 kernel (classic.py:8-42: conv2d whose padding exceeds kernel - 1): channel mixing
+ * c_in -> c_out (1 or 4) of an (H, W) image placed in the middle of an (H_out, W_out) frame that holds the
+ * bias (H_out - H and W_out - W even, >= 0).  x (N, c_in, H, W) with x_stride floats between images (a view
+ * of wider rows is fine), weight (c_out, c_in), out (N, c_out, H_out, W_out) contiguous. */
+int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, const float *bias, float *out,
+                      int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out,
+                      void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

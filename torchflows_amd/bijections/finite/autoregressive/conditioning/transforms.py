@@ -82,7 +82,10 @@ class ConditionerTransform(nn.Module):
                 out[..., ~self.global_parameter_mask] = self.predict_theta_flat(x, context)
         lo, hi = self.output_lower_bound, self.output_upper_bound
         if lo > -math.inf and hi < math.inf:
-            out = torch.sigmoid(out) * (hi - lo) + lo
+            if torch.is_grad_enabled() and out.requires_grad:
+                out = torch.sigmoid(out) * (hi - lo) + lo
+            else:               # same values, no temporaries (the parameter tensor is the largest one around)
+                out = torch.sigmoid(out).mul_(hi - lo).add_(lo)
         elif lo > -math.inf:
             out = torch.exp(out) + lo
         elif hi < math.inf:

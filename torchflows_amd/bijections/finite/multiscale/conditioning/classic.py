@@ -44,8 +44,24 @@ class ConvModifier(nn.Module):
         self._eff_pad = (min(ph, kh - 1), min(pw, kw - 1))
         self._frame = (pw - self._eff_pad[1], pw - self._eff_pad[1], ph - self._eff_pad[0], ph - self._eff_pad[0])
 
+    def _native_ok(self, x) -> bool:
+        from torchflows_amd import native
+        w = self.conv.weight
+        if tuple(w.shape[2:]) != (1, 1) or w.shape[0] not in (1, 4) or x.dim() != 4 or not w.is_contiguous():
+            return False
+        n, c, h, wd = x.shape
+        if h > self.output_shape[1] or wd > self.output_shape[2]:
+            return False
+        images_ok = n <= 1 or (x.stride(3) == 1 and x.stride(2) == wd and x.stride(1) == h * wd
+                               and x.stride(0) >= c * h * wd)
+        return images_ok and native.eligible(x, w, self.conv.bias)
+
     def forward(self, x):
         w = self.conv.weight
+        if self._native_ok(x):              # channel mixing + frame in one launch (csrc/tfk_convblock.hip)
+            from torchflows_amd import native
+            return native.conv1x1_frame(x, w.detach(), self.conv.bias.detach(), *self.output_shape[1:])
+        bias = self.conv.bias.view(1, -1, 1, 1)
         if w.shape[2] == 1 and w.shape[3] == 1:
             # a 1x1 convolution is a channel-mixing GEMM: one strided-batched rocBLAS call over the
             # whole batch (MIOpen runs these shapes as one tiny GEMM per image)
@@ -53,9 +69,15 @@ class ConvModifier(nn.Module):
             y = torch.matmul(w.view(w.shape[0], c), x.reshape(n, c, h * wd)).view(n, w.shape[0], h, wd)
         else:
             y = nn.functional.conv2d(x, w, None, padding=self._eff_pad)
-        if any(self._frame):
-            y = nn.functional.pad(y, self._frame)
-        return y + self.conv.bias.view(1, -1, 1, 1)
+        if not any(self._frame):
+            return y + bias
+        if torch.is_grad_enabled() and (y.requires_grad or bias.requires_grad):
+            return nn.functional.pad(y, self._frame) + bias
+        # inference: the constant frame is the bias; the interior is written once, bias added on the way
+        left, right, top, bottom = self._frame
+        out = bias.expand(y.shape[0], y.shape[1], y.shape[2] + top + bottom, y.shape[3] + left + right).contiguous()
+        torch.add(y, bias, out=out[:, :, top:top + y.shape[2], left:left + y.shape[3]])
+        return out
 
 
 class ConvNet(nn.Module):
@@ -79,11 +101,16 @@ class ConvNet(nn.Module):
         def forward(self, x):
             bn = self.bn
             if self._native_ok(x):          # the whole block in one launch (csrc/tfk_convblock.hip)
-                from torchflows_amd import native
-                scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
-                shift = (bn.bias - bn.running_mean * scale).detach()
-                return native.conv3x3_relu_pool_affine(x.contiguous(), self.conv.weight.detach().contiguous(),
-                                                       self.conv.bias.detach(), scale, shift)
+                from torchflows_amd import fused, native
+                version = fused._params_version(self)
+                hit = self.__dict__.get("_tfk_bn_affine")
+                if hit is None or hit[0] != version:     # (8 tiny launches per block otherwise)
+                    scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+                    shift = (bn.bias - bn.running_mean * scale).detach()
+                    hit = self.__dict__["_tfk_bn_affine"] = (version, scale, shift,
+                                                              self.conv.weight.detach().contiguous())
+                return native.conv3x3_relu_pool_affine(x.contiguous(), hit[3], self.conv.bias.detach(),
+                                                       hit[1], hit[2])
             y = self.pool(torch.relu(self.conv(x)))
             if bn.training or not bn.track_running_stats or y.device.type != "cuda":
                 return bn(y)

@@ -97,6 +97,40 @@ __global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
     }
 }
 
+// ConvModifier (classic.py:8-42) with a 1x1 kernel: a channel-mixing GEMM whose result sits in the middle
+// of a larger frame (padding beyond kernel - 1 only adds positions that equal the bias).  One lane per
+// output pixel, all COUT channels; x may be a row-strided view (x_stride floats between images).
+template <int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv1x1_frame(
+    const float *__restrict__ x, long long x_stride, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ out, long long N, int C, int H, int W, int HT, int WT,
+    int top, int left)
+{
+    const long long total = N * (long long)HT * WT;
+    const long long plane_in = (long long)H * W, plane_out = (long long)HT * WT;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const int j = (int)(idx % WT);
+        const int i = (int)((idx / WT) % HT);
+        const long long n = idx / plane_out;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+        const int ii = i - top, jj = j - left;
+        if (ii >= 0 && ii < H && jj >= 0 && jj < W) {
+            const float *src = x + n * x_stride + (long long)ii * W + jj;
+            for (int c = 0; c < C; ++c) {
+                const float v = src[c * plane_in];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(weight[co * C + c], v, acc[co]);
+            }
+        }
+        float *dst = out + n * COUT * plane_out + (long long)i * WT + j;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) dst[co * plane_out] = acc[co] + bias[co];
+    }
+}
+
 }  // namespace tfk
 
 using namespace tfk;
@@ -137,6 +171,31 @@ int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const floa
     else if (c_in == 8 && c_out == 4) TFK_CB(8, 4);
     else if (c_in == 4 && c_out == 4) TFK_CB(4, 4);
 #undef TFK_CB
+    return check_launch(fn);
+}
+
+int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, const float *bias, float *out,
+                      int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out,
+                      void *stream)
+{
+    const char *fn = "tfk_conv1x1_frame";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (c_out != 1 && c_out != 4) return fail(TFK_EINVAL, "%s: c_out = %d (kernels exist for 1 and 4)", fn, c_out);
+    if (c_in < 1 || H < 1 || W < 1 || H_out < H || W_out < W || ((H_out - H) & 1) || ((W_out - W) & 1))
+        return fail(TFK_EINVAL, "%s: need c_in >= 1 and an even, non-negative frame (%dx%d -> %dx%d)", fn, H, W,
+                    H_out, W_out);
+    if (x_stride < (int64_t)c_in * H * W) return fail(TFK_EINVAL, "%s: x_stride %lld < c_in*H*W", fn, (long long)x_stride);
+    if (N == 0) return TFK_OK;
+    if (!x || !weight || !bias || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(N * (int64_t)H_out * W_out, kBlock);
+    const int top = (H_out - H) / 2, left = (W_out - W) / 2;
+    if (c_out == 4)
+        hipLaunchKernelGGL((k_conv1x1_frame<4>), dim3(grid), dim3(kBlock), 0, s, x, (long long)x_stride, weight, bias,
+                           out, (long long)N, c_in, H, W, H_out, W_out, top, left);
+    else
+        hipLaunchKernelGGL((k_conv1x1_frame<1>), dim3(grid), dim3(kBlock), 0, s, x, (long long)x_stride, weight, bias,
+                           out, (long long)N, c_in, H, W, H_out, W_out, top, left);
     return check_launch(fn);
 }
 

@@ -42,10 +42,10 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
     "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
     "tfk_made_affine_sequential",
-    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine",
+    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame",
 )
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class NativeError(RuntimeError):
@@ -117,6 +117,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_made_affine_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
     L.tfk_conv3x3_block_supported.argtypes = [_i32, _i32]
     L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
+    L.tfk_conv1x1_frame.argtypes = [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -503,6 +504,29 @@ def conv3x3_relu_pool_affine(x, weight, bias, scale, shift):
             _f32(out, name), N, c_in, c_out, H, W)
     with _device_guard(x):
         rc = lib().tfk_conv3x3_relu_pool_affine(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+    return out
+
+
+def conv1x1_frame(x, weight, bias, h_out: int, w_out: int):
+    """1x1 convolution c_in -> c_out placed in the middle of an (h_out, w_out) frame that holds the bias.
+    ``x`` (N, C, H, W) may be a view whose images are contiguous but further apart than C*H*W."""
+    global calls
+    name = "tfk_conv1x1_frame"
+    if x.dim() != 4 or x.dtype != torch.float32 or x.device.type != "cuda":
+        raise NativeError(f"{name}: x must be a float32 (N, C, H, W) tensor on a HIP device")
+    N, c_in, H, W = x.shape
+    if N > 1 and (x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W):
+        raise NativeError(f"{name}: the images of x must be contiguous")
+    c_out = weight.shape[0]
+    if weight.numel() != c_out * c_in or bias.numel() != c_out:
+        raise NativeError(f"{name}: weight (c_out, c_in[, 1, 1]) and bias (c_out,) expected")
+    x_stride = x.stride(0) if N > 1 else c_in * H * W
+    out = torch.empty(N, c_out, h_out, w_out, dtype=torch.float32, device=x.device)
+    with _device_guard(x):
+        rc = lib().tfk_conv1x1_frame(x.data_ptr(), x_stride, _f32(weight, name), _f32(bias, name), _f32(out, name),
+                                     N, c_in, c_out, H, W, h_out, w_out, _stream(x))
     calls += 1
     _check(rc, name)
     return out
