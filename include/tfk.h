@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 12
+#define TFK_ABI_VERSION 13
 
 enum {
     TFK_OK = 0,
@@ -260,6 +260,10 @@ int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const floa
 int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, const float *bias, float *out,
                       int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out,
                       void *stream);
+
+/* Bounded conditioner output (conditioning/transforms.py:107-113, used by ConvNetConditioner with (-2, 2)):
+ * out = lo + (hi - lo) * sigmoid(h) over n floats, the three roundings of the reference kept; h may alias out. */
+int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float hi, void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

@@ -84,7 +84,10 @@ class ConditionerTransform(nn.Module):
         if lo > -math.inf and hi < math.inf:
             if torch.is_grad_enabled() and out.requires_grad:
                 out = torch.sigmoid(out) * (hi - lo) + lo
-            else:               # same values, no temporaries (the parameter tensor is the largest one around)
+            elif out.device.type == "cuda" and out.dtype == torch.float32 and out.is_contiguous():
+                from torchflows_amd import native      # same three roundings in one pass (tfk_convblock.hip)
+                out = native.bounded_sigmoid(out, lo, hi)
+            else:
                 out = torch.sigmoid(out).mul_(hi - lo).add_(lo)
         elif lo > -math.inf:
             out = torch.exp(out) + lo

@@ -100,34 +100,75 @@ __global__ __launch_bounds__(kBlock) void k_conv3x3_relu_pool_affine(
 // ConvModifier (classic.py:8-42) with a 1x1 kernel: a channel-mixing GEMM whose result sits in the middle
 // of a larger frame (padding beyond kernel - 1 only adds positions that equal the bias).  One lane per
 // output pixel, all COUT channels; x may be a row-strided view (x_stride floats between images).
-template <int COUT>
+template <int COUT, int PX>
 __global__ __launch_bounds__(kBlock) void k_conv1x1_frame(
     const float *__restrict__ x, long long x_stride, const float *__restrict__ weight,
     const float *__restrict__ bias, float *__restrict__ out, long long N, int C, int H, int W, int HT, int WT,
     int top, int left)
 {
-    const long long total = N * (long long)HT * WT;
+    // PX = 4: four consecutive output pixels per lane, float4 stores (WT % 4 == 0, out 16-byte aligned)
+    const int WQ = WT / PX;
+    const long long total = N * (long long)HT * WQ;
     const long long plane_in = (long long)H * W, plane_out = (long long)HT * WT;
     for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * kBlock) {
-        const int j = (int)(idx % WT);
-        const int i = (int)((idx / WT) % HT);
-        const long long n = idx / plane_out;
-        float acc[COUT];
+        const int j = (int)(idx % WQ) * PX;
+        const int i = (int)((idx / WQ) % HT);
+        const long long n = idx / ((long long)WQ * HT);
+        float acc[COUT][PX];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[co][p] = 0.0f;
         const int ii = i - top, jj = j - left;
-        if (ii >= 0 && ii < H && jj >= 0 && jj < W) {
-            const float *src = x + n * x_stride + (long long)ii * W + jj;
-            for (int c = 0; c < C; ++c) {
-                const float v = src[c * plane_in];
+        if (ii >= 0 && ii < H && jj + PX > 0 && jj < W) {
+            const float *src = x + n * x_stride + (long long)ii * W;
+            bool ok[PX];
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(weight[co * C + c], v, acc[co]);
+            for (int p = 0; p < PX; ++p) ok[p] = (jj + p >= 0) && (jj + p < W);
+            for (int c = 0; c < C; ++c) {
+                float v[PX];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) v[p] = ok[p] ? src[c * plane_in + jj + p] : 0.0f;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float wv = weight[co * C + c];
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) acc[co][p] = fmaf(wv, v[p], acc[co][p]);
+                }
             }
         }
         float *dst = out + n * COUT * plane_out + (long long)i * WT + j;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) dst[co * plane_out] = acc[co] + bias[co];
+        for (int co = 0; co < COUT; ++co) {
+            const float b = bias[co];
+            if (PX == 4) {
+                *reinterpret_cast<float4 *>(dst + co * plane_out) =
+                    make_float4(acc[co][0] + b, acc[co][1] + b, acc[co][2] + b, acc[co][3] + b);
+            } else {
+#pragma unroll
+                for (int p = 0; p < PX; ++p) dst[co * plane_out + p] = acc[co][p] + b;
+            }
+        }
+    }
+}
+
+// Bounded conditioner output (transforms.py:107-113): out = lo + (hi - lo) * sigmoid(h), the
+// reference's three roundings (sigmoid, multiply, add) kept; in may alias h.
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_bounded_sigmoid(const float *in, float *h, long long n, float lo, float range)
+{
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        if (V == 4) {
+            float4 v = reinterpret_cast<const float4 *>(in)[i];
+            v.x = 1.0f / (1.0f + expf(-v.x)) * range + lo;
+            v.y = 1.0f / (1.0f + expf(-v.y)) * range + lo;
+            v.z = 1.0f / (1.0f + expf(-v.z)) * range + lo;
+            v.w = 1.0f / (1.0f + expf(-v.w)) * range + lo;
+            reinterpret_cast<float4 *>(h)[i] = v;
+        } else {
+            h[i] = 1.0f / (1.0f + expf(-in[i])) * range + lo;
+        }
     }
 }
 
@@ -154,18 +195,13 @@ int tfk_conv3x3_relu_pool_affine(const float *x, const float *weight, const floa
     if (N == 0) return TFK_OK;
     if (!x || !weight || !bias || !scale || !shift || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int px = ((W / 2) % 2 == 0) ? 2 : 1;
-    const int64_t total = N * (int64_t)(H / 2) * ((W / 2) / px);
+    // one pooled pixel per lane: 122 VGPRs = 4 waves / SIMD.  Two per lane (PX = 2: shared weights and patch
+    // columns, 160 VGPRs) measured 5-25 % slower on the Glow shapes -- occupancy matters more here.
+    const int64_t total = N * (int64_t)(H / 2) * (W / 2);
     const int grid = grid_for(total, kBlock);
 #define TFK_CB(CI, CO)                                                                                       \
-    do {                                                                                                     \
-        if (px == 2)                                                                                         \
-            hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO, 2>), dim3(grid), dim3(kBlock), 0, s, x,   \
-                               weight, bias, scale, shift, out, (long long)N, H, W);                         \
-        else                                                                                                 \
-            hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO, 1>), dim3(grid), dim3(kBlock), 0, s, x,   \
-                               weight, bias, scale, shift, out, (long long)N, H, W);                         \
-    } while (0)
+    hipLaunchKernelGGL((k_conv3x3_relu_pool_affine<CI, CO, 1>), dim3(grid), dim3(kBlock), 0, s, x, weight,   \
+                       bias, scale, shift, out, (long long)N, H, W)
     if (c_in == 4 && c_out == 8) TFK_CB(4, 8);
     else if (c_in == 8 && c_out == 8) TFK_CB(8, 8);
     else if (c_in == 8 && c_out == 4) TFK_CB(8, 4);
@@ -188,14 +224,34 @@ int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, con
     if (N == 0) return TFK_OK;
     if (!x || !weight || !bias || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(N * (int64_t)H_out * W_out, kBlock);
+    const int px = ((W_out % 4) == 0 && aligned16(out)) ? 4 : 1;
+    const int grid = grid_for(N * (int64_t)H_out * (W_out / px), kBlock);
     const int top = (H_out - H) / 2, left = (W_out - W) / 2;
-    if (c_out == 4)
-        hipLaunchKernelGGL((k_conv1x1_frame<4>), dim3(grid), dim3(kBlock), 0, s, x, (long long)x_stride, weight, bias,
-                           out, (long long)N, c_in, H, W, H_out, W_out, top, left);
+#define TFK_CF(CO, PX)                                                                                          \
+    hipLaunchKernelGGL((k_conv1x1_frame<CO, PX>), dim3(grid), dim3(kBlock), 0, s, x, (long long)x_stride, weight, \
+                       bias, out, (long long)N, c_in, H, W, H_out, W_out, top, left)
+    if (c_out == 4 && px == 4) TFK_CF(4, 4);
+    else if (c_out == 4) TFK_CF(4, 1);
+    else if (px == 4) TFK_CF(1, 4);
+    else TFK_CF(1, 1);
+#undef TFK_CF
+    return check_launch(fn);
+}
+
+int tfk_bounded_sigmoid(const float *in, float *h, int64_t n, float lo, float hi, void *stream)
+{
+    const char *fn = "tfk_bounded_sigmoid";
+    if (n < 0) return fail(TFK_EINVAL, "%s: n = %lld < 0", fn, (long long)n);
+    if (!(lo < hi)) return fail(TFK_EINVAL, "%s: need lo < hi", fn);
+    if (n == 0) return TFK_OK;
+    if (!h || !in) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((n % 4) == 0 && aligned16(h) && aligned16(in))
+        hipLaunchKernelGGL((k_bounded_sigmoid<4>), dim3(grid_for(n / 4, kBlock)), dim3(kBlock), 0, s, in, h,
+                           (long long)(n / 4), lo, hi - lo);
     else
-        hipLaunchKernelGGL((k_conv1x1_frame<1>), dim3(grid), dim3(kBlock), 0, s, x, (long long)x_stride, weight, bias,
-                           out, (long long)N, c_in, H, W, H_out, W_out, top, left);
+        hipLaunchKernelGGL((k_bounded_sigmoid<1>), dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, in, h,
+                           (long long)n, lo, hi - lo);
     return check_launch(fn);
 }
 

@@ -42,10 +42,10 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
     "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
     "tfk_made_affine_sequential",
-    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame",
+    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class NativeError(RuntimeError):
@@ -117,6 +117,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_made_affine_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
     L.tfk_conv3x3_block_supported.argtypes = [_i32, _i32]
     L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
+    L.tfk_bounded_sigmoid.argtypes = [_vp, _vp, _i64, C.c_float, C.c_float, _vp]
     L.tfk_conv1x1_frame.argtypes = [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
@@ -504,6 +505,18 @@ def conv3x3_relu_pool_affine(x, weight, bias, scale, shift):
             _f32(out, name), N, c_in, c_out, H, W)
     with _device_guard(x):
         rc = lib().tfk_conv3x3_relu_pool_affine(*args, _stream(x))
+    calls += 1
+    _check(rc, name)
+    return out
+
+
+def bounded_sigmoid(h: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """``lo + (hi - lo) * sigmoid(h)`` in one pass (ATen: three kernels, two temporaries)."""
+    global calls
+    name = "tfk_bounded_sigmoid"
+    out = torch.empty_like(h)
+    with _device_guard(h):
+        rc = lib().tfk_bounded_sigmoid(_f32(h, name), _f32(out, name), h.numel(), float(lo), float(hi), _stream(h))
     calls += 1
     _check(rc, name)
     return out
