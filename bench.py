@@ -75,7 +75,12 @@ class KernelTimer:
                             # fused training backward: x read, g read + written, gld
                             ("affine_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + 4 * a[1].shape[0]),
                             # RQS training backward: x read, g read + written, gld, dL/dh (768) and dL/dpre (16) written
-                            ("rqs_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + a[1].shape[0] * (4 + 4 * 784))):
+                            ("rqs_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + a[1].shape[0] * (4 + 4 * 784)),
+                            # Glow ConvNet conditioner (csrc/tfk_convblock.hip): input read, output written
+                            ("conv3x3_relu_pool_affine",
+                             lambda a, k: 4 * (a[0].numel() + a[0].shape[0] * a[1].shape[0] * (a[0].shape[2] // 2) * (a[0].shape[3] // 2))),
+                            ("conv1x1_frame", lambda a, k: 4 * (a[0].numel() + a[0].shape[0] * a[1].shape[0] * a[3] * a[4])),
+                            ("bounded_sigmoid", lambda a, k: 8 * a[0].numel())):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -136,6 +141,10 @@ class KernelTimer:
             if name.endswith("_coupling") and name != "conv1x1_coupling":
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
             flops = self._flow_flops(a, name == "flow_run_mfma") if name.startswith("flow_run") else 0
+            if name == "conv3x3_relu_pool_affine":      # 2 * 9 * c_in * c_out per output position of the convolution
+                n_, ci_, hh_, ww_ = a[0].shape
+                variant += f"[{ci_}->{a[1].shape[0]}@{hh_}x{ww_}]"
+                flops = 18 * ci_ * a[1].shape[0] * hh_ * ww_ * n_
             if name == "affine_coupling_train_bwd":
                 # conditioner re-evaluation + MLP backward + weight gradients: 3 x the forward's
                 # 2*(S*H + H*T*P) per row, true (unpadded) hidden width
@@ -363,6 +372,15 @@ def main():
                 rate = valu / (dom["avg_us"] * 1e-6)
                 roofline["valu_insts_per_launch"] = valu
                 roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
+        elif dom_name.startswith("conv3x3_relu_pool_affine"):
+            # direct convolution on the vector ALUs (c_out = 8 would waste half of a 16-wide MFMA tile and
+            # the fp32 MFMA peak equals the vector peak): priced against the fp32 vector peak
+            roofline = {"bound": "valu", "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
+                        "note": "conv3x3 + ReLU + MaxPool + BatchNorm-affine block of the ConvNet conditioner, one "
+                                "launch: 2*9*c_in*c_out FLOPs per convolution output / launch time against the "
+                                "fp32 vector peak",
+                        "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
         else:
             roofline = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
