@@ -331,7 +331,8 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 // programs keep their occupancy).
 // MADE: the program holds MADE ops (their own instantiation: they need more registers).
 template <int EPL, int BLOCK, int HTMAX, bool MADE>
-__global__ __launch_bounds__(BLOCK) void k_flow_run_mfma(
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((EPL == 32 && BLOCK == 768) ? 3 : 1)))
+void k_flow_run_mfma(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
     const float *__restrict__ params, int n_params, MProgram prog, int flags)
@@ -480,6 +481,11 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
         return big ? TFK_MB(512, 1, true) : TFK_MB(kBlock, 1, true);
     }
     if (wide) return big ? TFK_MB(512, 4, false) : TFK_MB(kBlock, 4, false);
+    if constexpr (EPL == 32) {
+        // D = 256: 64 row elements per lane = 181 VGPRs = 2 waves / SIMD, and the parameter block (~85 KB for
+        // 4 layers) allows one workgroup per CU: 768 threads at 168 VGPRs put 3 waves on every SIMD
+        if (big) return TFK_MB(768, 1, false);
+    }
     return big ? TFK_MB(512, 1, false) : TFK_MB(kBlock, 1, false);
 #undef TFK_MB
 }
