@@ -105,7 +105,7 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int e = 2 * t + i;
-                const float al = aff_alpha(o[2 * i]);               // affine.py:33-34
+                const float al = aff_alpha_lean(o[2 * i]);          // affine.py:33-34
                 const float be = o[2 * i + 1];
                 part += log_normal(al);                             // affine.py:42
                 if constexpr (KIND == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
@@ -163,7 +163,7 @@ __device__ __forceinline__ void made_m(const MOp op, const float *prm, int lane,
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + k) * 64 + lane], hid[k], o, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float al = aff_alpha(o[2 * i]);
+            const float al = aff_alpha_lean(o[2 * i]);
             const float be = o[2 * i + 1];
             part += log_normal(al);
             float &v = (t < T2) ? a[2 * t + i] : b[2 * (t - T2) + i];

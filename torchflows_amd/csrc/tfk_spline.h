@@ -62,8 +62,9 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
         float sx = 0.0f, sy = 0.0f;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {                     // softmax numerators, :46
-            ex[j] = exp_noovf(ex[j] - mx);                 // argument <= 0
-            ey[j] = exp_noovf(ey[j] - my);
+            // argument <= 0; the flow programs (REGS) are VALU-issue bound: 6-op exp, within 1 ulp
+            ex[j] = REGS ? exp_lean(ex[j] - mx) : exp_noovf(ex[j] - mx);
+            ey[j] = REGS ? exp_lean(ey[j] - my) : exp_noovf(ey[j] - my);
             sx += ex[j];
             sy += ey[j];
         }
