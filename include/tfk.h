@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 13
+#define TFK_ABI_VERSION 14
 
 enum {
     TFK_OK = 0,
@@ -283,6 +283,10 @@ int tfk_shift_coupling_bwd(const float *g, float *gh, int64_t N, int32_t D, cons
                            int32_t T, int32_t inverse, void *stream);
 int tfk_rqs_coupling_bwd_supported(int32_t n_bins);             /* 4, 8, 16 */
 int tfk_rqs_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
+                         int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t n_bins,
+                         float boundary, int32_t inverse, void *stream);
+/* linear rational spline (linear_rational.py:33-182), n_bins in {4, 8}; h / gh (N, T, 4 n_bins) */
+int tfk_lrs_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh,
                          int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T, int32_t n_bins,
                          float boundary, int32_t inverse, void *stream);
 /* ElementwiseAffine / ActNorm with batch-constant value (D, 2): g updated in place over all D

@@ -465,6 +465,32 @@ def gen_grads_maf():
     _flow_grads("flow_marqnsf5.npz", MaskedAutoregressiveRQNSF, 5, dict(n_layers=2))
 
 
+def gen_grads_lrs():
+    """Linear rational spline: the reference's autograd at transformer level (inputs of lrs.npz) and
+    through CouplingLRS(16)."""
+    from torchflows.bijections.finite.autoregressive.transformers.spline.linear_rational import LinearRational
+    from torchflows.bijections.finite.autoregressive.architectures import CouplingLRS
+    lr = np.load(os.path.join(OUT, "lrs.npz"))
+    out, cases = {}, []
+    torch.manual_seed(11)
+    for tag, boundary, n_bins in (("B50_K8", 50.0, 8), ("B5_K8", 5.0, 8), ("B5_K4", 5.0, 4)):
+        x = torch.from_numpy(lr[f"{tag}_x"])
+        h = torch.from_numpy(lr[f"{tag}_h"])
+        tr = LinearRational((x.shape[1],), boundary=boundary, n_bins=n_bins)
+        gz, gld = torch.randn(*x.shape), torch.randn(x.shape[0])
+        out[f"{tag}_gz"], out[f"{tag}_gld"] = np32(gz), np32(gld)
+        for inverse in (False, True):
+            for dt, t2 in ((torch.float32, ""), (torch.float64, "64")):
+                gx, gh = _tr_grads(tr, x, h, gz, gld, inverse, dt)
+                d = "inv" if inverse else "fwd"
+                out[f"{tag}_{d}_gx{t2}"] = gx
+                out[f"{tag}_{d}_gh{t2}"] = gh
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    save("grads_lrs.npz", **out)
+    _flow_grads("flow_lrs16.npz", CouplingLRS, 16, dict(n_layers=3))
+
+
 # ---------------------------------------------------------------- F9 sibling layers (SURVEY 8f-4)
 def gen_siblings():
     from torchflows.bijections.finite.autoregressive.layers import (

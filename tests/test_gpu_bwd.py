@@ -60,6 +60,9 @@ def run_coupling_bwd(native, kind, x_rows, h, g_rows, gld, tgt, masked, inverse,
     before = native.calls
     if kind == "affine":
         native.affine_coupling_bwd(dev(x_rows), dev(h), g, dev(gld), gh, t_idx, T, inverse=inverse)
+    elif kind == "lrs":
+        native.lrs_coupling_bwd(dev(x_rows), dev(h), g, dev(gld), gh, t_idx, T, kw["n_bins"],
+                                kw["boundary"], inverse=inverse)
     else:
         native.rqs_coupling_bwd(dev(x_rows), dev(h), g, dev(gld), gh, t_idx, T, kw["n_bins"],
                                 kw["boundary"], inverse=inverse)
@@ -159,6 +162,28 @@ def test_rqs_bwd_golden(native):
                 bound = (1e-4 * np.maximum(1.0, np.abs(r64)) + 4 * np.abs(r32 - r64))[regular]
                 bad = int((err > bound).sum())
                 print(f"rqs {tag} {d} {key}: max err {err.max():.2e}, beyond bound {bad} of {err.size}")
+                assert np.isfinite(mine).all()
+                assert bad == 0
+
+
+def test_lrs_bwd_golden(native):
+    """tfk_lrs_coupling_bwd against the reference's autograd through LinearRational.forward / inverse
+    (tests/golden/grads_lrs.npz, fp32 and fp64) on the stress inputs of lrs.npz: per element within
+    1e-4 * max(1, |ref|) + 4 x the reference's own fp32-vs-fp64 distance."""
+    gr, lr = load_golden("grads_lrs.npz"), load_golden("lrs.npz")
+    for tag, B, K in (("B50_K8", 50.0, 8), ("B5_K8", 5.0, 8), ("B5_K4", 5.0, 4)):
+        x, h = lr[f"{tag}_x"], lr[f"{tag}_h"]
+        T = x.shape[1]
+        tgt = np.arange(T, dtype=np.int32)
+        for inverse, d in ((False, "fwd"), (True, "inv")):
+            g, gh = run_coupling_bwd(native, "lrs", x, h, gr[f"{tag}_gz"], gr[f"{tag}_gld"], tgt, False, inverse,
+                                     n_bins=K, boundary=B)
+            for mine, key in ((g, "gx"), (gh, "gh")):
+                r32, r64 = gr[f"{tag}_{d}_{key}"], gr[f"{tag}_{d}_{key}64"]
+                err = np.abs(mine - r64)
+                bound = 1e-4 * np.maximum(1.0, np.abs(r64)) + 4 * np.abs(r32 - r64)
+                bad = int((err > bound).sum())
+                print(f"lrs {tag} {d} {key}: max err {err.max():.2e}, beyond bound {bad} of {err.size}")
                 assert np.isfinite(mine).all()
                 assert bad == 0
 

@@ -116,9 +116,11 @@ def test_flow_grads_vs_oracle_large_batch(native, oracle, arch, D, n_layers):
 
 
 @pytest.mark.parametrize("arch,D,direction", [("MAF", 64, "log_prob"), ("MaskedAutoregressiveRQNSF", 16, "log_prob"),
-                                              ("IAF", 64, "inverse")])
+                                              ("IAF", 64, "inverse"), ("CouplingLRS", 16, "log_prob"),
+                                              ("CouplingLRS", 64, "inverse"), ("MaskedAutoregressiveLRS", 8, "log_prob")])
 def test_made_flow_grads_vs_fp64(native, arch, D, direction):
-    """MADE-based flows, parallel direction (MAF density, IAF sampling), 4 096 seeded rows: the HIP
+    """MADE-based flows, parallel direction (MAF density, IAF sampling), and linear-rational-spline flows
+    (both directions of the coupling), 4 096 seeded rows: the HIP
     gradient must be as close to fp64 autograd (ATen composite path on the host) as the host's own
     fp32 autograd is (3x), or within 1e-5 norm-wise; the chain must be ONE autograd node."""
     import copy

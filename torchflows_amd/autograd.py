@@ -54,6 +54,8 @@ def _step_kind(layer) -> Optional[str]:
             return "made"
         if kind == "rqs" and native.lib().tfk_rqs_coupling_bwd_supported(int(layer.transformer.n_bins)):
             return "made"
+        if kind == "lrs" and int(layer.transformer.n_bins) in (4, 8):
+            return "made"
         return None
     if isinstance(layer, ElementwiseBijection):
         ok = layer.use_global_parameters and layer.transformer.native_kind in ("affine", "inverse_affine")
@@ -65,6 +67,8 @@ def _step_kind(layer) -> Optional[str]:
         if kind in ("affine", "inverse_affine", "shift"):
             return "coupling"
         if kind == "rqs" and native.lib().tfk_rqs_coupling_bwd_supported(int(layer.transformer.n_bins)):
+            return "coupling"
+        if kind == "lrs" and int(layer.transformer.n_bins) in (4, 8):
             return "coupling"
     return None
 
@@ -532,6 +536,9 @@ class ChainFunction(torch.autograd.Function):
                 if tk == "rqs":
                     native.rqs_coupling(cur, h, out, logdet, None, D, tr.n_bins, tr.boundary,
                                         accumulate=started, inverse=False)
+                elif tk == "lrs":
+                    native.lrs_coupling(cur, h, out, logdet, None, D, tr.n_bins, tr.boundary,
+                                        accumulate=started, inverse=False)
                 else:       # the parallel pass always applies transformer.forward (layers_base.py:196-199)
                     native.affine_coupling(cur, h, out, logdet, None, D, accumulate=started,
                                            inverse=(tk == "inverse_affine"))
@@ -590,6 +597,9 @@ class ChainFunction(torch.autograd.Function):
                                            inverse=_affine_form_is_inverse(layer, d))
                 elif tk == "rqs":
                     native.rqs_coupling(cur, h, out, logdet, tgt, T, layer.transformer.n_bins,
+                                        layer.transformer.boundary, accumulate=started, inverse=(d == INVERSE))
+                elif tk == "lrs":
+                    native.lrs_coupling(cur, h, out, logdet, tgt, T, layer.transformer.n_bins,
                                         layer.transformer.boundary, accumulate=started, inverse=(d == INVERSE))
                 else:
                     native.shift_coupling(cur, h, out, logdet, tgt, T, accumulate=started, inverse=(d == INVERSE))
@@ -659,6 +669,8 @@ class ChainFunction(torch.autograd.Function):
                 gh = torch.empty_like(hc)
                 if tk == "rqs":
                     native.rqs_coupling_bwd(x_in, hc, g, gld, gh, None, D, tr.n_bins, tr.boundary, inverse=False)
+                elif tk == "lrs":
+                    native.lrs_coupling_bwd(x_in, hc, g, gld, gh, None, D, tr.n_bins, tr.boundary, inverse=False)
                 else:
                     native.affine_coupling_bwd(x_in, hc, g, gld, gh, None, D, inverse=(tk == "inverse_affine"))
                 if mlp is not None:
@@ -744,6 +756,9 @@ class ChainFunction(torch.autograd.Function):
                                                inverse=_affine_form_is_inverse(layer, d))
                 elif tk == "rqs":
                     native.rqs_coupling_bwd(x_in, hc, g, gld, gh, tgt, T, layer.transformer.n_bins,
+                                            layer.transformer.boundary, inverse=(d == INVERSE))
+                elif tk == "lrs":
+                    native.lrs_coupling_bwd(x_in, hc, g, gld, gh, tgt, T, layer.transformer.n_bins,
                                             layer.transformer.boundary, inverse=(d == INVERSE))
                 else:
                     native.shift_coupling_bwd(g, gh, tgt, T, inverse=(d == INVERSE))

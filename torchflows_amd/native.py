@@ -35,7 +35,7 @@ SYMBOLS = (
     "tfk_flow_supported", "tfk_flow_run",
     "tfk_flow_mfma_supported", "tfk_flow_run_mfma",
     "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
-    "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd",
+    "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd", "tfk_lrs_coupling_bwd",
     "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
     "tfk_diag_gauss_logprob_bwd",
     "tfk_coupling_train_bwd_supported", "tfk_coupling_train_bwd_out_floats",
@@ -45,7 +45,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class NativeError(RuntimeError):
@@ -99,6 +99,8 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_shift_coupling_bwd.argtypes = [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
     L.tfk_rqs_coupling_bwd_supported.argtypes = [_i32]
     L.tfk_rqs_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32,
+                                       C.c_float, _i32, _vp]
+    L.tfk_lrs_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32,
                                        C.c_float, _i32, _vp]
     L.tfk_elementwise_affine_bwd_workspace_bytes.argtypes = [_i64, _i32]
     L.tfk_elementwise_affine_bwd_workspace_bytes.restype = _i64
@@ -387,6 +389,21 @@ def rqs_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_bins, boundary, inverse=Fal
             _idx(tgt_idx, name), T, int(n_bins), C.c_float(float(boundary)), 1 if inverse else 0)
     with _device_guard(g):
         rc = lib().tfk_rqs_coupling_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def lrs_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_bins, boundary, inverse=False):
+    global calls
+    name = "tfk_lrs_coupling_bwd"
+    N, D = _bwd_common(name, x, g, gld, tgt_idx, T)
+    P = 4 * int(n_bins)
+    if h.numel() != N * T * P or gh.numel() != N * T * P:
+        raise NativeError(f"{name}: h / gh must hold N*T*P = {N * T * P} elements")
+    args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
+            _idx(tgt_idx, name), T, int(n_bins), C.c_float(float(boundary)), 1 if inverse else 0)
+    with _device_guard(g):
+        rc = lib().tfk_lrs_coupling_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
 
