@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 14
+#define TFK_ABI_VERSION 15
 
 enum {
     TFK_OK = 0,
@@ -243,6 +243,17 @@ int tfk_lrs_coupling_inv(const float *z, const float *h, float *x, float *logdet
 int tfk_made_affine_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
                                const float *W1t, const float *b1, const float *W2, const float *b2,
                                int32_t hidden_padded, int32_t divide, int32_t accumulate, void *stream);
+
+/* The same walk for a MADE-based rational-quadratic spline layer (n_bins = 8): element i's 23 parameters
+ * come from rows [23 i, 23 i + 23) of W2 (D, 23, hidden_padded), b2 (D, 23); the spline is inverted
+ * (rational_quadratic.py:147-200).  hidden_padded in {8, 16}.  The log-det is the one the reference returns:
+ * that of its LAST pass (layers_base.py:213-221), i.e. elements j < D-1 evaluated at their inverted values.
+ * tfk_made_rqs_sequential_lds_bytes: LDS the launch needs at its smallest workgroup (must be <= 160 KiB). */
+int64_t tfk_made_rqs_sequential_lds_bytes(int32_t D, int32_t hidden_padded, int32_t n_bins);
+int tfk_made_rqs_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
+                            const float *W1t, const float *b1, const float *W2, const float *b2,
+                            int32_t hidden_padded, int32_t n_bins, float boundary, int32_t accumulate,
+                            void *stream);
 
 /* One block of the Glow ConvNet conditioner (multiscale/conditioning/classic.py, ConvNetBlock.forward) in
  * one launch: conv3x3 (padding 1) -> ReLU -> MaxPool2d(2) -> inference BatchNorm2d given as per-channel

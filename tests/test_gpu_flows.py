@@ -300,3 +300,53 @@ def test_made_sequential_map_in_one_launch(pkg, oracle, arch, D, n_hidden):
              xr=rel(xr.cpu().numpy(), xr_ref), ldi=rel(ldi.cpu().numpy(), ldi_ref))
     print(arch, D, n_hidden, launches, {k: f"{v:.1e}" for k, v in e.items()})
     assert max(e.values()) < 1e-5 * max(1.0, D / 64), e
+
+
+@pytest.mark.parametrize("arch", ["MaskedAutoregressiveRQNSF", "InverseAutoregressiveRQNSF"])
+@pytest.mark.parametrize("D,n_hidden", [(5, None), (16, 12), (64, None)])
+def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch, D, n_hidden):
+    """The sequential map of MADE-based RQ-spline layers as ONE launch per layer (tfk_made_rqs_sequential),
+    including the reference's last-pass log-det (layers_base.py:213-221): parity with the oracle's D-pass
+    restatement and with this package's own D-pass loop on the device."""
+    from torchflows_amd import native
+    torch.manual_seed(D + (n_hidden or 0))
+    kw = dict(n_layers=2)
+    if n_hidden is not None:
+        kw["conditioner_kwargs"] = dict(n_hidden=n_hidden)
+    flow = pkg.Flow(getattr(pkg, arch)(D, **kw))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(2048, D))
+    flow.eval()
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, 2, sd)
+    x = torch.randn(160, D) * 1.5
+    seq = "inverse" if arch.startswith("Masked") else "forward"
+    import copy
+    with torch.no_grad():                      # the ATen composite path on the host: fp64 truth, fp32 floor
+        y64, ld64 = getattr(copy.deepcopy(flow).double().bijection, seq)(x.double())
+        y32, ld32 = getattr(flow.bijection, seq)(x)
+    floor = max(rel(y32.numpy(), y64.numpy()), rel(ld32.numpy(), ld64.numpy()))
+    flow = flow.cuda()
+
+    def run():
+        before = native.calls
+        with torch.no_grad():
+            out = getattr(flow.bijection, seq)(x.cuda())
+        return out, native.calls - before
+
+    (y, ld), launches = run()
+    assert launches <= 2 * len(flow.bijection.layers), launches          # no D-pass loops
+    monkeypatch.setenv("TORCHFLOWS_AMD_MADE_FUSED", "0")
+    (y_loop, ld_loop), launches_loop = run()
+    monkeypatch.setenv("TORCHFLOWS_AMD_MADE_FUSED", "1")
+    assert launches_loop >= 2 * D
+    y_ref, ld_ref = getattr(ref, seq)(x.numpy())
+    e = dict(y=rel(y.cpu().numpy(), y64.numpy()), ld=rel(ld.cpu().numpy(), ld64.numpy()),
+             y_oracle=rel(y_ref, y64.numpy()), ld_oracle=rel(ld_ref, ld64.numpy()),
+             y_loop=rel(y_loop.cpu().numpy(), y64.numpy()), ld_loop=rel(ld_loop.cpu().numpy(), ld64.numpy()))
+    print(arch, D, n_hidden, launches, launches_loop, f"floor {floor:.1e}", {k: f"{v:.1e}" for k, v in e.items()})
+    # every element's spline parameters depend on the elements inverted before it: rounding differences are
+    # amplified along the row, so each implementation is held to the fp64 result at 3x the host's own
+    # fp32-vs-fp64 distance (or 4e-5)
+    assert max(e.values()) < max(4e-5, 3 * floor), (e, floor)

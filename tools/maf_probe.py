@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""MAF(64, 8 layers) sampling = the sequential map: one launch per layer vs the reference's D passes."""
+"""MAF(64, 8 layers) sampling = the sequential map: one launch per layer vs the reference's D passes.
+Usage: maf_probe.py [MAF|MaskedAutoregressiveRQNSF]"""
 import os, sys, time, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import torchflows_amd as tfa
 torch.manual_seed(0)
-flow = tfa.Flow(tfa.MAF(64, n_layers=8))
+arch = sys.argv[1] if len(sys.argv) > 1 else "MAF"
+flow = tfa.Flow(getattr(tfa, arch)(64, n_layers=8))
 flow.train()
 with torch.no_grad():
     flow.log_prob(torch.randn(4096, 64))

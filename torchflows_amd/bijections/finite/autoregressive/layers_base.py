@@ -261,17 +261,22 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
                                 accumulate=accumulate, inverse=transformer_inverse)
 
     def _made_pack(self):
-        """(W1t, b1, W2, b2) for tfk_made_affine_sequential -- masked, transposed, zero-padded to
-        8 / 16 / 32 / 64 hidden units -- when the layer qualifies (affine transformer, MADE with two
-        masked linear layers and no global parameters); cached until a weight changes."""
+        """(W1t, b1, W2, b2) for tfk_made_affine_sequential / tfk_made_rqs_sequential -- masked,
+        transposed, zero-padded to 8 / 16 / 32 / 64 hidden units -- when the layer qualifies (affine or
+        8-bin RQ-spline transformer, MADE with two masked linear layers and no global parameters); cached
+        until a weight changes."""
         import os
         import torch.nn as nn
         from torchflows_amd import fused
         if os.environ.get("TORCHFLOWS_AMD_MADE_FUSED", "1") == "0":      # (comparison runs)
             return None
         ct = self.conditioner_transform
-        if self.transformer.native_kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+        kind = self.transformer.native_kind
+        if kind == "rqs" and self.transformer.n_bins != 8:
             return None
+        if kind not in ("affine", "inverse_affine", "rqs") or ct.n_global_parameters != 0:
+            return None
+        P = 23 if kind == "rqs" else 2
         mods = list(ct.sequential)
         if not (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
                 and isinstance(mods[2], MADE.MaskedLinear)):
@@ -285,7 +290,10 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
         if hit is not None and hit[0] == version:
             return hit[1]
         HP = 8 if H <= 8 else (16 if H <= 16 else (32 if H <= 32 else 64))
-        if 4 * (3 * D * HP + HP + 2 * D) + 4 * 64 * (D + 1) > 160 * 1024:
+        if kind == "rqs":
+            if HP > 16 or native.lib().tfk_made_rqs_sequential_lds_bytes(D, HP, 8) > 160 * 1024:
+                return None
+        elif 4 * (3 * D * HP + HP + 2 * D) + 4 * 64 * (D + 1) > 160 * 1024:
             return None                                  # weights + 64 staged rows do not fit the LDS
         with torch.no_grad():
             w1 = mods[0].weight * mods[0].mask                       # (H, D)
@@ -294,9 +302,9 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
             W1t[:, :H] = w1.t()
             b1 = w1.new_zeros(HP)
             b1[:H] = mods[0].bias
-            W2 = w1.new_zeros(D, 2, HP)
-            W2[:, :, :H] = w2.view(D, 2, H)
-            b2 = mods[2].bias.detach().view(D, 2).contiguous()
+            W2 = w1.new_zeros(D, P, HP)
+            W2[:, :, :H] = w2.view(D, P, H)
+            b2 = mods[2].bias.detach().view(D, P).contiguous()
         packed = (W1t.contiguous(), b1, W2.contiguous(), b2)
         self.__dict__["_tfk_made_pack"] = (version, packed)
         return packed
@@ -313,8 +321,12 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
         packed = self._made_pack() if context is None else None
         if packed is not None:                               # the D passes in ONE launch (tfk_made.hip)
             out = rows if state.owned else state.out_buffer()
-            divide = self.transformer.native_kind == "affine"      # Affine.inverse divides
-            native.made_affine_sequential(rows, out, state.logdet, *packed, divide, accumulate=state.started)
+            if self.transformer.native_kind == "rqs":
+                native.made_rqs_sequential(rows, out, state.logdet, *packed, self.transformer.n_bins,
+                                           self.transformer.boundary, accumulate=state.started)
+            else:
+                divide = self.transformer.native_kind == "affine"      # Affine.inverse divides
+                native.made_affine_sequential(rows, out, state.logdet, *packed, divide, accumulate=state.started)
             state.started = True
             state.commit(out)
             return
