@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 15
+#define TFK_ABI_VERSION 16
 
 enum {
     TFK_OK = 0,
@@ -251,6 +251,12 @@ int tfk_made_affine_sequential(const float *z, float *x, float *logdet, int64_t 
  * tfk_made_rqs_sequential_lds_bytes: LDS the launch needs at its smallest workgroup (must be <= 160 KiB). */
 int64_t tfk_made_rqs_sequential_lds_bytes(int32_t D, int32_t hidden_padded, int32_t n_bins);
 int tfk_made_rqs_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
+                            const float *W1t, const float *b1, const float *W2, const float *b2,
+                            int32_t hidden_padded, int32_t n_bins, float boundary, int32_t accumulate,
+                            void *stream);
+/* ... and for a MADE-based linear rational spline layer (n_bins = 8): W2 (D, 32, hidden_padded), b2 (D, 32). */
+int64_t tfk_made_lrs_sequential_lds_bytes(int32_t D, int32_t hidden_padded, int32_t n_bins);
+int tfk_made_lrs_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
                             const float *W1t, const float *b1, const float *W2, const float *b2,
                             int32_t hidden_padded, int32_t n_bins, float boundary, int32_t accumulate,
                             void *stream);

@@ -302,10 +302,11 @@ def test_made_sequential_map_in_one_launch(pkg, oracle, arch, D, n_hidden):
     assert max(e.values()) < 1e-5 * max(1.0, D / 64), e
 
 
-@pytest.mark.parametrize("arch", ["MaskedAutoregressiveRQNSF", "InverseAutoregressiveRQNSF"])
+@pytest.mark.parametrize("arch", ["MaskedAutoregressiveRQNSF", "InverseAutoregressiveRQNSF",
+                                  "MaskedAutoregressiveLRS", "InverseAutoregressiveLRS"])
 @pytest.mark.parametrize("D,n_hidden", [(5, None), (16, 12), (64, None)])
 def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch, D, n_hidden):
-    """The sequential map of MADE-based RQ-spline layers as ONE launch per layer (tfk_made_rqs_sequential),
+    """The sequential map of MADE-based spline layers as ONE launch per layer (tfk_made_{rqs,lrs}_sequential),
     including the reference's last-pass log-det (layers_base.py:213-221): parity with the oracle's D-pass
     restatement and with this package's own D-pass loop on the device."""
     from torchflows_amd import native

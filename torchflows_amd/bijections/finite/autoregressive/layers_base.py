@@ -272,11 +272,11 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
             return None
         ct = self.conditioner_transform
         kind = self.transformer.native_kind
-        if kind == "rqs" and self.transformer.n_bins != 8:
+        if kind in ("rqs", "lrs") and self.transformer.n_bins != 8:
             return None
-        if kind not in ("affine", "inverse_affine", "rqs") or ct.n_global_parameters != 0:
+        if kind not in ("affine", "inverse_affine", "rqs", "lrs") or ct.n_global_parameters != 0:
             return None
-        P = 23 if kind == "rqs" else 2
+        P = {"rqs": 23, "lrs": 32}.get(kind, 2)
         mods = list(ct.sequential)
         if not (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
                 and isinstance(mods[2], MADE.MaskedLinear)):
@@ -290,8 +290,10 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
         if hit is not None and hit[0] == version:
             return hit[1]
         HP = 8 if H <= 8 else (16 if H <= 16 else (32 if H <= 32 else 64))
-        if kind == "rqs":
-            if HP > 16 or native.lib().tfk_made_rqs_sequential_lds_bytes(D, HP, 8) > 160 * 1024:
+        if kind in ("rqs", "lrs"):
+            need = (native.lib().tfk_made_rqs_sequential_lds_bytes if kind == "rqs"
+                    else native.lib().tfk_made_lrs_sequential_lds_bytes)
+            if HP > 16 or need(D, HP, 8) > 160 * 1024:
                 return None
         elif 4 * (3 * D * HP + HP + 2 * D) + 4 * 64 * (D + 1) > 160 * 1024:
             return None                                  # weights + 64 staged rows do not fit the LDS
@@ -321,9 +323,10 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
         packed = self._made_pack() if context is None else None
         if packed is not None:                               # the D passes in ONE launch (tfk_made.hip)
             out = rows if state.owned else state.out_buffer()
-            if self.transformer.native_kind == "rqs":
+            if self.transformer.native_kind in ("rqs", "lrs"):
                 native.made_rqs_sequential(rows, out, state.logdet, *packed, self.transformer.n_bins,
-                                           self.transformer.boundary, accumulate=state.started)
+                                           self.transformer.boundary, accumulate=state.started,
+                                           lrs=self.transformer.native_kind == "lrs")
             else:
                 divide = self.transformer.native_kind == "affine"      # Affine.inverse divides
                 native.made_affine_sequential(rows, out, state.logdet, *packed, divide, accumulate=state.started)

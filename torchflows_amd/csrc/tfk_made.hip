@@ -18,6 +18,7 @@
 // weights are LDS broadcasts.  bytes per row: 8 D + 4 (+4).
 #include "tfk_common.h"
 #include "tfk_spline.h"
+#include "tfk_lrs.h"
 
 namespace tfk {
 
@@ -126,14 +127,24 @@ static int launch_made(const float *z, float *x, float *logdet, int64_t N, int D
 //   elements j < D-1 already hold their inverted values: sum_{j<D-1} ld_inv(x_j; h_j) + ld_inv(z_{D-1};
 //   h_{D-1}) -- for a spline this is NOT the log-det of the map; it is reproduced here (a second
 //   evaluation at x_j), so that the drop-in returns what the reference returns.
+// LRS: the linear rational spline instead (MaskedAutoregressiveLRS / InverseAutoregressiveLRS; 4K parameters
+// per element, linear_rational.py:137-182).
 // Dynamic LDS: W1t[D][HMAX] | b1[HMAX] | W2[D][P][HMAX] | b2[D][P] | rows[BLOCK][D + 1]
-template <int HMAX, int KT>
+template <int KT, bool LRS, typename CT>
+__device__ __forceinline__ void spline_inverse(const float (&p)[LRS ? 4 * KT : 3 * KT - 1], float v, const CT &C,
+                                               float &out, float &l)
+{
+    if constexpr (LRS) lrs_eval<KT, true>(p, v, C, out, l);
+    else rqs_eval<KT, true, false, float[3 * KT - 1]>(p, KT, v, C, out, l);
+}
+
+template <int HMAX, int KT, bool LRS, typename CT>
 __global__ void k_made_rqs_sequential(
     const float *__restrict__ z, float *__restrict__ x, float *logdet, long long N, int D,
     const float *__restrict__ W1t, const float *__restrict__ b1, const float *__restrict__ W2,
-    const float *__restrict__ b2, RqsConst C, int accumulate)
+    const float *__restrict__ b2, CT C, int accumulate)
 {
-    constexpr int P = 3 * KT - 1;
+    constexpr int P = LRS ? 4 * KT : 3 * KT - 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *w1 = lds;
     float *bb1 = w1 + D * HMAX;
@@ -178,11 +189,11 @@ __global__ void k_made_rqs_sequential(
                 }
                 const float v = mine[i];
                 float out = v, l = 0.0f;                             // identity outside the box
-                if (v > C.minimum && v < C.maximum) rqs_eval<KT, true, false, float[P]>(p, KT, v, C, out, l);
+                if (v > C.minimum && v < C.maximum) spline_inverse<KT, LRS>(p, v, C, out, l);
                 if (i < D - 1) {                                     // what the reference's last pass sees
                     float o2 = out;
                     l = 0.0f;
-                    if (out > C.minimum && out < C.maximum) rqs_eval<KT, true, false, float[P]>(p, KT, out, C, o2, l);
+                    if (out > C.minimum && out < C.maximum) spline_inverse<KT, LRS>(p, out, C, o2, l);
                 }
                 ld += l;
                 mine[i] = out;
@@ -201,18 +212,18 @@ __global__ void k_made_rqs_sequential(
     }
 }
 
-template <int HMAX, int KT>
+template <int HMAX, int KT, bool LRS, typename CT>
 static int launch_made_rqs(const float *z, float *x, float *logdet, int64_t N, int D, const float *W1t,
-                           const float *b1, const float *W2, const float *b2, const RqsConst &C, int accumulate,
+                           const float *b1, const float *W2, const float *b2, const CT &C, int accumulate,
                            hipStream_t s, const char *fn)
 {
-    constexpr int P = 3 * KT - 1;
+    constexpr int P = LRS ? 4 * KT : 3 * KT - 1;
     const size_t weights = ((size_t)D * HMAX + HMAX + (size_t)P * D * HMAX + (size_t)P * D) * sizeof(float);
     int block = 256;
     while (block > 64 && weights + (size_t)block * (D + 1) * sizeof(float) > 150 * 1024) block >>= 1;
     const size_t lds = weights + (size_t)block * (D + 1) * sizeof(float);
     if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: D = %d, hidden <= %d needs %zu bytes of LDS", fn, D, HMAX, lds);
-    const void *kern = reinterpret_cast<const void *>(&k_made_rqs_sequential<HMAX, KT>);
+    const void *kern = reinterpret_cast<const void *>(&k_made_rqs_sequential<HMAX, KT, LRS, CT>);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -220,7 +231,7 @@ static int launch_made_rqs(const float *z, float *x, float *logdet, int64_t N, i
     }
     int64_t grid = (N + block - 1) / block;
     if (grid > kMaxGrid) grid = kMaxGrid;
-    hipLaunchKernelGGL((k_made_rqs_sequential<HMAX, KT>), dim3((int)grid), dim3(block), lds, s, z, x, logdet,
+    hipLaunchKernelGGL((k_made_rqs_sequential<HMAX, KT, LRS, CT>), dim3((int)grid), dim3(block), lds, s, z, x, logdet,
                        (long long)N, D, W1t, b1, W2, b2, C, accumulate);
     return check_launch(fn);
 }
@@ -251,6 +262,36 @@ int tfk_made_affine_sequential(const float *z, float *x, float *logdet, int64_t 
     }
 }
 
+int64_t tfk_made_lrs_sequential_lds_bytes(int32_t D, int32_t hidden_padded, int32_t n_bins)
+{
+    const int64_t P = 4 * (int64_t)n_bins;
+    return 4 * ((int64_t)D * hidden_padded + hidden_padded + P * D * hidden_padded + P * D) + 4 * 64 * ((int64_t)D + 1);
+}
+
+int tfk_made_lrs_sequential(const float *z, float *x, float *logdet, int64_t N, int32_t D,
+                            const float *W1t, const float *b1, const float *W2, const float *b2,
+                            int32_t hidden_padded, int32_t n_bins, float boundary, int32_t accumulate,
+                            void *stream)
+{
+    const char *fn = "tfk_made_lrs_sequential";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D < 1 || D > 1024) return fail(TFK_EINVAL, "%s: D = %d not in [1, 1024]", fn, D);
+    if (hidden_padded != 8 && hidden_padded != 16) return fail(TFK_EINVAL, "%s: hidden_padded = %d must be 8 or 16", fn, hidden_padded);
+    if (n_bins != 8) return fail(TFK_EINVAL, "%s: n_bins = %d (the kernel is built for 8)", fn, n_bins);
+    if (!(boundary > 0.0f)) return fail(TFK_EINVAL, "%s: boundary must be positive", fn);
+    if (N == 0) return TFK_OK;
+    if (!z || !x || !logdet || !W1t || !b1 || !W2 || !b2) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    LrsConst C;
+    C.minimum = -boundary;
+    C.maximum = boundary;
+    C.span = (float)((double)boundary + (double)boundary);
+    C.scale = (float)(1.0 - 1e-2 * (double)n_bins);
+    C.c = (float)log(exp(1.0 - 1e-5) - 1.0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hidden_padded == 8) return launch_made_rqs<8, 8, true>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
+    return launch_made_rqs<16, 8, true>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
+}
+
 int64_t tfk_made_rqs_sequential_lds_bytes(int32_t D, int32_t hidden_padded, int32_t n_bins)
 {
     const int64_t P = 3 * (int64_t)n_bins - 1;
@@ -278,8 +319,8 @@ int tfk_made_rqs_sequential(const float *z, float *x, float *logdet, int64_t N, 
     C.scale = (float)(1.0 - 1e-3 * (double)n_bins);
     C.c = (float)log(expm1(1.0 - 1e-5));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hidden_padded == 8) return launch_made_rqs<8, 8>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
-    return launch_made_rqs<16, 8>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
+    if (hidden_padded == 8) return launch_made_rqs<8, 8, false>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
+    return launch_made_rqs<16, 8, false>(z, x, logdet, N, D, W1t, b1, W2, b2, C, accumulate, s, fn);
 }
 
 }  // extern "C"

@@ -42,10 +42,11 @@ SYMBOLS = (
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
     "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
     "tfk_made_affine_sequential", "tfk_made_rqs_sequential_lds_bytes", "tfk_made_rqs_sequential",
+    "tfk_made_lrs_sequential_lds_bytes", "tfk_made_lrs_sequential",
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class NativeError(RuntimeError):
@@ -120,6 +121,9 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_made_rqs_sequential_lds_bytes.argtypes = [_i32, _i32, _i32]
     L.tfk_made_rqs_sequential_lds_bytes.restype = _i64
     L.tfk_made_rqs_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32, _vp]
+    L.tfk_made_lrs_sequential_lds_bytes.argtypes = [_i32, _i32, _i32]
+    L.tfk_made_lrs_sequential_lds_bytes.restype = _i64
+    L.tfk_made_lrs_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32, _vp]
     L.tfk_conv3x3_block_supported.argtypes = [_i32, _i32]
     L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
     L.tfk_bounded_sigmoid.argtypes = [_vp, _vp, _i64, C.c_float, C.c_float, _vp]
@@ -510,20 +514,21 @@ def made_affine_sequential(z, out, logdet, W1t, b1, W2, b2, divide, accumulate=F
     _check(rc, name)
 
 
-def made_rqs_sequential(z, out, logdet, W1t, b1, W2, b2, n_bins, boundary, accumulate=False):
-    """The sequential map of a MADE-based RQ-spline layer in one launch; W1t (D, HP), b1 (HP,),
-    W2 (D, 3 n_bins - 1, HP), b2 (D, 3 n_bins - 1) masked and zero-padded to HP hidden units."""
+def made_rqs_sequential(z, out, logdet, W1t, b1, W2, b2, n_bins, boundary, accumulate=False, lrs=False):
+    """The sequential map of a MADE-based RQ-spline (or, ``lrs``, linear-rational-spline) layer in one
+    launch; W1t (D, HP), b1 (HP,), W2 (D, P, HP), b2 (D, P) masked and zero-padded to HP hidden units,
+    P = 3 n_bins - 1 (RQ) or 4 n_bins (LRS)."""
     global calls
-    name = "tfk_made_rqs_sequential"
+    name = "tfk_made_lrs_sequential" if lrs else "tfk_made_rqs_sequential"
     N, D = _rows(z, name)
-    HP, P = b1.numel(), 3 * int(n_bins) - 1
+    HP, P = b1.numel(), (4 * int(n_bins) if lrs else 3 * int(n_bins) - 1)
     if out.shape != z.shape or logdet.numel() != N or W1t.numel() != D * HP or W2.numel() != P * D * HP \
             or b2.numel() != P * D:
         raise NativeError(f"{name}: bad tensor shapes")
     args = (_f32(z, name), _f32(out, name), _f32(logdet, name), N, D, _f32(W1t, name), _f32(b1, name),
             _f32(W2, name), _f32(b2, name), HP, int(n_bins), C.c_float(float(boundary)), 1 if accumulate else 0)
     with _device_guard(z):
-        rc = lib().tfk_made_rqs_sequential(*args, _stream(z))
+        rc = getattr(lib(), name)(*args, _stream(z))
     calls += 1
     _check(rc, name)
 
