@@ -340,3 +340,48 @@ def test_views_into_larger_buffers(pkg, oracle, monkeypatch, arch, D):
         x2, _ = flow.bijection.inverse(off)
         x3, _ = flow.bijection.inverse(off.clone())
         assert torch.equal(x2, x3)
+
+
+@pytest.mark.parametrize("arch,D,n_hidden", [("MaskedAutoregressiveRQNSF", 64, None), ("InverseAutoregressiveRQNSF", 64, None),
+                                             ("MaskedAutoregressiveRQNSF", 128, None)])
+def test_made_spline_parallel_map_as_flow_program(pkg, oracle, monkeypatch, arch, D, n_hidden):
+    """The parallel map of MADE-based RQ-spline layers (MA-RQNSF density, IA-RQNSF sampling) as matrix-core
+    flow-program ops (TFK_OP_MADE_RQS): fused vs layer by layer vs the oracle."""
+    from torchflows_amd import native
+    torch.manual_seed(D)
+    kw = dict(n_layers=3)
+    if n_hidden is not None:
+        kw["conditioner_kwargs"] = dict(n_hidden=n_hidden)
+    flow = data_init(pkg.Flow(getattr(pkg, arch)(D, **kw)), D)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, 3, sd)
+    x = torch.randn(777, D) * 1.3
+    par = "forward" if arch.startswith("Masked") else "inverse"
+    import copy
+    with torch.no_grad():                      # ATen composite path on the host: fp64 truth and fp32 floor
+        y64, ld64 = getattr(copy.deepcopy(flow).double().bijection, par)(x.double())
+        y32, ld32 = getattr(flow.bijection, par)(x)
+    floor_y, floor_ld = rel(y32.numpy(), y64.numpy()), rel(ld32.numpy(), ld64.numpy())
+    flow = flow.cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", mode)
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        before = native.calls
+        with torch.no_grad():
+            y, ld = getattr(flow.bijection, par)(x.cuda())
+        res[mode] = (y.cpu().numpy(), ld.cpu().numpy(), native.calls - before)
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
+    assert res["1"][2] < res["0"][2] and res["1"][2] <= 6, (res["1"][2], res["0"][2])   # one launch per MADE layer (+ the rest)
+    y_ref, ld_ref = getattr(ref, par)(x.numpy())
+    e = dict(y=rel(res["1"][0], y64.numpy()), ld=rel(res["1"][1], ld64.numpy()),
+             y_lw=rel(res["0"][0], y64.numpy()), ld_lw=rel(res["0"][1], ld64.numpy()),
+             y_oracle=rel(y_ref, y64.numpy()), ld_oracle=rel(ld_ref, ld64.numpy()),
+             y_norm=normwise(res["1"][0], y64.numpy()))
+    print(arch, D, n_hidden, res["1"][2], res["0"][2], f"floor {floor_y:.1e} / {floor_ld:.1e}",
+          {k: f"{v:.1e}" for k, v in e.items()})
+    # three stacked spline layers amplify rounding differences elementwise (1 / bin width): every
+    # implementation is held to the fp64 result at 3x the host's own fp32-vs-fp64 distance (or 4e-5)
+    assert max(e["y"], e["y_lw"], e["y_oracle"]) < max(4e-5, 3 * floor_y)
+    assert max(e["ld"], e["ld_lw"], e["ld_oracle"]) < max(4e-5 * max(1.0, D / 64), 3 * floor_ld)
+    assert e["y_norm"] < 2e-5

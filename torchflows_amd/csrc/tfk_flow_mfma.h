@@ -174,6 +174,65 @@ __device__ __forceinline__ void made_m(const MOp op, const float *prm, int lane,
     ld = ld + (DIVIDE ? -part : part);
 }
 
+// MADE-based RQ-spline layer, parallel map (MaskedAutoregressiveRQNSF.forward / InverseAutoregressiveRQNSF
+// .inverse): GEMM 1 over BOTH planes as in made_m, then for each of the lane's 2 EPL elements its 23 spline
+// parameters as 6 tiles (made of the untouched row's hidden activations) and the spline's forward map.
+// Parameter block: A1[2 EPL][64] | b1[4][4] | A2[2 EPL * 6][steps2][64] | b2[2 EPL * 6][4][4]; tiles
+// [0, 6 EPL) belong to plane A, the rest to plane B.
+template <int EPL>
+__device__ __forceinline__ void made_rqs_m(const MOp op, const float *prm, int lane, int q,
+                                           float (&a)[EPL], float (&b)[EPL], float &ld)
+{
+    constexpr int T2 = EPL * 6;
+    const float *A1 = prm;
+    const float *b1 = prm + 2 * EPL * 64;
+    const float *A2 = b1 + 16;
+    const float *b2 = A2 + 2 * T2 * op.steps2 * 64;
+    RqsConst C;
+    C.minimum = -op.boundary;
+    C.maximum = op.boundary;
+    C.span = op.boundary + op.boundary;
+    C.scale = op.scale;
+    C.c = op.c;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], a[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(EPL + s) * 64 + lane], b[s], acc, 0, 0, 0);
+    }
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);
+    float part = 0.0f;
+    for (int e = 0; e < 2 * EPL; ++e) {
+        float p[24];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int t = e * 6 + c;
+            f32x4 o = *reinterpret_cast<const f32x4 *>(b2 + (t * 4 + q) * 4);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2) * 64 + lane], hid[0], o, 0, 0, 0);
+            if (op.steps2 > 1) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 1) * 64 + lane], hid[1], o, 0, 0, 0);
+            if (op.steps2 > 2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 2) * 64 + lane], hid[2], o, 0, 0, 0);
+            if (op.steps2 > 3) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[(t * op.steps2 + 3) * 64 + lane], hid[3], o, 0, 0, 0);
+            p[4 * c] = o[0]; p[4 * c + 1] = o[1]; p[4 * c + 2] = o[2]; p[4 * c + 3] = o[3];
+        }
+        float v = a[0];
+#pragma unroll
+        for (int i = 1; i < EPL; ++i) v = (e == i) ? a[i] : v;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) v = (e == EPL + i) ? b[i] : v;
+        float out = v, l = 0.0f;
+        if (v > C.minimum && v < C.maximum) rqs_eval<8, false, true, float[24]>(p, 8, v, C, out, l);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            a[i] = (e == i) ? out : a[i];
+            b[i] = (e == EPL + i) ? out : b[i];
+        }
+        part += l;
+    }
+    ld = ld + part;
+}
+
 // RQ-spline coupling on the matrix cores (layers.py:154-163): GEMM 1 as above; GEMM 2 produces,
 // for each of this lane's EPL target elements, its 23 (+1 pad) spline parameters as 6 tiles of
 // 4 (D-row 4q+r of tile 6e+c <-> parameter 4c+r of target element EPL*q+e), i.e. the record
@@ -310,6 +369,10 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
             else if (op.steps2 <= 8) { if (div) made_m<EPL, true, 2>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 2>(op, prm, lane, q, a, b, ld); }
             else { if (div) made_m<EPL, true, 4>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 4>(op, prm, lane, q, a, b, ld); }
         }
+        return;
+    }
+    if constexpr (MADE && EPL <= kMaxEplRqs) if (op.kind == TFK_OP_MADE_RQS) {
+        made_rqs_m<EPL>(op, prm, lane, q, a, b, ld);
         return;
     }
     // the spline op exists for D <= 128 only: at D = 256 one coupling's parameters (209 KB) exceed
@@ -470,7 +533,7 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
     bool wide = false;                     // a coupling with hidden width > 16 in the program?
     for (int i = 0; i < prog.n_ops; ++i)
         wide = wide || (((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||
-                         prog.op[i].kind >= TFK_OP_MADE_FWD) && prog.op[i].steps2 > 4);
+                         (prog.op[i].kind == TFK_OP_MADE_FWD || prog.op[i].kind == TFK_OP_MADE_INV)) && prog.op[i].steps2 > 4);
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     bool made = false;
     for (int i = 0; i < prog.n_ops; ++i) made = made || prog.op[i].kind >= TFK_OP_MADE_FWD;

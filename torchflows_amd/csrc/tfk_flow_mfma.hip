@@ -68,6 +68,13 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
             if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
             const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
             need = (int64_t)2 * EPL * HT * 64 + HT * 16 + (int64_t)EPL * o.steps2 * 64 + (int64_t)EPL * 16;
+        } else if (o.kind == TFK_OP_MADE_RQS) {
+            if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
+            if (EPL > kMaxEplRqs) return fail(TFK_EINVAL, "%s: op %d: spline ops need D <= %d on the MFMA path", fn, i, 8 * kMaxEplRqs);
+            if (o.K != 8) return fail(TFK_EINVAL, "%s: op %d: fused RQS supports n_bins = 8, got %d", fn, i, o.K);
+            if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
+            const int T2 = EPL * 6;
+            need = (int64_t)2 * EPL * 64 + 16 + (int64_t)2 * T2 * o.steps2 * 64 + (int64_t)2 * T2 * 16;
         } else return fail(TFK_EINVAL, "%s: op %d: kind %d is not supported on the MFMA path", fn, i, o.kind);
         if (o.offset < 0 || (o.offset & 3) || o.offset + need > n_params)
             return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i,

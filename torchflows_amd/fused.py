@@ -31,7 +31,7 @@ import torch.nn as nn
 from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
-    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV = range(10)
+    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS = range(11)
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
 MAX_HIDDEN_RQS = 32
 FORWARD, INVERSE = 0, 1
@@ -348,7 +348,7 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int):
         return None
     kind = layer.transformer.native_kind
     ct = layer.conditioner_transform
-    if kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+    if kind not in ("affine", "inverse_affine", "rqs") or ct.n_global_parameters != 0:
         return None
     if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
         return None
@@ -359,6 +359,8 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int):
     H = mods[0].out_features
     if mods[0].in_features != D or H > 64 or (D == 256 and H > 16):
         return None
+    if kind == "rqs":
+        return _made_rqs_op(layer, mods, pos, D, H)
     half, EPL = D // 2, D // 8
     T2 = EPL // 2
     steps2 = (H + 3) // 4
@@ -391,6 +393,47 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int):
     block = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1), torch.stack(b2m).reshape(-1)])
     divide = (kind == "inverse_affine")                # the parallel map uses transformer.forward
     return (OP_MADE_INV if divide else OP_MADE_FWD, 0, steps2), block
+
+
+def _made_rqs_op(layer, mods, pos: torch.Tensor, D: int, H: int):
+    """The parallel map of a MADE-based RQ-spline layer (8 bins, hidden <= 16, D <= 128) as one matrix-core
+    op (tfk_flow_mfma.h: made_rqs_m): A1[2 EPL][64] | b1[4][4] | A2[2 EPL 6][steps2][64] | b2[2 EPL 6][4][4]."""
+    import math
+    import numpy as np
+    tr = layer.transformer
+    if tr.n_bins != 8 or H > 16 or D > 128:
+        return None
+    half, EPL = D // 2, D // 8
+    steps2 = (H + 3) // 4
+    W1 = (mods[0].weight * mods[0].mask).detach()                       # (H, D) logical columns
+    W2 = (mods[2].weight * mods[2].mask).detach().view(D, 23, H)       # logical element, parameter, unit
+    dev, dt = W1.device, W1.dtype
+    W1p = torch.zeros(16, D, dtype=dt, device=dev)
+    W1p[:H, pos] = W1                                                   # physical columns
+    b1p = torch.zeros(16, dtype=dt, device=dev)
+    b1p[:H] = mods[0].bias.detach()
+    W2p = torch.zeros(D, 24, 16, dtype=dt, device=dev)
+    W2p[pos, :23, :H] = W2                                              # physical elements, 23 + 1 pad
+    b2p = torch.zeros(D, 24, dtype=dt, device=dev)
+    b2p[pos, :23] = mods[2].bias.detach().view(D, 23)
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    q2, r2 = il >> 2, il & 3
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    A1 = torch.stack([W1p[unit1, plane * half + EPL * ql + s] for plane in range(2) for s in range(EPL)])
+    b1m = b1p[4 * rr + qq]
+    A2, b2m = [], []
+    for plane in range(2):
+        for e in range(EPL):
+            for c in range(6):
+                for r1 in range(steps2):
+                    A2.append(W2p[plane * half + EPL * q2 + e, 4 * c + r2, 4 * r1 + ql])
+                b2m.append(b2p[plane * half + EPL * qq + e, 4 * c + rr])
+    block = torch.cat([A1.reshape(-1), b1m.reshape(-1), torch.stack(A2).reshape(-1), torch.stack(b2m).reshape(-1)])
+    head = (OP_MADE_RQS, 0, steps2, 8, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)),
+            float(np.float32(math.log(math.expm1(1 - tr.min_delta)))))
+    return head, block
 
 
 def compile_chain(composition, direction: int, device: torch.device,
