@@ -57,6 +57,7 @@ class KernelTimer:
         self.native = native
         self.active = False
         self.records = []   # (name, bytes, start_event, end_event)
+        self.mfma_insts = {}   # kernel -> v_mfma_f32_16x16x4_f32 wave-instructions issued while active
         for fn, byte_fn in (("affine_coupling", self._coupling_bytes(2)),
                             ("shift_coupling", self._coupling_bytes(1)),
                             ("rqs_coupling", self._rqs_bytes),
@@ -151,9 +152,36 @@ class KernelTimer:
                 n_rows, d_ = a[1].shape
                 h_ = KernelTimer.true_hidden.get(d_, 16)
                 flops = n_rows * 6 * h_ * (d_ // 2 + d_)
+            if name == "flow_run_mfma":
+                self.mfma_insts[variant] = self.mfma_insts.get(variant, 0) + self._flow_mfmas(a)
             self.records.append((variant, byte_fn(a, k), s, e, flops))
             return r
         setattr(self.native, name, timed)
+
+    @staticmethod
+    def _flow_mfmas(a):
+        """v_mfma_f32_16x16x4_f32 wave-instructions of one flow_run_mfma launch (tfk_flow_mfma.h): per wave
+        of 16 rows, GEMM 1 issues EPL x HT (both planes for MADE ops) and GEMM 2 tiles x k-steps."""
+        x, ops = a[0], a[6]
+        N, D = x.shape
+        EPL = D // 8
+        if not isinstance(ops, (list, tuple)):
+            ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
+        per_wave = 0
+        for op in ops:
+            kind, steps2 = op[0], op[2]
+            HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
+            if kind in (2, 3):
+                per_wave += EPL * HT + (EPL // 2) * steps2
+            elif kind in (4, 5):
+                per_wave += EPL * HT + (EPL // 4) * steps2
+            elif kind in (6, 7):
+                per_wave += EPL + 6 * EPL * steps2
+            elif kind in (8, 9):
+                per_wave += 2 * EPL * HT + EPL * steps2
+            elif kind == 10:
+                per_wave += 2 * EPL + 12 * EPL * steps2
+        return per_wave * ((N + 15) // 16)
 
     @staticmethod
     def _flow_flops(a, mfma=False):
@@ -372,6 +400,14 @@ def main():
                 rate = valu / (dom["avg_us"] * 1e-6)
                 roofline["valu_insts_per_launch"] = valu
                 roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
+                n_mfma = timer.mfma_insts.get(dom_name, 0) / max(dom["launches"], 1)
+                if n_mfma:
+                    # the f32-input MFMA runs at the vector rate on the SIMD's FP32 datapath (64 FLOP/clk/SIMD,
+                    # MI355X_MICROARCH.md) and did not overlap with vector work in this kernel (ablation in
+                    # DESIGN.md 3.4): SIMD cycles = 4 per vector wave-instruction + 32 per v_mfma_f32_16x16x4_f32
+                    busy = 4.0 * valu + 32.0 * n_mfma
+                    roofline["mfma_insts_per_launch"] = n_mfma
+                    roofline["fp32_datapath_frac"] = busy / (dom["avg_us"] * 1e-6 * 256 * 4 * 2.4e9)
         elif dom_name.startswith("conv3x3_relu_pool_affine"):
             # direct convolution on the vector ALUs (c_out = 8 would waste half of a 16-wide MFMA tile and
             # the fp32 MFMA peak equals the vector peak): priced against the fp32 vector peak
