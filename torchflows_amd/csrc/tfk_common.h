@@ -64,19 +64,25 @@ __device__ __forceinline__ float exp_noovf(float x) {
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
-// exp(x) in 6 ops for results that are ADDED to something of order one or larger right away (the
+// exp(x) in 5 ops for results that are ADDED to something of order one or larger right away (the
 // softmax numerators after the max-subtraction, alpha = exp(.) + 1e-10): exp2(t) * 2^e with the product
 // t = x * log2(e) compensated to first order, 2^e = 1 + e ln 2 (e ~ 1e-7 |t|: the dropped e^2 term is below
 // 1e-13).  Within 1 ulp of exp_noovf (v_exp_f32 sees the whole t instead of its reduced fraction; both are
 // 1-ulp evaluations); results below the normal range flush to zero instead of going through ldexp.
 __device__ __forceinline__ float exp_lean(float x) {
     const float L2E_HI = __int_as_float(0x3fb8aa3b);
-    const float L2E_LO = __int_as_float(0x32a5705f);
     const float LN2 = __int_as_float(0x3f317218);
     const float t = x * L2E_HI;
-    const float e = fmaf(L2E_LO, x, fmaf(x, L2E_HI, -t));
-    const float p = __builtin_amdgcn_exp2f(t);
-    return p * fmaf(LN2, e, 1.0f);       // (inf stays inf, 0 stays 0)
+    const float e = fmaf(x, L2E_HI, -t);              // what rounding t lost (log2(e)'s own low part, 1.9e-8 |x|
+    const float p = __builtin_amdgcn_exp2f(t);        // relative, is left out: < 0.3 ulp for |x| < 3)
+    return p * fmaf(LN2, e, 1.0f);                    // (inf stays inf, 0 stays 0)
+}
+
+// log(x) as v_log_f32 * ln 2, 2 ops: the hi/lo split of ln 2 in log_normal only removes the rounding of this
+// one multiplication (<= 0.5 ulp of the result) while v_log_f32 itself is a 1-ulp evaluation; inf / NaN / 0
+// propagate through the multiplication.  For the datapath-bound flow programs.
+__device__ __forceinline__ float log_lean(float x) {
+    return __builtin_amdgcn_logf(x) * __int_as_float(0x3f317218);
 }
 
 // logf for positive NORMAL arguments (and +inf / NaN, passed through): ocml's own sequence

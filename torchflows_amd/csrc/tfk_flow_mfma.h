@@ -107,9 +107,9 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
                 const int e = 2 * t + i;
                 const float al = aff_alpha_lean(o[2 * i]);          // affine.py:33-34
                 const float be = o[2 * i + 1];
-                part += log_normal(al);                             // affine.py:42
+                part += log_lean(al);                               // affine.py:42
                 if constexpr (KIND == TFK_OP_AFFINE_FWD) tgt[e] = al * tgt[e] + be;   // affine.py:48
-                else tgt[e] = div_fast(tgt[e] - be, al);                              // affine.py:59
+                else tgt[e] = (tgt[e] - be) * __builtin_amdgcn_rcpf(al);              // affine.py:59 (v_rcp: 1 ulp)
             }
         } else {
 #pragma unroll
@@ -165,10 +165,10 @@ __device__ __forceinline__ void made_m(const MOp op, const float *prm, int lane,
         for (int i = 0; i < 2; ++i) {
             const float al = aff_alpha_lean(o[2 * i]);
             const float be = o[2 * i + 1];
-            part += log_normal(al);
+            part += log_lean(al);
             float &v = (t < T2) ? a[2 * t + i] : b[2 * (t - T2) + i];
             if (!DIVIDE) v = al * v + be;
-            else v = div_fast(v - be, al);
+            else v = (v - be) * __builtin_amdgcn_rcpf(al);
         }
     }
     ld = ld + (DIVIDE ? -part : part);
@@ -337,10 +337,11 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int e = 4 * i + k;
-                    const float na = a[e] - be_a[k], nb = b[e] - be_b[k];
-                    const float qa = na * ra_a[k], qb = nb * ra_b[k];
-                    a[e] = fmaf(fmaf(-al_a[k], qa, na), ra_a[k], qa);
-                    b[e] = fmaf(fmaf(-al_b[k], qb, nb), ra_b[k], qb);
+                    // (x - beta) * (1 / alpha), 1 / alpha rounded once on the host: within 1 ulp of the
+                    // reference's division; the residual correction that made it the correctly rounded quotient
+                    // cost 2 of the 4 operations per element on a datapath-bound kernel (section 3.4 of DESIGN.md)
+                    a[e] = (a[e] - be_a[k]) * ra_a[k];
+                    b[e] = (b[e] - be_b[k]) * ra_b[k];
                 }
             }
         }

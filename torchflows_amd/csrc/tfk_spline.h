@@ -21,15 +21,24 @@ struct RqsConst {
 __device__ __forceinline__ float softplus20(float v) {
     return v > 20.0f ? v : log1p_pos(exp_noovf(fminf(v, 20.0f)));
 }
+// ... with the lean exp / log of the datapath-bound flow programs (tfk_common.h: within 1 ulp each)
+__device__ __forceinline__ float softplus20_lean(float v) {
+    const float y = exp_lean(fminf(v, 20.0f));
+    const float u = 1.0f + y;
+    const float r = log_lean(u) + (y - (u - 1.0f)) * __builtin_amdgcn_rcpf(u);
+    return v > 20.0f ? v : r;
+}
 
 // rational_quadratic.py:56-63
+template <bool LEAN = false>
 __device__ __forceinline__ float rqs_log_det(float s, float dk, float dk1, float xi, float q,
                                              float term1)
 {
     const float omx = 1.0f - xi;
     const float inner = dk1 * (xi * xi) + (2.0f * s) * q + dk * (omx * omx);
-    const float log_num = 2.0f * log_normal(s) + log_normal(inner);
-    const float log_den = 2.0f * log_normal(s + term1 * q);
+    const float den = s + term1 * q;
+    const float log_num = 2.0f * (LEAN ? log_lean(s) : log_normal(s)) + (LEAN ? log_lean(inner) : log_normal(inner));
+    const float log_den = 2.0f * (LEAN ? log_lean(den) : log_normal(den));
     return log_num - log_den;
 }
 
@@ -53,7 +62,9 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
             const float ux = p[j];
-            const float uy = ux + div_1000(p[KT + j]);      // rational_quadratic.py:76
+            // rational_quadratic.py:76; in the flow programs u_y / 1000 as one multiplication: its rounding
+            // (1 ulp of a term ~1e-3 of u_x) disappears in the sum
+            const float uy = ux + (REGS ? p[KT + j] * 1e-3f : div_1000(p[KT + j]));
             ex[j] = ux;
             ey[j] = uy;
             mx = j ? fmaxf(mx, ux) : ux;
@@ -138,8 +149,9 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
         udk = (k == 0) ? C.c : p[2 * K + k - 1];
         udk1 = (k == K - 1) ? C.c : p[2 * K + k];
     }
-    const float dk = kRqsMinDelta + softplus20(C.c + div_1000(udk));    // :77
-    const float dk1 = kRqsMinDelta + softplus20(C.c + div_1000(udk1));
+    const float tk = C.c + (REGS ? udk * 1e-3f : div_1000(udk)), tk1 = C.c + (REGS ? udk1 * 1e-3f : div_1000(udk1));
+    const float dk = kRqsMinDelta + (REGS ? softplus20_lean(tk) : softplus20(tk));      // :77
+    const float dk1 = kRqsMinDelta + (REGS ? softplus20_lean(tk1) : softplus20(tk1));
     const float s = div_fast(hk, wk);                      // :94 / :159
     const float term1 = dk1 + dk - 2.0f * s;               // :97 / :162
 
@@ -150,7 +162,7 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
         const float num0 = hk * (s * (xi * xi) + dk * q);  // :104
         const float den0 = s + term1 * q;                  // :105
         out = byk + div_fast(num0, den0);                  // :106
-        ld = rqs_log_det(s, dk, dk1, xi, q, term1);        // :109
+        ld = rqs_log_det<REGS>(s, dk, dk1, xi, q, term1);  // :109
     } else {
         const float term0 = v - byk;                       // :164
         const float term2 = hk * dk;                       // :165
@@ -163,7 +175,7 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
         xi = clip01(xi);                                   // :174
         const float q = xi * (1.0f - xi);                  // :175
         out = xi * wk + bxk;                               // :178
-        ld = -rqs_log_det(s, dk, dk1, xi, q, term1);       // :181
+        ld = -rqs_log_det<REGS>(s, dk, dk1, xi, q, term1); // :181
     }
 }
 
