@@ -15,7 +15,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 flow = bench.make_flow(arch, D, 8).cuda()
 x = torch.randn(1 << 18, D, device="cuda")
 flow.train()
-opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+import os
+opt = torch.optim.AdamW(flow.parameters(), lr=1e-4, fused=bool(int(os.environ.get("FUSED_OPT", "0"))))
 
 
 def step():

@@ -31,3 +31,5 @@ tot = sum(e.device_time_total for e in rows)
 print(f"{arch}({D}): {tot / 1e3:.2f} ms of GPU time over {sum(e.count for e in rows)} kernels")
 for e in rows[:25]:
     print(f"{e.device_time_total / 1e3:8.3f} ms {e.count:5d}  {e.key[:120]}")
+if len(sys.argv) > 3 and sys.argv[3] == "cpu":
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=30, max_name_column_width=60))
