@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 17
+#define TFK_ABI_VERSION 18
 
 enum {
     TFK_OK = 0,
@@ -207,7 +207,9 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  *   gemm2_steps <= 4 / 8 / 16,
  *   T2 = D/16 (affine), D/32 (shift), 6*D/8 (RQS, n_bins = 8: 6 tiles of 4 parameters per element)
  * accumulate: bit 0 = add to logdet instead of overwriting it; bit 1 = store the rows reversed
- *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store).
+ *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store);
+ *   bit 2 = logprob is the base density of the rows as they come IN plus the log-det (Flow.sample with
+ *   return_log_prob, flows.py:699-707: base_log_prob(z) + log_det of the inverse) instead of the rows going out.
  * A MADE op (TFK_OP_MADE_*: MaskedAutoregressiveBijection's parallel map, layers_base.py:201-206,
  * affine transformer, weights pre-multiplied by the MADE masks) reads BOTH halves of the row and
  * transforms both:  A1[2*D/8][HT][64] | b1[HT][4][4] | A2[2*D/16][gemm2_steps][64] | b2[2*D/16][4][4].

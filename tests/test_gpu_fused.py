@@ -385,3 +385,41 @@ def test_made_spline_parallel_map_as_flow_program(pkg, oracle, monkeypatch, arch
     assert max(e["y"], e["y_lw"], e["y_oracle"]) < max(4e-5, 3 * floor_y)
     assert max(e["ld"], e["ld_lw"], e["ld_oracle"]) < max(4e-5 * max(1.0, D / 64), 3 * floor_ld)
     assert e["y_norm"] < 2e-5
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("NICE", 64), ("MAF", 64)])
+def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
+    """Flow.sample(return_log_prob=True) = (inverse(z), base_log_prob(z) + log_det) (flows.py:699-707): when the
+    inverse chain is one matrix-core program the base density of the incoming rows is evaluated in the same
+    launch (flag bit 2 of tfk_flow_run_mfma); same values as the two-step path and the oracle."""
+    from torchflows_amd import native
+    torch.manual_seed(9)
+    flow = data_init(pkg.Flow(getattr(pkg, arch)(D, n_layers=3)), D)
+    with torch.no_grad():
+        flow.base.loc.normal_()
+        flow.base.log_scale.uniform_(-0.5, 0.5)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, 3, sd)
+    flow = flow.cuda()
+    z = (torch.randn(1000, D) * torch.exp(torch.tensor(sd["base.log_scale"])) + torch.tensor(sd["base.loc"])).cuda()
+    with torch.no_grad():
+        before = native.calls
+        got = flow._fused_sample(z)
+        launches = native.calls - before
+        x2, ld2 = flow.bijection.inverse(z)
+        lp2 = flow.base_log_prob(z) + ld2
+    if arch == "MAF":                      # its sequential map is not a flow program: the generic path stays
+        assert got is None
+        return
+    x1, lp1 = got
+    assert launches <= 2                  # the program (+ one permute: an odd number of reversals)
+    assert torch.equal(x1, x2)
+    assert rel(lp1.cpu().numpy(), lp2.cpu().numpy()) < 2e-6
+    x_ref, ld_ref = ref.inverse(z.cpu().numpy())
+    lp_ref = ref.base_log_prob(z.cpu().numpy()) + ld_ref if hasattr(ref, "base_log_prob") else None
+    assert normwise(x1.cpu().numpy(), x_ref) < 1e-5
+    if lp_ref is not None:
+        assert rel(lp1.cpu().numpy(), lp_ref) < 1e-5
+    torch.manual_seed(3)
+    xs, lps = flow.sample((512,), return_log_prob=True)      # the public entry point takes the same route
+    assert xs.shape == (512, D) and lps.shape == (512,) and torch.isfinite(lps).all()

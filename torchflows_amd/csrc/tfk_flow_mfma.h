@@ -405,6 +405,7 @@ void k_flow_run_mfma(
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;          // store z[row, D-1-c] = value of column c
+    const bool base_of_input = (flags & 4) != 0;        // logprob = base density of the INPUT rows + log-det
     {
         const float4 *src = reinterpret_cast<const float4 *>(params);
         float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -438,10 +439,23 @@ void k_flow_run_mfma(
         }
         // per-lane share of the row's log-det; lane q == 0 carries the running value
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
+        float lp = 0.0f;
+        if (logprob && base_of_input) {                             // Flow.sample: base_log_prob(z) of the rows
+#pragma unroll                                                      // as they come in (flows.py:699-707)
+            for (int e = 0; e < EPL; ++e) {
+                const int ia = EPL * q + e, ib = HALF + EPL * q + e;
+                const float ta = div_fast(a[e] - base_s[ia], base_s[D + ia]);
+                const float tb = div_fast(b[e] - base_s[ib], base_s[D + ib]);
+                float ua = 0.5f * (ta * ta), ub = 0.5f * (tb * tb);
+                ua = ua + kHalfLog2Pi; ub = ub + kHalfLog2Pi;
+                ua = ua + base_s[2 * D + ia]; ub = ub + base_s[2 * D + ib];
+                lp += -ua;
+                lp += -ub;
+            }
+        }
         for (int o = 0; o < prog.n_ops; ++o)
             apply_op_m<EPL, HTMAX, MADE>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
-        float lp = 0.0f;
-        if (logprob) {                                              // gaussian.py:46-54
+        if (logprob && !base_of_input) {                            // gaussian.py:46-54
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int ia = EPL * q + e, ib = HALF + EPL * q + e;

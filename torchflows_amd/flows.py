@@ -100,6 +100,27 @@ class Flow(BaseFlow):
                                    base=(self.base.loc.detach(), self.base.log_scale.detach()))
         return (z.view(x.shape) if want_z else None), lp.view(batch)
 
+    def _fused_sample(self, z: torch.Tensor):
+        """``(x, base_log_prob(z) + log_det)`` of ``sample(return_log_prob=True)`` (flows.py:699-707) as ONE
+        flow-program launch when the inverse chain is a single matrix-core program; else None."""
+        from torchflows_amd import fused, native
+        from torchflows_amd.bijections.base import (BijectiveComposition, _params_ok,
+                                                    method_direction)
+        from torchflows_amd.utils import as_rows
+        b = self.bijection
+        if not (isinstance(b, BijectiveComposition) and isinstance(self.base, DiagonalGaussian)
+                and native.eligible(z, self.base.loc, self.base.log_scale) and _params_ok(self)):
+            return None
+        d = method_direction(b.inverse)
+        chain = None if d is None else fused.get_compiled(b, d, z.device)
+        if not fused.sample_ready(chain):
+            return None
+        rows, batch = as_rows(z, self.event_shape)
+        with torch.no_grad():
+            x, _, lp = fused.run_chain(chain, rows, want_rows=True, base_of_input=True,
+                                       base=(self.base.loc.detach(), self.base.log_scale.detach()))
+        return x.view(z.shape), lp.view(batch)
+
     def forward_with_log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         context = self._checked_context(x, context)
         if context is None:
@@ -439,6 +460,10 @@ class Flow(BaseFlow):
                 sample_shape = (*sample_shape, n_ctx)
         z = self.base_sample(sample_shape=sample_shape)
         z_in = z.view(*sample_shape, *self.bijection.event_shape)
+        if return_log_prob and context is None and (no_grad or not torch.is_grad_enabled()):
+            fused_out = self._fused_sample(z_in)
+            if fused_out is not None:
+                return fused_out
         if no_grad:
             with torch.no_grad():
                 x, log_det = self.bijection.inverse(z_in.detach(), context=context)[:2]

@@ -503,6 +503,11 @@ def compile_chain(composition, direction: int, device: torch.device,
     return CompiledChain(D, segments, pos, identity, _params_version(composition))
 
 
+def sample_ready(chain: Optional[CompiledChain]) -> bool:
+    """One matrix-core launch: the base density of the incoming rows can ride along (flag bit 2)."""
+    return chain is not None and len(chain.segments) == 1 and chain.segments[0].mfma
+
+
 def invalidate(module: nn.Module) -> None:
     """Drop cached flow programs below ``module``.  Needed after parameters were changed behind
     autograd's back (a replayed hipGraph updates them without moving their version counters)."""
@@ -523,10 +528,24 @@ def get_compiled(composition, direction: int, device: torch.device) -> Optional[
     return chain
 
 
-def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None):
+def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False):
     """Apply the compiled chain to ``rows`` (N, D).  Returns ``(out_rows or None, logdet or
     None, logprob or None)``; with ``base`` (loc, log_scale in logical order) the final launch
-    also evaluates the diagonal-Gaussian log-density and adds the log-det (flows.py:647-648)."""
+    also evaluates the diagonal-Gaussian log-density and adds the log-det (flows.py:647-648).
+    ``base_of_input`` (single-launch matrix-core programs only, see ``sample_ready``): the density is that
+    of the rows as they come in -- ``Flow.sample``'s ``base_log_prob(z) + log_det`` in the same launch."""
+    if base_of_input:
+        assert sample_ready(chain) and base is not None
+        N, D = rows.shape
+        logprob = torch.empty(N, dtype=torch.float32, device=rows.device)
+        out = torch.empty_like(rows)
+        seg = chain.segments[0]
+        native.flow_run_mfma(rows, out, None, base[0], base[1], logprob, seg.packed_ops(), seg.params,
+                             base_of_input=True)
+        if not chain.identity_out:
+            cur, out = out, torch.empty_like(out)
+            native.permute(cur, chain.pos.to(torch.int32), out)
+        return out, None, logprob
     N, D = rows.shape
     dev = rows.device
     n_seg = len(chain.segments)

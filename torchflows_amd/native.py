@@ -46,7 +46,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class NativeError(RuntimeError):
@@ -629,7 +629,7 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
 
 
 def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False,
-                  reverse_out=False):
+                  reverse_out=False, base_of_input=False):
     """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
     ops: list of (kind, src_plane, gemm2_steps, offset); params packed by fused._pack_mfma."""
     global calls
@@ -641,7 +641,8 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
             raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
             _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, _n_ops(ops),
-            _f32(params, name), params.numel(), (1 if accumulate else 0) | (2 if reverse_out else 0))
+            _f32(params, name), params.numel(),
+            (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0))
     with _device_guard(x):
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
