@@ -298,11 +298,18 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                      f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (rehearsal on a one-GPU box: TORCHFLOWS_AMD_DIST_BACKEND=gloo runs the ranks on the same card; RCCL
+    # refuses two ranks per device)
+    backend = os.environ.get("TORCHFLOWS_AMD_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from torchflows_amd import native
     from torchflows_amd.distributed import sharded_log_likelihood, sharded_log_likelihood_async
