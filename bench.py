@@ -345,6 +345,8 @@ def main():
         pending.clear()
 
     with torch.no_grad():
+        step()                      # module load, LDS attributes, RCCL communicator: never inside the timed region,
+        drain()                     # whatever --warmup says
         for _ in range(args.warmup):
             step()
         drain()
