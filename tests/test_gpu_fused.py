@@ -423,3 +423,42 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
     torch.manual_seed(3)
     xs, lps = flow.sample((512,), return_log_prob=True)      # the public entry point takes the same route
     assert xs.shape == (512, D) and lps.shape == (512,) and torch.isfinite(lps).all()
+
+
+@pytest.mark.parametrize("arch,D,n_layers", [("RealNVP", 6, 2), ("RealNVP", 22, 3), ("NICE", 40, 4), ("RealNVP", 62, 8),
+                                             ("RealNVP", 100, 3), ("RealNVP", 200, 2)])
+def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, arch, D, n_layers):
+    """Event sizes that are even but not 64 / 128 / 256: both halves of the row are padded to the next
+    supported plane width (zero weights => identity on the padding, a base log_scale of -0.5 log 2 pi => no
+    density term), the whole chain still runs as matrix-core flow programs.  Parity with the oracle and with
+    the layer-by-layer path; the padded path must actually be taken."""
+    from torchflows_amd import native
+    torch.manual_seed(D)
+    from torchflows_amd.base_distributions.gaussian import DiagonalGaussian
+    base = DiagonalGaussian(torch.randn(D) * 0.3, torch.rand(D) + 0.5)
+    flow = data_init(pkg.Flow(getattr(pkg, arch)(D, n_layers=n_layers), base_distribution=base), D)
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    ref = oracle.preset_from_state_dict(arch, D, n_layers, sd)
+    x = torch.randn(700, D)
+    flow = flow.cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TORCHFLOWS_AMD_FUSED_PAD", mode)
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        before = native.calls
+        with torch.no_grad():
+            lp = flow.log_prob(x.cuda())
+            z, ld = flow.bijection.forward(x.cuda())
+            xr, ldi = flow.bijection.inverse(z)
+        res[mode] = (lp, z, ld, xr, ldi, native.calls - before)
+    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED_PAD", "1")
+    assert res["1"][5] < res["0"][5] and res["1"][5] <= 3 * 4, (res["1"][5], res["0"][5])
+    z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
+    lp, z, ld, xr, ldi, _ = res["1"]
+    e = dict(lp=rel(lp.cpu().numpy(), lp_ref), z=normwise(z.cpu().numpy(), z_ref),
+             lp_lw=rel(lp.cpu().numpy(), res["0"][0].cpu().numpy()), ld_lw=rel(ld.cpu().numpy(), res["0"][2].cpu().numpy()),
+             round_trip=normwise(xr.cpu().numpy(), x.numpy()), ld_sum=rel((ld + ldi).cpu().numpy(), 0.0))
+    print(arch, D, n_layers, res["1"][5], res["0"][5], {k: f"{v:.1e}" for k, v in e.items()})
+    assert z.shape == x.shape and xr.shape == x.shape
+    assert max(e["lp"], e["lp_lw"], e["ld_lw"]) < 1e-5 * max(1.0, D / 64) and e["z"] < 1e-5
+    assert e["round_trip"] < 1e-5 and e["ld_sum"] < 1e-4

@@ -73,11 +73,13 @@ class Segment:
 
 @dataclass
 class CompiledChain:
-    D: int
+    D: int                     # width of the rows the kernels see (padded: 64 / 128 / 256)
     segments: List[Segment]
-    pos: torch.Tensor          # int64 (D,): physical position of logical element l at the end
-    identity_out: bool         # pos == arange(D)
+    pos: torch.Tensor          # int64 (D_log,): physical position of logical element l at the end
+    identity_out: bool         # rows come out in logical order
     version: int
+    D_log: int = 0             # event size; < D when the two halves are padded to a supported width
+    pos_in: Optional[torch.Tensor] = None     # padded chains: physical position of logical element l on entry
 
 
 def _pad4(t: torch.Tensor) -> torch.Tensor:
@@ -177,7 +179,7 @@ def any_requires_grad(module: nn.Module) -> bool:
     return any(t.requires_grad for _, _, t in slots)
 
 
-def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
+def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int, Dp: Optional[int] = None):
     from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
     kind = layer.transformer.native_kind
     if kind not in ("affine", "inverse_affine") or not layer.use_global_parameters:
@@ -190,8 +192,9 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int):
     subdiv = (d == INVERSE) != (kind == "inverse_affine")
     ld = torch.log(alpha).sum()
     ld = -ld if subdiv else ld
-    alpha_p = torch.empty_like(alpha)
-    beta_p = torch.empty_like(beta)
+    Dp = D if Dp is None else Dp
+    alpha_p = alpha.new_ones(Dp)               # padding elements: alpha = 1, beta = 0 (identity, log alpha = 0)
+    beta_p = beta.new_zeros(Dp)
     alpha_p[pos] = alpha
     beta_p[pos] = beta
     parts = [alpha_p, beta_p, ld.reshape(1), ld.new_zeros(3)]
@@ -264,7 +267,7 @@ def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p)
     return (op, plane, steps2), block
 
 
-def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
+def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, Dp: Optional[int] = None):
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
     kind = layer.transformer.native_kind
     if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
@@ -292,20 +295,25 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False):
     if W1.shape[1] != half or W2.shape[0] != half * P or W2.shape[1] != H:
         return None
     src_pos, tgt_pos = pos[:half], pos[half:]
-    plane = int(src_pos[0].item()) // half
-    if not bool(((src_pos // half) == plane).all()) or not bool(((tgt_pos // half) == 1 - plane).all()):
+    Dp = D if Dp is None else Dp
+    hp = Dp // 2                              # plane width the kernel sees (> half when padded)
+    if Dp != D and (kind == "rqs" or not mfma):
+        return None                           # padded planes: affine / shift on the matrix-core path only
+    plane = int(src_pos[0].item()) // hp
+    if not bool(((src_pos // hp) == plane).all()) or not bool(((tgt_pos // hp) == 1 - plane).all()):
         return None
-    W1t = torch.empty_like(W1)
-    W1t[:, src_pos - plane * half] = W1
-    m_t = tgt_pos - (1 - plane) * half
-    W2p = torch.empty(half, P, H, dtype=W2.dtype, device=W2.device)
+    # padding elements: zero weights => h = 0 => alpha = exp(c0) + 1e-10 = 1, beta = 0, log alpha = 0 exactly
+    W1t = W1.new_zeros(H, hp)
+    W1t[:, src_pos - plane * hp] = W1
+    m_t = tgt_pos - (1 - plane) * hp
+    W2p = torch.zeros(hp, P, H, dtype=W2.dtype, device=W2.device)
     W2p[m_t] = W2.reshape(half, P, H)
-    b2p = torch.empty(half, P, dtype=b2.dtype, device=b2.device)
+    b2p = torch.zeros(hp, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(half, P)
     if mfma:
         if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and D > 128):
             return None
-        head, block = _pack_mfma(kind, d, plane, H, D, W1t, b1, W2p, b2p)
+        head, block = _pack_mfma(kind, d, plane, H, Dp, W1t, b1, W2p, b2p)
         if kind == "rqs":
             import math
             import numpy as np
@@ -446,19 +454,33 @@ def compile_chain(composition, direction: int, device: torch.device,
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
 
     D = composition.n_dim
-    if not enabled() or not native.lib().tfk_flow_supported(D):
+    if not enabled():
         return None
+    # even event sizes that are not 64 / 128 / 256: both halves are padded to the next supported plane width
+    # (the rows are padded on the way in, run_chain) -- matrix-core programs with affine / shift couplings only
+    Dp = D
+    if not native.lib().tfk_flow_mfma_supported(D) and D % 2 == 0 and 4 <= D < 256:
+        Dp = 64 if D < 64 else (128 if D < 128 else 256)
     if mfma is None:
-        if mfma_enabled() and native.lib().tfk_flow_mfma_supported(D):
+        if mfma_enabled() and native.lib().tfk_flow_mfma_supported(Dp) and padded_enabled(D, Dp):
             chain = compile_chain(composition, direction, device, mfma=True)
             if chain is not None:
                 return chain
         mfma = False
+    if not mfma:
+        Dp = D
+    elif Dp != D and not padded_enabled(D, Dp):
+        return None
+    if not native.lib().tfk_flow_supported(Dp):
+        return None
     order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
     plan = _flatten(order, "forward" if direction == FORWARD else "inverse")
     if plan is None:
         return None
     pos = torch.arange(D, device=device)
+    if Dp != D:                                  # second half of the row starts at the padded plane boundary
+        pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
+    pos_in = pos.clone()
     items = []                                   # [(op triple, block)]
     with torch.no_grad():
         for layer, d in plan:
@@ -467,11 +489,11 @@ def compile_chain(composition, direction: int, device: torch.device,
                 pos = pos[perm]                  # new logical j = old logical perm[j]
                 continue
             if isinstance(layer, ElementwiseBijection):
-                item = _elementwise_op(layer, d, pos, D)
+                item = _elementwise_op(layer, d, pos, D, Dp)
             elif isinstance(layer, CouplingBijection):
-                item = _coupling_op(layer, d, pos, D, mfma=mfma)
+                item = _coupling_op(layer, d, pos, D, mfma=mfma, Dp=Dp)
             elif isinstance(layer, MaskedAutoregressiveBijection):
-                item = _made_op(layer, d, pos, D) if mfma else None
+                item = _made_op(layer, d, pos, D) if (mfma and Dp == D) else None
             else:
                 item = None
             if item is None:
@@ -489,7 +511,7 @@ def compile_chain(composition, direction: int, device: torch.device,
         # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
         # gets a launch of its own, and the small elementwise ops around it ride along
         small = kind in (OP_EW_MULADD, OP_EW_SUBDIV)
-        budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(D, 0)) if mfma else MAX_PARAM_BYTES
+        budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0)) if mfma else MAX_PARAM_BYTES
         over = (used + n) * 4 > budget
         if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
             segments.append(Segment(ops, torch.cat(blocks).contiguous(), mfma))
@@ -499,13 +521,21 @@ def compile_chain(composition, direction: int, device: torch.device,
         used += n
     if ops:
         segments.append(Segment(ops, torch.cat(blocks).contiguous(), mfma))
-    identity = bool(torch.equal(pos, torch.arange(D, device=device)))
-    return CompiledChain(D, segments, pos, identity, _params_version(composition))
+    identity = bool(torch.equal(pos, pos_in))
+    if Dp != D and not segments:
+        return None
+    return CompiledChain(Dp, segments, pos, identity, _params_version(composition), D_log=D,
+                         pos_in=pos_in if Dp != D else None)
+
+
+def padded_enabled(D: int, Dp: int) -> bool:
+    return Dp == D or os.environ.get("TORCHFLOWS_AMD_FUSED_PAD", "1") != "0"
 
 
 def sample_ready(chain: Optional[CompiledChain]) -> bool:
     """One matrix-core launch: the base density of the incoming rows can ride along (flag bit 2)."""
-    return chain is not None and len(chain.segments) == 1 and chain.segments[0].mfma
+    return (chain is not None and len(chain.segments) == 1 and chain.segments[0].mfma
+            and chain.pos_in is None)
 
 
 def invalidate(module: nn.Module) -> None:
@@ -549,6 +579,13 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     N, D = rows.shape
     dev = rows.device
     n_seg = len(chain.segments)
+    padded = chain.pos_in is not None
+    if padded:                                   # (N, D_log) -> (N, D): each half at the head of its plane
+        half, hp = chain.D_log // 2, chain.D // 2
+        wide = rows.new_zeros(N, chain.D)
+        wide[:, :half] = rows[:, :half]
+        wide[:, hp:hp + half] = rows[:, half:]
+        rows = wide
     logprob = torch.empty(N, dtype=torch.float32, device=dev) if base is not None else None
     logdet = torch.empty(N, dtype=torch.float32, device=dev) if (base is None or n_seg > 1) else None
     cur = rows
@@ -566,8 +603,10 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         key = (base[0].data_ptr(), base[0]._version, base[1].data_ptr(), base[1]._version)
         hit = chain.__dict__.get("_base_cache")
         if hit is None or hit[0] != key:
-            loc_p = torch.empty_like(base[0])
-            ls_p = torch.empty_like(base[1])
+            # padding elements hold 0 throughout: loc 0 and log_scale = -0.5 log(2 pi) make their density term
+            # -(0 + 0.5 log(2 pi) + log_scale) vanish exactly
+            loc_p = base[0].new_zeros(chain.D)
+            ls_p = base[1].new_full((chain.D,), -0.9189385332046727)
             loc_p[chain.pos] = base[0]
             ls_p[chain.pos] = base[1]
             chain.__dict__["_base_cache"] = hit = (key, loc_p, ls_p)
@@ -587,7 +626,9 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         if need_rows:
             cur = out
     out_rows = None
-    if want_rows:
+    if want_rows and padded:
+        out_rows = cur.index_select(1, chain.pos)            # logical order, padding dropped
+    elif want_rows:
         if chain.identity_out:
             out_rows = cur
         else:                                     # logical l <- physical pos[l]
