@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 18
+#define TFK_ABI_VERSION 19
 
 enum {
     TFK_OK = 0,
@@ -187,7 +187,9 @@ enum {
     TFK_OP_RQS_INV = 7,
     TFK_OP_MADE_FWD = 8,   /* MADE + Affine on the whole row, parallel map (tfk_flow_run_mfma only) */
     TFK_OP_MADE_INV = 9,   /* same with (x - beta) / alpha */
-    TFK_OP_MADE_RQS = 10   /* MADE + RQ spline (8 bins) on the whole row, parallel map; hidden <= 16, D <= 128 */
+    TFK_OP_MADE_RQS = 10,  /* MADE + RQ spline (8 bins) on the whole row, parallel map; hidden <= 16, D <= 128 */
+    TFK_OP_PLANE_SWAP = 11 /* tfk_flow_run_mfma: mask[D/2] floats, != 0 exchanges x[i] and x[D/2 + i] (odd event sizes,
+                              padded so that every element keeps its index in both halves) */
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

@@ -426,12 +426,16 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
 
 
 @pytest.mark.parametrize("arch,D,n_layers", [("RealNVP", 6, 2), ("RealNVP", 22, 3), ("NICE", 40, 4), ("RealNVP", 62, 8),
-                                             ("RealNVP", 100, 3), ("RealNVP", 200, 2)])
+                                             ("RealNVP", 100, 3), ("RealNVP", 200, 2),
+                                             ("RealNVP", 3, 2), ("RealNVP", 7, 3), ("NICE", 21, 4), ("RealNVP", 43, 8),
+                                             ("RealNVP", 63, 5), ("RealNVP", 77, 2), ("RealNVP", 127, 3)])
 def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, arch, D, n_layers):
-    """Event sizes that are even but not 64 / 128 / 256: both halves of the row are padded to the next
-    supported plane width (zero weights => identity on the padding, a base log_scale of -0.5 log 2 pi => no
-    density term), the whole chain still runs as matrix-core flow programs.  Parity with the oracle and with
-    the layer-by-layer path; the padded path must actually be taken."""
+    """Event sizes other than 64 / 128 / 256.  Even: both halves of the row are padded to the next supported
+    plane width (zero weights => identity on the padding, a base log_scale of -0.5 log 2 pi => no density
+    term).  Odd (HalfSplit moves one element across the halves at every reversal): every element keeps its
+    own index in both planes and changes planes by TFK_OP_PLANE_SWAP.  The whole chain still runs as
+    matrix-core flow programs.  Parity with the oracle and with the layer-by-layer path; the padded path
+    must actually be taken."""
     from torchflows_amd import native
     torch.manual_seed(D)
     from torchflows_amd.base_distributions.gaussian import DiagonalGaussian

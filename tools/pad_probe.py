@@ -3,7 +3,7 @@
 import os, sys, time, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import torchflows_amd as tfa
-for D in (8, 22, 62, 100):
+for D in (8, 22, 62, 100, 3, 21, 43, 63):
     torch.manual_seed(0)
     flow = tfa.Flow(tfa.RealNVP(D, n_layers=8))
     flow.train()

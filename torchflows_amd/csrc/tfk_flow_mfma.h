@@ -310,6 +310,23 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
                                            float (&a)[EPL], float (&b)[EPL], float &ld)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    if (op.kind == TFK_OP_PLANE_SWAP) {
+        // odd event sizes (one element changes halves at every reversal): mask[HALF] != 0 exchanges the
+        // elements at that index of the two planes -- both live in this lane's registers
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const float4 m = *reinterpret_cast<const float4 *>(prm + EPL * q + 4 * i);
+            const float mk[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * i + k;
+                const float ta = a[e], tb = b[e];
+                a[e] = mk[k] != 0.0f ? tb : ta;
+                b[e] = mk[k] != 0.0f ? ta : tb;
+            }
+        }
+        return;
+    }
     if (op.kind == TFK_OP_EW_MULADD || op.kind == TFK_OP_EW_SUBDIV) {
         // this lane's EPL columns of each plane, four at a time: float4 reads (the address depends
         // on q only); chunked so that D = 256 (64 row registers per lane) does not spill

@@ -48,7 +48,8 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
         memcpy(&o.scale, rec + 6, 4);
         memcpy(&o.c, rec + 7, 4);
         int64_t need;
-        if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
+        if (o.kind == TFK_OP_PLANE_SWAP) need = D / 2;
+        else if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
         else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
             if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);

@@ -31,7 +31,7 @@ import torch.nn as nn
 from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
-    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS = range(11)
+    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP = range(12)
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
 MAX_HIDDEN_RQS = 32
 FORWARD, INVERSE = 0, 1
@@ -276,9 +276,11 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
         return None                       # the fused spline op is built for the default 8 bins
     half = D // 2
     c = layer.coupling
-    if not (c.source_is_head and c.target_is_tail and c.source_event_size == half
-            and c.target_event_size == half):
+    S, T = c.source_event_size, c.target_event_size        # HalfSplit: D // 2 and D - D // 2 (coupling_masks.py:78-81)
+    if not (c.source_is_head and c.target_is_tail and S == half and S + T == D):
         return None
+    if T != S and (Dp is None or Dp == D or kind == "rqs" or not mfma):
+        return None                           # odd event sizes: padded matrix-core programs only
     ct = layer.conditioner_transform
     if type(ct) is not FeedForward or ct.n_global_parameters != 0:
         return None
@@ -292,9 +294,9 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     W1, b1 = mods[0].weight.detach(), mods[0].bias.detach()          # (H, S), (H,)
     W2, b2 = mods[2].weight.detach(), mods[2].bias.detach()          # (T*P, H), (T*P,)
     H = W1.shape[0]
-    if W1.shape[1] != half or W2.shape[0] != half * P or W2.shape[1] != H:
+    if W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
         return None
-    src_pos, tgt_pos = pos[:half], pos[half:]
+    src_pos, tgt_pos = pos[:S], pos[S:]
     Dp = D if Dp is None else Dp
     hp = Dp // 2                              # plane width the kernel sees (> half when padded)
     if Dp != D and (kind == "rqs" or not mfma):
@@ -307,9 +309,9 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     W1t[:, src_pos - plane * hp] = W1
     m_t = tgt_pos - (1 - plane) * hp
     W2p = torch.zeros(hp, P, H, dtype=W2.dtype, device=W2.device)
-    W2p[m_t] = W2.reshape(half, P, H)
+    W2p[m_t] = W2.reshape(T, P, H)
     b2p = torch.zeros(hp, P, dtype=b2.dtype, device=b2.device)
-    b2p[m_t] = b2.reshape(half, P)
+    b2p[m_t] = b2.reshape(T, P)
     if mfma:
         if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and D > 128):
             return None
@@ -346,6 +348,29 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     else:
         op = OP_AFFINE_FWD if (d == FORWARD) != (kind == "inverse_affine") else OP_AFFINE_INV
     return (op, plane, H), block
+
+
+def _plane_swap(layer, pos: torch.Tensor, Dp: int):
+    """Odd event sizes run in a layout where logical element l owns index l of BOTH planes (Dp >= 2 D), so an
+    element changes planes by a swap with the zero that sits at its index in the other plane.  Returns
+    ``(item or None, new pos)`` such that the coupling's source elements share one plane and its targets the
+    other (the assignment that needs fewer swaps)."""
+    hp = Dp // 2
+    S = layer.coupling.source_event_size
+    plane = pos // hp
+    src, tgt = plane[:S], plane[S:]
+    cost0 = int((src != 0).sum() + (tgt != 1).sum())        # sources in plane 0, targets in plane 1
+    cost1 = int((src != 1).sum() + (tgt != 0).sum())
+    want_src = 0 if cost0 <= cost1 else 1
+    want = torch.cat([torch.full_like(src, want_src), torch.full_like(tgt, 1 - want_src)])
+    wrong = plane != want
+    if not bool(wrong.any()):
+        return None, pos
+    slot = pos % hp
+    mask = torch.zeros(hp, dtype=torch.float32, device=pos.device)
+    mask[slot[wrong]] = 1.0
+    new_pos = torch.where(wrong, want * hp + slot, pos)
+    return ((OP_PLANE_SWAP, 0, 0), mask), new_pos
 
 
 def _made_op(layer, d: int, pos: torch.Tensor, D: int):
@@ -461,6 +486,11 @@ def compile_chain(composition, direction: int, device: torch.device,
     Dp = D
     if not native.lib().tfk_flow_mfma_supported(D) and D % 2 == 0 and 4 <= D < 256:
         Dp = 64 if D < 64 else (128 if D < 128 else 256)
+    # odd event sizes: HalfSplit moves one element across the halves at every reversal, so every element gets
+    # its own index in both planes (plane width >= D) and changes planes by TFK_OP_PLANE_SWAP
+    slots = D % 2 == 1 and 3 <= D <= 128
+    if slots:
+        Dp = 64 if D <= 32 else (128 if D <= 64 else 256)
     if mfma is None:
         if mfma_enabled() and native.lib().tfk_flow_mfma_supported(Dp) and padded_enabled(D, Dp):
             chain = compile_chain(composition, direction, device, mfma=True)
@@ -478,9 +508,9 @@ def compile_chain(composition, direction: int, device: torch.device,
     if plan is None:
         return None
     pos = torch.arange(D, device=device)
-    if Dp != D:                                  # second half of the row starts at the padded plane boundary
+    if Dp != D and not slots:                    # second half of the row starts at the padded plane boundary
         pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
-    pos_in = pos.clone()
+    pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
     items = []                                   # [(op triple, block)]
     with torch.no_grad():
         for layer, d in plan:
@@ -491,6 +521,10 @@ def compile_chain(composition, direction: int, device: torch.device,
             if isinstance(layer, ElementwiseBijection):
                 item = _elementwise_op(layer, d, pos, D, Dp)
             elif isinstance(layer, CouplingBijection):
+                if slots and Dp != D:
+                    swap, pos = _plane_swap(layer, pos, Dp)
+                    if swap is not None:
+                        items.append(swap)
                 item = _coupling_op(layer, d, pos, D, mfma=mfma, Dp=Dp)
             elif isinstance(layer, MaskedAutoregressiveBijection):
                 item = _made_op(layer, d, pos, D) if (mfma and Dp == D) else None
@@ -510,7 +544,7 @@ def compile_chain(composition, direction: int, device: torch.device,
             return None                          # a single op larger than LDS: not fusable here
         # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
         # gets a launch of its own, and the small elementwise ops around it ride along
-        small = kind in (OP_EW_MULADD, OP_EW_SUBDIV)
+        small = kind in (OP_EW_MULADD, OP_EW_SUBDIV, OP_PLANE_SWAP)
         budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0)) if mfma else MAX_PARAM_BYTES
         over = (used + n) * 4 > budget
         if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
@@ -581,10 +615,13 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     n_seg = len(chain.segments)
     padded = chain.pos_in is not None
     if padded:                                   # (N, D_log) -> (N, D): each half at the head of its plane
-        half, hp = chain.D_log // 2, chain.D // 2
         wide = rows.new_zeros(N, chain.D)
-        wide[:, :half] = rows[:, :half]
-        wide[:, hp:hp + half] = rows[:, half:]
+        if chain.D_log % 2 == 0:                 # each half at the head of its plane: two strided copies
+            half, hp = chain.D_log // 2, chain.D // 2
+            wide[:, :half] = rows[:, :half]
+            wide[:, hp:hp + half] = rows[:, half:]
+        else:                                    # odd sizes: the row at the head of plane 0
+            wide[:, :chain.D_log] = rows
         rows = wide
     logprob = torch.empty(N, dtype=torch.float32, device=dev) if base is not None else None
     logdet = torch.empty(N, dtype=torch.float32, device=dev) if (base is None or n_seg > 1) else None
