@@ -188,7 +188,7 @@ enum {
     TFK_OP_MADE_FWD = 8,   /* MADE + Affine on the whole row, parallel map (tfk_flow_run_mfma only) */
     TFK_OP_MADE_INV = 9,   /* same with (x - beta) / alpha */
     TFK_OP_MADE_RQS = 10,  /* MADE + RQ spline (8 bins) on the whole row, parallel map; hidden <= 16, D <= 128 */
-    TFK_OP_PLANE_SWAP = 11 /* tfk_flow_run_mfma: mask[D/2] floats, != 0 exchanges x[i] and x[D/2 + i] (odd event sizes,
+    TFK_OP_PLANE_SWAP = 11 /* tfk_flow_run_mfma: mask[D/2] floats, != 0 exchanges x[i] and x[D/2 + i] (D <= 128; odd event sizes,
                               padded so that every element keeps its index in both halves) */
 };
 int tfk_flow_supported(int32_t D);

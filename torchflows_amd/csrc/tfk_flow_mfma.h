@@ -310,7 +310,7 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
                                            float (&a)[EPL], float (&b)[EPL], float &ld)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
-    if (op.kind == TFK_OP_PLANE_SWAP) {
+    if constexpr (EPL <= 16) if (op.kind == TFK_OP_PLANE_SWAP) {      // (not at D = 256: 64 more live registers there)
         // odd event sizes (one element changes halves at every reversal): mask[HALF] != 0 exchanges the
         // elements at that index of the two planes -- both live in this lane's registers
 #pragma unroll

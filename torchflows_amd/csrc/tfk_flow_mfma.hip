@@ -48,7 +48,10 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
         memcpy(&o.scale, rec + 6, 4);
         memcpy(&o.c, rec + 7, 4);
         int64_t need;
-        if (o.kind == TFK_OP_PLANE_SWAP) need = D / 2;
+        if (o.kind == TFK_OP_PLANE_SWAP) {
+            if (D > 128) return fail(TFK_EINVAL, "%s: op %d: plane swaps exist for D <= 128", fn, i);
+            need = D / 2;
+        }
         else if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
         else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {

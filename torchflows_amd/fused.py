@@ -488,9 +488,9 @@ def compile_chain(composition, direction: int, device: torch.device,
         Dp = 64 if D < 64 else (128 if D < 128 else 256)
     # odd event sizes: HalfSplit moves one element across the halves at every reversal, so every element gets
     # its own index in both planes (plane width >= D) and changes planes by TFK_OP_PLANE_SWAP
-    slots = D % 2 == 1 and 3 <= D <= 128
+    slots = D % 2 == 1 and 3 <= D <= 64          # (the swap op is not built for 256-wide rows)
     if slots:
-        Dp = 64 if D <= 32 else (128 if D <= 64 else 256)
+        Dp = 64 if D <= 32 else 128
     if mfma is None:
         if mfma_enabled() and native.lib().tfk_flow_mfma_supported(Dp) and padded_enabled(D, Dp):
             chain = compile_chain(composition, direction, device, mfma=True)
