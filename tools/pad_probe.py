@@ -3,9 +3,11 @@
 import os, sys, time, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import torchflows_amd as tfa
-for D in (8, 22, 62, 100, 3, 21, 43, 63):
+arch = sys.argv[1] if len(sys.argv) > 1 else "RealNVP"
+sizes = [int(v) for v in sys.argv[2:]] or [8, 22, 62, 100, 3, 21, 43, 63]
+for D in sizes:
     torch.manual_seed(0)
-    flow = tfa.Flow(tfa.RealNVP(D, n_layers=8))
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=8))
     flow.train()
     with torch.no_grad():
         flow.log_prob(torch.randn(4096, D))
@@ -15,7 +17,8 @@ for D in (8, 22, 62, 100, 3, 21, 43, 63):
         os.environ["TORCHFLOWS_AMD_FUSED_PAD"] = mode
         flow.bijection.__dict__.pop("_tfk_compiled", None)
         with torch.no_grad():
-            flow.log_prob(x); torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(5): lp = flow.log_prob(x)
+            from torchflows_amd.distributed import sharded_log_likelihood as sll
+            sll(flow, x, chunk_rows=1 << 18); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5): lp = sll(flow, x, chunk_rows=1 << 18)
             torch.cuda.synchronize()
-        print(f"RealNVP({D}) {'padded flow program' if mode == '1' else 'layer by layer'}: {(1 << 20) * 5 / (time.perf_counter() - t0):.3e} evals/s")
+        print(f"{arch}({D}) {'padded flow program' if mode == '1' else 'layer by layer'}: {(1 << 20) * 5 / (time.perf_counter() - t0):.3e} evals/s")

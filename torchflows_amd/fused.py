@@ -279,7 +279,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     S, T = c.source_event_size, c.target_event_size        # HalfSplit: D // 2 and D - D // 2 (coupling_masks.py:78-81)
     if not (c.source_is_head and c.target_is_tail and S == half and S + T == D):
         return None
-    if T != S and (Dp is None or Dp == D or kind == "rqs" or not mfma):
+    if T != S and (Dp is None or Dp == D or not mfma):
         return None                           # odd event sizes: padded matrix-core programs only
     ct = layer.conditioner_transform
     if type(ct) is not FeedForward or ct.n_global_parameters != 0:
@@ -299,8 +299,10 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     src_pos, tgt_pos = pos[:S], pos[S:]
     Dp = D if Dp is None else Dp
     hp = Dp // 2                              # plane width the kernel sees (> half when padded)
-    if Dp != D and (kind == "rqs" or not mfma):
-        return None                           # padded planes: affine / shift on the matrix-core path only
+    if Dp != D and not mfma:
+        return None                           # padded planes: matrix-core path only
+    # (a padded RQ-spline element has all-zero parameters: equal bins, unit derivatives -- the identity at its
+    # value 0, log-det 0 up to the 1 ulp of softplus(c) + 1e-5 vs 1)
     plane = int(src_pos[0].item()) // hp
     if not bool(((src_pos // hp) == plane).all()) or not bool(((tgt_pos // hp) == 1 - plane).all()):
         return None
@@ -313,7 +315,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     b2p = torch.zeros(hp, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(T, P)
     if mfma:
-        if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and D > 128):
+        if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and Dp > 128):
             return None
         head, block = _pack_mfma(kind, d, plane, H, Dp, W1t, b1, W2p, b2p)
         if kind == "rqs":
