@@ -14,10 +14,17 @@ list:
   ``FeedForward`` (Linear, Tanh, Linear) become coupling ops; after the folded reversals
   the conditioner's input must still be exactly one half ("plane") of the physical row.
 
-Anything else (other masks, context, deeper / non-tanh conditioners, RQ splines, ActNorm
-that still has to initialise itself from data) makes ``compile_chain`` return ``None`` and
-the composition runs layer by layer (bijections/base.py).  Programs are cached per
-(direction, device) and rebuilt when any parameter version changes.
+* RQ-spline couplings (8 bins) and the parallel map of MADE-based affine / RQ-spline layers have
+  ops of their own on the matrix-core kernel (``tfk_flow_run_mfma``: event sizes 64 / 128 / 256);
+* other event sizes ride on the same kernel padded: even sizes with each half at the head of its
+  plane, odd sizes (HalfSplit moves one element across the halves at every reversal) with every
+  element owning an index in both planes and ``OP_PLANE_SWAP`` ops in front of the couplings --
+  padding elements see zero weights, i.e. the identity with log-det 0.
+
+Anything else (other masks, context, deeper / non-tanh conditioners, ActNorm that still has to
+initialise itself from data) makes ``compile_chain`` return ``None`` and the composition runs
+layer by layer (bijections/base.py).  Programs are cached per (direction, device) and rebuilt
+when any parameter version changes.
 """
 from __future__ import annotations
 
