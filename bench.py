@@ -395,13 +395,13 @@ def main():
             roofline = {"bound": "mfma" if dom_name == "flow_run_mfma" else "valu",
                         "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
-                        "limiter": "valu-issue",
+                        "limiter": "fp32-datapath",
                         "note": "fused flow program (conditioner in-kernel" +
                                 (", GEMMs as v_mfma_f32_16x16x4_f32" if dom_name == "flow_run_mfma" else "") +
                                 "); achieved = algorithmic conditioner FLOPs 2*(S*H+H*T*P) per row-layer "
                                 "/ launch time (the transform's transcendentals are not counted); peak = "
-                                "dense fp32 matrix peak; the kernel is limited by vector-ALU issue, see "
-                                "valu_issue_frac",
+                                "dense fp32 matrix peak; the kernel is limited by the SIMD FP32 datapath that "
+                                "vector instructions and f32-input MFMAs share, see fp32_datapath_frac",
                         "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
             if valu is not None:
                 # wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / live duration
