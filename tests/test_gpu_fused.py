@@ -429,7 +429,9 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
                                              ("RealNVP", 100, 3), ("RealNVP", 200, 2),
                                              ("RealNVP", 3, 2), ("RealNVP", 7, 3), ("NICE", 21, 4), ("RealNVP", 43, 8),
                                              ("RealNVP", 63, 5), ("CouplingRQNSF", 22, 3), ("CouplingRQNSF", 8, 2),
-                                             ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2)])
+                                             ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2),
+                                             ("MAF", 6, 2), ("MAF", 21, 3), ("MAF", 43, 2), ("MAF", 100, 2),
+                                             ("MaskedAutoregressiveRQNSF", 22, 2)])
 def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, arch, D, n_layers):
     """Event sizes other than 64 / 128 / 256.  Even: both halves of the row are padded to the next supported
     plane width (zero weights => identity on the padding, a base log_scale of -0.5 log 2 pi => no density
@@ -457,7 +459,7 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
             xr, ldi = flow.bijection.inverse(z)
         res[mode] = (lp, z, ld, xr, ldi, native.calls - before)
     monkeypatch.setenv("TORCHFLOWS_AMD_FUSED_PAD", "1")
-    assert res["1"][5] < res["0"][5] and res["1"][5] <= 3 * 4, (res["1"][5], res["0"][5])
+    assert res["1"][5] < res["0"][5] and res["1"][5] <= 3 * 4 + (n_layers if "M" == arch[0] else 0), (res["1"][5], res["0"][5])
     z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
     lp, z, ld, xr, ldi, _ = res["1"]
     e = dict(lp=rel(lp.cpu().numpy(), lp_ref), z=normwise(z.cpu().numpy(), z_ref),

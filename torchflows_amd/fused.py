@@ -382,7 +382,7 @@ def _plane_swap(layer, pos: torch.Tensor, Dp: int):
     return ((OP_PLANE_SWAP, 0, 0), mask), new_pos
 
 
-def _made_op(layer, d: int, pos: torch.Tensor, D: int):
+def _made_op(layer, d: int, pos: torch.Tensor, D: int, Dp: Optional[int] = None):
     """A MADE-based affine layer's PARALLEL map as one matrix-core op (tfk_flow_mfma.hip: made_m).
     None for the sequential map, other transformers, deeper MADEs, a context."""
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import MADE
@@ -399,24 +399,25 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int):
             and isinstance(mods[2], MADE.MaskedLinear)):
         return None
     H = mods[0].out_features
-    if mods[0].in_features != D or H > 64 or (D == 256 and H > 16):
+    Dp = D if Dp is None else Dp              # padded row width: padding elements get zero weights (identity)
+    if mods[0].in_features != D or H > 64 or (Dp == 256 and H > 16):
         return None
     if kind == "rqs":
-        return _made_rqs_op(layer, mods, pos, D, H)
-    half, EPL = D // 2, D // 8
+        return _made_rqs_op(layer, mods, pos, D, H, Dp)
+    half, EPL = Dp // 2, Dp // 8
     T2 = EPL // 2
     steps2 = (H + 3) // 4
     HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
     W1 = (mods[0].weight * mods[0].mask).detach()                       # (H, D) logical columns
     W2 = (mods[2].weight * mods[2].mask).detach().view(D, 2, H)        # logical element, parameter, unit
     dev, dt = W1.device, W1.dtype
-    W1p = torch.zeros(16 * HT, D, dtype=dt, device=dev)
+    W1p = torch.zeros(16 * HT, Dp, dtype=dt, device=dev)
     W1p[:H, pos] = W1                                                   # physical columns
     b1p = torch.zeros(16 * HT, dtype=dt, device=dev)
     b1p[:H] = mods[0].bias.detach()
-    W2p = torch.zeros(D, 2, 16 * HT, dtype=dt, device=dev)
+    W2p = torch.zeros(Dp, 2, 16 * HT, dtype=dt, device=dev)
     W2p[pos, :, :H] = W2                                                # physical elements
-    b2p = torch.empty(D, 2, dtype=dt, device=dev)
+    b2p = torch.zeros(Dp, 2, dtype=dt, device=dev)
     b2p[pos] = mods[2].bias.detach().view(D, 2)
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
@@ -437,26 +438,27 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int):
     return (OP_MADE_INV if divide else OP_MADE_FWD, 0, steps2), block
 
 
-def _made_rqs_op(layer, mods, pos: torch.Tensor, D: int, H: int):
+def _made_rqs_op(layer, mods, pos: torch.Tensor, D: int, H: int, Dp: Optional[int] = None):
     """The parallel map of a MADE-based RQ-spline layer (8 bins, hidden <= 16, D <= 128) as one matrix-core
     op (tfk_flow_mfma.h: made_rqs_m): A1[2 EPL][64] | b1[4][4] | A2[2 EPL 6][steps2][64] | b2[2 EPL 6][4][4]."""
     import math
     import numpy as np
     tr = layer.transformer
-    if tr.n_bins != 8 or H > 16 or D > 128:
+    Dp = D if Dp is None else Dp
+    if tr.n_bins != 8 or H > 16 or Dp > 128:
         return None
-    half, EPL = D // 2, D // 8
+    half, EPL = Dp // 2, Dp // 8
     steps2 = (H + 3) // 4
     W1 = (mods[0].weight * mods[0].mask).detach()                       # (H, D) logical columns
     W2 = (mods[2].weight * mods[2].mask).detach().view(D, 23, H)       # logical element, parameter, unit
     dev, dt = W1.device, W1.dtype
-    W1p = torch.zeros(16, D, dtype=dt, device=dev)
+    W1p = torch.zeros(16, Dp, dtype=dt, device=dev)
     W1p[:H, pos] = W1                                                   # physical columns
     b1p = torch.zeros(16, dtype=dt, device=dev)
     b1p[:H] = mods[0].bias.detach()
-    W2p = torch.zeros(D, 24, 16, dtype=dt, device=dev)
+    W2p = torch.zeros(Dp, 24, 16, dtype=dt, device=dev)
     W2p[pos, :23, :H] = W2                                              # physical elements, 23 + 1 pad
-    b2p = torch.zeros(D, 24, dtype=dt, device=dev)
+    b2p = torch.zeros(Dp, 24, dtype=dt, device=dev)
     b2p[pos, :23] = mods[2].bias.detach().view(D, 23)
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
@@ -536,7 +538,7 @@ def compile_chain(composition, direction: int, device: torch.device,
                         items.append(swap)
                 item = _coupling_op(layer, d, pos, D, mfma=mfma, Dp=Dp)
             elif isinstance(layer, MaskedAutoregressiveBijection):
-                item = _made_op(layer, d, pos, D) if (mfma and Dp == D) else None
+                item = _made_op(layer, d, pos, D, Dp) if mfma else None
             else:
                 item = None
             if item is None:
