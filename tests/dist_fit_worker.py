@@ -59,6 +59,33 @@ def main():
     dist.all_gather(other, flat)
     assert all(torch.equal(o, other[0]) for o in other)
     assert adam_losses[-1] < adam_losses[0]
+    # shards whose step counts differ (513 rows: 257 + 256 at 64 rows per rank and step = 5 and 4 steps):
+    # every rank must run the same number of collectives (this used to hang) and stay identical
+    g2 = torch.Generator().manual_seed(11)
+    x2 = torch.randn(513, 6, generator=g2)
+    lo2, hi2 = shard_bounds(513, rank, world)
+    torch.manual_seed(0)
+    ragged = tfa.Flow(tfa.RealNVP(6, n_layers=2))
+    single2 = copy.deepcopy(ragged)
+    r_losses = sharded_fit(ragged, x2[lo2:hi2], n_epochs=2, lr=0.01, batch_size=128, shuffle=False, optimizer=sgd)
+    assert len(r_losses) == 2 * 5, len(r_losses)
+    bounds2 = [shard_bounds(513, r, world) for r in range(world)]
+    opt2 = torch.optim.SGD(single2.parameters(), lr=0.01)
+    single2.train()
+    ref2 = []
+    for _ in range(2):
+        for b in range(0, 5 * per, per):
+            xb = torch.cat([x2[min(l + b, h):min(l + b + per, h)] for l, h in bounds2])
+            opt2.zero_grad()
+            loss = -single2.log_prob(xb).mean() / single2.event_size + single2.regularization()
+            loss.backward()
+            opt2.step()
+            ref2.append(float(loss.detach()))
+    assert max(abs(a - b) for a, b in zip(r_losses, ref2)) < 2e-5, (r_losses, ref2)
+    flat = torch.cat([p.detach().reshape(-1) for p in ragged.parameters()])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(o, other[0]) for o in other)
     dist.barrier()
     if rank == 0:
         print("DIST_FIT_OK", losses[0], losses[-1])

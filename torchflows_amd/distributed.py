@@ -135,8 +135,11 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
     """Data-parallel ``Flow.fit`` (flows.py:226-455 semantics for the loss: ``-mean(log_prob * w) /
     event_size + regularization`` over the GLOBAL batch): every rank holds a replica and its own
     shard of the training rows (already on its device), takes ``batch_size // world_size`` of them
-    per step, and the ranks exchange exactly one all-reduce(SUM) of the flat gradient (a few tens
-    of KB: latency-bound on xGMI) before the identical AdamW update -- replicas stay bit-identical.
+    per step, and the ranks exchange exactly one all-reduce(SUM) per step -- the flat gradient with the
+    loss riding along (a few tens of KB: latency-bound on xGMI) -- before the identical AdamW update:
+    replicas stay bit-identical.  Shards may differ in size: the ranks exchange their row counts once,
+    every rank runs the longest shard's number of steps, and a rank without rows left contributes an
+    empty batch.
     ActNorm takes its initial statistics from the global first batch (one more all-reduce, once).
     ``optimizer``: ``callable(parameters, lr)`` (default AdamW, as ``Flow.fit``).
     Returns the list of global per-step training losses."""
@@ -150,6 +153,17 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
     params = [p for p in flow.parameters() if p.requires_grad]
     if not params:
         return []
+    # Shard sizes may differ (shard_bounds hands out shards one row apart), so the ranks agree ONCE on
+    # every rank's row count: the number of steps per epoch (the longest shard's) and the global row
+    # count of every step follow from it on the host, and a rank that has run out of rows contributes
+    # an empty batch (zero data gradient) instead of leaving the others waiting in the all-reduce.
+    if distributed:
+        sizes_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes_t, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+        sizes = [int(t.item()) for t in sizes_t]
+    else:
+        sizes = [n_local]
+    steps_per_epoch = max(-(-n // local_bs) for n in sizes)
     opt = (optimizer or (lambda ps, lr_: torch.optim.AdamW(ps, lr=lr_)))(flow.parameters(), lr)
     gen = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
     flow.train()
@@ -160,29 +174,33 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
     try:
         for _ in range(n_epochs):
             order = torch.randperm(n_local, generator=gen).to(dev) if shuffle and n_local > 1 else None
-            for lo in range(0, n_local, local_bs):
+            for step in range(steps_per_epoch):
+                lo = step * local_bs
+                count = sum(min(local_bs, max(0, n - lo)) for n in sizes)        # global batch rows (host, no sync)
                 idx = slice(lo, lo + local_bs) if order is None else order[lo:lo + local_bs]
                 xb, wb = x_local[idx], w_local[idx]
-                count = torch.tensor([float(xb.shape[0])], dtype=torch.float64, device=dev)
-                if distributed:
-                    dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)     # global batch rows
                 opt.zero_grad(set_to_none=True)
-                lp = flow.log_prob(xb)
-                loss = -(lp * wb).sum() / (float(count) * flow.event_size) + flow.regularization() / world
-                loss.backward()
+                loss = flow.regularization() / world
+                if xb.shape[0] > 0:
+                    lp = flow.log_prob(xb)
+                    loss = loss - (lp * wb).sum() / (float(count) * flow.event_size)
+                if isinstance(loss, torch.Tensor) and loss.requires_grad:
+                    loss.backward()
+                loss_t = loss.detach().reshape(1).to(dev) if isinstance(loss, torch.Tensor) \
+                    else torch.tensor([float(loss)], device=dev)
                 flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                  for p in params] + [loss.detach().reshape(1)])
+                                  for p in params] + [loss_t.to(params[0].dtype)])
                 if distributed:
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)     # THE exchange step
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)     # THE exchange step (the only one)
                 lo_f = 0
                 for p in params:
                     n = p.numel()
                     p.grad = flat[lo_f:lo_f + n].view_as(p)
                     lo_f += n
-                losses.append(float(flat[-1]))
+                losses.append(flat[-1])                                          # stays on the device: no host sync per step
                 opt.step()
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
     flow.eval()
-    return losses
+    return [float(v) for v in torch.stack(losses).cpu()] if losses else []
