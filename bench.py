@@ -30,9 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
+np = torch = dist = None      # imported in main() AFTER the launcher check: the parent of an N > 1 run never
+                              # touches torch, the GPU or RCCL -- it only starts the ranks and relays their output
 
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4     # wave64 instructions / s (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
@@ -197,11 +196,13 @@ class KernelTimer:
             ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         for op in ops:
             kind, H = op[0], op[2]
-            if mfma and kind in (2, 3, 4, 5):
-                H = KernelTimer.true_hidden.get(D, 4 * H)
+            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10):
+                H = KernelTimer.true_hidden.get(D, 4 * H)       # the matrix-core ops record ceil(H / 4)
             P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23}.get(kind)
             if P is not None:
                 per_row += 2 * (half * H + H * half * P)
+            elif kind in (8, 9, 10):                            # MADE ops: both planes in, every element a target
+                per_row += 2 * (D * H + H * D * (2 if kind != 10 else 23))
         return N * per_row
 
     def summary(self):
@@ -232,6 +233,18 @@ def make_flow(arch, D, n_layers):
     with torch.no_grad():
         flow.log_prob(torch.randn(512 if isinstance(D, tuple) else 4096, *shape))
     return flow.eval()
+
+
+def csrc_sha256() -> str:
+    """sha256 over the kernel sources (torchflows_amd/csrc/*, include/tfk.h): ties PMC summaries to a build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "torchflows_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "tfk.h")]):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def host_cores() -> int:
@@ -270,6 +283,58 @@ def cpu_baseline(arch, D, n_layers, flow_host, target_seconds=12.0):
                       f"{threads} threads, {dt:.1f} s"}, ref
 
 
+def cpu_baseline_aten(flow_host, shape, batch_rows, target_seconds=8.0):
+    """SURVEY.md 8(d) "CPU comparison in the same run": this package's own ATen (pure PyTorch) path on the host
+    cores -- the same op chains the reference runs on a CPU (it matches the reference's golden outputs to ~1e-7,
+    tests/test_host_cpu.py / test_host_image_cpu.py); the reference itself cannot travel to the GPU box."""
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch_rows, *shape, generator=g)
+    with torch.no_grad():
+        flow_host.log_prob(x[:max(1, batch_rows // 8)])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            flow_host.log_prob(x)
+            n += batch_rows
+            dt = time.perf_counter() - t0
+            if dt >= target_seconds:
+                break
+    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} rows ({n // batch_rows} batches of {batch_rows}) of the same workload through this "
+                      f"package's ATen composite path (torchflows_amd on CPU tensors = the reference's op chains), "
+                      f"torch.set_num_threads({threads}), {dt:.1f} s"}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process
+    (python -m torch.distributed.run, one rank per GPU over RCCL), relay rank 0's JSON line on stdout and
+    everything else on stderr, and exit with the child's code.  This parent never imports torch and never
+    touches the GPU (replacing a GPU-initialised process by exec is forbidden on this pool; a child is not)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    printed = False
+    for line in proc.stdout:
+        if line.startswith("{") and not printed:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            printed = True
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and not printed:
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +342,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="realnvp64", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the config's)")
+    ap.add_argument("--total-rows", type=int, default=None,
+                    help="strong scaling: this many rows in total, split evenly over the ranks "
+                         "(config 4: --workload realnvp256 --total-rows 4194304 --gpus 8)")
+    ap.add_argument("--stats-steps", type=int, default=100,
+                    help="extra steps, timed one by one with HIP events AFTER the K timed steps (median / min / max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true",
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
@@ -290,13 +360,17 @@ def main():
         os.environ["TORCHFLOWS_AMD_FUSED"] = "0"
     if args.no_mfma:
         os.environ["TORCHFLOWS_AMD_MFMA"] = "0"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])          # does not return
+    global np, torch, dist
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        sys.exit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     # (rehearsal on a one-GPU box: TORCHFLOWS_AMD_DIST_BACKEND=gloo runs the ranks on the same card; RCCL
     # refuses two ranks per device)
@@ -318,6 +392,8 @@ def main():
 
     arch, D, n_layers, rows, chunk = WORKLOADS[args.workload]
     rows = args.rows or rows
+    if args.total_rows:
+        rows = args.total_rows // world
     flow_host = make_flow(arch, D, n_layers)
     for layer in flow_host.bijection.modules():
         seq = getattr(getattr(layer, "conditioner_transform", None), "sequential", None)
@@ -363,35 +439,49 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         timer.active = False
+        # distribution of the step time: stats_steps MORE steps (not part of `value`), each bracketed by its own
+        # HIP events on the launch stream; the 8-byte all-reduces stay in flight as above
+        step_ms = []
+        if args.stats_steps > 0:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.stats_steps + 1)]
+            marks[0].record()
+            for i in range(args.stats_steps):
+                step()
+                marks[i + 1].record()
+            drain()
+            torch.cuda.synchronize()
+            step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.stats_steps))
+    rows_total = world * rows
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(rows)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        r = t[1:].clone()
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        elapsed, rows_total = float(t[0].item()), int(r.item())
 
     if rank == 0:
         kernels = timer.summary()
         dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
         dom = kernels[dom_name]
-        traffic = None     # PMC counters need their own rocprofv3 passes: read the committed summary
+        # PMC counters need their own rocprofv3 passes: the committed summary is read -- but only if it was taken
+        # from THESE kernel sources (profiles/traffic.json carries the sha256 of torchflows_amd/csrc/ at the time of
+        # the PMC run, tools/summarize_profile.py); a kernel change leaves traffic / valu_insts null, not stale
+        traffic_db, traffic_stale = {}, None
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(dom_name)
-            if traffic is not None and rows != WORKLOADS[args.workload][3]:
-                traffic = None
-        except (OSError, KeyError, ValueError):
+            db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic_stale = db.get("csrc_sha256") != csrc_sha256()
+            if not traffic_stale and rows == WORKLOADS[args.workload][3]:
+                traffic_db = db.get(args.workload, {})
+        except (OSError, ValueError):
             pass
+        traffic = traffic_db.get(dom_name)
         if dom_name.startswith("flow_run"):
             # conditioner fused in-kernel: h never reaches HBM.  SURVEY.md 8(d): report the fused
             # kernel against the fp32 matrix / vector peak (the same 157.3 TFLOP/s) and say so.
             # The GEMMs of flow_run_mfma run on the matrix cores ("mfma"); what actually limits
             # both kernels is vector-ALU issue of the transform's exp / log / divide ("limiter").
-            valu = None
-            try:
-                valu = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(
-                    dom_name + ":valu_insts")
-                if valu is not None and rows != WORKLOADS[args.workload][3]:
-                    valu = None
-            except (OSError, KeyError, ValueError):
-                pass
+            valu = traffic_db.get(dom_name + ":valu_insts")
+            mfma_pmc = traffic_db.get(dom_name + ":mfma_insts")
             roofline = {"bound": "mfma" if dom_name == "flow_run_mfma" else "valu",
                         "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
@@ -410,6 +500,14 @@ def main():
                 roofline["valu_insts_per_launch"] = valu
                 roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
                 n_mfma = timer.mfma_insts.get(dom_name, 0) / max(dom["launches"], 1)
+                if mfma_pmc is not None:
+                    # measured: rocprofv3 SQ_INSTS_VALU_MFMA_MOPS_F32 / SQ_INSTS_MFMA pass (tools/profile.sh); the
+                    # analytic count above must agree with it
+                    roofline["mfma_insts_per_launch_pmc"] = mfma_pmc
+                    roofline["mfma_insts_model_vs_pmc"] = n_mfma / mfma_pmc if mfma_pmc else None
+                for key in ("mfma_busy_cycles", "mfma_coexec_cycles", "sq_busy_cycles", "mfma_util"):
+                    if traffic_db.get(dom_name + ":" + key) is not None:
+                        roofline[key] = traffic_db[dom_name + ":" + key]
                 if n_mfma:
                     # the f32-input MFMA runs at the vector rate on the SIMD's FP32 datapath (64 FLOP/clk/SIMD,
                     # MI355X_MICROARCH.md) and did not overlap with vector work in this kernel (ablation in
@@ -434,14 +532,14 @@ def main():
         result = {
             "metric": "log_prob evals/sec (RealNVP D=64)" if args.workload == "realnvp64"
                       else f"log_prob evals/sec ({args.workload})",
-            "value": world * rows * args.steps / elapsed,
+            "value": rows_total * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_rows else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -449,7 +547,21 @@ def main():
                                    f"{' + 8-byte RCCL all-reduce' if world > 1 else ''}, "
                                    f"{rows} standard-Gaussian rows per GPU resident in HBM, "
                                    f"data-initialised weights (seed 0)",
-                       "rows_per_gpu": rows, "parallelism": f"batch-sharded replicas x{world}"},
+                       "rows_per_gpu": rows, "rows_total": rows_total,
+                       "parallelism": f"batch-sharded replicas x{world}"},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (backend if world > 1 else None),
+            "rows_all_ranks": rows_total,
+            "log_likelihood_sum": float(total.item()),
+            "step_stats": ({"steps": len(step_ms), "median_ms": step_ms[len(step_ms) // 2], "min_ms": step_ms[0],
+                            "max_ms": step_ms[-1], "p10_ms": step_ms[len(step_ms) // 10],
+                            "p90_ms": step_ms[(9 * len(step_ms)) // 10],
+                            "evals_per_s_at_median": rows / (step_ms[len(step_ms) // 2] * 1e-3) * world,
+                            "note": "per-step HIP-event times of stats_steps further steps on rank 0 (not part of value)"}
+                           if step_ms else None),
+            "traffic_source": (None if traffic_stale is None else
+                               ("stale: profiles/traffic.json was taken from other kernel sources -- traffic / "
+                                "valu_insts withheld" if traffic_stale else "profiles/traffic.json (csrc sha256 matches)")),
             "roofline": roofline,
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                             "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
@@ -476,13 +588,7 @@ def main():
             os.environ["TORCHFLOWS_AMD_FUSED"] = "1"
             lw = timer.summary()
             lw_name = max(lw, key=lambda k: lw[k]["ms"])
-            tr = None
-            try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload].get(lw_name)
-                if rows != WORKLOADS[args.workload][3]:
-                    tr = None
-            except (OSError, KeyError, ValueError):
-                pass
+            tr = traffic_db.get(lw_name)
             result["roofline_layerwise"] = {
                 "bound": "hbm", "achieved": lw[lw_name]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": lw[lw_name]["GBps"] / HBM_PEAK_GBS, "traffic": tr, "kernel": lw_name,
@@ -595,10 +701,32 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not isinstance(D, tuple):
             base, ref = cpu_baseline(arch, D, n_layers, flow_host)
             result["cpu_baseline"] = base
+            result["cpu_baseline_aten"] = cpu_baseline_aten(flow_host, (D,), 1 << 14)
             idx = torch.arange(0, rows, max(rows // 2048, 1), device=dev)[:2048]
             lp_ref = ref.log_prob(x[idx].cpu().numpy())
-            err = np.max(np.abs(lp[idx].cpu().numpy() - lp_ref) / np.maximum(1.0, np.abs(lp_ref)))
-            result["parity"] = {"log_prob_max_rel_vs_oracle": float(err), "rows_checked": int(idx.numel())}
+            d = np.abs(lp[idx].cpu().numpy() - lp_ref)
+            err = np.max(d / np.maximum(1.0, np.abs(lp_ref)))
+            result["parity"] = {"log_prob_max_rel_vs_oracle": float(err), "rows_checked": int(idx.numel()),
+                                "pass_rate_1e-5": float(np.mean(d <= 1e-5 * np.maximum(1.0, np.abs(lp_ref))))}
+        if world == 1 and not args.no_cpu_baseline and isinstance(D, tuple):
+            # config 5: the oracle's C port covers the image LAYERS (masks, squeeze, 1x1 convolution), not the ConvNet
+            # conditioner, so the CPU leg is this package's ATen path on the host cores and parity is taken against
+            # the REFERENCE's own outputs for this model (tests/golden/flow_glow_3x32x32.npz, make_golden.py gen_glow32)
+            result["cpu_baseline"] = cpu_baseline_aten(flow_host, D, 256, target_seconds=12.0)
+            result["cpu_baseline_aten"] = result["cpu_baseline"]
+            if D == (3, 32, 32):
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from golden_util import load_glow32
+                gflow, fx = load_glow32()
+                gflow = gflow.to(dev)
+                with torch.no_grad():
+                    glp = gflow.log_prob(torch.from_numpy(fx["x"]).to(dev)).cpu().numpy()
+                d = np.abs(glp - fx["log_prob"])
+                result["parity"] = {"log_prob_max_rel_vs_reference": float(np.max(d / np.maximum(1.0, np.abs(fx["log_prob"])))),
+                                    "rows_checked": int(glp.shape[0]),
+                                    "pass_rate_1e-5": float(np.mean(d <= 1e-5 * np.maximum(1.0, np.abs(fx["log_prob"])))),
+                                    "note": "HIP path vs the reference's own log_prob of the config-5 model "
+                                            "(seed-0 weights pinned by sha256, data-dependent state from the fixture)"}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

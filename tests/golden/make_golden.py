@@ -370,6 +370,55 @@ def gen_image():
     save("flow_glow_3x8x8.npz", **out)
 
 
+def state_hash(tensors):
+    """sha256 over the fp32 / int64 bytes of a list of (name, tensor), in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sorted(tensors, key=lambda kv: kv[0]):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(np32(v)).tobytes())
+    return h.hexdigest()
+
+
+def gen_glow32():
+    """Config 5 AS CONFIGURED: AffineGlow((3, 32, 32)) (auto n_layers = 3, 3.2 M parameters), seed 0,
+    data-initialised on 64 rows.  The seed-reproducible tensors (every weight: 3 143 560 of 3 205 817 entries)
+    are NOT stored -- the build constructs the same model from the same seed and the fixture pins their sha256;
+    the tensors the train-mode pass changed (ActNorm values, BatchNorm statistics: 62 257 entries) are stored."""
+    from torchflows.bijections.finite.multiscale.architectures import AffineGlow
+    torch.manual_seed(0)
+    flow = Flow(AffineGlow((3, 32, 32)))
+    sd0 = {k: v.clone() for k, v in flow.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 3, 32, 32, generator=g)
+    z_in = torch.randn(8, 3, 32, 32, generator=g)
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(64, 3, 32, 32, generator=g))
+    flow.eval()
+    sd1 = flow.state_dict()
+    changed = [k for k in sd1 if not torch.equal(sd0[k], sd1[k])]
+    fixed = [(k, v) for k, v in sd1.items() if k not in changed and k.split(".")[-1] != "device_buffer"]
+    out = {"n_params": np.int64(sum(p.numel() for p in flow.parameters())),
+           "seed_state_sha256": np.array(state_hash(fixed)),
+           "seed_state_entries": np.int64(sum(v.numel() for _, v in fixed))}
+    for k in changed:
+        out[f"sd/{k}"] = np32(sd1[k])
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(x)
+        lp = flow.log_prob(x)
+        xr, ldr = flow.bijection.inverse(z_in)
+        f64 = Flow(AffineGlow((3, 32, 32))).double()
+        f64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd1.items()})
+        f64.eval()
+        lp64 = f64.log_prob(x.double())
+        z64, ld64 = f64.bijection.forward(x.double())
+    out.update({"x": np32(x), "z_in": np32(z_in), "z": np32(z), "log_det": np32(ld), "log_prob": np32(lp),
+                "x_inv": np32(xr), "log_det_inv": np32(ldr), "log_prob64": np32(lp64), "log_det64": np32(ld64),
+                "z64": np32(z64).astype(np.float32)})
+    save("flow_glow_3x32x32.npz", **out)
+
+
 # ---------------------------------------------------------------- F8 gradients (SURVEY 8f-2)
 def _tr_grads(tr, x, h, gz, gld, inverse, dtype):
     x = x.to(dtype).clone().requires_grad_(True)

@@ -112,6 +112,59 @@ def test_affine_glow_golden_on_hip(native):
     assert rel(xr.cpu().numpy(), fx["x_inv"]) < 1e-4 and rel(ldr.cpu().numpy(), fx["log_det_inv"]) < 2e-5
 
 
+def test_affine_glow_config5_golden_on_hip(native):
+    """Config 5 as configured -- AffineGlow((3, 32, 32)), 3.2 M parameters -- on the HIP path against the
+    REFERENCE's outputs (tests/golden/flow_glow_3x32x32.npz): log_prob within 1e-5, z / log-det / x within 2e-5
+    (the reference's own fp32-vs-fp64 distance on these rows is printed beside the error)."""
+    from golden_util import load_glow32
+    flow, fx = load_glow32()
+    flow = flow.cuda()
+    x, z_in = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["z_in"]).cuda()
+    before = native.calls
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        z, ld = flow.bijection.forward(x)
+        xr, ldr = flow.bijection.inverse(z_in)
+    assert native.calls - before > 100
+    e = dict(log_prob=rel(lp.cpu().numpy(), fx["log_prob"]), z=rel(z.cpu().numpy(), fx["z"]),
+             log_det=rel(ld.cpu().numpy(), fx["log_det"]), x_inv=rel(xr.cpu().numpy(), fx["x_inv"]),
+             log_det_inv=rel(ldr.cpu().numpy(), fx["log_det_inv"]))
+    floor = dict(log_prob=rel(fx["log_prob"], fx["log_prob64"]), z=rel(fx["z"], fx["z64"]),
+                 log_det=rel(fx["log_det"], fx["log_det64"]))
+    print("glow32 vs reference:", e, "reference fp32-vs-fp64:", floor)
+    assert e["log_prob"] < 1e-5 and e["log_det"] < 1e-5 and e["log_det_inv"] < 1e-5, e
+    assert e["z"] < 2e-5 and e["x_inv"] < 2e-5, e
+
+
+def test_affine_glow_config5_full_size_properties(native):
+    """Config 5 at its full size, N = 2^18 rows of (3, 32, 32) (3 GiB) evaluated in chunks: the first 8 rows ARE
+    the fixture's (reference log_prob within 1e-5), chunk-size invariance, round trip, ld_fwd = -ld_inv, and the
+    fp64 sum of the log-likelihood against a host fp64 sum."""
+    from golden_util import load_glow32
+    from torchflows_amd.distributed import sharded_log_likelihood
+    flow, fx = load_glow32()
+    flow = flow.cuda()
+    N = 1 << 18
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(N, 3, 32, 32, device="cuda", generator=g)
+    x[:8] = torch.from_numpy(fx["x"]).cuda()
+    with torch.no_grad():
+        lp, total = sharded_log_likelihood(flow, x, chunk_rows=1 << 13)
+        assert rel(lp[:8].cpu().numpy(), fx["log_prob"]) < 1e-5
+        assert torch.isfinite(lp).all()
+        host_sum = float(lp.cpu().double().sum())
+        assert abs(float(total) - host_sum) <= 1e-9 * abs(host_sum)
+        # chunk invariance: rows are independent, so a differently chunked pass gives the same values
+        sel = torch.arange(0, N, 37, device="cuda")[:5000]
+        lp_b = flow.log_prob(x[sel])
+        assert rel(lp_b.cpu().numpy(), lp[sel].cpu().numpy()) < 2e-6
+        # round trip on a strided subset
+        z, ld = flow.bijection.forward(x[sel])
+        xr, ldr = flow.bijection.inverse(z)
+        assert float((xr - x[sel]).abs().max()) < 1e-3            # the reference's own round-trip bar
+        assert rel((-ldr).cpu().numpy(), ld.cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])
 def test_glow_hip_vs_host_config5(native, event_shape, n):
     """Config 5 model (AffineGlow on 32x32x3, 3.2 M parameters), HIP path vs this package's

@@ -143,3 +143,21 @@ def test_squeeze_roundtrip_and_layout():
     assert torch.equal(z[..., 0:3, :, :], x[..., ::2, ::2]) and torch.equal(z[..., 9:12, :, :], x[..., 1::2, 1::2])
     xr, _ = sq.inverse(z)
     assert torch.equal(xr, x)
+
+
+def test_affine_glow_config5_size_matches_reference():
+    """Config 5 AS CONFIGURED -- AffineGlow((3, 32, 32)), auto n_layers = 3, 3 198 855 parameters (Q10: 1x1
+    convolutions only in the 3 top-level channel-wise layers): the build's seed-0 weights hash to the
+    reference's, and its ATen path reproduces the reference's outputs (tests/golden/flow_glow_3x32x32.npz,
+    written by make_golden.py gen_glow32 from the reference itself)."""
+    from golden_util import load_glow32
+    flow, fx = load_glow32()
+    assert int(fx["n_params"]) == 3198855
+    x, z_in = torch.from_numpy(fx["x"]), torch.from_numpy(fx["z_in"])
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        z, ld = flow.bijection.forward(x)
+        xr, ldr = flow.bijection.inverse(z_in)
+    assert rel(lp.numpy(), fx["log_prob"]) < 2e-6 and rel(ld.numpy(), fx["log_det"]) < 2e-6
+    assert rel(z.numpy(), fx["z"]) < 5e-6
+    assert rel(xr.numpy(), fx["x_inv"]) < 5e-6 and rel(ldr.numpy(), fx["log_det_inv"]) < 2e-6

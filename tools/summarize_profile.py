@@ -32,3 +32,11 @@ with open(os.path.join(out, "pmc_summary.csv"), "w") as f:
         hbm = (2 * mean.get("FETCH_SIZE", 0) + mean.get("WRITE_SIZE", 0)) * 1024
         f.write('"%s",%d,%s,%.0f\n' % (k, n, ",".join("%.1f" % mean.get(c, float("nan")) for c in names), hbm))
 print(open(os.path.join(out, "pmc_summary.csv")).read()[:3000])
+
+# the sources these counters were taken from (bench.py withholds roofline.traffic / valu_insts when they differ)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    from bench import csrc_sha256
+    open(os.path.join(out, "csrc_sha256.txt"), "w").write(csrc_sha256() + "\n")
+except Exception as exc:                                     # noqa: BLE001
+    print("csrc hash not written:", exc)
