@@ -34,3 +34,35 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["parity"]["log_prob_max_rel_vs_oracle"] < 1e-5
+    s = d["step_stats"]
+    assert s["steps"] == 100 and s["min_ms"] <= s["median_ms"] <= s["max_ms"]
+    assert d["cpu_baseline_aten"]["value"] > 0 and d["rccl_ranks"] == 1
+    assert d["parity"]["pass_rate_1e-5"] == 1.0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher on the command line (the driver's form): the parent starts the two
+    ranks as a child process and relays rank 0's line.  On this one-GPU box the ranks share the card and talk over
+    gloo (TORCHFLOWS_AMD_DIST_BACKEND=gloo: RCCL refuses two ranks per device); on the driver's 8-GPU node the same
+    command runs one rank per GPU over RCCL."""
+    env = dict(os.environ, TORCHFLOWS_AMD_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--rows", "65536", "--stats-steps", "10"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    assert d["rows_all_ranks"] == 2 * 65536 and d["config"]["rows_total"] == 2 * 65536
+    assert abs(d["value"] - 2 * 65536 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
+    # strong-scaling form of config 4: a fixed total split over the ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "realnvp256", "--total-rows", "65536", "--stats-steps", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["rows_all_ranks"] == 65536 and d["config"]["rows_per_gpu"] == 32768

@@ -2,9 +2,11 @@
 running on the HIP kernels, against (1) the reference's golden outputs and (2) the CPU
 oracle on seeded inputs, then size-independent properties at the BASELINE.json sizes.
 
-Tolerances: RealNVP / NICE log_prob and reconstructed x within 1e-5 relative (the
-north-star bound); RQ-spline flows within max(4e-5, 3 x the reference's own fp32-vs-fp64
-distance on the same inputs) -- the floor is printed next to each error.
+Tolerances: log_prob within 1e-5 relative for EVERY flow, RQ-spline ones included (the north-star bound; only
+where the reference's own fp32-vs-fp64 distance on the same rows is itself above 1e-5/3 does 3 x that floor
+apply); RealNVP / NICE z and reconstructed x within 1e-5; RQ-spline z / x -- whose knots are
+100 cumsum(softmax) - 50, 1 ulp = 3.8e-6 amplified by 1 / bin width -- within max(4e-5, 3 x floor), with the
+elementwise |d| <= 1e-5 max(1, |ref|) pass rate printed beside the reference's own (hard part 1).
 """
 import numpy as np
 import pytest
@@ -19,6 +21,13 @@ def rel(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def pass_rate(a, b, tol=1e-5):
+    """share of entries with |a - b| <= tol * max(1, |b|)"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.mean(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))) if a.size else 1.0
 
 
 def normwise(a, b):
@@ -93,8 +102,12 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     e_x = normwise(xr.cpu().numpy(), g("x_inv"))
     e_ld = rel(ldr.cpu().numpy(), g("log_det_inv"))
     print(f"{name} {variant}: log_prob {e_lp:.2e} (floor {floor_lp:.2e}), z nw {e_z:.2e}, "
-          f"x_inv nw {e_x:.2e} (floor {floor_x:.2e}), log_det_inv {e_ld:.2e} (floor {floor_ld:.2e})")
-    assert e_lp < max(tol, 3 * floor_lp)
+          f"x_inv nw {e_x:.2e} (floor {floor_x:.2e}), log_det_inv {e_ld:.2e} (floor {floor_ld:.2e}); "
+          f"elementwise 1e-5 pass rate: z {pass_rate(z.cpu().numpy(), g('z')):.4f} "
+          f"(reference fp32 vs fp64 {pass_rate(g('z'), g('z64')):.4f}), x_inv {pass_rate(xr.cpu().numpy(), g('x_inv')):.4f} "
+          f"(reference {pass_rate(g('x_inv'), g('x_inv64')):.4f}), log_prob {pass_rate(lp.cpu().numpy(), g('log_prob')):.4f} "
+          f"(reference {pass_rate(g('log_prob'), g('log_prob64')):.4f})")
+    assert e_lp < max(1e-5, 3 * floor_lp)            # log_prob: the stated 1e-5, splines included
     assert e_z < max(tol, 3 * normwise(g("z"), g("z64")))
     assert e_x < max(tol, 3 * floor_x)
     # log-dets sum D/2 terms per layer that largely cancel: the bound is per 32 terms (as in
@@ -129,7 +142,9 @@ def test_flow_vs_oracle_seeded(pkg, oracle, arch, D, n_layers, N):
     tol = 4e-5 if arch == "CouplingRQNSF" else 1e-5
     e = dict(lp=rel(lp.cpu().numpy(), lp_ref), z=normwise(z.cpu().numpy(), z_ref),
              x=normwise(xr.cpu().numpy(), xr_ref), ld=rel(ld.cpu().numpy(), ld_ref))
-    print(arch, D, e)
+    print(arch, D, e, "elementwise 1e-5 pass rate: z", pass_rate(z.cpu().numpy(), z_ref), "x", pass_rate(xr.cpu().numpy(), xr_ref),
+          "log_prob", pass_rate(lp.cpu().numpy(), lp_ref))
+    assert e["lp"] < 1e-5, e                         # log_prob: 1e-5 for every flow, splines included
     assert max(e.values()) < tol, e
 
 
@@ -237,8 +252,9 @@ def test_full_size_properties(pkg, oracle, arch, D, N, chunk):
     idx = torch.randperm(N, generator=torch.Generator().manual_seed(0))[:4096]
     lp_ref = ref.log_prob(x[idx.cuda()].cpu().numpy())
     e = rel(lp[idx.cuda()].cpu().numpy(), lp_ref)
-    print(f"{arch} D={D} N={N}: log_prob vs oracle on 4096 rows: {e:.2e}")
-    assert e < tol
+    print(f"{arch} D={D} N={N}: log_prob vs oracle on 4096 rows: {e:.2e}, 1e-5 pass rate "
+          f"{pass_rate(lp[idx.cuda()].cpu().numpy(), lp_ref):.4f}")
+    assert e < 1e-5                                  # log_prob: 1e-5 for every config, config 3 included
     total = native.sum_f32(lp).item()
     assert abs(total - float(lp.double().sum().item())) < 1e-6 * abs(total)
 

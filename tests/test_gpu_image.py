@@ -254,3 +254,37 @@ def test_bounded_sigmoid_kernel_matches_aten(n):
     assert float((out - ref).abs().max()) <= 2.4e-7          # <= 1 ulp at |value| <= 2
     ref64 = torch.sigmoid(h.double()) * 4.0 - 2.0
     assert float((out.double() - ref64).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("event_shape", [(3, 56, 56), (3, 64, 64), (12289,)])
+def test_large_event_elementwise_and_base_density(native, event_shape):
+    """events beyond the 64 KiB LDS parameter cache (D > 8064 for ActNorm / ElementwiseAffine, D > 5461 for
+    the base density) -- every multiscale block starts with an ActNorm over the whole image -- go through column
+    tiles instead of raising.  Against the same layers on the host (ATen), fp32."""
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm, ElementwiseAffine
+    torch.manual_seed(4)
+    N = 37
+    x = torch.randn(N, *event_shape)
+    for cls in (ElementwiseAffine, ActNorm):
+        layer = cls(event_shape).eval()
+        with torch.no_grad():
+            layer.value.mul_(0.3)
+            z_h, ld_h = layer.forward(x)
+            xi_h, ldi_h = layer.inverse(x)
+        layer = layer.cuda()
+        before = native.calls
+        with torch.no_grad():
+            z_d, ld_d = layer.forward(x.cuda())
+            xi_d, ldi_d = layer.inverse(x.cuda())
+        assert native.calls - before == 2
+        assert rel(z_d.cpu().numpy(), z_h.numpy()) < 1e-5 and rel(xi_d.cpu().numpy(), xi_h.numpy()) < 1e-5
+        assert rel(ld_d.cpu().numpy(), ld_h.numpy()) < 1e-5 and rel(ldi_d.cpu().numpy(), ldi_h.numpy()) < 1e-5
+    flow = tfa.Flow(ElementwiseAffine(event_shape)).eval()
+    with torch.no_grad():
+        flow.bijection.value.mul_(0.3)
+        lp_h = flow.log_prob(x)
+        lp_d = flow.cuda().log_prob(x.cuda())
+        xs, lps = flow.sample((5,), return_log_prob=True)
+    assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 1e-5
+    assert xs.shape == (5, *event_shape) and torch.isfinite(lps).all()

@@ -388,3 +388,43 @@ def test_flow_mixture():
     assert mix.n_components == 2 and abs(float(mix.weights.sum()) - 1.0) < 1e-6
     with pytest.raises(AssertionError):
         FlowMixture(flows, weights=[0.5, 0.6])
+
+
+def test_bench_launcher_starts_ranks_without_touching_torch():
+    """`python bench.py --gpus 2` (no launcher around it) must start its ranks as a child process and relay their exit
+    code.  Without a GPU the two ranks stop at bench.py's own "needs a GPU" assertion -- which proves that both were
+    started through torch.distributed.run and that the parent relayed the failure instead of printing a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""
+    assert out.stderr.count("bench.py needs a GPU") >= 2, out.stderr[-2000:]
+
+
+def test_invalidate_native_caches_clears_every_pack():
+    """the packed-weight caches are keyed on version counters / data pointers, which an edit through
+    ``.data`` does not move; ``invalidate_native_caches`` (public, also run by train() / eval() / load_state_dict)
+    must drop EVERY ``_tfk_*`` cache, not just the compiled flow programs."""
+    import pickle
+    import torchflows_amd as tfa
+    flow = tfa.Flow(tfa.MAF(6, n_layers=2))
+    mods = list(flow.modules())
+    for i, m in enumerate(mods):
+        m.__dict__["_tfk_compiled"] = {"k": i}
+        m.__dict__["_tfk_made_pack"] = (0, None)
+        m.__dict__["_tfk_ew_block"] = (0, None)
+        m.__dict__["_tfk_bn_affine"] = (0, None)
+        m.__dict__["_tfk_slots"] = []
+    flow.invalidate_native_caches()
+    assert not any(k.startswith("_tfk_") for m in mods for k in m.__dict__)
+    for trigger in (lambda: flow.eval(), lambda: flow.train(), lambda: flow.load_state_dict(flow.state_dict()),
+                    lambda: flow.bijection.invalidate_native_caches()):
+        for m in mods:
+            m.__dict__["_tfk_made_pack"] = (0, None)
+        trigger()
+        assert not any(k.startswith("_tfk_") for m in flow.bijection.modules() for k in m.__dict__)
+    # the direction tags on the methods are not caches and survive; the module still pickles / deep-copies
+    from torchflows_amd.bijections.base import method_direction
+    assert method_direction(flow.bijection.forward) == 0
+    pickle.loads(pickle.dumps(flow))

@@ -43,6 +43,11 @@ def method_direction(bound) -> Optional[int]:
     return getattr(getattr(bound, "__func__", bound), "_tfk_direction", None)
 
 
+def _drop_native_caches(module, incompatible_keys=None) -> None:
+    from torchflows_amd import fused
+    fused.invalidate(module)
+
+
 class Bijection(nn.Module):
     """Invertible map with a tractable log|det J| (reference bijections/base.py:11-156)."""
 
@@ -52,6 +57,20 @@ class Bijection(nn.Module):
         self.event_shape = event_shape
         self.n_dim = event_size(event_shape)
         self.context_shape = context_shape
+        self.register_load_state_dict_post_hook(_drop_native_caches)
+
+    # -- packed-weight caches of the HIP path (new; no reference counterpart) ---
+    def invalidate_native_caches(self) -> None:
+        """Drop every packed copy of this module's parameters kept for the HIP kernels (flow programs, MADE packs,
+        elementwise blocks, BatchNorm scale / shift).  They are refreshed automatically when a parameter is modified
+        through autograd-visible in-place ops, moved or replaced, on ``train()`` / ``eval()`` and on
+        ``load_state_dict``; an edit through ``.data`` is invisible to those checks and needs this call."""
+        from torchflows_amd import fused
+        fused.invalidate(self)
+
+    def train(self, mode: bool = True):
+        self.invalidate_native_caches()
+        return super().train(mode)
 
     # -- the two maps ------------------------------------------------------
     def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:

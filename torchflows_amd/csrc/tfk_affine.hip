@@ -197,6 +197,76 @@ __global__ __launch_bounds__(kBlock) void k_elementwise_affine(
     }
 }
 
+
+// The same for event sizes whose parameters do not fit the LDS (images beyond (3, 32, 32): every multiscale block
+// starts with an ActNorm over the whole image).  Columns go through the LDS in tiles of kColTile; one wavefront
+// per row and tile (a row tile is >= 16 KB, so a wave's loads are long coalesced runs); the row-constant log-det is
+// the same fixed-order sum as above (thread t adds columns t, t + 256, ... in that order), written after the last
+// tile.
+constexpr int kColTile = 4096;
+
+template <bool DIVIDE, bool VEC4>
+__global__ __launch_bounds__(kBlock) void k_elementwise_affine_tiled(
+    const float *x, const float *__restrict__ value, float *z, float *logdet,
+    long long N, int D, int accumulate)
+{
+    __shared__ __attribute__((aligned(16))) float alpha_s[kColTile];
+    __shared__ __attribute__((aligned(16))) float beta_s[kColTile];
+    __shared__ float red[kBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    constexpr int rows_per_block = kBlock / kWave;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    float part = 0.0f;
+    for (int c0 = 0; c0 < D; c0 += kColTile) {
+        const int cn = (D - c0 < kColTile) ? D - c0 : kColTile;
+        __syncthreads();                                  // the previous tile's readers are done
+        for (int e = threadIdx.x; e < cn; e += kBlock) {
+            const float a = aff_alpha(value[2 * (c0 + e)]);
+            alpha_s[e] = a;
+            beta_s[e] = value[2 * (c0 + e) + 1];
+            part += log_normal(a);
+        }
+        __syncthreads();
+        for (long long row = (long long)blockIdx.x * rows_per_block + wave; row < N; row += stride) {
+            if (VEC4) {
+                const float4 *xr = reinterpret_cast<const float4 *>(x + row * D + c0);
+                float4 *zr = reinterpret_cast<float4 *>(z + row * D + c0);
+                const float4 *a4 = reinterpret_cast<const float4 *>(alpha_s);
+                const float4 *b4 = reinterpret_cast<const float4 *>(beta_s);
+                for (int v = lane; v < (cn >> 2); v += kWave) {
+                    const float4 xv = xr[v], a = a4[v], b = b4[v];
+                    float4 o;
+                    if (!DIVIDE) {
+                        o.x = a.x * xv.x + b.x; o.y = a.y * xv.y + b.y;
+                        o.z = a.z * xv.z + b.z; o.w = a.w * xv.w + b.w;
+                    } else {
+                        o.x = (xv.x - b.x) / a.x; o.y = (xv.y - b.y) / a.y;
+                        o.z = (xv.z - b.z) / a.z; o.w = (xv.w - b.w) / a.w;
+                    }
+                    zr[v] = o;
+                }
+            } else {
+                const float *xr = x + row * D + c0;
+                float *zr = z + row * D + c0;
+                for (int e = lane; e < cn; e += kWave) {
+                    const float xv = xr[e], a = alpha_s[e], b = beta_s[e];
+                    zr[e] = DIVIDE ? (xv - b) / a : a * xv + b;
+                }
+            }
+        }
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float ld = DIVIDE ? -red[0] : red[0];
+    if (lane == 0)
+        for (long long row = (long long)blockIdx.x * rows_per_block + wave; row < N; row += stride)
+            logdet[row] = accumulate ? logdet[row] + ld : ld;
+}
+
 // ---------------------------------------------------------------------------
 // Permutation: z[n, j] = x[n, perm[j]] (permutation.py:19-23).  REVERSE_V4: the
 // reversal read as mirrored float4s with swapped components (fully coalesced).
@@ -271,6 +341,61 @@ __global__ __launch_bounds__(kBlock) void k_diag_gauss(
         }
         acc = group_sum(acc, G);
         if (lane == 0) out[row] = logdet_in ? acc + logdet_in[row] : acc;   // flows.py:648
+    }
+}
+
+
+// The same for event sizes whose base parameters do not fit the LDS: column tiles of kColTile, one wavefront per row
+// and tile, the row's partial sum carried in `out` from tile to tile (the first tile stores, the others add; the
+// log-det is added with the last).
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void k_diag_gauss_tiled(
+    const float *__restrict__ z, const float *__restrict__ loc,
+    const float *__restrict__ log_scale, const float *logdet_in, float *out,
+    long long N, int D)
+{
+    __shared__ __attribute__((aligned(16))) float loc_s[kColTile];
+    __shared__ __attribute__((aligned(16))) float scale_s[kColTile];
+    __shared__ __attribute__((aligned(16))) float ls_s[kColTile];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    constexpr int rows_per_block = kBlock / kWave;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    for (int c0 = 0; c0 < D; c0 += kColTile) {
+        const int cn = (D - c0 < kColTile) ? D - c0 : kColTile;
+        const bool last = c0 + cn >= D;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cn; e += kBlock) {
+            loc_s[e] = loc[c0 + e];
+            ls_s[e] = log_scale[c0 + e];
+            scale_s[e] = expf(log_scale[c0 + e]);
+        }
+        __syncthreads();
+        for (long long row = (long long)blockIdx.x * rows_per_block + wave; row < N; row += stride) {
+            float acc = 0.0f;
+            auto term = [&](float v, int e) {
+                const float t = (v - loc_s[e]) / scale_s[e];
+                float q = 0.5f * (t * t);
+                q = q + kHalfLog2Pi;
+                q = q + ls_s[e];
+                acc += -q;
+            };
+            if (VEC4) {
+                const float4 *zr = reinterpret_cast<const float4 *>(z + row * D + c0);
+                for (int v = lane; v < (cn >> 2); v += kWave) {
+                    const float4 q = zr[v];
+                    term(q.x, 4 * v); term(q.y, 4 * v + 1); term(q.z, 4 * v + 2); term(q.w, 4 * v + 3);
+                }
+            } else {
+                const float *zr = z + row * D + c0;
+                for (int e = lane; e < cn; e += kWave) term(zr[e], e);
+            }
+            acc = group_sum(acc, kWave);
+            if (lane == 0) {
+                float v = c0 == 0 ? acc : out[row] + acc;
+                if (last && logdet_in) v = v + logdet_in[row];
+                out[row] = v;
+            }
+        }
     }
 }
 
@@ -387,10 +512,18 @@ static int elementwise_affine(const float *x, const float *value, float *z, floa
     if (N == 0) return TFK_OK;
     if (!x || !value || !z || !logdet) return fail(TFK_EINVAL, "%s: null pointer", fn);
     const size_t lds = ((size_t)2 * D + kBlock) * sizeof(float);
-    if (lds > 64 * 1024)
-        return fail(TFK_EINVAL, "%s: D = %d exceeds the LDS parameter cache (D <= 8064)", fn, D);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(z);
+    if (lds > 64 * 1024) {                    // parameters through the LDS in column tiles (D > 8064)
+        const int grid = grid_for(N, kBlock / kWave);
+        if (vec)
+            hipLaunchKernelGGL((k_elementwise_affine_tiled<DIVIDE, true>), dim3(grid), dim3(kBlock), 0, s,
+                               x, value, z, logdet, (long long)N, D, accumulate);
+        else
+            hipLaunchKernelGGL((k_elementwise_affine_tiled<DIVIDE, false>), dim3(grid), dim3(kBlock), 0, s,
+                               x, value, z, logdet, (long long)N, D, accumulate);
+        return check_launch(fn);
+    }
     const int G = lanes_per_row(vec ? D / 4 : D);
     const int grid = grid_for(N, kBlock / G);
     if (vec)
@@ -494,9 +627,19 @@ int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_sc
     if (N == 0) return TFK_OK;
     if (!z || !loc || !log_scale || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
     const size_t lds = (size_t)3 * D * sizeof(float);
-    if (lds > 64 * 1024) return fail(TFK_EINVAL, "%s: D = %d exceeds the LDS parameter cache (D <= 5461)", fn, D);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = (D % 4 == 0) && aligned16(z);
+    if (lds > 64 * 1024) {                    // base parameters through the LDS in column tiles (D > 5461)
+        if (logdet_in == out) return fail(TFK_EINVAL, "%s: out must not alias logdet_in for D > 5461", fn);
+        const int grid = grid_for(N, kBlock / kWave);
+        if (vec)
+            hipLaunchKernelGGL((k_diag_gauss_tiled<true>), dim3(grid), dim3(kBlock), 0, s, z, loc, log_scale,
+                               logdet_in, out, (long long)N, D);
+        else
+            hipLaunchKernelGGL((k_diag_gauss_tiled<false>), dim3(grid), dim3(kBlock), 0, s, z, loc, log_scale,
+                               logdet_in, out, (long long)N, D);
+        return check_launch(fn);
+    }
     const int G = lanes_per_row(vec ? D / 4 : D);
     const int grid = grid_for(N, kBlock / G);
     if (vec)

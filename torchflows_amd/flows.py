@@ -29,6 +29,10 @@ from torchflows_amd.bijections.base import Bijection
 from torchflows_amd.utils import event_size, flatten_event, get_batch_shape, unflatten_event
 
 
+def _drop_native_caches(module, incompatible_keys=None) -> None:
+    module.invalidate_native_caches()
+
+
 class BaseFlow(nn.Module):
     def __init__(self, event_shape,
                  base_distribution: Union[torch.distributions.Distribution, str] = "standard_normal"):
@@ -46,6 +50,17 @@ class BaseFlow(nn.Module):
             raise ValueError(f"Invalid base distribution: {base_distribution}")
         self.register_buffer("device_buffer", torch.empty(size=()))
         self._optimizer = None
+        self.register_load_state_dict_post_hook(_drop_native_caches)
+
+    def invalidate_native_caches(self) -> None:
+        """Drop every packed copy of the parameters kept for the HIP kernels (see ``Bijection.invalidate_native_caches``):
+        needed only after edits the version counters do not see (``p.data.mul_(...)``, manual weight averaging)."""
+        from torchflows_amd import fused
+        fused.invalidate(self)
+
+    def train(self, mode: bool = True):
+        self.invalidate_native_caches()
+        return super().train(mode)
 
     def get_device(self) -> torch.device:
         return self.device_buffer.device

@@ -584,10 +584,29 @@ def sample_ready(chain: Optional[CompiledChain]) -> bool:
 
 
 def invalidate(module: nn.Module) -> None:
-    """Drop cached flow programs below ``module``.  Needed after parameters were changed behind
-    autograd's back (a replayed hipGraph updates them without moving their version counters)."""
+    """Drop EVERY cached packing below ``module``: compiled flow programs (``_tfk_compiled``), MADE weight packs,
+    elementwise blocks, BatchNorm scale / shift, training packs, the flat tensor lists.  The caches are keyed on the
+    tensors' autograd version counters, data pointers and slot identity -- which an in-place edit through ``.data``
+    (``p.data.mul_(0.5)``, manual weight averaging or clamping) or a replayed hipGraph does NOT move.  After such an
+    edit call this (``Bijection.invalidate_native_caches()`` / ``Flow.invalidate_native_caches()``); ``train()`` /
+    ``eval()`` and ``load_state_dict`` call it themselves."""
     for m in module.modules():
-        m.__dict__.pop("_tfk_compiled", None)
+        d = m.__dict__
+        for k in [k for k in d if k.startswith("_tfk_")]:
+            del d[k]
+
+
+_CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
+_cache_calls = 0
+
+
+def _live_checksum(module: nn.Module) -> float:
+    """fp64 sum of all floating-point tensors below ``module`` (one host sync: debug only)."""
+    acc = 0.0
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_floating_point() and t.numel():
+            acc += float(t.detach().double().sum()) + 3.0 * float(t.detach().double().abs().sum())
+    return acc
 
 
 def get_compiled(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
@@ -597,9 +616,18 @@ def get_compiled(composition, direction: int, device: torch.device) -> Optional[
     hit = cache.get(key)
     version = _params_version(composition)
     if hit is not None and hit[0] == version:
+        if _CACHE_CHECK:
+            # opt-in debug check (TORCHFLOWS_AMD_CACHE_CHECK=N): every N-th hit compares a checksum of the LIVE
+            # tensors with the one taken when the program was packed -- catches edits through ``.data``
+            global _cache_calls
+            _cache_calls += 1
+            if _cache_calls % _CACHE_CHECK == 0 and len(hit) > 2 and hit[2] != _live_checksum(composition):
+                raise RuntimeError(
+                    "torchflows_amd: parameters below this composition changed without their version counters "
+                    "moving (an in-place edit through .data?): call invalidate_native_caches() after such edits")
         return hit[1]
     chain = compile_chain(composition, direction, device)
-    cache[key] = (version, chain)
+    cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
     return chain
 
 
