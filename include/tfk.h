@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 19
+#define TFK_ABI_VERSION 20
 
 enum {
     TFK_OK = 0,
@@ -134,16 +134,22 @@ int tfk_permute(const float *x, const int32_t *perm, float *z, int64_t N, int32_
  * final add of Flow.forward_with_log_prob (flows.py:647-648):
  *   out[n] = sum_d -(0.5*((z-loc)/exp(log_scale))^2 + 0.5*log(2pi) + log_scale)
  *            + (logdet_in ? logdet_in[n] : 0)
- * out may alias logdet_in. */
+ * out may alias logdet_in (for D > 5461 -- column-tiled -- an aliased log-det is added with the first tile
+ * instead of after the last). */
 int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_scale,
                            const float *logdet_in, float *out, int64_t N, int32_t D,
                            void *stream);
 
 /* ---- reduction feeding the multi-GPU all-reduce --------------------------------
- * out[0] = sum_n in[n] accumulated in fp64, deterministic (fixed tree).
- * workspace: device buffer of at least tfk_sum_workspace_bytes(N) bytes. */
+ * out_scalar[0] = sum_n in[n] accumulated in fp64 (the partial sum of log-likelihoods a rank contributes to the
+ * single all-reduce; fp64 so that the 2^22-term sum of config 4 stays within 1e-5).  Both forms are deterministic
+ * (fixed trees) and neither allocates:
+ *   tfk_sum_f32     SURVEY.md 8(b)'s four-argument form: one workgroup, no scratch memory -- for short vectors;
+ *   tfk_sum_f32_ws  two stages over the whole chip with a caller-owned device workspace of at least
+ *                   tfk_sum_workspace_bytes(N) bytes -- what Flow / bench.py use at N >= 2^16. */
+int tfk_sum_f32(const float *in, double *out_scalar, int64_t N, void *stream);
 int64_t tfk_sum_workspace_bytes(int64_t N);
-int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *stream);
+int tfk_sum_f32_ws(const float *in, double *out_scalar, void *workspace, int64_t N, void *stream);
 
 /* ---- fused flow program (conditioner in-kernel, layers folded) -----------------
  * Runs a chain of layers on rows held in registers: ONE launch replaces the Python loop of

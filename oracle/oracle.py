@@ -61,7 +61,8 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "oracle.c")
     hdr = os.path.join(_HERE, "oracle.h")
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH)
+        for p in (src, hdr, os.path.join(_HERE, "oracle_tfk.c"), os.path.join(_HERE, "..", "include", "tfk.h")))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
                        stdout=subprocess.DEVNULL)

@@ -470,3 +470,52 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
     tol = 4e-5 if "RQ" in arch else 1e-5
     assert max(e["lp"], e["lp_lw"], e["ld_lw"]) < tol * max(1.0, D / 64) and e["z"] < 2 * tol
     assert e["round_trip"] < 10 * tol and e["ld_sum"] < 1e-4
+
+
+def test_data_edit_needs_invalidate_and_invalidate_refreshes_every_pack():
+    """an in-place edit through ``.data`` does not move the version counters the packed-weight caches are
+    keyed on; ``invalidate_native_caches()`` must refresh every pack (flow programs, MADE packs).  load_state_dict and
+    train() / eval() refresh by themselves."""
+    import torchflows_amd as tfa
+    for ctor in (tfa.RealNVP, tfa.MAF):
+        torch.manual_seed(0)
+        flow = tfa.Flow(ctor(64, n_layers=2)).eval()
+        x = torch.randn(300, 64)
+        dev_flow = tfa.Flow(ctor(64, n_layers=2)).eval()
+        dev_flow.load_state_dict(flow.state_dict())
+        dev_flow = dev_flow.cuda()
+        with torch.no_grad():
+            before = dev_flow.log_prob(x.cuda()).cpu()
+            for p, q in zip(flow.parameters(), dev_flow.parameters()):
+                if p.requires_grad:
+                    p.data.mul_(0.5)
+                    q.data.mul_(0.5)          # invisible to _version
+            want = flow.log_prob(x)
+            dev_flow.invalidate_native_caches()
+            got = dev_flow.log_prob(x.cuda()).cpu()
+        assert not torch.allclose(before, want, atol=1e-3)
+        assert rel(got.numpy(), want.numpy()) < 1e-5
+        # load_state_dict refreshes without being asked
+        with torch.no_grad():
+            sd = {k: (v * 2 if v.is_floating_point() and "weight" in k else v) for k, v in flow.state_dict().items()}
+            flow.load_state_dict(sd)
+            dev_flow.load_state_dict(sd)
+            assert rel(dev_flow.log_prob(x.cuda()).cpu().numpy(), flow.log_prob(x).numpy()) < 1e-5
+
+
+def test_nested_composition_with_unsupported_layer_falls_back():
+    """a BijectiveComposition nested in another one, holding a layer without a native step
+    (ElementwiseRQSpline), must make the OUTER composition take the ATen loop instead of raising NativeError."""
+    from torchflows_amd.bijections.base import BijectiveComposition
+    from torchflows_amd.bijections.finite.autoregressive.layers import AffineCoupling, ElementwiseRQSpline, ActNorm
+    torch.manual_seed(0)
+    inner = BijectiveComposition([ElementwiseRQSpline((6,)), AffineCoupling((6,))])
+    outer = BijectiveComposition([ActNorm((6,)), inner, AffineCoupling((6,))]).eval()
+    x = torch.randn(50, 6)
+    with torch.no_grad():
+        z_h, ld_h = outer.forward(x)
+        outer = outer.cuda()
+        z_d, ld_d = outer.forward(x.cuda())
+        xr, ldr = outer.inverse(z_d)
+    assert rel(z_d.cpu().numpy(), z_h.numpy()) < 4e-5 and rel(ld_d.cpu().numpy(), ld_h.numpy()) < 4e-5
+    assert torch.allclose(xr.cpu(), x, atol=1e-4)

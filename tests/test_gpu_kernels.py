@@ -342,3 +342,48 @@ def test_lrs_golden_on_hip(native):
             f_l = rel(fx[f"{tag}_{lk}"], fx[f"{tag}_{lk}64"])
             print(f"lrs {tag} inverse={inverse}: out {e_z:.2e} (floor {f_z:.2e}), log-det {e_l:.2e} (floor {f_l:.2e})")
             assert e_z < max(1e-5, 3 * f_z) and e_l < max(1e-5, 3 * f_l)
+
+
+def test_same_abi_two_libraries(oracle):
+    """libtfk.so (device pointers, a HIP stream) and the CPU restatement (host pointers, stream NULL) export
+    the SAME tfk_* symbols: one ctypes call sequence, run against both, must agree."""
+    import ctypes as C
+    from torchflows_amd import native
+    native.lib()
+    gpu, cpu = C.CDLL(native.LIB_PATH), C.CDLL(oracle.build())
+    vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+    sigs = {"tfk_affine_coupling_fwd": [vp, vp, vp, vp, i64, i32, vp, i32, i32, vp],
+            "tfk_rqs_coupling_inv": [vp, vp, vp, vp, i64, i32, vp, i32, i32, f32, i32, vp],
+            "tfk_diag_gauss_logprob": [vp, vp, vp, vp, vp, i64, i32, vp], "tfk_sum_f32": [vp, vp, i64, vp]}
+    for L in (gpu, cpu):
+        for n, a in sigs.items():
+            getattr(L, n).argtypes = a
+    rng = np.random.default_rng(3)
+    N, D, T, K = 777, 24, 12, 8
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    h2 = rng.standard_normal((N, T, 2)).astype(np.float32)
+    h23 = rng.standard_normal((N, T, 3 * K - 1)).astype(np.float32)
+    loc, ls = rng.standard_normal(D).astype(np.float32), (0.1 * rng.standard_normal(D)).astype(np.float32)
+
+    def run(L, to_dev):
+        bufs = {k: to_dev(v) for k, v in dict(x=x, h2=h2, h23=h23, loc=loc, ls=ls, z=np.empty_like(x), y=np.empty_like(x),
+                                              ld=np.empty(N, np.float32), lp=np.empty(N, np.float32),
+                                              total=np.zeros(1, np.float64)).items()}
+        p = {k: (v.data_ptr() if hasattr(v, "data_ptr") else v.ctypes.data) for k, v in bufs.items()}
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if to_dev is dev_any else None
+        assert L.tfk_affine_coupling_fwd(p["x"], p["h2"], p["z"], p["ld"], N, D, None, T, 0, stream) == 0
+        assert L.tfk_rqs_coupling_inv(p["z"], p["h23"], p["y"], p["ld"], N, D, None, T, K, f32(50.0), 1, stream) == 0
+        assert L.tfk_diag_gauss_logprob(p["y"], p["loc"], p["ls"], p["ld"], p["lp"], N, D, stream) == 0
+        assert L.tfk_sum_f32(p["lp"], p["total"], N, stream) == 0
+        if to_dev is dev_any:
+            torch.cuda.synchronize()
+            return bufs["y"].cpu().numpy(), bufs["lp"].cpu().numpy(), float(bufs["total"].cpu()[0])
+        return bufs["y"], bufs["lp"], float(bufs["total"][0])
+
+    def dev_any(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    y_d, lp_d, tot_d = run(gpu, dev_any)
+    y_h, lp_h, tot_h = run(cpu, lambda a: np.ascontiguousarray(a))
+    assert rel(y_d, y_h) < 4e-5 and rel(lp_d, lp_h) < 1e-5
+    assert abs(tot_d - tot_h) < 1e-5 * abs(tot_h)

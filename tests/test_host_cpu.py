@@ -428,3 +428,38 @@ def test_invalidate_native_caches_clears_every_pack():
     from torchflows_amd.bijections.base import method_direction
     assert method_direction(flow.bijection.forward) == 0
     pickle.loads(pickle.dumps(flow))
+
+
+def test_torchflows_import_alias_resolves_to_the_build():
+    """north_star: "drops into Flow.log_prob/.sample unchanged" -- the reference's import paths
+    (test/test_cuda.py:4, test/test_fit.py ...) resolve to this build's modules, the same objects as the
+    ``torchflows_amd`` spelling."""
+    code = (
+        "import torch\n"
+        "from torchflows.flows import Flow\n"
+        "from torchflows.bijections.finite.autoregressive.architectures import RealNVP, CouplingRQNSF\n"
+        "from torchflows.bijections.finite.autoregressive.layers import AffineCoupling\n"
+        "from torchflows.bijections.base import Bijection, BijectiveComposition, invert\n"
+        "from torchflows.bijections.finite.multiscale.architectures import AffineGlow\n"
+        "from torchflows.base_distributions.gaussian import DiagonalGaussian\n"
+        "from torchflows.utils import get_batch_shape\n"
+        "import torchflows, torchflows_amd\n"
+        "import torchflows_amd.flows as f2, torchflows_amd.bijections.finite.autoregressive.architectures as a2\n"
+        "assert Flow is f2.Flow and RealNVP is a2.RealNVP and torchflows.Flow is f2.Flow\n"
+        "import torchflows.bijections.finite.autoregressive.architectures as a1\n"
+        "assert a1 is a2\n"
+        "torch.manual_seed(0)\n"
+        "flow = Flow(RealNVP(3))\n"
+        "x = torch.randn(1000, 3)\n"
+        "lp = flow.log_prob(x); xs = flow.sample((1000,))\n"
+        "assert lp.shape == (1000,) and xs.shape == (1000, 3)\n"
+        "assert isinstance(flow.bijection, torchflows_amd.bijections.base.Bijection)\n"
+        "try:\n"
+        "    import torchflows.bijections.continuous.rnode\n"
+        "    raise SystemExit('out-of-scope module resolved')\n"
+        "except ModuleNotFoundError:\n"
+        "    pass\n"
+        "print('ALIAS_OK')\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert out.returncode == 0 and "ALIAS_OK" in out.stdout, out.stdout + out.stderr

@@ -275,7 +275,13 @@ class BijectiveComposition(Bijection):
                 total = total + torch.dot(flat, flat) * coef
         return total
 
-    # a composition nested in a composition is itself a native step
+    # a composition nested in a composition is itself a native step -- if every layer inside has one (both
+    # directions: the outer plan may run either); otherwise the OUTER composition drops to the ATen loop instead
+    # of raising from inside _native_step
+    def _native_supported(self) -> bool:
+        return (self._native_plan(self.layers, "forward") is not None
+                and self._native_plan(list(self.layers)[::-1], "inverse") is not None)
+
     def _native_step(self, state: RowState, context, d: int) -> None:
         order = self.layers if d == FORWARD else list(self.layers)[::-1]
         plan = self._native_plan(order, "forward" if d == FORWARD else "inverse")

@@ -391,8 +391,10 @@ __global__ __launch_bounds__(kBlock) void k_diag_gauss_tiled(
             }
             acc = group_sum(acc, kWave);
             if (lane == 0) {
+                // (an aliased log-det would be overwritten by the first tile's store: it is added there instead)
+                const bool aliased = (logdet_in == out);
                 float v = c0 == 0 ? acc : out[row] + acc;
-                if (last && logdet_in) v = v + logdet_in[row];
+                if (logdet_in && (aliased ? c0 == 0 : last)) v = v + logdet_in[row];
                 out[row] = v;
             }
         }
@@ -430,6 +432,21 @@ __global__ __launch_bounds__(kBlock) void k_sum_final(const double *__restrict__
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// one workgroup, no scratch memory (tfk_sum_f32): thread t adds in[t], in[t + 1024], ... then a fixed tree
+__global__ __launch_bounds__(1024) void k_sum_single(const float *__restrict__ in, double *out, long long N)
+{
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < N; i += 1024) acc += (double)in[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -630,7 +647,6 @@ int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_sc
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = (D % 4 == 0) && aligned16(z);
     if (lds > 64 * 1024) {                    // base parameters through the LDS in column tiles (D > 5461)
-        if (logdet_in == out) return fail(TFK_EINVAL, "%s: out must not alias logdet_in for D > 5461", fn);
         const int grid = grid_for(N, kBlock / kWave);
         if (vec)
             hipLaunchKernelGGL((k_diag_gauss_tiled<true>), dim3(grid), dim3(kBlock), 0, s, z, loc, log_scale,
@@ -657,9 +673,19 @@ int64_t tfk_sum_workspace_bytes(int64_t N)
     return (int64_t)kSumBlocks * (int64_t)sizeof(double);
 }
 
-int tfk_sum_f32(const float *in, double *out, void *workspace, int64_t N, void *stream)
+int tfk_sum_f32(const float *in, double *out, int64_t N, void *stream)
 {
     const char *fn = "tfk_sum_f32";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!out) return fail(TFK_EINVAL, "%s: null out", fn);
+    if (N > 0 && !in) return fail(TFK_EINVAL, "%s: null input", fn);
+    hipLaunchKernelGGL(k_sum_single, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), in, out, (long long)N);
+    return check_launch(fn);
+}
+
+int tfk_sum_f32_ws(const float *in, double *out, void *workspace, int64_t N, void *stream)
+{
+    const char *fn = "tfk_sum_f32_ws";
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
     if (!out || !workspace) return fail(TFK_EINVAL, "%s: null out/workspace", fn);
     if (N > 0 && !in) return fail(TFK_EINVAL, "%s: null input", fn);

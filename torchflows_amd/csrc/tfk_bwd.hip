@@ -934,7 +934,8 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
         (void)hipGetLastError();
         per_cu = 1;
     }
-    constexpr int rows_per_block = (kBlock / 64) * 16;
+    if (per_cu > 8) per_cu = 8;                          // the workspace holds kCUs * 8 partial rows
+    constexpr int rows_per_block = (kBlock / 64) * 16;  // (tfk_coupling_train_bwd_workspace_bytes)
     int64_t grid = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu;          // one resident set: few partial rows to add
     if (grid > cap) grid = cap;

@@ -568,7 +568,8 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
                          (prog.op[i].kind == TFK_OP_MADE_FWD || prog.op[i].kind == TFK_OP_MADE_INV)) && prog.op[i].steps2 > 4);
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     bool made = false;
-    for (int i = 0; i < prog.n_ops; ++i) made = made || prog.op[i].kind >= TFK_OP_MADE_FWD;
+    for (int i = 0; i < prog.n_ops; ++i)      // (TFK_OP_PLANE_SWAP = 11 lies above the MADE kinds: not a MADE op)
+        made = made || (prog.op[i].kind >= TFK_OP_MADE_FWD && prog.op[i].kind <= TFK_OP_MADE_RQS);
 #define TFK_MB(BLOCK_, HT_, MADE_) \
     launch_mb<EPL, BLOCK_, HT_, MADE_>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn)
     if (made) {

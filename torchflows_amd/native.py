@@ -31,7 +31,7 @@ SYMBOLS = (
     "tfk_conv1x1_coupling_fwd", "tfk_conv1x1_coupling_inv",
     "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
     "tfk_permute", "tfk_diag_gauss_logprob",
-    "tfk_sum_workspace_bytes", "tfk_sum_f32",
+    "tfk_sum_workspace_bytes", "tfk_sum_f32", "tfk_sum_f32_ws",
     "tfk_flow_supported", "tfk_flow_run",
     "tfk_flow_mfma_supported", "tfk_flow_run_mfma",
     "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
@@ -46,7 +46,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class NativeError(RuntimeError):
@@ -90,7 +90,8 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_diag_gauss_logprob.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
     L.tfk_sum_workspace_bytes.argtypes = [_i64]
     L.tfk_sum_workspace_bytes.restype = _i64
-    L.tfk_sum_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
+    L.tfk_sum_f32.argtypes = [_vp, _vp, _i64, _vp]
+    L.tfk_sum_f32_ws.argtypes = [_vp, _vp, _vp, _i64, _vp]
     L.tfk_flow_supported.argtypes = [_i32]
     L.tfk_flow_run.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_i32), _i32,
                                _vp, _i64, _i32, _vp]
@@ -656,11 +657,17 @@ def sum_f32(values: torch.Tensor) -> torch.Tensor:
     N = v.numel()
     _f32(v, "tfk_sum_f32")
     out = torch.empty(1, dtype=torch.float64, device=v.device)
+    if N < (1 << 14):                 # one workgroup, no workspace (SURVEY 8(b)'s four-argument form)
+        with _device_guard(v):
+            rc = lib().tfk_sum_f32(_f32(v, "tfk_sum_f32"), out.data_ptr(), N, _stream(v))
+        calls += 1
+        _check(rc, "tfk_sum_f32")
+        return out
     ws = torch.empty(int(lib().tfk_sum_workspace_bytes(N)), dtype=torch.uint8, device=v.device)
     with _device_guard(v):
-        rc = lib().tfk_sum_f32(_f32(v, "tfk_sum_f32"), out.data_ptr(), ws.data_ptr(), N, _stream(v))
+        rc = lib().tfk_sum_f32_ws(_f32(v, "tfk_sum_f32_ws"), out.data_ptr(), ws.data_ptr(), N, _stream(v))
     calls += 1
-    _check(rc, "tfk_sum_f32")
+    _check(rc, "tfk_sum_f32_ws")
     return out
 
 
