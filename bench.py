@@ -36,6 +36,7 @@ np = torch = dist = None      # imported in main() AFTER the launcher check: the
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4     # wave64 instructions / s (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak (= fp32-input MFMA peak), same guide
+PRIMING_STEPS = 40             # untimed, before the requested warm-ups (reported in the JSON)
 WORKLOADS = {
     # name: (arch, D, n_layers, rows per GPU, chunk rows)
     "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
@@ -170,9 +171,9 @@ class KernelTimer:
         for op in ops:
             kind, steps2 = op[0], op[2]
             HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
-            if kind in (2, 3):
+            if kind in (2, 3, 12, 13):
                 per_wave += EPL * HT + (EPL // 2) * steps2
-            elif kind in (4, 5):
+            elif kind in (4, 5, 14, 15):
                 per_wave += EPL * HT + (EPL // 4) * steps2
             elif kind in (6, 7):
                 per_wave += EPL + 6 * EPL * steps2
@@ -196,9 +197,9 @@ class KernelTimer:
             ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         for op in ops:
             kind, H = op[0], op[2]
-            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10):
+            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15):
                 H = KernelTimer.true_hidden.get(D, 4 * H)       # the matrix-core ops record ceil(H / 4)
-            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23}.get(kind)
+            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23, 12: 2, 13: 2, 14: 1, 15: 1}.get(kind)
             if P is not None:
                 per_row += 2 * (half * H + H * half * P)
             elif kind in (8, 9, 10):                            # MADE ops: both planes in, every element a target
@@ -423,6 +424,10 @@ def main():
     with torch.no_grad():
         step()                      # module load, LDS attributes, RCCL communicator: never inside the timed region,
         drain()                     # whatever --warmup says
+        n_prime = PRIMING_STEPS if not isinstance(D, tuple) else 0      # (a config-5 step is 0.25 s: no ramp to hide)
+        for _ in range(n_prime):        # ... and the clocks: the first ~20 launches after idle run 7 % slower (r02 step_stats)
+            step()
+        drain()
         for _ in range(args.warmup):
             step()
         drain()
@@ -549,6 +554,7 @@ def main():
                                    f"data-initialised weights (seed 0)",
                        "rows_per_gpu": rows, "rows_total": rows_total,
                        "parallelism": f"batch-sharded replicas x{world}"},
+            "priming_steps": 1 + n_prime,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "collective_backend": (backend if world > 1 else None),
             "rows_all_ranks": rows_total,

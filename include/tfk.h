@@ -194,8 +194,22 @@ enum {
     TFK_OP_MADE_FWD = 8,   /* MADE + Affine on the whole row, parallel map (tfk_flow_run_mfma only) */
     TFK_OP_MADE_INV = 9,   /* same with (x - beta) / alpha */
     TFK_OP_MADE_RQS = 10,  /* MADE + RQ spline (8 bins) on the whole row, parallel map; hidden <= 16, D <= 128 */
-    TFK_OP_PLANE_SWAP = 11 /* tfk_flow_run_mfma: mask[D/2] floats, != 0 exchanges x[i] and x[D/2 + i] (D <= 128; odd event sizes,
+    TFK_OP_PLANE_SWAP = 11, /* tfk_flow_run_mfma: mask[D/2] floats, != 0 exchanges x[i] and x[D/2 + i] (D <= 128; odd event sizes,
                               padded so that every element keeps its index in both halves) */
+    /* "lean" programs of tfk_flow_run_mfma (ABI v20): a chain of couplings of ONE kind and one hidden width (<= 16)
+     * whose source plane alternates, optionally ended by one TFK_OP_EW_FMA; they run on a straight-line kernel
+     * (csrc/tfk_flow_chain.h) and cannot be mixed with the kinds above.  The elementwise layers between the
+     * couplings are folded by the packer (torchflows_amd/fused.py): into W1 / b1 where an element feeds the
+     * conditioner, into the coupling's pre-affine (s, t) where it is transformed -- x_t <- fma(s, x_t, t) first.
+     * Block: A1[D/32][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[D/2] | pre_t[D/2], lane-major
+     * A-operands (nA2 = T2 * gemm2_steps rounded up to 4; entry t * gemm2_steps + k = tile t, step k), with W1 / b1
+     * multiplied by 2 log2(e) and the scale-logit rows of W2 / b2 by log2(e) / 2 (b2 += log(1 - 1e-10) log2(e)):
+     * tanh = 1 - 2 / (exp2(.) + 1), alpha = exp2(.) + 1e-10, log-det accumulated in base 2. */
+    TFK_OP_AFFINE_FWD_LEAN = 12,
+    TFK_OP_AFFINE_INV_LEAN = 13,
+    TFK_OP_SHIFT_FWD_LEAN = 14,
+    TFK_OP_SHIFT_INV_LEAN = 15,
+    TFK_OP_EW_FMA = 16      /* s[D] | t[D] | logdet_const | pad[3]:  z = fma(s, x, t), logdet += logdet_const */
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

@@ -463,3 +463,43 @@ def test_torchflows_import_alias_resolves_to_the_build():
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
     assert out.returncode == 0 and "ALIAS_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("arch,D,n_layers,direction", [("RealNVP", 64, 8, 0), ("RealNVP", 64, 3, 1), ("NICE", 64, 4, 0),
+                                                       ("RealNVP", 128, 2, 0), ("RealNVP", 22, 3, 0), ("NICE", 8, 3, 1)])
+def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction):
+    """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
+    pre-affines, pre-scaled logits, lane-major operands): an fp64 emulator that decodes the packed blocks exactly as
+    csrc/tfk_flow_chain.h reads them must reproduce the composition's forward / inverse."""
+    from lean_emulator import run_lean
+    from torchflows_amd import fused
+    import torchflows_amd as tfa
+    torch.manual_seed(3)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(512, D) * 1.5 + 0.3)
+    flow.eval()
+    comp = flow.bijection.double()
+    Dp = D if D in (64, 128, 256) else (64 if D < 64 else 128)
+    order = comp.layers if direction == 0 else list(comp.layers)[::-1]
+    plan = fused._flatten(order, "forward" if direction == 0 else "inverse")
+    pos = torch.arange(D)
+    if Dp != D:
+        pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
+    chain = fused._compile_lean(comp, plan, torch.device("cpu"), D, Dp, pos.clone(), pos.clone())
+    assert chain is not None and chain.D == Dp
+    x = torch.randn(64, D, dtype=torch.float64)
+    with torch.no_grad():
+        want, ld_want = (comp.forward if direction == 0 else comp.inverse)(x)
+    rows = torch.zeros(64, Dp, dtype=torch.float64)
+    rows[:, pos] = x
+    ld = torch.zeros(64, dtype=torch.float64)
+    for seg in chain.segments:
+        assert seg.mfma and all(12 <= op[0] <= 16 for op in seg.ops)
+        rows, l = run_lean(seg.ops, seg.params, rows, Dp)
+        ld = ld + l
+    got = rows[:, chain.pos]
+    # the blocks are stored in fp32: agreement at fp32 resolution of the weights
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+    assert float((ld - ld_want).abs().max() / max(1.0, float(ld_want.abs().max()))) < 2e-5

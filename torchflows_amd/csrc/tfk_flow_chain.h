@@ -1,0 +1,309 @@
+// tfk_flow_chain.h -- straight-line matrix-core kernel for CHAINS of affine / shift couplings
+// (templates; instantiated per row width in tfk_flow_chain_{8,16,32}.hip, dispatched from tfk_flow_run_mfma).
+//
+// The interpreter of tfk_flow_mfma.h spends most of its vector instructions on things that are not the
+// transform (rocprofv3 + the ISA of k_flow_run_mfma<8,512,1,false>, profiles/r02/isa/): per wave and layer of
+// RealNVP-64, ~100 for the transform's exp / log in their range-reduced forms, 32 for the ActNorm that follows
+// every coupling, ~25 register moves where the two planes change roles, ~10 v_cndmask / v_cmp for the run-time
+// GEMM-2 step count, plus the dispatch.  This kernel removes them for the programs that are nothing but a chain
+// of couplings of ONE kind whose source plane alternates (every RealNVP / NICE preset after the reversals have
+// been folded into the weight order):
+//
+//   * the elementwise layers between the couplings are DEFERRED by the host compiler (fused.py): an element keeps
+//     a pending affine map (s, t) that is folded into W1 / b1 where the element is a conditioner input and applied
+//     as ONE fma where it is transformed ("pre-affine of the target plane"); whatever is still pending at the end
+//     is one fma per element (TFK_OP_EW_FMA) and all the constant log-dets are one number;
+//   * W1 / b1 arrive multiplied by 2 log2(e) and the scale-logit rows of W2 / b2 by log2(e) / 2 (+ c0 log2(e)), so
+//     tanh is 1 - 2 / (exp2(.) + 1) and alpha = exp2(.) + 1e-10 with no multiplications in the kernel; the
+//     log-det is accumulated in base 2 and scaled by ln 2 once per row;
+//   * the number of GEMM-2 steps, the kind and the roles of the planes are compile-time constants: no dispatch,
+//     no moves, no selects; A-operands are stored lane-major so that four k-steps arrive per ds_read_b128.
+//
+// Parameter block of a lean coupling op (floats), EPL source k-steps, T2 tiles of GEMM 2:
+//   A1[EPL/4][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[HALF] | pre_t[HALF]
+//   nA2 = T2 * STEPS2 rounded up to a multiple of 4; lane l's value for (tile t, step k) is entry t * STEPS2 + k.
+// TFK_OP_EW_FMA: s[D] | t[D] | logdet_const | pad[3]      z = fma(s, x, t)
+#pragma once
+#include "tfk_common.h"
+
+namespace tfk {
+
+constexpr int kMaxChainOps = 64;
+
+struct ChainProg {
+    int n_c;          // couplings
+    int first_src;    // source plane of the first coupling (they alternate)
+    int ew_offset;    // TFK_OP_EW_FMA that ends the program (-1: none)
+    int pad;
+    int offset[kMaxChainOps];
+};
+
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+
+// KIND: 0 affine fwd, 1 affine inv, 2 shift fwd, 3 shift inv
+template <int EPL, int STEPS2, int KIND>
+__device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, const float (&src)[EPL],
+                                            float (&tgt)[EPL], float &ld2)
+{
+    constexpr bool affine = KIND < 2;
+    constexpr int HALF = 4 * EPL;
+    constexpr int T2 = affine ? EPL / 2 : EPL / 4;
+    constexpr int NA2 = (T2 * STEPS2 + 3) & ~3;
+    const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(prm);
+    const float *b1 = prm + EPL * 64;
+    const cf32x4 *A2 = reinterpret_cast<const cf32x4 *>(b1 + 16);
+    const float *b2 = b1 + 16 + NA2 * 64;
+    const float *pre = b2 + T2 * 16;
+
+    // GEMM 1 (weights pre-scaled by 2 log2 e): exp2(acc) = exp(2 * pre-activation)
+    cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+#pragma unroll
+    for (int g = 0; g < EPL / 4; ++g) {
+        const cf32x4 w = A1[g * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+    }
+    // the elements about to be transformed take their pending elementwise layers now (one fma)
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+        const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
+    }
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                              // tanh, transforms.py:293-304
+        hid[r] = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[r]) + 1.0f), 1.0f);
+
+    float a2[NA2];
+#pragma unroll
+    for (int g = 0; g < NA2 / 4; ++g) {
+        const cf32x4 w = A2[g * 64 + lane];
+        a2[4 * g] = w[0]; a2[4 * g + 1] = w[1]; a2[4 * g + 2] = w[2]; a2[4 * g + 3] = w[3];
+    }
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        cf32x4 o = *reinterpret_cast<const cf32x4 *>(b2 + (t * 4 + q) * 4);
+#pragma unroll
+        for (int k = 0; k < STEPS2; ++k)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t * STEPS2 + k], hid[k], o, 0, 0, 0);
+        if constexpr (affine) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                // affine.py:33-34 with the logit row pre-scaled: o = (u / 2 + c0) log2 e
+                const float al = __builtin_amdgcn_exp2f(o[2 * i]) + kAffMinScale;
+                ld2 += __builtin_amdgcn_logf(al);                                    // log2 alpha; affine.py:42
+                if constexpr (KIND == 0) tgt[e] = fmaf(al, tgt[e], o[2 * i + 1]);    // affine.py:48
+                else tgt[e] = (tgt[e] - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al);   // affine.py:59
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * t + i;
+                if constexpr (KIND == 2) tgt[e] = tgt[e] + o[i];                     // affine.py:150
+                else tgt[e] = tgt[e] - o[i];                                         // affine.py:158
+            }
+        }
+    }
+}
+
+template <int EPL, int BLOCK, int STEPS2, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_flow_chain(
+    const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
+    const float *__restrict__ gauss_log_scale, float *logprob, long long N,
+    const float *__restrict__ params, int n_params, ChainProg prog, int flags)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    const int accumulate = flags & 1;
+    const bool reverse_out = (flags & 2) != 0;
+    const bool base_of_input = (flags & 4) != 0;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(params);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
+    }
+    // base density as  -0.5 sum ((z - loc) / scale)^2 - sum (log scale + 0.5 log 2 pi):  loc[D] | 1/scale[D] | const
+    float *base_s = lds + n_params;
+    if (logprob) {
+        for (int e = threadIdx.x; e < D; e += BLOCK) {
+            base_s[e] = gauss_loc[e];
+            base_s[D + e] = expf(-gauss_log_scale[e]);
+        }
+        if (threadIdx.x < 64) {
+            float c = 0.0f;
+            for (int e = threadIdx.x; e < D; e += 64) c += gauss_log_scale[e] + kHalfLog2Pi;
+            c = group_sum(c, 64);
+            if (threadIdx.x == 0) base_s[2 * D] = c;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    const float base_const = logprob ? base_s[2 * D] : 0.0f;
+    for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * 16; row0 < N; row0 += stride) {
+        const long long row = row0 + j;
+        const long long rr = row < N ? row : N - 1;    // tail: compute a valid row, store nothing
+        float a[EPL], b[EPL];
+        const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+        const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const float4 va = pa[i], vb = pb[i];
+            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+        }
+        float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
+        float sq = 0.0f;                                              // sum of squared standardised elements
+        auto base_terms = [&]() {                                     // gaussian.py:46-54
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const cf32x4 la = *reinterpret_cast<const cf32x4 *>(base_s + EPL * q + 4 * i);
+                const cf32x4 lb = *reinterpret_cast<const cf32x4 *>(base_s + HALF + EPL * q + 4 * i);
+                const cf32x4 ia = *reinterpret_cast<const cf32x4 *>(base_s + D + EPL * q + 4 * i);
+                const cf32x4 ib = *reinterpret_cast<const cf32x4 *>(base_s + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ta = (a[4 * i + k] - la[k]) * ia[k];
+                    const float tb = (b[4 * i + k] - lb[k]) * ib[k];
+                    sq = fmaf(ta, ta, sq);
+                    sq = fmaf(tb, tb, sq);
+                }
+            }
+        };
+        if (logprob && base_of_input) base_terms();                   // Flow.sample (flows.py:699-707)
+
+        float ld2 = 0.0f;                                             // this lane's share, in base 2
+        int o = 0;
+        if (prog.first_src == 1 && prog.n_c > 0) {
+            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
+            o = 1;
+        }
+        for (; o + 1 < prog.n_c; o += 2) {
+            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
+        }
+        if (o < prog.n_c) couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+        if constexpr (KIND == 0) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
+        else if constexpr (KIND == 1) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
+
+        if (prog.ew_offset >= 0) {                                    // what is still pending, one fma per element
+            const float *ew = lds + prog.ew_offset;
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
+                const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(ew + HALF + EPL * q + 4 * i);
+                const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(ew + D + EPL * q + 4 * i);
+                const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(ew + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
+                    b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+                }
+            }
+            if (q == 0) ld = ld + ew[2 * D];
+        }
+        if (logprob && !base_of_input) base_terms();
+
+        ld += __shfl_xor(ld, 16, kWave);
+        ld += __shfl_xor(ld, 32, kWave);
+        if (logprob) {
+            sq += __shfl_xor(sq, 16, kWave);
+            sq += __shfl_xor(sq, 32, kWave);
+        }
+        if (row < N) {
+            if (z && !reverse_out) {
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + EPL * q);
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+                    qb[i] = make_float4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+                }
+            } else if (z) {                                           // a reversal after the program, folded into the store
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + D - EPL * (q + 1));
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF - EPL * (q + 1));
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[EPL - 1 - 4 * i], a[EPL - 2 - 4 * i], a[EPL - 3 - 4 * i], a[EPL - 4 - 4 * i]);
+                    qb[i] = make_float4(b[EPL - 1 - 4 * i], b[EPL - 2 - 4 * i], b[EPL - 3 - 4 * i], b[EPL - 4 - 4 * i]);
+                }
+            }
+            if (q == 0) {
+                if (logdet) logdet[row] = ld;
+                if (logprob) logprob[row] = (fmaf(-0.5f, sq, -base_const)) + ld;          // flows.py:648
+            }
+        }
+    }
+}
+
+template <int EPL, int BLOCK, int STEPS2, int KIND>
+static int launch_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                          float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
+                          int flags, hipStream_t s, const char *fn)
+{
+    constexpr int D = 8 * EPL;
+    const size_t lds = ((size_t)n_params + 2 * D + 4) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
+    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const int64_t want = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
+                       params, n_params, prog, flags);
+    return check_launch(fn);
+}
+
+template <int EPL, int KIND>
+static int launch_chain_k(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                          float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
+                          int steps2, int flags, hipStream_t s, const char *fn)
+{
+    const bool big = N >= (int64_t)kCUs * 3 * 128;
+#define TFK_CB(BLOCK_, ST_) \
+    launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, s, fn)
+    switch (steps2) {
+    case 1: return big ? TFK_CB(512, 1) : TFK_CB(kBlock, 1);
+    case 2: return big ? TFK_CB(512, 2) : TFK_CB(kBlock, 2);
+    case 3: return big ? TFK_CB(512, 3) : TFK_CB(kBlock, 3);
+    case 4: return big ? TFK_CB(512, 4) : TFK_CB(kBlock, 4);
+    default: return fail(TFK_EINVAL, "%s: lean couplings need 1..4 GEMM-2 steps, got %d", fn, steps2);
+    }
+#undef TFK_CB
+}
+
+template <int EPL>
+static int launch_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                        float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
+                        int kind, int steps2, int flags, hipStream_t s, const char *fn)
+{
+    switch (kind) {
+    case 0: return launch_chain_k<EPL, 0>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, s, fn);
+    case 1: return launch_chain_k<EPL, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, s, fn);
+    case 2: return launch_chain_k<EPL, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, s, fn);
+    default: return launch_chain_k<EPL, 3>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, s, fn);
+    }
+}
+
+}  // namespace tfk

@@ -1,8 +1,68 @@
 // tfk_flow_mfma.hip -- C-ABI entry point of the matrix-core flow programs (kernels: tfk_flow_mfma.h,
 // instantiated per row width in tfk_flow_mfma_{8,16,32}.hip).
 #include "tfk_flow_mfma.h"
+#include "tfk_flow_chain.h"
 
 namespace tfk {
+int flow_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                        const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+int flow_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                         const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+int flow_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                         const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+
+// A program made of lean ops only (TFK_OP_*_LEAN couplings of one kind and one GEMM-2 step count whose source
+// plane alternates, optionally ended by one TFK_OP_EW_FMA) runs on the straight-line kernel of tfk_flow_chain.h.
+static int run_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                     float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
+                     int64_t n_params, int32_t flags, hipStream_t s, const char *fn)
+{
+    const int EPL = D / 8, HALF = D / 2;
+    ChainProg prog;
+    prog.n_c = 0;
+    prog.first_src = 0;
+    prog.ew_offset = -1;
+    prog.pad = 0;
+    int kind = -1, steps2 = 1;
+    for (int i = 0; i < n_ops; ++i) {
+        const int32_t *rec = ops + 8 * i;
+        const int k = rec[0], src = rec[1], st = rec[2], off = rec[3];
+        int64_t need;
+        if (k == TFK_OP_EW_FMA) {
+            if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
+            need = 2 * (int64_t)D + 4;
+            prog.ew_offset = off;
+        } else if (k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN) {
+            if (prog.n_c == kMaxChainOps) return fail(TFK_EINVAL, "%s: more than %d lean couplings", fn, kMaxChainOps);
+            if (src != 0 && src != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, src);
+            if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
+            if (prog.n_c == 0) {
+                kind = k - TFK_OP_AFFINE_FWD_LEAN;
+                steps2 = st;
+                prog.first_src = src;
+            } else {
+                if (k - TFK_OP_AFFINE_FWD_LEAN != kind || st != steps2)
+                    return fail(TFK_EINVAL, "%s: op %d: a lean program holds couplings of one kind and one hidden width", fn, i);
+                if (src != ((prog.first_src + prog.n_c) & 1))
+                    return fail(TFK_EINVAL, "%s: op %d: the source plane of lean couplings must alternate", fn, i);
+            }
+            const int T2 = (kind < 2) ? EPL / 2 : EPL / 4;
+            const int nA2 = (T2 * st + 3) & ~3;
+            need = (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF;
+            prog.offset[prog.n_c++] = off;
+        } else {
+            return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean ops", fn, i, k);
+        }
+        if (off < 0 || (off & 3) || off + need > n_params)
+            return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i,
+                        off, (long long)(off + need), (long long)n_params);
+    }
+    if (kind < 0) kind = 2;
+    if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
+    if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
+    return flow_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
+}
+
 int flow_mfma_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
                        const float *, int, const MProgram &, int, hipStream_t, const char *);
 int flow_mfma_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -33,6 +93,9 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if (!aligned16(x) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
+    if (n_ops > 0 && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA)
+        return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
+                         accumulate, static_cast<hipStream_t>(stream), fn);
     const int EPL = D / 8;
     MProgram prog;
     prog.n_ops = n_ops;

@@ -38,7 +38,10 @@ import torch.nn as nn
 from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
-    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP = range(12)
+    OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
+    OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA = range(17)
+LOG2E = 1.4426950408889634
+AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
 MAX_HIDDEN_RQS = 32
 FORWARD, INVERSE = 0, 1
@@ -480,6 +483,196 @@ def _made_rqs_op(layer, mods, pos: torch.Tensor, D: int, H: int, Dp: Optional[in
     return head, block
 
 
+# ---------------------------------------------------------------------------------------------
+# lean chains (csrc/tfk_flow_chain.h): couplings of one kind, elementwise layers deferred
+# ---------------------------------------------------------------------------------------------
+def lean_enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_LEAN", "1") != "0"
+
+
+def _lean_elementwise(layer, d: int, D: int):
+    """(alpha, beta, divide) of an ElementwiseAffine / ActNorm with global parameters in LOGICAL order, fp64 --
+    ``z = alpha x + beta`` or, with ``divide``, ``z = (x - beta) / alpha`` -- or None."""
+    from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
+    kind = layer.transformer.native_kind
+    if kind not in ("affine", "inverse_affine") or not layer.use_global_parameters:
+        return None
+    if isinstance(layer, ActNorm) and layer.training and layer.first_training_batch_pass:
+        return None
+    value = layer.value.detach().reshape(D, 2)
+    alpha = layer.transformer.constrain_scale(value[:, 0]).double()      # the fp32 scale the reference uses
+    beta = value[:, 1].double()
+    return alpha, beta, (d == INVERSE) != (kind == "inverse_affine")
+
+
+def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
+    """Physical-order conditioner weights of an affine / shift HalfSplit coupling with the default FeedForward(tanh)
+    conditioner of hidden width <= 16: (lean kind 0..3, source plane, H, W1t (H, hp), b1, W2p (hp, P, H), b2p (hp, P))
+    in fp64, or None (the checks of ``_coupling_op``)."""
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
+    kind = layer.transformer.native_kind
+    if kind not in ("affine", "inverse_affine", "shift") or layer.context_shape is not None:
+        return None
+    half = D // 2
+    c = layer.coupling
+    S, T = c.source_event_size, c.target_event_size
+    if not (c.source_is_head and c.target_is_tail and S == half and S + T == D and T == S):
+        return None
+    ct = layer.conditioner_transform
+    if type(ct) is not FeedForward or ct.n_global_parameters != 0:
+        return None
+    if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
+        return None
+    mods = list(ct.sequential)
+    if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
+        return None
+    P = 1 if kind == "shift" else 2
+    W1, b1 = mods[0].weight.detach().double(), mods[0].bias.detach().double()
+    W2, b2 = mods[2].weight.detach().double(), mods[2].bias.detach().double()
+    H = W1.shape[0]
+    if H > 16 or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
+        return None
+    hp = Dp // 2
+    src_pos, tgt_pos = pos[:S], pos[S:]
+    plane = int(src_pos[0].item()) // hp
+    if not bool(((src_pos // hp) == plane).all()) or not bool(((tgt_pos // hp) == 1 - plane).all()):
+        return None
+    W1t = W1.new_zeros(H, hp)
+    W1t[:, src_pos - plane * hp] = W1
+    m_t = tgt_pos - (1 - plane) * hp
+    W2p = W2.new_zeros(hp, P, H)
+    W2p[m_t] = W2.reshape(T, P, H)
+    b2p = b2.new_zeros(hp, P)
+    b2p[m_t] = b2.reshape(T, P)
+    if kind == "shift":
+        lk = 2 if d == FORWARD else 3
+    else:
+        lk = 0 if (d == FORWARD) != (kind == "inverse_affine") else 1
+    return lk, plane, H, W1t, b1, W2p, b2p
+
+
+def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t) -> torch.Tensor:
+    """Parameter block of a lean coupling op (csrc/tfk_flow_chain.h): lane-major MFMA A-operands
+    A1[EPL/4][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[hp] | pre_t[hp], with W1 / b1 multiplied by
+    2 log2(e) and (affine) the scale-logit rows of W2 / b2 by log2(e) / 2, b2 += c0 log2(e).  Inputs fp64, physical
+    order, the pending elementwise maps of the source plane already folded into W1t / b1."""
+    hp, EPL = Dp // 2, Dp // 8
+    dev = W1t.device
+    P = W2p.shape[1]
+    steps2 = (H + 3) // 4
+    W1pad = torch.zeros(16, hp, dtype=torch.float64, device=dev)
+    W1pad[:H] = W1t * (2.0 * LOG2E)
+    b1pad = torch.zeros(16, dtype=torch.float64, device=dev)
+    b1pad[:H] = b1 * (2.0 * LOG2E)
+    W2pad = torch.zeros(hp, P, 16, dtype=torch.float64, device=dev)
+    W2pad[:, :, :H] = W2p
+    b2q = b2p.clone()
+    if lk < 2:                                   # alpha = exp(u / 2 + c0) + 1e-10 = exp2((u / 2 + c0) log2 e) + 1e-10
+        W2pad[:, 0, :] *= 0.5 * LOG2E
+        b2q[:, 0] = (b2q[:, 0] * 0.5 + AFF_C0) * LOG2E
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)])                 # (EPL, 64)
+    A1 = A1.reshape(EPL // 4, 4, 64).permute(0, 2, 1)                                  # lane-major groups of 4 k-steps
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    b1m = b1pad[4 * rr + qq]                                                           # [q][r]
+    q2, r2 = il >> 2, il & 3
+    T2 = EPL // 2 if P == 2 else EPL // 4
+    A2, b2m = [], []
+    for t in range(T2):
+        if P == 2:
+            m_l, p_l = EPL * q2 + 2 * t + (r2 >> 1), r2 & 1
+            m_b, p_b = EPL * qq + 2 * t + (rr >> 1), rr & 1
+        else:
+            m_l, p_l = EPL * q2 + 4 * t + r2, torch.zeros_like(r2)
+            m_b, p_b = EPL * qq + 4 * t + rr, torch.zeros_like(rr)
+        for r1 in range(steps2):
+            A2.append(W2pad[m_l, p_l, 4 * r1 + ql])
+        b2m.append(b2q[m_b, p_b])
+    nA2 = (T2 * steps2 + 3) & ~3
+    A2 = torch.stack(A2 + [torch.zeros(64, dtype=torch.float64, device=dev)] * (nA2 - T2 * steps2))
+    A2 = A2.reshape(nA2 // 4, 4, 64).permute(0, 2, 1)
+    return torch.cat([A1.reshape(-1), b1m.reshape(-1), A2.reshape(-1), torch.stack(b2m).reshape(-1),
+                      pre_s, pre_t]).float()
+
+
+def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor):
+    """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
+    folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
+    alternates -- every RealNVP / NICE preset.  The elementwise layers are deferred: physical column c carries a
+    pending map x -> s[c] x + t[c] (fp64 on the host) that is folded into W1 / b1 where c feeds a conditioner,
+    applied by the coupling that transforms c (its pre-affine), and flushed by one TFK_OP_EW_FMA at the end together
+    with the sum of the constant log-dets."""
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import CouplingBijection, ElementwiseBijection
+    from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
+    hp = Dp // 2
+    s = torch.ones(Dp, dtype=torch.float64, device=device)
+    t = torch.zeros(Dp, dtype=torch.float64, device=device)
+    ld_const = torch.zeros((), dtype=torch.float64, device=device)
+    items = []          # (lean kind, plane, steps2, block)
+    kind0 = steps0 = None
+    with torch.no_grad():
+        for layer, d in plan:
+            if isinstance(layer, PermutationMatrix):
+                perm = (layer._fwd_index if d == FORWARD else layer._inv_index).to(device)
+                pos = pos[perm]
+            elif isinstance(layer, ElementwiseBijection):
+                got = _lean_elementwise(layer, d, D)
+                if got is None:
+                    return None
+                alpha, beta, divide = got
+                if divide:
+                    s[pos] = s[pos] / alpha
+                    t[pos] = (t[pos] - beta) / alpha
+                    ld_const = ld_const - torch.log(alpha).sum()
+                else:
+                    s[pos] = alpha * s[pos]
+                    t[pos] = alpha * t[pos] + beta
+                    ld_const = ld_const + torch.log(alpha).sum()
+            elif isinstance(layer, CouplingBijection):
+                got = _lean_coupling(layer, d, pos, D, Dp)
+                if got is None:
+                    return None
+                lk, plane, H, W1t, b1, W2p, b2p = got
+                steps2 = (H + 3) // 4
+                if kind0 is None:
+                    kind0, steps0 = lk, steps2
+                elif (lk, steps2) != (kind0, steps0) or plane != 1 - items[-1][1]:
+                    return None
+                src = torch.arange(plane * hp, (plane + 1) * hp, device=device)
+                tgt = torch.arange((1 - plane) * hp, (2 - plane) * hp, device=device)
+                b1f = b1 + W1t @ t[src]                      # W1 (s x + t) + b1 = (W1 s) x + (W1 t + b1)
+                W1f = W1t * s[src]
+                block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone())
+                s[tgt] = 1.0
+                t[tgt] = 0.0
+                items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block))
+            else:
+                return None
+    flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
+    items.append((OP_EW_FMA, 0, 0, flush))
+    budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
+    segments: List[Segment] = []
+    ops, blocks, used = [], [], 0
+    for kind, plane, steps2, block in items:
+        n = block.numel()
+        if n * 4 > 150 * 1024:
+            return None
+        over = (used + n) * 4 > budget
+        if ops and kind != OP_EW_FMA and (over or len(ops) >= 60):
+            segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
+            ops, blocks, used = [], [], 0
+        ops.append((kind, plane, steps2, used))
+        blocks.append(block)
+        used += n
+    segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
+    identity = bool(torch.equal(pos, pos_in))
+    return CompiledChain(Dp, segments, pos, identity, _params_version(composition), D_log=D,
+                         pos_in=pos_in if Dp != D else None)
+
+
 def compile_chain(composition, direction: int, device: torch.device,
                   mfma: Optional[bool] = None) -> Optional[CompiledChain]:
     """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None.
@@ -522,6 +715,10 @@ def compile_chain(composition, direction: int, device: torch.device,
     if Dp != D and not slots:                    # second half of the row starts at the padded plane boundary
         pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
     pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
+    if mfma and not slots and lean_enabled():
+        chain = _compile_lean(composition, plan, device, D, Dp, pos.clone(), pos_in)
+        if chain is not None:
+            return chain
     items = []                                   # [(op triple, block)]
     with torch.no_grad():
         for layer, d in plan:
