@@ -506,18 +506,26 @@ def main():
                 roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
                 n_mfma = timer.mfma_insts.get(dom_name, 0) / max(dom["launches"], 1)
                 if mfma_pmc is not None:
-                    # measured: rocprofv3 SQ_INSTS_VALU_MFMA_MOPS_F32 / SQ_INSTS_MFMA pass (tools/profile.sh); the
-                    # analytic count above must agree with it
+                    # measured: rocprofv3 SQ_INSTS_VALU_MFMA_F32 (tools/profile.sh pass 5); the analytic count must agree
                     roofline["mfma_insts_per_launch_pmc"] = mfma_pmc
                     roofline["mfma_insts_model_vs_pmc"] = n_mfma / mfma_pmc if mfma_pmc else None
-                for key in ("mfma_busy_cycles", "mfma_coexec_cycles", "sq_busy_cycles", "mfma_util"):
-                    if traffic_db.get(dom_name + ":" + key) is not None:
-                        roofline[key] = traffic_db[dom_name + ":" + key]
-                if n_mfma:
-                    # the f32-input MFMA runs at the vector rate on the SIMD's FP32 datapath (64 FLOP/clk/SIMD,
-                    # MI355X_MICROARCH.md) and did not overlap with vector work in this kernel (ablation in
-                    # DESIGN.md 3.4): SIMD cycles = 4 per vector wave-instruction + 32 per v_mfma_f32_16x16x4_f32
-                    busy = 4.0 * valu + 32.0 * n_mfma
+                gui = traffic_db.get(dom_name + ":grbm_gui_active")
+                busy_mfma = traffic_db.get(dom_name + ":mfma_busy_cycles")
+                if gui and busy_mfma is not None:
+                    # matrix-pipe utilisation as the profiler's MfmaUtil defines it: SQ_VALU_MFMA_BUSY_CYCLES over
+                    # (kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs; COEXEC = cycles in which a vector
+                    # instruction issued while the matrix pipe was busy (0 for the f32-input MFMA: it occupies the
+                    # SIMD's FP32 datapath, nothing runs beside it)
+                    simd_cycles = gui / 8.0 * 256 * 4
+                    roofline["mfma_util"] = busy_mfma / simd_cycles
+                    roofline["mfma_coexec_frac"] = (traffic_db.get(dom_name + ":mfma_coexec_cycles") or 0.0) / simd_cycles
+                    trans = traffic_db.get(dom_name + ":trans_insts") or 0.0
+                    vec = valu - (mfma_pmc or 0.0)              # SQ_INSTS_VALU counts the MFMAs too
+                    roofline["vector_insts_per_launch"] = vec
+                    # SIMD cycles accounted for: 4 per vector instruction (+4 for a transcendental) + the matrix pipe
+                    roofline["fp32_datapath_frac"] = (4.0 * vec + 4.0 * trans + busy_mfma) / simd_cycles
+                elif n_mfma:
+                    busy = 4.0 * (valu - n_mfma) + 32.0 * n_mfma
                     roofline["mfma_insts_per_launch"] = n_mfma
                     roofline["fp32_datapath_frac"] = busy / (dom["avg_us"] * 1e-6 * 256 * 4 * 2.4e9)
         elif dom_name.startswith("conv3x3_relu_pool_affine"):
