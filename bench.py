@@ -175,7 +175,7 @@ class KernelTimer:
                 per_wave += EPL * HT + (EPL // 2) * steps2
             elif kind in (4, 5, 14, 15):
                 per_wave += EPL * HT + (EPL // 4) * steps2
-            elif kind in (6, 7):
+            elif kind in (6, 7, 17, 18):
                 per_wave += EPL + 6 * EPL * steps2
             elif kind in (8, 9):
                 per_wave += 2 * EPL * HT + EPL * steps2
@@ -197,9 +197,9 @@ class KernelTimer:
             ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         for op in ops:
             kind, H = op[0], op[2]
-            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15):
+            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15, 17, 18):
                 H = KernelTimer.true_hidden.get(D, 4 * H)       # the matrix-core ops record ceil(H / 4)
-            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23, 12: 2, 13: 2, 14: 1, 15: 1}.get(kind)
+            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23, 12: 2, 13: 2, 14: 1, 15: 1, 17: 23, 18: 23}.get(kind)
             if P is not None:
                 per_row += 2 * (half * H + H * half * P)
             elif kind in (8, 9, 10):                            # MADE ops: both planes in, every element a target

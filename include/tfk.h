@@ -209,7 +209,18 @@ enum {
     TFK_OP_AFFINE_INV_LEAN = 13,
     TFK_OP_SHIFT_FWD_LEAN = 14,
     TFK_OP_SHIFT_INV_LEAN = 15,
-    TFK_OP_EW_FMA = 16      /* s[D] | t[D] | logdet_const | pad[3]:  z = fma(s, x, t), logdet += logdet_const */
+    TFK_OP_EW_FMA = 16,     /* s[D] | t[D] | logdet_const | pad[3]:  z = fma(s, x, t), logdet += logdet_const */
+    /* lean SPLINE programs (ABI v20): a chain of RQ-spline couplings (8 bins) of one direction, one hidden width
+     * (<= 16) and one spline box, source plane alternating, parameter blocks at a constant stride, optionally ended
+     * by one TFK_OP_EW_FMA: ONE launch for the whole chain (csrc/tfk_flow_rqs_chain.h) -- the rows stay in registers
+     * and the operands are streamed per layer from `params` (global memory: a chain does not have to fit the LDS).
+     * Block: A1[D/32][64][4] | b1[4][4] | pre_s[D/2] | pre_t[D/2], then D/64 chunks of A2[48][64][4] | b2[48][4][4]
+     * (tile 6 e + c of a chunk = parameters 4 c .. 4 c + 3 of the lane-group's target element 8 chunk + e, lane-major
+     * over <= 4 k-steps).  Per element 24 parameters: [0, 8) width logits u_x, [8, 16) height logits u_x + u_y / 1000,
+     * [16, 23) derivative logits c + u_d / 1000 -- ALL multiplied by log2(e) by the packer -- and one pad; W1 / b1
+     * times 2 log2(e) as for the affine lean ops.  Op record as for TFK_OP_RQS_*: K = 8, boundary, scale, c. */
+    TFK_OP_RQS_FWD_LEAN = 17,
+    TFK_OP_RQS_INV_LEAN = 18
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

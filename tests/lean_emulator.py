@@ -24,6 +24,48 @@ def _mfma(A_lane, B_lane, acc):
     return out
 
 
+def rqs_lean_eval(p, v, C, inverse):
+    """The spline element of csrc/tfk_flow_rqs_chain.h in fp64: p (..., 24) pre-scaled parameters, v (...) inputs.
+    Returns (out, log2-det)."""
+    minimum, maximum, g, cmin, d_edge = C
+    ux, uy, ud = p[..., 0:8], p[..., 8:16], p[..., 16:23]
+    ex = torch.exp2(ux - ux.max(-1, keepdim=True).values)
+    ey = torch.exp2(uy - uy.max(-1, keepdim=True).values)
+    gx, gy = g / ex.sum(-1, keepdim=True), g / ey.sum(-1, keepdim=True)
+    jj = torch.arange(1, 8, dtype=torch.float64)
+    X = torch.cat([torch.full_like(v[..., None], minimum), torch.cumsum(ex * gx, -1)[..., :7] + minimum + jj * cmin,
+                   torch.full_like(v[..., None], maximum)], -1)
+    Y = torch.cat([torch.full_like(v[..., None], minimum), torch.cumsum(ey * gy, -1)[..., :7] + minimum + jj * cmin,
+                   torch.full_like(v[..., None], maximum)], -1)
+    Dl = torch.cat([torch.full_like(v[..., None], d_edge), ud, torch.full_like(v[..., None], d_edge)], -1)
+    S = Y if inverse else X
+    k = ((S[..., 1:8] < v[..., None]).sum(-1, keepdim=True)).clamp(0, 7)
+    pick = lambda t, i: torch.gather(t, -1, i).squeeze(-1)
+    bxk, bxk1, byk, byk1 = pick(X, k), pick(X, k + 1), pick(Y, k), pick(Y, k + 1)
+    dk = 1e-5 + LN2 * torch.log2(1 + torch.exp2(pick(Dl, k)))
+    dk1 = 1e-5 + LN2 * torch.log2(1 + torch.exp2(pick(Dl, k + 1)))
+    wk, hk = bxk1 - bxk, byk1 - byk
+    s = hk / wk
+    term1 = dk1 + dk - 2 * s
+    if not inverse:
+        xi = ((v - bxk) / wk).clamp(0, 1)
+    else:
+        term0 = v - byk
+        term2 = hk * dk
+        a = (hk * s - term2) + term0 * term1
+        b = term2 - term0 * term1
+        c = -s * term0
+        r = torch.sqrt((b * b - 4 * a * c).clamp(min=0))
+        xi = (2 * c / (-b - r)).clamp(0, 1)
+    q = xi * (1 - xi)
+    den = s + term1 * q
+    out = byk + hk * (s * xi * xi + dk * q) / den if not inverse else xi * wk + bxk
+    inner = dk1 * xi * xi + 2 * s * q + dk * (1 - xi) ** 2
+    l2 = torch.log2((s / den) ** 2 * inner)
+    inb = (v > minimum) & (v < maximum)
+    return torch.where(inb, out, v), torch.where(inb, -l2 if inverse else l2, torch.zeros_like(l2))
+
+
 def run_lean(ops, params, rows, D):
     """rows (N, D) fp64, N a multiple of 16 -> (rows out, logdet) of one lean segment."""
     EPL, HALF = D // 8, D // 2
@@ -40,12 +82,51 @@ def run_lean(ops, params, rows, D):
     ld = torch.zeros(64, W, dtype=torch.float64)
     prm = params.double()
     sign = 0.0
-    for kind, plane, steps2, off in ops:
+    op_extra = {(op[0], op[3]): op[4:8] for op in ops if len(op) > 4}
+    for kind, plane, steps2, off in [op[:4] for op in ops]:
         if kind == 16:                                        # TFK_OP_EW_FMA
             s, t = prm[off:off + D], prm[off + D:off + 2 * D]
             a = s[idx][:, :, None] * a + t[idx][:, :, None]
             b = s[HALF + idx][:, :, None] * b + t[HALF + idx][:, :, None]
             ld[q == 0] += prm[off + 2 * D]
+            continue
+        if kind in (17, 18):                                  # lean RQ-spline coupling
+            K, boundary, scale, cdelta = op_extra[(kind, off)]
+            HEAD = EPL * 64 + 16 + 2 * HALF
+            A1 = prm[off:off + EPL * 64].reshape(EPL // 4, 64, 4)
+            b1 = prm[off + EPL * 64:off + EPL * 64 + 16]
+            pre = prm[off + EPL * 64 + 16:off + HEAD]
+            src, tgt = (a, b) if plane == 0 else (b, a)
+            acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+            for s_ in range(EPL):
+                acc = _mfma(A1[s_ // 4, :, s_ % 4], src[:, s_], acc)
+            tgt = pre[idx][:, :, None] * tgt + pre[HALF + idx][:, :, None]
+            hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)
+            tgt = tgt.clone()
+            span = 2.0 * boundary
+            C = (-boundary, boundary, span * scale, span * 1e-3, (cdelta + cdelta / 1000.0) * 1.4426950408889634)
+            CH = 48 * 256 + 48 * 16
+            for ch in range(EPL // 8):
+                base = off + HEAD + ch * CH
+                A2 = prm[base:base + 48 * 256].reshape(48, 64, 4)
+                b2 = prm[base + 48 * 256:base + CH]
+                for e in range(8):
+                    pp = []
+                    for c in range(6):
+                        t_ = e * 6 + c
+                        o = b2[((t_ * 4 + q) * 4)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+                        for k in range(steps2):
+                            o = _mfma(A2[t_, :, k], hid[:, k], o)
+                        pp.append(o)
+                    pvec = torch.cat(pp, 1).permute(0, 2, 1)                       # (64, W, 24)
+                    out, l2 = rqs_lean_eval(pvec, tgt[:, 8 * ch + e], C, kind == 18)
+                    tgt[:, 8 * ch + e] = out
+                    ld2 = ld2 + l2
+            sign = 1.0
+            if plane == 0:
+                b = tgt
+            else:
+                a = tgt
             continue
         lk = kind - 12
         affine = lk < 2

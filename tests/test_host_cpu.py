@@ -466,7 +466,9 @@ def test_torchflows_import_alias_resolves_to_the_build():
 
 
 @pytest.mark.parametrize("arch,D,n_layers,direction", [("RealNVP", 64, 8, 0), ("RealNVP", 64, 3, 1), ("NICE", 64, 4, 0),
-                                                       ("RealNVP", 128, 2, 0), ("RealNVP", 22, 3, 0), ("NICE", 8, 3, 1)])
+                                                       ("RealNVP", 128, 2, 0), ("RealNVP", 22, 3, 0), ("NICE", 8, 3, 1),
+                                                       ("CouplingRQNSF", 64, 3, 0), ("CouplingRQNSF", 64, 2, 1),
+                                                       ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1)])
 def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction):
     """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
     pre-affines, pre-scaled logits, lane-major operands): an fp64 emulator that decodes the packed blocks exactly as
@@ -496,7 +498,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction):
     rows[:, pos] = x
     ld = torch.zeros(64, dtype=torch.float64)
     for seg in chain.segments:
-        assert seg.mfma and all(12 <= op[0] <= 16 for op in seg.ops)
+        assert seg.mfma and all(12 <= op[0] <= 18 for op in seg.ops)
         rows, l = run_lean(seg.ops, seg.params, rows, Dp)
         ld = ld + l
     got = rows[:, chain.pos]

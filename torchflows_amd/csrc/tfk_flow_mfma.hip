@@ -2,6 +2,7 @@
 // instantiated per row width in tfk_flow_mfma_{8,16,32}.hip).
 #include "tfk_flow_mfma.h"
 #include "tfk_flow_chain.h"
+#include "tfk_flow_rqs_chain.h"
 
 namespace tfk {
 int flow_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -10,6 +11,79 @@ int flow_chain_launch_16(const float *, float *, float *, const float *, const f
                          const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
                          const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+
+int flow_rqs_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                            const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+int flow_rqs_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                             const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+int flow_rqs_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                             const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+
+// A program of lean spline couplings (TFK_OP_RQS_*_LEAN of one direction, one hidden width, one spline box, blocks
+// at a constant stride, source plane alternating; optionally ended by one TFK_OP_EW_FMA): ONE launch of
+// tfk_flow_rqs_chain.h, the operands streamed layer by layer from `params` (global memory).
+static int run_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                         float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
+                         int64_t n_params, int32_t flags, hipStream_t s, const char *fn)
+{
+    const int EPL = D / 8, HALF = D / 2;
+    const int64_t block = (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
+    RqsChainProg prog;
+    memset(&prog, 0, sizeof(prog));
+    prog.ew_offset = -1;
+    int kind = -1, steps2 = 0;
+    float boundary = 0.0f, scale = 0.0f, c = 0.0f;
+    for (int i = 0; i < n_ops; ++i) {
+        const int32_t *rec = ops + 8 * i;
+        const int k = rec[0], src = rec[1], st = rec[2], off = rec[3];
+        if (k == TFK_OP_EW_FMA) {
+            if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
+            if (off < 0 || (off & 3) || off + 2 * (int64_t)D + 4 > n_params)
+                return fail(TFK_EINVAL, "%s: op %d: parameters outside the block", fn, i);
+            prog.ew_offset = off;
+            continue;
+        }
+        if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN)
+            return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean spline ops", fn, i, k);
+        float bnd, sc, cc;
+        memcpy(&bnd, rec + 5, 4);
+        memcpy(&sc, rec + 6, 4);
+        memcpy(&cc, rec + 7, 4);
+        if (rec[4] != 8) return fail(TFK_EINVAL, "%s: op %d: lean spline ops support n_bins = 8, got %d", fn, i, rec[4]);
+        if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
+        if (src != 0 && src != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, src);
+        if (!(bnd > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
+        if (off < 0 || (off & 3) || off + block > n_params)
+            return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i, off,
+                        (long long)(off + block), (long long)n_params);
+        if (prog.n_layers == 0) {
+            kind = k; steps2 = st; boundary = bnd; scale = sc; c = cc;
+            prog.first_src = src;
+            prog.offset0 = off;
+        } else {
+            if (k != kind || st != steps2 || bnd != boundary || sc != scale || cc != c)
+                return fail(TFK_EINVAL, "%s: op %d: a lean spline program holds couplings of one direction, hidden width and box", fn, i);
+            if (src != ((prog.first_src + prog.n_layers) & 1))
+                return fail(TFK_EINVAL, "%s: op %d: the source plane of lean couplings must alternate", fn, i);
+            const int64_t stride = (int64_t)off - (prog.offset0 + (int64_t)(prog.n_layers - 1) * prog.layer_stride);
+            if (prog.n_layers == 1) prog.layer_stride = (int)stride;
+            else if (stride != prog.layer_stride)
+                return fail(TFK_EINVAL, "%s: op %d: lean spline blocks must lie at a constant stride", fn, i);
+        }
+        ++prog.n_layers;
+    }
+    if (prog.n_layers == 0) return fail(TFK_EINVAL, "%s: a lean spline program needs at least one coupling", fn);
+    const double span = 2.0 * (double)boundary;
+    prog.C.minimum = -boundary;
+    prog.C.maximum = boundary;
+    prog.C.g = (float)(span * (double)scale);
+    prog.C.cmin = (float)(span * 1e-3);
+    prog.C.d_edge = (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
+    const int inverse = kind == TFK_OP_RQS_INV_LEAN;
+    if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
+    if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
+    return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
+}
 
 // A program made of lean ops only (TFK_OP_*_LEAN couplings of one kind and one GEMM-2 step count whose source
 // plane alternates, optionally ended by one TFK_OP_EW_FMA) runs on the straight-line kernel of tfk_flow_chain.h.
@@ -93,6 +167,9 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if (!aligned16(x) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
+    if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN))
+        return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
+                             accumulate, static_cast<hipStream_t>(stream), fn);
     if (n_ops > 0 && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA)
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                          accumulate, static_cast<hipStream_t>(stream), fn);

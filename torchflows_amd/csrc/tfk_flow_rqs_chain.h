@@ -1,0 +1,420 @@
+// tfk_flow_rqs_chain.h -- a whole chain of rational-quadratic-spline couplings in ONE launch
+// (templates; instantiated per row width in tfk_flow_rqs_chain_{8,16,32}.hip, dispatched from tfk_flow_run_mfma).
+//
+// A spline coupling needs 23 parameters per target element: GEMM 2's A-operands are 49 KB per 8 target elements per
+// lane-group, far more than a whole chain's worth fits the LDS (the interpreter of tfk_flow_mfma.h therefore ran one
+// launch per coupling, and the rows crossed HBM 2 x 9 times for config 3).  Here the rows STAY in registers for the
+// whole chain and the operands come to them: the workgroup walks the layers together and stages, per layer, the
+// conditioner's first GEMM and then one CHUNK of 8 target elements' GEMM-2 operands at a time from global memory
+// (L2-resident: every workgroup reads the same 55 KB per layer) into LDS.  Rows are read once and, for log_prob,
+// never written: 4 D + 4 bytes per row instead of 17 x 4 D.
+//
+// The spline itself is evaluated in a form that costs ~170 vector instructions per element instead of ~420
+// (rocprofv3: SQ_INSTS_VALU 220 M -> see profiles/r02/):
+//   * the packer (fused.py) folds the reference's  u_x + u_y / 1000,  c + u_d / 1000  (rational_quadratic.py:76-77)
+//     and the factor log2(e) into W2 / b2, so the kernel receives softmax logits for exp2 directly;
+//   * knots are  minimum + j * span * min_bin + (span * scale / sum) * partial sums  (one fma + one add per knot);
+//   * the bin is found by a 3-level binary search that narrows knots, opposite knots and derivative logits together
+//     (30 selects instead of ~56), strict '<' as searchsorted(right=False) (an input on a knot goes left);
+//   * softplus as ln 2 * log2(1 + exp2(.)), divisions as v_rcp_f32 (1 ulp), the log-det as ONE logarithm of
+//     (s / den)^2 * inner, accumulated in base 2;
+//   * elementwise layers between the couplings are deferred exactly as in tfk_flow_chain.h (pre-affine of the target
+//     plane, folded into W1 / b1 for the source plane, TFK_OP_EW_FMA at the end).
+//
+// Parameter block of a lean RQS op (floats, GLOBAL memory), NC = EPL / 8 chunks:
+//   head   A1[EPL/4][64][4] | b1[4][4] | pre_s[HALF] | pre_t[HALF]
+//   chunk  A2[48][64][4] | b2[48][4][4]        tile 6 e + c of a chunk = parameters 4 c .. 4 c + 3 of the lane-group's
+//                                              target element 8 chunk + e; A2 lane-major over the (<= 4) k-steps
+//   parameters per element: [0, 8) width logits, [8, 16) height logits (u_x + u_y / 1000), [16, 23) derivative
+//   logits (c + u_d / 1000), all times log2(e); 23 = padding.
+#pragma once
+#include "tfk_common.h"
+#include "tfk_flow_chain.h"
+
+namespace tfk {
+
+struct RqsLean {
+    float minimum, maximum;   // -boundary, +boundary
+    float g;                  // span * (1 - min_bin * K)
+    float cmin;               // span * min_bin
+    float d_edge;             // (c + c / 1000) * log2(e): the padded derivative logits (rational_quadratic.py:127)
+};
+
+struct RqsChainProg {
+    int n_layers;
+    int first_src;
+    int ew_offset;            // TFK_OP_EW_FMA (global offset), -1: none
+    int layer_stride;         // floats between consecutive layers' blocks
+    int offset0;              // first layer's block
+    int pad[3];
+    RqsLean C;
+};
+
+constexpr int kRqsChunkFloats = 48 * 256 + 48 * 16;
+
+__device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float exp2_f(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ float log2_f(float v) { return __builtin_amdgcn_logf(v); }
+
+// One in-box element.  p: its 24 pre-scaled parameters (registers).  l2 = log2 |dz/dx| (forward) or of dx/dz (inverse).
+template <bool INVERSE>
+__device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, const RqsLean &C, float &out, float &l2)
+{
+    // softmax numerators, rational_quadratic.py:46 (logits arrive times log2 e)
+    float mx = p[0], my = p[8];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { mx = fmaxf(mx, p[j]); my = fmaxf(my, p[8 + j]); }
+    float ex[8], ey[8], sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ex[j] = exp2_f(p[j] - mx);
+        ey[j] = exp2_f(p[8 + j] - my);
+        sx += ex[j];
+        sy += ey[j];
+    }
+    const float gx = C.g * rcp_f(sx), gy = C.g * rcp_f(sy);
+    // knots :47-52:  span * cumsum(min_bin + scale * softmax) + minimum, ends pinned
+    float X[9], Y[9], Dl[9];
+    X[0] = C.minimum; Y[0] = C.minimum; X[8] = C.maximum; Y[8] = C.maximum;
+    Dl[0] = C.d_edge; Dl[8] = C.d_edge;
+    float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        ax = fmaf(ex[j - 1], gx, ax);
+        ay = fmaf(ey[j - 1], gy, ay);
+        const float cj = C.minimum + (float)j * C.cmin;       // uniform: scalar unit
+        X[j] = ax + cj;
+        Y[j] = ay + cj;
+        Dl[j] = p[15 + j];
+    }
+    // bin = number of knots strictly below v, minus one (:82 / :147); three halvings that carry the searched knots,
+    // the opposite knots and the derivative logits along
+    float S5[5], O5[5], D5[5];
+    {
+        const bool up = (INVERSE ? Y[4] : X[4]) < v;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            S5[i] = up ? (INVERSE ? Y[4 + i] : X[4 + i]) : (INVERSE ? Y[i] : X[i]);
+            O5[i] = up ? (INVERSE ? X[4 + i] : Y[4 + i]) : (INVERSE ? X[i] : Y[i]);
+            D5[i] = up ? Dl[4 + i] : Dl[i];
+        }
+    }
+    float S3[3], O3[3], D3[3];
+    {
+        const bool up = S5[2] < v;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            S3[i] = up ? S5[2 + i] : S5[i];
+            O3[i] = up ? O5[2 + i] : O5[i];
+            D3[i] = up ? D5[2 + i] : D5[i];
+        }
+    }
+    const bool up = S3[1] < v;
+    const float s0 = up ? S3[1] : S3[0], s1 = up ? S3[2] : S3[1];
+    const float o0 = up ? O3[1] : O3[0], o1 = up ? O3[2] : O3[1];
+    const float t0 = up ? D3[1] : D3[0], t1 = up ? D3[2] : D3[1];
+    const float bxk = INVERSE ? o0 : s0, bxk1 = INVERSE ? o1 : s1;
+    const float byk = INVERSE ? s0 : o0, byk1 = INVERSE ? s1 : o1;
+
+    const float wk = bxk1 - bxk;                              // :53
+    const float hk = byk1 - byk;
+    // delta = 1e-5 + softplus(.) = 1e-5 + ln 2 * log2(1 + exp2(.)), :77 (the logit is clamped so that exp2 stays
+    // finite; softplus's own threshold of 20 only swaps in an approximation that this form does not need)
+    const float LN2 = __int_as_float(0x3f317218);
+    const float dk = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t0, 126.0f))), kRqsMinDelta);
+    const float dk1 = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t1, 126.0f))), kRqsMinDelta);
+    const float rw = rcp_f(wk);
+    const float s = hk * rw;                                  // :94 / :159
+    const float term1 = fmaf(-2.0f, s, dk1 + dk);            // :97 / :162
+    float xi;
+    if constexpr (!INVERSE) {
+        xi = (v - bxk) * rw;                                  // :99
+        xi = fminf(fmaxf(xi, 0.0f), 1.0f);                    // :100
+    } else {
+        const float term0 = v - byk;                          // :164
+        const float term2 = hk * dk;                          // :165
+        const float tt = term0 * term1;
+        const float a = (hk * s - term2) + tt;                // :167
+        const float b = term2 - tt;                           // :168
+        const float c = (-s) * term0;                         // :169
+        float r = fmaf(b, b, -(4.0f * a) * c);                // :171
+        r = __builtin_sqrtf(fmaxf(r, 0.0f));
+        xi = (2.0f * c) * rcp_f((-b) - r);                    // :173
+        xi = fminf(fmaxf(xi, 0.0f), 1.0f);                    // :174
+    }
+    const float omx = 1.0f - xi;
+    const float q = xi * omx;                                 // :101 / :175
+    const float xi2 = xi * xi;
+    const float den = fmaf(term1, q, s);                      // :105
+    const float rden = rcp_f(den);
+    if constexpr (!INVERSE) {
+        const float num = hk * fmaf(dk, q, s * xi2);          // :104
+        out = fmaf(num, rden, byk);                           // :106
+    } else {
+        out = fmaf(xi, wk, bxk);                              // :178
+    }
+    // :56-63  2 log s + log(inner) - 2 log(den) = log((s / den)^2 inner)
+    const float inner = fmaf(dk1, xi2, fmaf(s + s, q, dk * (omx * omx)));
+    const float r = s * rden;
+    const float l = log2_f((r * r) * inner);
+    l2 = INVERSE ? -l : l;
+}
+
+// one layer with the roles of the planes fixed: src feeds the conditioner, tgt is transformed
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
+__device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float *stage, int lane, int q,
+                                          const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2)
+{
+    constexpr int HALF = 4 * EPL;
+    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
+    constexpr int NC = EPL / 8;
+    float *head_s = stage;                                    // [HEAD]
+    float *chunk_s = stage + HEAD;                            // [kRqsChunkFloats]
+    float hid[4];
+#pragma unroll 1
+    for (int ch = 0; ch < NC; ++ch) {
+        __syncthreads();                                      // every wave is done with the previous stage
+        {
+            const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * kRqsChunkFloats);
+            float4 *d4 = reinterpret_cast<float4 *>(chunk_s);
+            for (int i = threadIdx.x; i < kRqsChunkFloats / 4; i += BLOCK) d4[i] = g4[i];
+            if (ch == 0) {
+                const float4 *h4 = reinterpret_cast<const float4 *>(gprm);
+                float4 *e4 = reinterpret_cast<float4 *>(head_s);
+                for (int i = threadIdx.x; i < HEAD / 4; i += BLOCK) e4[i] = h4[i];
+            }
+        }
+        __syncthreads();
+        if (ch == 0) {
+            const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(head_s);
+            const float *b1 = head_s + EPL * 64;
+            const float *pre = b1 + 16;
+            cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+#pragma unroll
+            for (int g = 0; g < EPL / 4; ++g) {
+                const cf32x4 w = A1[g * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {                // pending elementwise layers of the target plane
+                const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+                const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hid[r] = fmaf(-2.0f, rcp_f(exp2_f(acc[r]) + 1.0f), 1.0f);
+        }
+        const cf32x4 *A2 = reinterpret_cast<const cf32x4 *>(chunk_s);
+        const float *b2 = chunk_s + 48 * 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float p[24];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int t = e * 6 + c;
+                cf32x4 o = *reinterpret_cast<const cf32x4 *>(b2 + (t * 4 + q) * 4);
+                const cf32x4 w = A2[t * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < STEPS2; ++k)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], hid[k], o, 0, 0, 0);
+                p[4 * c] = o[0]; p[4 * c + 1] = o[1]; p[4 * c + 2] = o[2]; p[4 * c + 3] = o[3];
+            }
+            // the element this (chunk, e) addresses: static when there is one chunk, else a select over the chunks
+            float v = tgt[e];
+            if constexpr (NC > 1) {
+#pragma unroll
+                for (int c2 = 1; c2 < NC; ++c2) v = (ch == c2) ? tgt[8 * c2 + e] : v;
+            }
+            float out = v, l = 0.0f;                           // spline/base.py:54-55
+            if (v > C.minimum && v < C.maximum)                // strict box, base.py:29-33
+                rqs_eval_lean<INVERSE>(p, v, C, out, l);
+            ld2 += l;
+            if constexpr (NC > 1) {
+#pragma unroll
+                for (int c2 = 0; c2 < NC; ++c2) tgt[8 * c2 + e] = (ch == c2) ? out : tgt[8 * c2 + e];
+            } else {
+                tgt[e] = out;
+            }
+        }
+    }
+}
+
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
+__global__ __launch_bounds__(BLOCK) void k_flow_rqs_chain(
+    const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
+    const float *__restrict__ gauss_log_scale, float *logprob, long long N,
+    const float *__restrict__ params, RqsChainProg prog, int flags)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
+    const int accumulate = flags & 1;
+    const bool reverse_out = (flags & 2) != 0;
+    const bool base_of_input = (flags & 4) != 0;
+    float *stage = lds;                                      // [HEAD + chunk]
+    float *ew_s = lds + HEAD + kRqsChunkFloats;              // s[D] | t[D] | ldc, pad[3]
+    float *base_s = ew_s + 2 * D + 4;                        // loc[D] | 1/scale[D] | const
+    if (prog.ew_offset >= 0)
+        for (int e = threadIdx.x; e < 2 * D + 4; e += BLOCK) ew_s[e] = params[prog.ew_offset + e];
+    if (logprob) {
+        for (int e = threadIdx.x; e < D; e += BLOCK) {
+            base_s[e] = gauss_loc[e];
+            base_s[D + e] = expf(-gauss_log_scale[e]);
+        }
+        if (threadIdx.x < 64) {
+            float c = 0.0f;
+            for (int e = threadIdx.x; e < D; e += 64) c += gauss_log_scale[e] + kHalfLog2Pi;
+            c = group_sum(c, 64);
+            if (threadIdx.x == 0) base_s[2 * D] = c;
+        }
+    }
+    __syncthreads();
+    const RqsLean C = prog.C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const long long stride = (long long)gridDim.x * rows_per_block;
+    const float base_const = logprob ? base_s[2 * D] : 0.0f;
+    // the trip count is the same for every wave of a workgroup (barriers inside): loop on the workgroup's first row
+    for (long long blk0 = (long long)blockIdx.x * rows_per_block; blk0 < N; blk0 += stride) {
+        const long long row = blk0 + wave * 16 + j;
+        const long long rr = row < N ? row : N - 1;
+        float a[EPL], b[EPL];
+        const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+        const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const float4 va = pa[i], vb = pb[i];
+            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+        }
+        float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
+        float sq = 0.0f;
+        auto base_terms = [&]() {
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const cf32x4 la = *reinterpret_cast<const cf32x4 *>(base_s + EPL * q + 4 * i);
+                const cf32x4 lb = *reinterpret_cast<const cf32x4 *>(base_s + HALF + EPL * q + 4 * i);
+                const cf32x4 ia = *reinterpret_cast<const cf32x4 *>(base_s + D + EPL * q + 4 * i);
+                const cf32x4 ib = *reinterpret_cast<const cf32x4 *>(base_s + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ta = (a[4 * i + k] - la[k]) * ia[k];
+                    const float tb = (b[4 * i + k] - lb[k]) * ib[k];
+                    sq = fmaf(ta, ta, sq);
+                    sq = fmaf(tb, tb, sq);
+                }
+            }
+        };
+        if (logprob && base_of_input) base_terms();
+        float ld2 = 0.0f;
+#pragma unroll 1
+        for (int l = 0; l < prog.n_layers; ++l) {
+            const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
+            if (((prog.first_src + l) & 1) == 0)
+                rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
+            else
+                rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+        }
+        ld = fmaf(ld2, __int_as_float(0x3f317218), ld);             // ln 2
+        if (prog.ew_offset >= 0) {
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew_s + EPL * q + 4 * i);
+                const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(ew_s + HALF + EPL * q + 4 * i);
+                const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(ew_s + D + EPL * q + 4 * i);
+                const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(ew_s + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
+                    b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+                }
+            }
+            if (q == 0) ld = ld + ew_s[2 * D];
+        }
+        if (logprob && !base_of_input) base_terms();
+        ld += __shfl_xor(ld, 16, kWave);
+        ld += __shfl_xor(ld, 32, kWave);
+        if (logprob) {
+            sq += __shfl_xor(sq, 16, kWave);
+            sq += __shfl_xor(sq, 32, kWave);
+        }
+        if (row < N) {
+            if (z && !reverse_out) {
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + EPL * q);
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF + EPL * q);
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+                    qb[i] = make_float4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+                }
+            } else if (z) {
+                float4 *qa = reinterpret_cast<float4 *>(z + row * D + D - EPL * (q + 1));
+                float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF - EPL * (q + 1));
+#pragma unroll
+                for (int i = 0; i < EPL / 4; ++i) {
+                    qa[i] = make_float4(a[EPL - 1 - 4 * i], a[EPL - 2 - 4 * i], a[EPL - 3 - 4 * i], a[EPL - 4 - 4 * i]);
+                    qb[i] = make_float4(b[EPL - 1 - 4 * i], b[EPL - 2 - 4 * i], b[EPL - 3 - 4 * i], b[EPL - 4 - 4 * i]);
+                }
+            }
+            if (q == 0) {
+                if (logdet) logdet[row] = ld;
+                if (logprob) logprob[row] = (fmaf(-0.5f, sq, -base_const)) + ld;
+            }
+        }
+    }
+}
+
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
+static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                              float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int flags,
+                              hipStream_t s, const char *fn)
+{
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
+    const size_t lds = ((size_t)HEAD + kRqsChunkFloats + 2 * (2 * D + 4)) * sizeof(float);
+    auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", fn, lds, hipGetErrorString(e));
+        }
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    constexpr int rows_per_block = (BLOCK / 64) * 16;
+    const int64_t want = (N + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
+                       params, prog, flags);
+    return check_launch(fn);
+}
+
+template <int EPL>
+static int launch_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
+                            float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int inverse,
+                            int steps2, int flags, hipStream_t s, const char *fn)
+{
+#define TFK_RC(ST_) \
+    (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, s, fn) \
+             : launch_rqs_chain_b<EPL, 512, ST_, false>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, s, fn))
+    switch (steps2) {
+    case 1: return TFK_RC(1);
+    case 2: return TFK_RC(2);
+    case 3: return TFK_RC(3);
+    case 4: return TFK_RC(4);
+    default: return fail(TFK_EINVAL, "%s: lean spline couplings need 1..4 GEMM-2 steps, got %d", fn, steps2);
+    }
+#undef TFK_RC
+}
+
+}  // namespace tfk

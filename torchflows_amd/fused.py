@@ -32,6 +32,7 @@ import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -39,7 +40,8 @@ from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
     OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
-    OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA = range(17)
+    OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA, \
+    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN = range(19)
 LOG2E = 1.4426950408889634
 AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
@@ -511,7 +513,9 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     in fp64, or None (the checks of ``_coupling_op``)."""
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
     kind = layer.transformer.native_kind
-    if kind not in ("affine", "inverse_affine", "shift") or layer.context_shape is not None:
+    if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
+        return None
+    if kind == "rqs" and layer.transformer.n_bins != 8:
         return None
     half = D // 2
     c = layer.coupling
@@ -527,7 +531,7 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
             and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
         return None
-    P = 1 if kind == "shift" else 2
+    P = {"shift": 1, "rqs": 23}.get(kind, 2)
     W1, b1 = mods[0].weight.detach().double(), mods[0].bias.detach().double()
     W2, b2 = mods[2].weight.detach().double(), mods[2].bias.detach().double()
     H = W1.shape[0]
@@ -547,6 +551,8 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     b2p[m_t] = b2.reshape(T, P)
     if kind == "shift":
         lk = 2 if d == FORWARD else 3
+    elif kind == "rqs":
+        lk = 4 if d == FORWARD else 5
     else:
         lk = 0 if (d == FORWARD) != (kind == "inverse_affine") else 1
     return lk, plane, H, W1t, b1, W2p, b2p
@@ -598,6 +604,47 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t) -> tor
                       pre_s, pre_t]).float()
 
 
+def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float) -> torch.Tensor:
+    """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out:
+    head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks A2[48][64][4] | b2[48][4][4].
+    Per target element 24 parameters, all times log2(e): [0, 8) u_x, [8, 16) u_x + u_y / 1000 (the reference's height
+    logits, rational_quadratic.py:76), [16, 23) c + u_d / 1000 (:77, c = boundary_u_delta), pad."""
+    hp, EPL = Dp // 2, Dp // 8
+    NC = EPL // 8
+    dev = W1t.device
+    W1pad = torch.zeros(16, hp, dtype=torch.float64, device=dev)
+    W1pad[:H] = W1t * (2.0 * LOG2E)
+    b1pad = torch.zeros(16, dtype=torch.float64, device=dev)
+    b1pad[:H] = b1 * (2.0 * LOG2E)
+    Q = torch.zeros(hp, 24, 16, dtype=torch.float64, device=dev)
+    Q[:, 0:8, :H] = W2p[:, 0:8] * LOG2E
+    Q[:, 8:16, :H] = (W2p[:, 0:8] + W2p[:, 8:16] / 1000.0) * LOG2E
+    Q[:, 16:23, :H] = W2p[:, 16:23] / 1000.0 * LOG2E
+    bq = torch.zeros(hp, 24, dtype=torch.float64, device=dev)
+    bq[:, 0:8] = b2p[:, 0:8] * LOG2E
+    bq[:, 8:16] = (b2p[:, 0:8] + b2p[:, 8:16] / 1000.0) * LOG2E
+    bq[:, 16:23] = (c_delta + b2p[:, 16:23] / 1000.0) * LOG2E
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)]).reshape(EPL // 4, 4, 64).permute(0, 2, 1)
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    b1m = b1pad[4 * rr + qq]
+    q2, r2 = il >> 2, il & 3
+    ch = torch.arange(NC, device=dev).view(NC, 1, 1, 1, 1)
+    e = torch.arange(8, device=dev).view(1, 8, 1, 1, 1)
+    c = torch.arange(6, device=dev).view(1, 1, 6, 1, 1)
+    r1 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
+    m = EPL * q2.view(1, 1, 1, 64, 1) + 8 * ch + e
+    A2 = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 4 * r1 + ql.view(1, 1, 1, 64, 1)]          # (NC, 8, 6, 64, 4)
+    mb = EPL * qq.view(1, 1, 1, 4, 4) + 8 * ch + e
+    b2 = bq[mb, 4 * c + rr.view(1, 1, 1, 4, 4)]                                            # (NC, 8, 6, 4, 4)
+    parts = [A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]
+    for k in range(NC):
+        parts += [A2[k].reshape(-1), b2[k].reshape(-1)]
+    return torch.cat(parts).float()
+
+
 def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor):
     """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
     folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
@@ -641,30 +688,46 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     kind0, steps0 = lk, steps2
                 elif (lk, steps2) != (kind0, steps0) or plane != 1 - items[-1][1]:
                     return None
+                if lk >= 4 and Dp > 128 and H > 16:
+                    return None
                 src = torch.arange(plane * hp, (plane + 1) * hp, device=device)
                 tgt = torch.arange((1 - plane) * hp, (2 - plane) * hp, device=device)
                 b1f = b1 + W1t @ t[src]                      # W1 (s x + t) + b1 = (W1 s) x + (W1 t + b1)
                 W1f = W1t * s[src]
-                block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone())
+                if lk >= 4:                                  # RQ spline: one launch for the chain, operands streamed
+                    tr = layer.transformer
+                    extra = (8, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)),
+                             float(np.float32(tr.boundary_u_delta)))
+                    if items and items[-1][4] != extra:
+                        return None
+                    block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
+                                           float(np.float32(tr.boundary_u_delta)))
+                    items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
+                else:
+                    block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone())
+                    items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block, ()))
                 s[tgt] = 1.0
                 t[tgt] = 0.0
-                items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block))
             else:
                 return None
     flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
-    items.append((OP_EW_FMA, 0, 0, flush))
+    streamed = kind0 is not None and kind0 >= 4          # spline chains read their operands from global memory
+    if not items and streamed:
+        return None
+    items.append((OP_EW_FMA, 0, 0, flush, ()))
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
-    for kind, plane, steps2, block in items:
+    for kind, plane, steps2, block, extra in items:
         n = block.numel()
-        if n * 4 > 150 * 1024:
-            return None
-        over = (used + n) * 4 > budget
-        if ops and kind != OP_EW_FMA and (over or len(ops) >= 60):
-            segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
-            ops, blocks, used = [], [], 0
-        ops.append((kind, plane, steps2, used))
+        if not streamed:
+            if n * 4 > 150 * 1024:
+                return None
+            over = (used + n) * 4 > budget
+            if ops and kind != OP_EW_FMA and (over or len(ops) >= 60):
+                segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
+                ops, blocks, used = [], [], 0
+        ops.append((kind, plane, steps2, used) + tuple(extra))
         blocks.append(block)
         used += n
     segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
