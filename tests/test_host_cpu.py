@@ -417,13 +417,14 @@ def test_invalidate_native_caches_clears_every_pack():
         m.__dict__["_tfk_bn_affine"] = (0, None)
         m.__dict__["_tfk_slots"] = []
     flow.invalidate_native_caches()
-    assert not any(k.startswith("_tfk_") for m in mods for k in m.__dict__)
+    left = {k for m in mods for k in m.__dict__ if k.startswith("_tfk_")}
+    assert left <= {"_tfk_slots"}, left          # (structural: tensor identities, no values -- kept on purpose)
     for trigger in (lambda: flow.eval(), lambda: flow.train(), lambda: flow.load_state_dict(flow.state_dict()),
                     lambda: flow.bijection.invalidate_native_caches()):
         for m in mods:
             m.__dict__["_tfk_made_pack"] = (0, None)
         trigger()
-        assert not any(k.startswith("_tfk_") for m in flow.bijection.modules() for k in m.__dict__)
+        assert not any(k.startswith("_tfk_") and k != "_tfk_slots" for m in flow.bijection.modules() for k in m.__dict__)
     # the direction tags on the methods are not caches and survive; the module still pickles / deep-copies
     from torchflows_amd.bijections.base import method_direction
     assert method_direction(flow.bijection.forward) == 0

@@ -344,7 +344,7 @@ class Flow(BaseFlow):
                         pbar.set_postfix_str(text)
                 if graphed is not None:       # replays move the weights, not their version counters
                     from torchflows_amd import fused
-                    fused.invalidate(self)
+                    fused.invalidate(self, compiled_only=True)
                 if diverged:
                     break
                 average = total / count

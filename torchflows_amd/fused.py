@@ -843,17 +843,29 @@ def sample_ready(chain: Optional[CompiledChain]) -> bool:
             and chain.pos_in is None)
 
 
-def invalidate(module: nn.Module) -> None:
+def invalidate(module: nn.Module, compiled_only: bool = False) -> None:
     """Drop EVERY cached packing below ``module``: compiled flow programs (``_tfk_compiled``), MADE weight packs,
     elementwise blocks, BatchNorm scale / shift, training packs, the flat tensor lists.  The caches are keyed on the
     tensors' autograd version counters, data pointers and slot identity -- which an in-place edit through ``.data``
     (``p.data.mul_(0.5)``, manual weight averaging or clamping) or a replayed hipGraph does NOT move.  After such an
     edit call this (``Bijection.invalidate_native_caches()`` / ``Flow.invalidate_native_caches()``); ``train()`` /
-    ``eval()`` and ``load_state_dict`` call it themselves."""
+    ``eval()`` and ``load_state_dict`` call it themselves.
+    ``compiled_only``: just the compiled flow programs -- what ``Flow.fit`` drops after an epoch of hipGraph replays
+    (the captured graph keeps READING the other packs' tensors on every replay, so those must stay allocated)."""
     for m in module.modules():
         d = m.__dict__
-        for k in [k for k in d if k.startswith("_tfk_")]:
+        if compiled_only:
+            d.pop("_tfk_compiled", None)
+            continue
+        for k in [k for k in d if k.startswith("_tfk_") and k not in _STRUCTURAL_CACHES]:
             del d[k]
+
+
+# caches that hold no parameter VALUES -- index maps of the training packs (keyed on layer identity, direction and
+# device), the flat tensor-slot list and the dtype / device check -- and therefore never go stale through a value
+# edit.  They must survive invalidate(): a captured hipGraph of the training step (Flow.fit, TORCHFLOWS_AMD_GRAPH=1)
+# reads the packs' index tensors on every replay, and fit() invalidates after every epoch of replays.
+_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_static_ok")
 
 
 _CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
