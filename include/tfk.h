@@ -254,6 +254,15 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                       const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
                       int32_t accumulate, void *stream);
+/* The same with input rows NARROWER than the kernel's row width (event sizes that are not 64 / 128 / 256): x is
+ * (N, x_width), x_width even and <= D; its first half is read into the head of plane A, its second half into the head
+ * of plane B, zeros behind them -- the layout the packer pads such flows to (zero weights make the padding an exact
+ * identity), without a host-side padding pass over the rows.  Lean programs only; z / logdet / logprob as above
+ * (z in the kernel's D-wide physical layout). */
+int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
+                         const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                         const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                         int32_t accumulate, void *stream);
 
 /* Linear rational spline coupling: MonotonicSpline + LinearRational
  * (spline/base.py:53-72, spline/linear_rational.py:9-182) inside CouplingBijection.forward / inverse.

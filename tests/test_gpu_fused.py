@@ -519,3 +519,54 @@ def test_nested_composition_with_unsupported_layer_falls_back():
         xr, ldr = outer.inverse(z_d)
     assert rel(z_d.cpu().numpy(), z_h.numpy()) < 4e-5 and rel(ld_d.cpu().numpy(), ld_h.numpy()) < 4e-5
     assert torch.allclose(xr.cpu(), x, atol=1e-4)
+
+
+def test_declined_composition_warns_once():
+    """A composition the flow-program compiler declines (here: a context-conditioned coupling) runs layer by layer --
+    about 10x slower -- and says so ONCE (fused.NativeRouteWarning); a compiled one stays silent."""
+    import warnings
+    import torchflows_amd as tfa
+    from torchflows_amd import fused
+    torch.manual_seed(0)
+    cond = tfa.Flow(tfa.RealNVP(6, context_shape=(3,), n_layers=2)).eval().cuda()
+    x, ctx = torch.randn(40, 6, device="cuda"), torch.randn(40, 3, device="cuda")
+    with torch.no_grad():
+        with pytest.warns(fused.NativeRouteWarning, match="context"):
+            cond.log_prob(x, context=ctx)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", fused.NativeRouteWarning)
+            cond.log_prob(x, context=ctx)                       # second call: silent
+            plain = tfa.Flow(tfa.RealNVP(64, n_layers=2)).eval().cuda()
+            plain.log_prob(torch.randn(40, 64, device="cuda"))   # compiled: silent
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 22), ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("CouplingRQNSF", 22),
+                                    ("CouplingRQNSF", 6)])
+def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
+    """Event sizes that are not 64 / 128 / 256: lean programs read the caller's (N, D) rows themselves
+    (tfk_flow_run_mfma_in) instead of a host-side padding pass; same values as with the padding pass, and as the
+    host (ATen) path."""
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    torch.manual_seed(1)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=3))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow.eval()
+    x = torch.randn(1000, D)
+    with torch.no_grad():
+        lp_h = flow.log_prob(x)
+        flow = flow.cuda()
+        xd = x.cuda()
+        before = native.calls
+        z1, lp1 = flow.forward_with_log_prob(xd)
+        n_calls = native.calls - before
+        xr1, ld1 = flow.bijection.inverse(z1)
+        monkeypatch.setenv("TORCHFLOWS_AMD_NARROW_IN", "0")
+        z0, lp0 = flow.forward_with_log_prob(xd)
+    assert n_calls == 1                                         # one launch, no padding kernels
+    tol = 4e-5 if "RQ" in arch else 1e-5
+    assert rel(lp1.cpu().numpy(), lp_h.numpy()) < tol
+    assert torch.equal(lp1, lp0) and torch.equal(z1, z0)
+    assert torch.allclose(xr1.cpu(), x, atol=1e-3)

@@ -222,6 +222,9 @@ class BijectiveComposition(Bijection):
                 fused_out = self._run_fused(x, FORWARD)
                 if fused_out is not None:
                     return fused_out
+            else:
+                from torchflows_amd import fused
+                fused.warn_declined(self, FORWARD)
             plan = self._native_plan(self.layers, "forward")
             if plan is not None:
                 return self._run_native(plan, x, context)
@@ -245,6 +248,9 @@ class BijectiveComposition(Bijection):
                 fused_out = self._run_fused(z, INVERSE)
                 if fused_out is not None:
                     return fused_out
+            else:
+                from torchflows_amd import fused
+                fused.warn_declined(self, INVERSE)
             plan = self._native_plan(order, "inverse")
             if plan is not None:
                 return self._run_native(plan, z, context)

@@ -5,9 +5,9 @@ namespace tfk {
 
 int flow_chain_launch_16(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                          float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
-                         int kind, int steps2, int flags, hipStream_t s, const char *fn)
+                         int kind, int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
-    return launch_chain<16>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, kind, steps2, flags, s, fn);
+    return launch_chain<16>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, kind, steps2, flags, xw, s, fn);
 }
 
 }  // namespace tfk

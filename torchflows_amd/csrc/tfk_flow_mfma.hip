@@ -6,25 +6,25 @@
 
 namespace tfk {
 int flow_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                        const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+                        const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                         const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+                         const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                         const float *, int, const ChainProg &, int, int, int, hipStream_t, const char *);
+                         const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 
 int flow_rqs_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                            const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_rqs_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                             const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_rqs_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                             const float *, const RqsChainProg &, int, int, int, hipStream_t, const char *);
+                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
 
 // A program of lean spline couplings (TFK_OP_RQS_*_LEAN of one direction, one hidden width, one spline box, blocks
 // at a constant stride, source plane alternating; optionally ended by one TFK_OP_EW_FMA): ONE launch of
 // tfk_flow_rqs_chain.h, the operands streamed layer by layer from `params` (global memory).
 static int run_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                          float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
-                         int64_t n_params, int32_t flags, hipStream_t s, const char *fn)
+                         int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn)
 {
     const int EPL = D / 8, HALF = D / 2;
     const int64_t block = (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
@@ -80,16 +80,16 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     prog.C.cmin = (float)(span * 1e-3);
     prog.C.d_edge = (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
     const int inverse = kind == TFK_OP_RQS_INV_LEAN;
-    if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
-    if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
-    return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, s, fn);
+    if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
+    if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
+    return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
 }
 
 // A program made of lean ops only (TFK_OP_*_LEAN couplings of one kind and one GEMM-2 step count whose source
 // plane alternates, optionally ended by one TFK_OP_EW_FMA) runs on the straight-line kernel of tfk_flow_chain.h.
 static int run_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
-                     int64_t n_params, int32_t flags, hipStream_t s, const char *fn)
+                     int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn)
 {
     const int EPL = D / 8, HALF = D / 2;
     ChainProg prog;
@@ -132,9 +132,9 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
                         off, (long long)(off + need), (long long)n_params);
     }
     if (kind < 0) kind = 2;
-    if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
-    if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
-    return flow_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, s, fn);
+    if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
+    if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
+    return flow_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
 }
 
 int flow_mfma_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -151,12 +151,11 @@ extern "C" {
 
 int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128 || D == 256) ? 1 : 0; }
 
-int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
-                      const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
-                      const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
-                      int32_t accumulate, void *stream)
+static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
+                              const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                              const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                              int32_t accumulate, void *stream, const char *fn)
 {
-    const char *fn = "tfk_flow_run_mfma";
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
     if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
@@ -165,14 +164,17 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     if (!x || (n_ops > 0 && (!ops || !params))) return fail(TFK_EINVAL, "%s: null pointer", fn);
     if (!z && !logdet && !logprob) return fail(TFK_EINVAL, "%s: no output requested", fn);
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
-    if (!aligned16(x) || (z && !aligned16(z)) || !aligned16(params))
+    if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
+    const bool lean = n_ops > 0 && ops && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN;
+    if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
+        return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
     if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN))
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                             accumulate, static_cast<hipStream_t>(stream), fn);
+                             accumulate, x_width, static_cast<hipStream_t>(stream), fn);
     if (n_ops > 0 && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA)
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                         accumulate, static_cast<hipStream_t>(stream), fn);
+                         accumulate, x_width, static_cast<hipStream_t>(stream), fn);
     const int EPL = D / 8;
     MProgram prog;
     prog.n_ops = n_ops;
@@ -230,6 +232,24 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
     if (EPL == 32)
         return flow_mfma_launch_32(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
     return flow_mfma_launch_16(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+}
+
+int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
+                      const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                      const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                      int32_t accumulate, void *stream)
+{
+    return flow_run_mfma_impl(x, D, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
+                              accumulate, stream, "tfk_flow_run_mfma");
+}
+
+int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
+                         const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                         const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                         int32_t accumulate, void *stream)
+{
+    return flow_run_mfma_impl(x, x_width, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params,
+                              n_params, accumulate, stream, "tfk_flow_run_mfma_in");
 }
 
 }  // extern "C"

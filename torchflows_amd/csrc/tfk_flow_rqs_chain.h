@@ -246,7 +246,7 @@ template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
 __global__ __launch_bounds__(BLOCK) void k_flow_rqs_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
-    const float *__restrict__ params, RqsChainProg prog, int flags)
+    const float *__restrict__ params, RqsChainProg prog, int flags, int xw)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
@@ -283,13 +283,28 @@ __global__ __launch_bounds__(BLOCK) void k_flow_rqs_chain(
         const long long row = blk0 + wave * 16 + j;
         const long long rr = row < N ? row : N - 1;
         float a[EPL], b[EPL];
-        const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
-        const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
+        if (xw == D) {
+            const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
+            const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
 #pragma unroll
-        for (int i = 0; i < EPL / 4; ++i) {
-            const float4 va = pa[i], vb = pb[i];
-            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
-            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+            for (int i = 0; i < EPL / 4; ++i) {
+                const float4 va = pa[i], vb = pb[i];
+                a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+                b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+            }
+        } else {
+            // rows narrower than the kernel's planes (event sizes that are not 64 / 128 / 256): the caller's rows are
+            // read as they are -- first half into the head of plane A, second half into the head of plane B, zeros
+            // behind them (the padding is an exact identity by construction of the weights, fused.py)
+            const int hl = xw >> 1;
+            const float *xr = x + rr * xw;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int col = EPL * q + e;
+                const bool ok = col < hl;
+                a[e] = ok ? xr[col] : 0.0f;
+                b[e] = ok ? xr[hl + col] : 0.0f;
+            }
         }
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         float sq = 0.0f;
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_flow_rqs_chain(
 template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
 static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                               float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int flags,
-                              hipStream_t s, const char *fn)
+                              int xw, hipStream_t s, const char *fn)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
@@ -395,18 +410,18 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
-                       params, prog, flags);
+                       params, prog, flags, xw);
     return check_launch(fn);
 }
 
 template <int EPL>
 static int launch_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                             float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int inverse,
-                            int steps2, int flags, hipStream_t s, const char *fn)
+                            int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
 #define TFK_RC(ST_) \
-    (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, s, fn) \
-             : launch_rqs_chain_b<EPL, 512, ST_, false>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, s, fn))
+    (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn) \
+             : launch_rqs_chain_b<EPL, 512, ST_, false>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn))
     switch (steps2) {
     case 1: return TFK_RC(1);
     case 2: return TFK_RC(2);

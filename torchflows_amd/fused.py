@@ -29,6 +29,7 @@ when any parameter version changes.
 from __future__ import annotations
 
 import os
+import warnings
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -833,6 +834,10 @@ def compile_chain(composition, direction: int, device: torch.device,
                          pos_in=pos_in if Dp != D else None)
 
 
+def narrow_enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_NARROW_IN", "1") != "0"
+
+
 def padded_enabled(D: int, Dp: int) -> bool:
     return Dp == D or os.environ.get("TORCHFLOWS_AMD_FUSED_PAD", "1") != "0"
 
@@ -865,7 +870,7 @@ def invalidate(module: nn.Module, compiled_only: bool = False) -> None:
 # device), the flat tensor-slot list and the dtype / device check -- and therefore never go stale through a value
 # edit.  They must survive invalidate(): a captured hipGraph of the training step (Flow.fit, TORCHFLOWS_AMD_GRAPH=1)
 # reads the packs' index tensors on every replay, and fit() invalidates after every epoch of replays.
-_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_static_ok")
+_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_static_ok", "_tfk_declined_warned")
 
 
 _CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
@@ -900,7 +905,65 @@ def get_compiled(composition, direction: int, device: torch.device) -> Optional[
         return hit[1]
     chain = compile_chain(composition, direction, device)
     cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
+    if chain is None:
+        warn_declined(composition, direction)
     return chain
+
+
+def warn_declined(composition, direction: int) -> None:
+    """Never silent: the layer-by-layer route (one libtfk kernel per reference layer + PyTorch-ROCm conditioner
+    GEMMs) is ~10x slower than a flow program.  Said once per composition."""
+    if not enabled() or composition.__dict__.get("_tfk_declined_warned"):
+        return
+    composition.__dict__["_tfk_declined_warned"] = True
+    warnings.warn("torchflows_amd: this composition is not compiled to a flow program and runs layer by layer on "
+                  "the HIP kernels (about 10x slower): " + _why_declined(composition, direction),
+                  NativeRouteWarning, stacklevel=4)
+
+
+class NativeRouteWarning(UserWarning):
+    """A composition runs on the slower layer-by-layer route (see ``get_compiled``)."""
+
+
+def _why_declined(composition, direction: int) -> str:
+    """First layer of the chain the flow-program compiler has no op for (best effort, for the warning)."""
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import (
+        CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
+    from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
+    D = composition.n_dim
+    order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
+    plan = _flatten(order, "forward" if direction == FORWARD else "inverse")
+    if plan is None:
+        return "a layer's forward / inverse is not one of this package's implementations"
+    if not (3 <= D <= 512):
+        return f"event size {D} is outside the supported range"
+    for layer, _ in plan:
+        if isinstance(layer, PermutationMatrix):
+            continue
+        name = type(layer).__name__
+        if isinstance(layer, (CouplingBijection, MaskedAutoregressiveBijection)):
+            ct = layer.conditioner_transform
+            what = (f"{name} (transformer {layer.transformer.native_kind or type(layer.transformer).__name__}, "
+                    f"conditioner {type(ct).__name__}")
+            if layer.context_shape is not None:
+                return what + f", context_shape {tuple(layer.context_shape)}): context-conditioned layers have no op yet"
+            seq = getattr(ct, "sequential", None)
+            hidden = getattr(seq[0], "out_features", None) if seq is not None and len(seq) else None
+            kind = layer.transformer.native_kind
+            plain = type(ct).__name__ in ("FeedForward", "MADE") and hidden is not None
+            if plain and kind in ("affine", "inverse_affine", "shift") and hidden <= 64:
+                continue
+            if plain and kind == "rqs" and hidden <= 16 and getattr(layer.transformer, "n_bins", 8) == 8 and D <= 128:
+                continue
+            return what + (f", hidden width {hidden}" if hidden else "") + f", event size {D})"
+        if isinstance(layer, ElementwiseBijection):
+            if getattr(layer, "first_training_batch_pass", False) and layer.training:
+                return f"{name} still has to initialise itself from a batch (train mode)"
+            if layer.transformer.native_kind not in ("affine", "inverse_affine") or not layer.use_global_parameters:
+                return f"{name} (transformer {type(layer.transformer).__name__})"
+            continue
+        return f"{name} has no flow-program op"
+    return f"event size {D} / layer mix not covered by one kernel"
 
 
 def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False):
@@ -925,7 +988,10 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     dev = rows.device
     n_seg = len(chain.segments)
     padded = chain.pos_in is not None
-    if padded:                                   # (N, D_log) -> (N, D): each half at the head of its plane
+    # lean programs read narrower rows themselves (tfk_flow_run_mfma_in): no padding pass over the rows
+    narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma
+                 and chain.segments[0].ops[0][0] >= OP_AFFINE_FWD_LEAN and narrow_enabled())
+    if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
         wide = rows.new_zeros(N, chain.D)
         if chain.D_log % 2 == 0:                 # each half at the head of its plane: two strided copies
             half, hp = chain.D_log // 2, chain.D // 2
@@ -965,12 +1031,13 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         out = None
         if need_rows:
             if buf is None:
-                buf = torch.empty_like(rows)
+                buf = torch.empty(N, chain.D, dtype=rows.dtype, device=dev)
             out = buf                             # in place from the second segment on
         run = native.flow_run_mfma if seg.mfma else native.flow_run
+        kw = dict(D=chain.D) if (narrow_in and i == 0) else {}
         run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
             loc_p if last else None, ls_p if last else None,
-            logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0))
+            logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0), **kw)
         if need_rows:
             cur = out
     out_rows = None
