@@ -959,7 +959,9 @@ def _why_declined(composition, direction: int) -> str:
         if isinstance(layer, ElementwiseBijection):
             if getattr(layer, "first_training_batch_pass", False) and layer.training:
                 return f"{name} still has to initialise itself from a batch (train mode)"
-            if layer.transformer.native_kind not in ("affine", "inverse_affine") or not layer.use_global_parameters:
+            if not layer.use_global_parameters:
+                return f"{name} takes its parameters from the context: context-conditioned layers have no op yet"
+            if layer.transformer.native_kind not in ("affine", "inverse_affine"):
                 return f"{name} (transformer {type(layer.transformer).__name__})"
             continue
         return f"{name} has no flow-program op"
