@@ -104,6 +104,14 @@ int tfk_conv1x1_coupling_fwd(const float *x, const float *h, float *z, float *lo
 int tfk_conv1x1_coupling_inv(const float *z, const float *h, float *x, float *logdet,
                              int64_t N, int32_t D, const int32_t *tgt_idx, int32_t T,
                              int32_t n_channels, int32_t accumulate, void *stream);
+/* Reverse mode of the two entry points above (the reference differentiates its ATen graph, convolution.py:33-64):
+ * x = the layer's INPUT rows, g (N, D) holds dL/d(out rows) on entry and dL/d(in rows) on return (only the T target
+ * positions change: the other positions pass through the coupling), gld (N) = dL/d(logdet), gh (N, n + n(n-1)) is
+ * OVERWRITTEN with dL/dh; one workgroup per sample, the sum over the pixels in a fixed order (deterministic).
+ * inverse != 0: gradients of tfk_conv1x1_coupling_inv. */
+int tfk_conv1x1_coupling_bwd(const float *x, const float *h, float *g, const float *gld, float *gh, int64_t N,
+                             int32_t D, const int32_t *tgt_idx, int32_t T, int32_t n_channels, int32_t inverse,
+                             void *stream);
 
 /* ---- elementwise affine (ElementwiseAffine, ActNorm) -------------------------
  * Replaces ElementwiseBijection.forward / inverse (layers_base.py:300-318) with

@@ -419,6 +419,42 @@ def gen_glow32():
     save("flow_glow_3x32x32.npz", **out)
 
 
+def gen_grads_glow():
+    """Reverse mode of the image path from the reference's autograd: (i) the 1x1-convolution transformer alone
+    (convolution.py:33-64), both directions, fp32 and fp64; (ii) d sum(log_prob) / d (x, parameters) of the whole
+    AffineGlow((3, 8, 8), n_layers=2) of flow_glow_3x8x8.npz (eval mode: BatchNorm on its running statistics)."""
+    from torchflows.bijections.finite.multiscale.architectures import AffineGlow
+    from torchflows.bijections.finite.autoregressive.transformers.linear.convolution import (
+        Invertible1x1ConvolutionTransformer)
+    out = {}
+    torch.manual_seed(11)
+    for n, hw in ((3, (4, 4)), (6, (8, 8)), (12, (2, 6))):
+        tr = Invertible1x1ConvolutionTransformer((n, *hw))
+        x = torch.randn(5, n, *hw)
+        h = torch.randn(5, *tr.parameter_shape)
+        gz, gld = torch.randn(5, n, *hw), torch.randn(5)
+        out.update({f"conv{n}_x": np32(x), f"conv{n}_h": np32(h), f"conv{n}_gz": np32(gz), f"conv{n}_gld": np32(gld)})
+        for inverse in (False, True):
+            for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+                gx, gh = _tr_grads(tr, x, h, gz, gld, inverse, dt)
+                d = "inv" if inverse else "fwd"
+                out[f"conv{n}_{d}_gx{tag}"] = gx
+                out[f"conv{n}_{d}_gh{tag}"] = gh
+    fx = np.load(os.path.join(OUT, "flow_glow_3x8x8.npz"))
+    for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+        torch.manual_seed(0)
+        flow = Flow(AffineGlow((3, 8, 8), n_layers=2))
+        flow.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")})
+        flow = flow.to(dt).eval()
+        x = torch.from_numpy(fx["x"]).to(dt).requires_grad_(True)
+        named = [(k, p) for k, p in flow.named_parameters() if p.requires_grad and p.numel()]
+        grads = torch.autograd.grad(flow.log_prob(x).sum(), [x] + [p for _, p in named], allow_unused=True)
+        out[f"glow_gx{tag}"] = np32(grads[0]).astype(np.float32)
+        for (k, p), g in zip(named, grads[1:]):
+            out[f"glow_g{tag}/{k}"] = (np32(g) if g is not None else np.zeros(tuple(p.shape))).astype(np.float32)
+    save("grads_glow_3x8x8.npz", **out)
+
+
 # ---------------------------------------------------------------- F8 gradients (SURVEY 8f-2)
 def _tr_grads(tr, x, h, gz, gld, inverse, dtype):
     x = x.to(dtype).clone().requires_grad_(True)

@@ -242,3 +242,77 @@ def test_bwd_argument_errors(native):
     with pytest.raises(native.NativeError):
         native.affine_coupling_bwd(g, torch.zeros(4, 4, 2, device="cuda"), g.clone(),
                                    torch.zeros(3, device="cuda"), torch.zeros(4, 4, 2, device="cuda"), None, 4)
+
+
+@pytest.mark.parametrize("n,hw", [(3, (4, 4)), (6, (8, 8)), (12, (2, 6))])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv1x1_coupling_bwd_golden(native, n, hw, inverse, masked):
+    """tfk_conv1x1_coupling_bwd against the reference's autograd through Invertible1x1ConvolutionTransformer
+    (tests/golden/grads_glow_3x8x8.npz): dL/dx at the target positions in place, dL/dh per sample summed over the
+    pixels; untouched positions of g pass through; masked = targets scattered over a wider row."""
+    gr = load_golden("grads_glow_3x8x8.npz")
+    d = "inv" if inverse else "fwd"
+    x, h = gr[f"conv{n}_x"], gr[f"conv{n}_h"]
+    N, T = x.shape[0], n * hw[0] * hw[1]
+    gz, gld = gr[f"conv{n}_gz"].reshape(N, T), gr[f"conv{n}_gld"]
+    if masked:
+        D = 2 * T + 3
+        rng = np.random.default_rng(n)
+        idx = np.sort(rng.choice(D, T, replace=False)).astype(np.int32)
+        rows = rng.standard_normal((N, D)).astype(np.float32)
+        rows[:, idx] = x.reshape(N, T)
+        g = rng.standard_normal((N, D)).astype(np.float32)
+        g0 = g.copy()
+        g[:, idx] = gz
+        tgt = torch.from_numpy(idx).cuda()
+    else:
+        D, idx, rows, g, tgt = T, np.arange(T), x.reshape(N, T).copy(), gz.copy(), None
+        g0 = None
+    g_d = torch.from_numpy(g).cuda()
+    gh = torch.empty(N, n * n, device="cuda")
+    native.conv1x1_coupling_bwd(torch.from_numpy(rows).cuda(), torch.from_numpy(h.reshape(N, -1)).cuda(), g_d,
+                                torch.from_numpy(gld).cuda(), gh, tgt, T, n, inverse=inverse)
+    got = g_d.cpu().numpy()
+    r32, r64 = gr[f"conv{n}_{d}_gx"].reshape(N, T), gr[f"conv{n}_{d}_gx64"].reshape(N, T)
+    assert normwise(got[:, idx], r32) < max(1e-5, 3 * normwise(r32, r64))
+    h32, h64 = gr[f"conv{n}_{d}_gh"].reshape(N, -1), gr[f"conv{n}_{d}_gh64"].reshape(N, -1)
+    assert normwise(gh.cpu().numpy(), h32) < max(1e-5, 3 * normwise(h32, h64))
+    if masked:
+        rest = np.setdiff1d(np.arange(D), idx)
+        assert np.array_equal(got[:, rest], g0[:, rest])
+    # deterministic: a second launch gives the same bits
+    g2 = torch.from_numpy(g).cuda()
+    gh2 = torch.empty_like(gh)
+    native.conv1x1_coupling_bwd(torch.from_numpy(rows).cuda(), torch.from_numpy(h.reshape(N, -1)).cuda(), g2,
+                                torch.from_numpy(gld).cuda(), gh2, tgt, T, n, inverse=inverse)
+    assert torch.equal(gh, gh2) and torch.equal(g_d, g2)
+
+
+def test_glow_trains_on_the_hip_path(native, monkeypatch):
+    """Config 5's layer mix in reverse mode: d sum(log_prob) / d (x, parameters) of AffineGlow((3, 8, 8)) with every
+    coupling -- the invertible 1x1 convolutions included -- on the reverse-mode kernels (the ConvNet conditioner's
+    own backward stays on PyTorch-ROCm), against the reference's autograd (tests/golden/grads_glow_3x8x8.npz)."""
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    gr, fx = load_golden("grads_glow_3x8x8.npz"), load_golden("flow_glow_3x8x8.npz")
+    torch.manual_seed(0)
+    flow = tfa.Flow(AffineGlow((3, 8, 8), n_layers=2))
+    flow.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")})
+    flow = flow.cuda().eval()
+    seen = []
+    inner = native.conv1x1_coupling_bwd
+    monkeypatch.setattr(native, "conv1x1_coupling_bwd", lambda *a, **k: (seen.append(1), inner(*a, **k))[1])
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    named = [(k, p) for k, p in flow.named_parameters() if p.requires_grad and p.numel()]
+    grads = torch.autograd.grad(flow.log_prob(x).sum(), [x] + [p for _, p in named], allow_unused=True)
+    assert len(seen) >= 1, "the 1x1-convolution couplings did not take the reverse-mode kernel"
+    assert normwise(grads[0].cpu().numpy(), gr["glow_gx"]) < max(2e-5, 3 * normwise(gr["glow_gx"], gr["glow_gx64"]))
+    worst = 0.0
+    for (k, p), g in zip(named, grads[1:]):
+        want, want64 = gr[f"glow_g/{k}"], gr[f"glow_g64/{k}"]
+        got = g.cpu().numpy() if g is not None else np.zeros(tuple(p.shape), np.float32)
+        e, bar = normwise(got, want), max(5e-5, 3 * normwise(want, want64))
+        worst = max(worst, e / bar)
+        assert e < bar, (k, e, bar)
+    print("glow gradients on the HIP path: worst error / bar =", worst)

@@ -58,11 +58,13 @@ def _step_kind(layer) -> Optional[str]:
             return "made"
         return None
     if isinstance(layer, ElementwiseBijection):
-        ok = layer.use_global_parameters and layer.transformer.native_kind in ("affine", "inverse_affine")
-        return "elementwise" if ok else None
-    if isinstance(layer, CouplingBijection):
-        if layer.context_shape is not None:
+        if layer.transformer.native_kind not in ("affine", "inverse_affine"):
             return None
+        # with a context the parameters come from a conditioner on it (layers_base.py:300-318): the affine coupling
+        # kernels with every position a target, the conditioner (default: Linear) on PyTorch-ROCm
+        return "elementwise" if layer.use_global_parameters else "elementwise_ctx"
+    if isinstance(layer, CouplingBijection):
+        # (a context only enters the conditioner, by concatenation: conditioning/context.py:38-64)
         kind = layer.transformer.native_kind
         if kind in ("affine", "inverse_affine", "shift"):
             return "coupling"
@@ -70,6 +72,8 @@ def _step_kind(layer) -> Optional[str]:
             return "coupling"
         if kind == "lrs" and int(layer.transformer.n_bins) in (4, 8):
             return "coupling"
+        if kind == "conv1x1" and int(layer.transformer.n_channels) <= 16:
+            return "coupling"           # Glow's invertible 1x1 convolution (linear/convolution.py:33-64)
     return None
 
 
@@ -79,7 +83,7 @@ def training_plan(composition, direction: int):
     flat = _flatten(order, "forward" if direction == FORWARD else "inverse")
     if flat is None:
         return None
-    plan = []
+    plan = Plan()
     for layer, d in flat:
         kind = _step_kind(layer)
         if kind is None or (kind == "made" and d == layer._sequential_when):
@@ -88,12 +92,19 @@ def training_plan(composition, direction: int):
     return plan
 
 
+class Plan(list):
+    """[(layer, direction, kind)] + the context rows (N, *context_shape) of this call, or None."""
+    context = None
+
+
 def applicable(composition, x: torch.Tensor, context) -> bool:
     """Autograd is on, something needs a gradient, and everything is fp32 on one HIP device."""
-    if not enabled() or context is not None or not torch.is_grad_enabled():
+    if not enabled() or not torch.is_grad_enabled():
         return False
     if x.device.type != "cuda" or x.dtype != torch.float32:
         return False
+    if context is not None and (context.device != x.device or context.dtype != torch.float32 or context.requires_grad):
+        return False            # (a gradient with respect to the context: the ATen graph)
     from torchflows_amd import fused
     if not fused.static_ok(composition):
         return False
@@ -106,17 +117,22 @@ def applicable(composition, x: torch.Tensor, context) -> bool:
 def _layer_params(layer, kind: str) -> List[torch.Tensor]:
     if kind == "elementwise":
         return [layer.value]
-    if kind in ("coupling", "made"):
+    if kind in ("coupling", "made", "elementwise_ctx"):
         return list(layer.conditioner_transform.parameters())
     return []
 
 
-def _conditioner(layer, x_in: torch.Tensor) -> torch.Tensor:
+def _conditioner(layer, x_in: torch.Tensor, context=None) -> torch.Tensor:
     """h (N, T*P) from the rows that enter the coupling (layers_base.py:117-143)."""
     N = x_in.shape[0]
     S = layer.coupling.source_event_size
     x_a = x_in[:, :S] if layer._source_is_head else x_in.index_select(1, layer._source_index)
-    return layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape), context=None)
+    return layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape), context=_layer_context(layer, context))
+
+
+def _layer_context(layer, context):
+    """The call's context rows for a layer that takes one, else None."""
+    return context if (context is not None and layer.context_shape is not None) else None
 
 
 def _plain_mlp(layer):
@@ -393,7 +409,7 @@ class _PlanPacks:
             self.rqs_fold[i] = (ew_step, rev_step)
             self.folded_steps.update(t for t in (ew_step, rev_step) if t is not None)
         self.slot = {i: k for k, (i, _, _, _) in enumerate(self.layers)}
-        self.plan = plan
+        self.plan = list(plan)        # (a plain copy: the call's context must not be kept alive by the cache)
         if self.layers:
             self.block_sizes = [int(t.numel()) for t in pidx]
             self.param_index = torch.cat(pidx)
@@ -529,6 +545,14 @@ class ChainFunction(torch.autograd.Function):
                 started = True
                 saved.append(cur if keep_input else None)
                 cur, cur_is_saved = out, False
+            elif kind == "elementwise_ctx":
+                h = layer.conditioner_transform(x=None, context=plan.context).reshape(N, -1).contiguous()
+                out = torch.empty_like(cur)
+                native.affine_coupling(cur, h, out, logdet, None, D, accumulate=started,
+                                       inverse=_affine_form_is_inverse(layer, d))
+                started = True
+                saved.append(cur)
+                cur, cur_is_saved = out, False
             elif kind == "made":
                 h = layer.conditioner_transform(cur.view(N, *layer.event_shape), None).reshape(N, -1).contiguous()
                 out = torch.empty_like(cur)
@@ -587,7 +611,7 @@ class ChainFunction(torch.autograd.Function):
                 rqs_blocks[step] = block
                 cur, cur_is_saved = out, False
             else:
-                h = _conditioner(layer, cur).reshape(N, -1).contiguous()
+                h = _conditioner(layer, cur, plan.context).reshape(N, -1).contiguous()
                 out = torch.empty_like(cur)
                 T = layer.coupling.target_event_size
                 tgt = None if layer._target_is_tail else layer._target_index32
@@ -601,6 +625,9 @@ class ChainFunction(torch.autograd.Function):
                 elif tk == "lrs":
                     native.lrs_coupling(cur, h, out, logdet, tgt, T, layer.transformer.n_bins,
                                         layer.transformer.boundary, accumulate=started, inverse=(d == INVERSE))
+                elif tk == "conv1x1":
+                    native.conv1x1_coupling(cur, h, out, logdet, tgt, T, layer.transformer.n_channels,
+                                            accumulate=started, inverse=(d == INVERSE))
                 else:
                     native.shift_coupling(cur, h, out, logdet, tgt, T, accumulate=started, inverse=(d == INVERSE))
                 started = True
@@ -650,6 +677,19 @@ class ChainFunction(torch.autograd.Function):
                 gv = native.elementwise_affine_bwd(x_in, layer.value.detach().reshape(D, 2).contiguous(), g,
                                                    gld, want, inverse=_affine_form_is_inverse(layer, d))
                 grads_per_step[i] = [gv.view_as(layer.value) if want else None]
+            elif kind == "elementwise_ctx":
+                cparams = list(layer.conditioner_transform.parameters())
+                with torch.enable_grad():
+                    h2 = layer.conditioner_transform(x=None, context=plan.context).reshape(N, -1)
+                hc = h2.detach().contiguous()
+                gh = torch.empty_like(hc)
+                native.affine_coupling_bwd(x_in, hc, g, gld, gh, None, D, inverse=_affine_form_is_inverse(layer, d))
+                wanted = [p for p in cparams if p.requires_grad]
+                outs = torch.autograd.grad(h2, wanted, gh, allow_unused=True) if wanted else ()
+                it = iter(outs)
+                grads_per_step[i] = [next(it) if p.requires_grad else None for p in cparams]
+                grads_per_step[i] = [torch.zeros_like(p) if (gp is None and p.requires_grad) else gp
+                                     for gp, p in zip(grads_per_step[i], cparams)]
             elif kind == "made":
                 # h depends on every input position (through the masks): re-evaluate MADE with a graph,
                 # the transformer's reverse-mode kernel gives dL/dh and the direct dL/dx, autograd the rest
@@ -748,7 +788,7 @@ class ChainFunction(torch.autograd.Function):
                     x_a = x_a.detach().requires_grad_(True)
                     with torch.enable_grad():
                         h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
-                                                         context=None).reshape(N, -1)
+                                                         context=_layer_context(layer, plan.context)).reshape(N, -1)
                     hc = h2.detach().contiguous()
                 gh = torch.empty_like(hc)
                 if tk in ("affine", "inverse_affine"):
@@ -760,6 +800,9 @@ class ChainFunction(torch.autograd.Function):
                 elif tk == "lrs":
                     native.lrs_coupling_bwd(x_in, hc, g, gld, gh, tgt, T, layer.transformer.n_bins,
                                             layer.transformer.boundary, inverse=(d == INVERSE))
+                elif tk == "conv1x1":
+                    native.conv1x1_coupling_bwd(x_in, hc, g, gld, gh, tgt, T, layer.transformer.n_channels,
+                                                inverse=(d == INVERSE))
                 else:
                     native.shift_coupling_bwd(g, gh, tgt, T, inverse=(d == INVERSE))
                 if mlp is not None:
@@ -823,9 +866,11 @@ class GaussLogProbFunction(torch.autograd.Function):
         return g, None, None, (glp if ctx.has_ld and ctx.needs_input_grad[3] else None)
 
 
-def run(composition, plan, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def run(composition, plan, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, torch.Tensor]:
     from torchflows_amd.utils import as_rows
     rows, batch = as_rows(x, composition.event_shape)
+    if context is not None:
+        plan.context = context.reshape(rows.shape[0], *composition.context_shape).contiguous()
     params: List[torch.Tensor] = []
     for layer, _, kind in plan:
         params.extend(_layer_params(layer, kind))

@@ -207,7 +207,7 @@ class BijectiveComposition(Bijection):
         plan = hip_autograd.training_plan(self, d)
         if plan is None:
             return None
-        return hip_autograd.run(self, plan, x)
+        return hip_autograd.run(self, plan, x, context)
 
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):

@@ -916,6 +916,8 @@ def warn_declined(composition, direction: int) -> None:
     if not enabled() or composition.__dict__.get("_tfk_declined_warned"):
         return
     composition.__dict__["_tfk_declined_warned"] = True
+    if len(tuple(composition.event_shape)) >= 3:
+        return          # image blocks (ConvNet conditioners): one kernel per layer IS their route, nothing was lost
     warnings.warn("torchflows_amd: this composition is not compiled to a flow program and runs layer by layer on "
                   "the HIP kernels (about 10x slower): " + _why_declined(composition, direction),
                   NativeRouteWarning, stacklevel=4)

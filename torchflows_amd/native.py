@@ -28,7 +28,7 @@ SYMBOLS = (
     "tfk_shift_coupling_fwd", "tfk_shift_coupling_inv",
     "tfk_rqs_coupling_fwd", "tfk_rqs_coupling_inv",
     "tfk_lrs_coupling_fwd", "tfk_lrs_coupling_inv",
-    "tfk_conv1x1_coupling_fwd", "tfk_conv1x1_coupling_inv",
+    "tfk_conv1x1_coupling_fwd", "tfk_conv1x1_coupling_inv", "tfk_conv1x1_coupling_bwd",
     "tfk_elementwise_affine_fwd", "tfk_elementwise_affine_inv",
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32", "tfk_sum_f32_ws",
@@ -83,6 +83,7 @@ def _bind(L: C.CDLL) -> None:
     conv = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]
     L.tfk_conv1x1_coupling_fwd.argtypes = conv
     L.tfk_conv1x1_coupling_inv.argtypes = conv
+    L.tfk_conv1x1_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]
     ew = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
     L.tfk_elementwise_affine_fwd.argtypes = ew
     L.tfk_elementwise_affine_inv.argtypes = ew
@@ -370,6 +371,22 @@ def affine_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, inverse=False):
             _idx(tgt_idx, name), T, 1 if inverse else 0)
     with _device_guard(g):
         rc = lib().tfk_affine_coupling_bwd(*args, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+def conv1x1_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_channels, inverse=False):
+    """Reverse mode of ``conv1x1_coupling``: in place on g (N, D) at the T target positions, gh (N, n + n(n-1)) written."""
+    global calls
+    name = "tfk_conv1x1_coupling_bwd"
+    N, D = _bwd_common(name, x, g, gld, tgt_idx, T)
+    n = int(n_channels)
+    if h.numel() != N * n * n or gh.numel() != N * n * n:
+        raise NativeError(f"{name}: h / gh must hold N * n^2 = {N * n * n} elements")
+    args = (_f32(x, name), _f32(h, name), _f32(g, name), _f32(gld, name), _f32(gh, name), N, D,
+            _idx(tgt_idx, name), T, n, 1 if inverse else 0)
+    with _device_guard(g):
+        rc = lib().tfk_conv1x1_coupling_bwd(*args, _stream(g))
     calls += 1
     _check(rc, name)
 
