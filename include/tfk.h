@@ -228,7 +228,16 @@ enum {
      * [16, 23) derivative logits c + u_d / 1000 -- ALL multiplied by log2(e) by the packer -- and one pad; W1 / b1
      * times 2 log2(e) as for the affine lean ops.  Op record as for TFK_OP_RQS_*: K = 8, boundary, scale, c. */
     TFK_OP_RQS_FWD_LEAN = 17,
-    TFK_OP_RQS_INV_LEAN = 18
+    TFK_OP_RQS_INV_LEAN = 18,
+    /* context-conditioned programs (tfk_flow_run_mfma_ctx): an elementwise affine layer whose (D, 2) parameters are
+     * predicted from the row's context by a Linear conditioner (ElementwiseBijection with a context_shape,
+     * layers_base.py:300-318) -- block Ac[D/8][cs][64] | bc[D/8][4][4], cs = ceil(C / 4) k-steps: tile t < D/16 holds
+     * the parameters of the lane-group's elements 2 t, 2 t + 1 of plane A, the other tiles those of plane B -- and
+     * couplings (TFK_OP_AFFINE_* / SHIFT_* / RQS_*, hidden width <= 16) whose conditioner sees [x_A || context]
+     * (conditioning/context.py:46-60): src_plane bits 4..7 = cs, and cs further GEMM-1 A-operand steps A1c[cs][64]
+     * follow the op's block. */
+    TFK_OP_EWC_MULADD = 19,
+    TFK_OP_EWC_SUBDIV = 20
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,
@@ -267,6 +276,12 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
  * of plane B, zeros behind them -- the layout the packer pads such flows to (zero weights make the padding an exact
  * identity), without a host-side padding pass over the rows.  Lean programs only; z / logdet / logprob as above
  * (z in the kernel's D-wide physical layout). */
+/* The same for context-conditioned flows: context (N, C) fp32, 1 <= C <= 16, one row per data row (Flow.log_prob(x,
+ * context=...), flows.py:628-658).  Programs of elementwise ops, TFK_OP_EWC_* and couplings only (no MADE / lean ops). */
+int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,
+                          const float *gauss_loc, const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                          const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                          int32_t accumulate, void *stream);
 int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
                          const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                          const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,

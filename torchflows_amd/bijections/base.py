@@ -179,14 +179,15 @@ class BijectiveComposition(Bijection):
             plan.append((layer, d))
         return plan
 
-    def _run_fused(self, x: torch.Tensor, d: int):
+    def _run_fused(self, x: torch.Tensor, d: int, context=None):
         """Whole chain as flow programs (conditioner in-kernel); None if not compilable."""
         from torchflows_amd import fused
-        chain = fused.get_compiled(self, d, x.device)
+        chain = fused.get_compiled(self, d, x.device, context=context is not None)
         if chain is None:
             return None
         rows, batch = as_rows(x, self.event_shape)
-        out, ld, _ = fused.run_chain(chain, rows, want_rows=True)
+        crows = None if context is None else context.reshape(rows.shape[0], -1).contiguous()
+        out, ld, _ = fused.run_chain(chain, rows, want_rows=True, context=crows)
         return out.view(x.shape), ld.view(batch)
 
     def _run_native(self, plan, x: torch.Tensor, context):
@@ -218,13 +219,9 @@ class BijectiveComposition(Bijection):
             if trained is not None:
                 return trained
         if not kwargs and native.eligible(x, context) and _params_ok(self):
-            if context is None:
-                fused_out = self._run_fused(x, FORWARD)
-                if fused_out is not None:
-                    return fused_out
-            else:
-                from torchflows_amd import fused
-                fused.warn_declined(self, FORWARD)
+            fused_out = self._run_fused(x, FORWARD, context)
+            if fused_out is not None:
+                return fused_out
             plan = self._native_plan(self.layers, "forward")
             if plan is not None:
                 return self._run_native(plan, x, context)
@@ -244,13 +241,9 @@ class BijectiveComposition(Bijection):
             if trained is not None:
                 return trained
         if not kwargs and native.eligible(z, context) and _params_ok(self):
-            if context is None:
-                fused_out = self._run_fused(z, INVERSE)
-                if fused_out is not None:
-                    return fused_out
-            else:
-                from torchflows_amd import fused
-                fused.warn_declined(self, INVERSE)
+            fused_out = self._run_fused(z, INVERSE, context)
+            if fused_out is not None:
+                return fused_out
             plan = self._native_plan(order, "inverse")
             if plan is not None:
                 return self._run_native(plan, z, context)

@@ -35,10 +35,11 @@ namespace tfk {
 
 constexpr int kMaxOpsM = 96;
 constexpr int kMaxEplRqs = 16;   // RQS couplings on this kernel: D <= 128
+constexpr int kCtxSteps = 4;     // context-conditioned programs: context size <= 16 (4 k-steps of 4)
 
 struct MOp {
     int kind;        // TFK_OP_*
-    int src_plane;   // coupling: which plane feeds the conditioner
+    int src_plane;   // coupling: which plane feeds the conditioner (bit 0); bits 4..7: k-steps of CONTEXT in GEMM 1
     int steps2;      // coupling: k-steps of GEMM 2 = ceil(H / 4)
     int offset;      // first float of the op's parameters in the staged block
     int K;           // RQS: number of bins (8)
@@ -65,9 +66,10 @@ __device__ __forceinline__ float tanh_act_m(float x) {       // see tanh_act in 
 // vector work of one tile under the MFMAs of the next.  apply_op_m dispatches once per op.
 // HT = 16-unit tiles of the hidden layer (hidden width <= 16 HT): GEMM 1 keeps HT accumulators,
 // GEMM 2 runs up to 4 HT k-steps (the unused ones are skipped uniformly).
-template <int EPL, int KIND, int HT>
+template <int EPL, int KIND, int HT, bool CTX = false>
 __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lane, int q,
-                                         const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+                                         const float (&src)[EPL], float (&tgt)[EPL], float &ld,
+                                         const float (&cx)[kCtxSteps] = {0.0f, 0.0f, 0.0f, 0.0f})
 {
     constexpr bool affine = (KIND == TFK_OP_AFFINE_FWD || KIND == TFK_OP_AFFINE_INV);
     constexpr int T2 = affine ? EPL / 2 : EPL / 4;
@@ -85,6 +87,19 @@ __device__ __forceinline__ void couple_m(const MOp op, const float *prm, int lan
 #pragma unroll
         for (int t = 0; t < HT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(s * HT + t) * 64 + lane], src[s], acc[t], 0, 0, 0);
+    if constexpr (CTX) {
+        // the context enters the conditioner by concatenation behind x_A (conditioning/context.py:46-60): its columns
+        // are further k-steps of GEMM 1, lane (q, j) supplying context element 4 s + q of row j
+        const int cs = op.src_plane >> 4;
+        const float *A1c = b2 + T2 * 16;
+#pragma unroll
+        for (int s = 0; s < kCtxSteps; ++s)
+            if (s < cs) {
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1c[(s * HT + t) * 64 + lane], cx[s], acc[t], 0, 0, 0);
+            }
+    }
     float hid[4 * HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t)
@@ -238,9 +253,10 @@ __device__ __forceinline__ void made_rqs_m(const MOp op, const float *prm, int l
 // 4 (D-row 4q+r of tile 6e+c <-> parameter 4c+r of target element EPL*q+e), i.e. the record
 // lands in 24 registers of the lane that owns the element; rqs_eval then runs out of registers.
 // The element loop is a run-time loop (one copy of the ~500-op spline per variant).
-template <int EPL, bool INVERSE>
+template <int EPL, bool INVERSE, bool CTX = false>
 __device__ __forceinline__ void couple_rqs_m(const MOp op, const float *prm, int lane, int q,
-                                             const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+                                             const float (&src)[EPL], float (&tgt)[EPL], float &ld,
+                                             const float (&cx)[kCtxSteps] = {0.0f, 0.0f, 0.0f, 0.0f})
 {
     constexpr int T2 = EPL * 6;
     const float *A1 = prm;
@@ -258,6 +274,13 @@ __device__ __forceinline__ void couple_rqs_m(const MOp op, const float *prm, int
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s * 64 + lane], src[s], acc, 0, 0, 0);
+    if constexpr (CTX) {
+        const int cs = op.src_plane >> 4;
+        const float *A1c = b2 + T2 * 16;
+#pragma unroll
+        for (int s = 0; s < kCtxSteps; ++s)
+            if (s < cs) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1c[s * 64 + lane], cx[s], acc, 0, 0, 0);
+    }
     float hid[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) hid[r] = tanh_act_m(acc[r]);
@@ -288,16 +311,48 @@ __device__ __forceinline__ void couple_rqs_m(const MOp op, const float *prm, int
     ld = ld + part;                                                 // base.py:59 + :222
 }
 
+// Elementwise affine layer whose parameters are predicted from the CONTEXT by a Linear conditioner
+// (ElementwiseBijection with a context_shape, layers_base.py:300-318): one GEMM context -> (D, 2), then the affine
+// transform of every element of both planes.  Block: Ac[EPL][cs][64] | bc[EPL][4][4]; tile t < EPL / 2 holds the
+// parameters of this lane's elements 2 t, 2 t + 1 of plane A, the other tiles those of plane B.
+template <int EPL, bool DIVIDE>
+__device__ __forceinline__ void ewc_m(const MOp op, const float *prm, int lane, int q, float (&a)[EPL], float (&b)[EPL],
+                                      float &ld, const float (&cx)[kCtxSteps])
+{
+    const int cs = op.src_plane >> 4;
+    const float *Ac = prm;
+    const float *bc = prm + EPL * cs * 64;
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        f32x4 o = *reinterpret_cast<const f32x4 *>(bc + (t * 4 + q) * 4);
+#pragma unroll
+        for (int s = 0; s < kCtxSteps; ++s)
+            if (s < cs) o = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[(t * cs + s) * 64 + lane], cx[s], o, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float al = aff_alpha_lean(o[2 * i]);
+            const float be = o[2 * i + 1];
+            part += log_lean(al);
+            float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
+            if (!DIVIDE) v = al * v + be;                                   // affine.py:48
+            else v = (v - be) * __builtin_amdgcn_rcpf(al);                  // affine.py:59
+        }
+    }
+    ld = ld + (DIVIDE ? -part : part);
+}
+
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
 //   A1[EPL][HT][64] | b1[HT][4][4] | A2[T2][steps2][64] | b2[T2][4][4],  HT = ceil(steps2 / 4) rounded
 //   up to 1, 2 or 4 (hidden width <= 64)
 // Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
-template <int EPL, int KIND, int HTMAX>
+template <int EPL, int KIND, int HTMAX, bool CTX = false>
 __device__ __forceinline__ void couple_any(const MOp op, const float *prm, int lane, int q,
-                                           const float (&src)[EPL], float (&tgt)[EPL], float &ld)
+                                           const float (&src)[EPL], float (&tgt)[EPL], float &ld,
+                                           const float (&cx)[kCtxSteps] = {0.0f, 0.0f, 0.0f, 0.0f})
 {
     if constexpr (HTMAX == 1) {
-        couple_m<EPL, KIND, 1>(op, prm, lane, q, src, tgt, ld);
+        couple_m<EPL, KIND, 1, CTX>(op, prm, lane, q, src, tgt, ld, cx);
     } else {
         if (op.steps2 <= 4) couple_m<EPL, KIND, 1>(op, prm, lane, q, src, tgt, ld);
         else if (op.steps2 <= 8) couple_m<EPL, KIND, 2>(op, prm, lane, q, src, tgt, ld);
@@ -305,9 +360,10 @@ __device__ __forceinline__ void couple_any(const MOp op, const float *prm, int l
     }
 }
 
-template <int EPL, int HTMAX, bool MADE>
+template <int EPL, int HTMAX, bool MADE, bool CTX = false>
 __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int lane, int q,
-                                           float (&a)[EPL], float (&b)[EPL], float &ld)
+                                           float (&a)[EPL], float (&b)[EPL], float &ld,
+                                           const float (&cx)[kCtxSteps] = {0.0f, 0.0f, 0.0f, 0.0f})
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     if constexpr (EPL <= 16) if (op.kind == TFK_OP_PLANE_SWAP) {      // (not at D = 256: 64 more live registers there)
@@ -365,16 +421,20 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
         if (q == 0) ld = ld + prm[2 * D];                           // base.py:222 (once per row)
         return;
     }
-    // (src_plane 1: plane B conditions plane A)
-    switch (op.kind * 2 + op.src_plane) {
-    case TFK_OP_AFFINE_FWD * 2: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_AFFINE_FWD * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_AFFINE_INV * 2: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_AFFINE_INV * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_SHIFT_FWD * 2: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_SHIFT_FWD * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX>(op, prm, lane, q, b, a, ld); return;
-    case TFK_OP_SHIFT_INV * 2: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX>(op, prm, lane, q, a, b, ld); return;
-    case TFK_OP_SHIFT_INV * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX>(op, prm, lane, q, b, a, ld); return;
+    if constexpr (CTX) {
+        if (op.kind == TFK_OP_EWC_MULADD) { ewc_m<EPL, false>(op, prm, lane, q, a, b, ld, cx); return; }
+        if (op.kind == TFK_OP_EWC_SUBDIV) { ewc_m<EPL, true>(op, prm, lane, q, a, b, ld, cx); return; }
+    }
+    // (src_plane bit 0 = 1: plane B conditions plane A)
+    switch (op.kind * 2 + (op.src_plane & 1)) {
+    case TFK_OP_AFFINE_FWD * 2: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+    case TFK_OP_AFFINE_FWD * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_FWD, HTMAX, CTX>(op, prm, lane, q, b, a, ld, cx); return;
+    case TFK_OP_AFFINE_INV * 2: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+    case TFK_OP_AFFINE_INV * 2 + 1: couple_any<EPL, TFK_OP_AFFINE_INV, HTMAX, CTX>(op, prm, lane, q, b, a, ld, cx); return;
+    case TFK_OP_SHIFT_FWD * 2: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+    case TFK_OP_SHIFT_FWD * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_FWD, HTMAX, CTX>(op, prm, lane, q, b, a, ld, cx); return;
+    case TFK_OP_SHIFT_INV * 2: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+    case TFK_OP_SHIFT_INV * 2 + 1: couple_any<EPL, TFK_OP_SHIFT_INV, HTMAX, CTX>(op, prm, lane, q, b, a, ld, cx); return;
     default: break;
     }
     if constexpr (MADE) if (op.kind == TFK_OP_MADE_FWD || op.kind == TFK_OP_MADE_INV) {
@@ -396,11 +456,11 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
     // the spline op exists for D <= 128 only: at D = 256 one coupling's parameters (209 KB) exceed
     // the LDS anyway, and its 24-register record beside 64 row registers would live in scratch
     if constexpr (EPL <= kMaxEplRqs) {
-        switch (op.kind * 2 + op.src_plane) {
-        case TFK_OP_RQS_FWD * 2: couple_rqs_m<EPL, false>(op, prm, lane, q, a, b, ld); return;
-        case TFK_OP_RQS_FWD * 2 + 1: couple_rqs_m<EPL, false>(op, prm, lane, q, b, a, ld); return;
-        case TFK_OP_RQS_INV * 2: couple_rqs_m<EPL, true>(op, prm, lane, q, a, b, ld); return;
-        case TFK_OP_RQS_INV * 2 + 1: couple_rqs_m<EPL, true>(op, prm, lane, q, b, a, ld); return;
+        switch (op.kind * 2 + (op.src_plane & 1)) {
+        case TFK_OP_RQS_FWD * 2: couple_rqs_m<EPL, false, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+        case TFK_OP_RQS_FWD * 2 + 1: couple_rqs_m<EPL, false, CTX>(op, prm, lane, q, b, a, ld, cx); return;
+        case TFK_OP_RQS_INV * 2: couple_rqs_m<EPL, true, CTX>(op, prm, lane, q, a, b, ld, cx); return;
+        case TFK_OP_RQS_INV * 2 + 1: couple_rqs_m<EPL, true, CTX>(op, prm, lane, q, b, a, ld, cx); return;
         default: break;
         }
     }
@@ -411,12 +471,13 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
 // D = 64); HTMAX = 4: up to 64 (more registers: its own instantiation so that the narrow
 // programs keep their occupancy).
 // MADE: the program holds MADE ops (their own instantiation: they need more registers).
-template <int EPL, int BLOCK, int HTMAX, bool MADE>
+template <int EPL, int BLOCK, int HTMAX, bool MADE, bool CTX = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((EPL == 32 && BLOCK == 768) ? 3 : 1)))
 void k_flow_run_mfma(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
-    const float *__restrict__ params, int n_params, MProgram prog, int flags)
+    const float *__restrict__ params, int n_params, MProgram prog, int flags,
+    const float *__restrict__ context = nullptr, int C = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
@@ -470,8 +531,14 @@ void k_flow_run_mfma(
                 lp += -ub;
             }
         }
+        float cx[kCtxSteps] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (CTX) {                                          // this lane's share of the row's context
+#pragma unroll
+            for (int s = 0; s < kCtxSteps; ++s)
+                cx[s] = (4 * s + q < C) ? context[rr * C + 4 * s + q] : 0.0f;
+        }
         for (int o = 0; o < prog.n_ops; ++o)
-            apply_op_m<EPL, HTMAX, MADE>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld);
+            apply_op_m<EPL, HTMAX, MADE, CTX>(prog.op[o], lds + prog.op[o].offset, lane, q, a, b, ld, cx);
         if (logprob && !base_of_input) {                            // gaussian.py:46-54
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
@@ -520,17 +587,18 @@ void k_flow_run_mfma(
     }
 }
 
-template <int EPL, int BLOCK, int HTMAX, bool MADE>
+template <int EPL, int BLOCK, int HTMAX, bool MADE, bool CTX = false>
 static int launch_mb(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, const float *params, int n_params,
-                     const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
+                     const MProgram &prog, int accumulate, hipStream_t s, const char *fn,
+                     const float *context = nullptr, int C = 0)
 {
     constexpr int D = 8 * EPL;
     const size_t lds = ((size_t)n_params + 3 * D) * sizeof(float);
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE, CTX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -540,7 +608,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     // resident workgroups per CU as the runtime computes them (registers, LDS, wave slots); the
     // grid is a few resident sets, grid-strided over the rows (kGridOversubscribe, tfk_common.h)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>, BLOCK, lds) != hipSuccess
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE, CTX>, BLOCK, lds) != hipSuccess
         || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -549,8 +617,8 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
-                       log_scale, logprob, (long long)N, params, n_params, prog, accumulate);
+    hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE, CTX>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
+                       log_scale, logprob, (long long)N, params, n_params, prog, accumulate, context, C);
     return check_launch(fn);
 }
 
@@ -560,8 +628,18 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
 template <int EPL>
 static int launch_m(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                     float *logprob, int64_t N, const float *params, int n_params,
-                    const MProgram &prog, int accumulate, hipStream_t s, const char *fn)
+                    const MProgram &prog, int accumulate, hipStream_t s, const char *fn,
+                    const float *context = nullptr, int C = 0)
 {
+    if (context) {
+        // context-conditioned programs: their own instantiation (hidden width <= 16, no MADE ops) so that the
+        // others keep their registers
+        const bool big_c = N >= (int64_t)kCUs * 3 * 128;
+        return big_c ? launch_mb<EPL, 512, 1, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog,
+                                                          accumulate, s, fn, context, C)
+                     : launch_mb<EPL, kBlock, 1, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
+                                                             prog, accumulate, s, fn, context, C);
+    }
     bool wide = false;                     // a coupling with hidden width > 16 in the program?
     for (int i = 0; i < prog.n_ops; ++i)
         wide = wide || (((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||

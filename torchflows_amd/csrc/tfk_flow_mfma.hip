@@ -138,11 +138,11 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
 }
 
 int flow_mfma_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                       const float *, int, const MProgram &, int, hipStream_t, const char *);
+                       const float *, int, const MProgram &, int, hipStream_t, const char *, const float *, int);
 int flow_mfma_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                        const float *, int, const MProgram &, int, hipStream_t, const char *);
+                        const float *, int, const MProgram &, int, hipStream_t, const char *, const float *, int);
 int flow_mfma_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                        const float *, int, const MProgram &, int, hipStream_t, const char *);
+                        const float *, int, const MProgram &, int, hipStream_t, const char *, const float *, int);
 }  // namespace tfk
 
 using namespace tfk;
@@ -154,8 +154,12 @@ int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128 || D == 256
 static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
                               const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                               const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
-                              int32_t accumulate, void *stream, const char *fn)
+                              int32_t accumulate, void *stream, const char *fn,
+                              const float *context = nullptr, int32_t C = 0)
 {
+    if (context && (C < 1 || C > 4 * kCtxSteps))
+        return fail(TFK_EINVAL, "%s: context size %d must be in [1, %d]", fn, C, 4 * kCtxSteps);
+    const int cs_want = context ? (C + 3) / 4 : 0;
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
     if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
@@ -167,6 +171,7 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
     const bool lean = n_ops > 0 && ops && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN;
+    if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
     if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN))
@@ -190,7 +195,13 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         memcpy(&o.scale, rec + 6, 4);
         memcpy(&o.c, rec + 7, 4);
         int64_t need;
-        if (o.kind == TFK_OP_PLANE_SWAP) {
+        const int cs = o.src_plane >> 4;                 // k-steps of context in GEMM 1 (couplings) / in the one GEMM (EWC)
+        if (cs != 0 && (cs != cs_want || !context))
+            return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, cs, C);
+        if (o.kind == TFK_OP_EWC_MULADD || o.kind == TFK_OP_EWC_SUBDIV) {
+            if (!context || cs < 1) return fail(TFK_EINVAL, "%s: op %d: a context-conditioned elementwise op needs a context", fn, i);
+            need = (int64_t)EPL * cs * 64 + (int64_t)EPL * 16;
+        } else if (o.kind == TFK_OP_PLANE_SWAP) {
             if (D > 128) return fail(TFK_EINVAL, "%s: op %d: plane swaps exist for D <= 128", fn, i);
             need = D / 2;
         }
@@ -198,18 +209,19 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
         else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
             if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
-            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            if ((o.src_plane & ~0xf1) != 0) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             const int T2 = (o.kind <= TFK_OP_AFFINE_INV) ? EPL / 2 : EPL / 4;
             const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
-            need = (int64_t)EPL * HT * 64 + HT * 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+            if (cs && HT != 1) return fail(TFK_EINVAL, "%s: op %d: context-conditioned couplings need hidden width <= 16", fn, i);
+            need = (int64_t)EPL * HT * 64 + HT * 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16 + (int64_t)cs * HT * 64;
         } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
             if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);
-            if (o.src_plane != 0 && o.src_plane != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
+            if ((o.src_plane & ~0xf1) != 0) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             if (EPL > kMaxEplRqs) return fail(TFK_EINVAL, "%s: op %d: RQS couplings need D <= %d on the MFMA path", fn, i, 8 * kMaxEplRqs);
             if (o.K != 8) return fail(TFK_EINVAL, "%s: op %d: fused RQS supports n_bins = 8, got %d", fn, i, o.K);
             if (!(o.boundary > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
             const int T2 = EPL * 6;
-            need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16;
+            need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16 + (int64_t)cs * 64;
         } else if (o.kind == TFK_OP_MADE_FWD || o.kind == TFK_OP_MADE_INV) {
             if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
             const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
@@ -226,12 +238,20 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
             return fail(TFK_EINVAL, "%s: op %d: parameters [%d, %lld) outside the block of %lld floats", fn, i,
                         o.offset, (long long)(o.offset + need), (long long)n_params);
     }
+    if (context)
+        for (int i = 0; i < n_ops; ++i) {
+            const int k = prog.op[i].kind;
+            if (k >= TFK_OP_MADE_FWD && k <= TFK_OP_MADE_RQS)
+                return fail(TFK_EINVAL, "%s: op %d: MADE ops take no context", fn, i);
+            if (k >= TFK_OP_AFFINE_FWD && k <= TFK_OP_SHIFT_INV && prog.op[i].steps2 > 4)
+                return fail(TFK_EINVAL, "%s: op %d: context-conditioned programs need hidden width <= 16", fn, i);
+        }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (EPL == 8)
-        return flow_mfma_launch_8(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+        return flow_mfma_launch_8(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn, context, C);
     if (EPL == 32)
-        return flow_mfma_launch_32(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
-    return flow_mfma_launch_16(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn);
+        return flow_mfma_launch_32(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn, context, C);
+    return flow_mfma_launch_16(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, params, (int)n_params, prog, accumulate, s, fn, context, C);
 }
 
 int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
@@ -250,6 +270,17 @@ int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logde
 {
     return flow_run_mfma_impl(x, x_width, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params,
                               n_params, accumulate, stream, "tfk_flow_run_mfma_in");
+}
+
+int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,
+                          const float *gauss_loc, const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                          const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                          int32_t accumulate, void *stream)
+{
+    const char *fn = "tfk_flow_run_mfma_ctx";
+    if (!context) return fail(TFK_EINVAL, "%s: null context", fn);
+    return flow_run_mfma_impl(x, D, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
+                              accumulate, stream, fn, context, C);
 }
 
 }  // extern "C"

@@ -6,9 +6,9 @@ namespace tfk {
 
 int flow_mfma_launch_16(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                         float *logprob, int64_t N, const float *params, int n_params, const MProgram &prog,
-                        int accumulate, hipStream_t s, const char *fn)
+                        int accumulate, hipStream_t s, const char *fn, const float *context, int C)
 {
-    return launch_m<16>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn);
+    return launch_m<16>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn, context, C);
 }
 
 }  // namespace tfk

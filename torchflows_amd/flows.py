@@ -95,7 +95,7 @@ class Flow(BaseFlow):
             raise AssertionError("x and context must share their batch shape")
         return context.to(self.get_device())
 
-    def _fused_log_prob(self, x: torch.Tensor, want_z: bool):
+    def _fused_log_prob(self, x: torch.Tensor, want_z: bool, context: torch.Tensor = None):
         """log_prob (and z) as flow programs ending in the base log-density: 4*D + 4 bytes of
         HBM traffic per evaluation.  None when the chain is not compilable."""
         from torchflows_amd import fused, native
@@ -106,13 +106,16 @@ class Flow(BaseFlow):
         if not (isinstance(b, BijectiveComposition) and isinstance(self.base, DiagonalGaussian)
                 and native.eligible(x, self.base.loc, self.base.log_scale) and _params_ok(self)):
             return None
+        if context is not None and not native.eligible(context):
+            return None
         d = method_direction(b.forward)
-        chain = None if d is None else fused.get_compiled(b, d, x.device)
+        chain = None if d is None else fused.get_compiled(b, d, x.device, context=context is not None)
         if chain is None:
             return None
         rows, batch = as_rows(x, self.event_shape)
+        crows = None if context is None else context.reshape(rows.shape[0], -1).contiguous()
         z, _, lp = fused.run_chain(chain, rows, want_rows=want_z,
-                                   base=(self.base.loc.detach(), self.base.log_scale.detach()))
+                                   base=(self.base.loc.detach(), self.base.log_scale.detach()), context=crows)
         return (z.view(x.shape) if want_z else None), lp.view(batch)
 
     def _fused_sample(self, z: torch.Tensor):
@@ -138,10 +141,9 @@ class Flow(BaseFlow):
 
     def forward_with_log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         context = self._checked_context(x, context)
-        if context is None:
-            fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=True)
-            if fused_out is not None:
-                return fused_out
+        fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=True, context=context)
+        if fused_out is not None:
+            return fused_out
         z, log_det = self.bijection.forward(x.to(self.get_device()), context=context)[:2]
         zf = flatten_event(z, self.event_shape)
         if isinstance(self.base, DiagonalGaussian):
@@ -452,10 +454,10 @@ class Flow(BaseFlow):
         self.eval()
 
     def log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
-        if context is None:
-            fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=False)
-            if fused_out is not None:
-                return fused_out[1]
+        ctx = None if context is None else self._checked_context(x, context)
+        fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=False, context=ctx)
+        if fused_out is not None:
+            return fused_out[1]
         return self.forward_with_log_prob(x, context)[1]
 
     def sample(self, sample_shape: Union[int, torch.Size, Tuple[int, ...]],

@@ -42,7 +42,8 @@ from torchflows_amd import native
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
     OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
     OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA, \
-    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN = range(19)
+    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV = range(21)
+MAX_CONTEXT = 16      # context elements a flow program takes (4 k-steps of 4, csrc/tfk_flow_mfma.h: kCtxSteps)
 LOG2E = 1.4426950408889634
 AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
 RQS_PAD = 24          # 23 spline parameters per element, padded to 6 float4
@@ -282,9 +283,13 @@ def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p)
 
 def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, Dp: Optional[int] = None):
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
+    from torchflows_amd.utils import event_size as _esize
     kind = layer.transformer.native_kind
-    if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
+    if kind not in ("affine", "inverse_affine", "shift", "rqs"):
         return None
+    C = _esize(layer.context_shape) if layer.context_shape is not None else 0
+    if C and (not mfma or C > MAX_CONTEXT):
+        return None                       # a context: matrix-core interpreter only (tfk_flow_run_mfma_ctx)
     if kind == "rqs" and layer.transformer.n_bins != 8:
         return None                       # the fused spline op is built for the default 8 bins
     half = D // 2
@@ -307,7 +312,11 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     W1, b1 = mods[0].weight.detach(), mods[0].bias.detach()          # (H, S), (H,)
     W2, b2 = mods[2].weight.detach(), mods[2].bias.detach()          # (T*P, H), (T*P,)
     H = W1.shape[0]
-    if W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
+    if W1.shape[1] != S + C or W2.shape[0] != T * P or W2.shape[1] != H:
+        return None
+    W1c = W1[:, S:] if C else None            # [x_A || context]: the context's columns (context.py:46-60)
+    W1 = W1[:, :S]
+    if C and H > 16:
         return None
     src_pos, tgt_pos = pos[:S], pos[S:]
     Dp = D if Dp is None else Dp
@@ -331,6 +340,16 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
         if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and Dp > 128):
             return None
         head, block = _pack_mfma(kind, d, plane, H, Dp, W1t, b1, W2p, b2p)
+        if C:                                 # further GEMM-1 k-steps: A1c[cs][64], lane (q, i) <-> context element 4 s + q
+            cs = (C + 3) // 4
+            W1cp = W1c.new_zeros(16, 4 * cs)
+            W1cp[:H, :C] = W1c
+            lane = torch.arange(64, device=W1c.device)
+            ql, il = lane >> 4, lane & 15
+            unit1 = 4 * (il & 3) + (il >> 2)
+            A1c = torch.stack([W1cp[unit1, 4 * s_ + ql] for s_ in range(cs)])
+            block = torch.cat([block, A1c.reshape(-1).to(block.dtype)])
+            head = (head[0], head[1] | (cs << 4)) + tuple(head[2:])
         if kind == "rqs":
             import math
             import numpy as np
@@ -363,6 +382,44 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     else:
         op = OP_AFFINE_FWD if (d == FORWARD) != (kind == "inverse_affine") else OP_AFFINE_INV
     return (op, plane, H), block
+
+
+def _elementwise_ctx_op(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
+    """An elementwise affine layer whose parameters come from the CONTEXT through the default Linear conditioner
+    (layers_base.py:300-318) as a TFK_OP_EWC_* op: Ac[EPL][cs][64] | bc[EPL][4][4] (csrc/tfk_flow_mfma.h: ewc_m)."""
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import Linear
+    from torchflows_amd.utils import event_size as _esize
+    kind = layer.transformer.native_kind
+    ct = layer.conditioner_transform
+    if kind not in ("affine", "inverse_affine") or layer.use_global_parameters or type(ct) is not Linear:
+        return None
+    if ct.n_global_parameters != 0 or ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
+        return None
+    lin = ct.sequential[0]
+    C = _esize(layer.context_shape)
+    if not isinstance(lin, nn.Linear) or lin.in_features != C or lin.out_features != 2 * D or C > MAX_CONTEXT:
+        return None
+    cs = (C + 3) // 4
+    EPL, hp = Dp // 8, Dp // 2
+    dev = lin.weight.device
+    W = torch.zeros(Dp, 2, 4 * cs, dtype=lin.weight.dtype, device=dev)      # physical element, parameter, context column
+    W[pos, :, :C] = lin.weight.detach().view(D, 2, C)
+    bq = torch.zeros(Dp, 2, dtype=lin.bias.dtype, device=dev)               # padding: zero logits = the identity
+    bq[pos] = lin.bias.detach().view(D, 2)
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    q2, r2 = il >> 2, il & 3
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    A, bm = [], []
+    for t in range(EPL):
+        plane, tt = (0, t) if t < EPL // 2 else (1, t - EPL // 2)
+        m_l = plane * hp + EPL * q2 + 2 * tt + (r2 >> 1)
+        for s_ in range(cs):
+            A.append(W[m_l, r2 & 1, 4 * s_ + ql])
+        bm.append(bq[plane * hp + EPL * qq + 2 * tt + (rr >> 1), rr & 1])
+    block = torch.cat([torch.stack(A).reshape(-1), torch.stack(bm).reshape(-1)])
+    subdiv = (d == INVERSE) != (kind == "inverse_affine")
+    return (OP_EWC_SUBDIV if subdiv else OP_EWC_MULADD, cs << 4, 0), block
 
 
 def _plane_swap(layer, pos: torch.Tensor, Dp: int):
@@ -738,7 +795,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
 
 
 def compile_chain(composition, direction: int, device: torch.device,
-                  mfma: Optional[bool] = None) -> Optional[CompiledChain]:
+                  mfma: Optional[bool] = None, context: bool = False) -> Optional[CompiledChain]:
     """Flow programs for ``composition.forward`` (direction 0) or ``.inverse`` (1), or None.
     ``mfma`` None: use the matrix-core kernel when the chain qualifies (D in {64, 128}, affine /
     shift couplings, hidden width <= 16), else the vector-ALU one."""
@@ -761,10 +818,12 @@ def compile_chain(composition, direction: int, device: torch.device,
         Dp = 64 if D <= 32 else 128
     if mfma is None:
         if mfma_enabled() and native.lib().tfk_flow_mfma_supported(Dp) and padded_enabled(D, Dp):
-            chain = compile_chain(composition, direction, device, mfma=True)
+            chain = compile_chain(composition, direction, device, mfma=True, context=context)
             if chain is not None:
                 return chain
         mfma = False
+    if context and not mfma:
+        return None                              # context-conditioned programs: matrix-core interpreter only
     if not mfma:
         Dp = D
     elif Dp != D and not padded_enabled(D, Dp):
@@ -779,7 +838,7 @@ def compile_chain(composition, direction: int, device: torch.device,
     if Dp != D and not slots:                    # second half of the row starts at the padded plane boundary
         pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
     pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
-    if mfma and not slots and lean_enabled():
+    if mfma and not slots and lean_enabled() and not context:
         chain = _compile_lean(composition, plan, device, D, Dp, pos.clone(), pos_in)
         if chain is not None:
             return chain
@@ -791,7 +850,10 @@ def compile_chain(composition, direction: int, device: torch.device,
                 pos = pos[perm]                  # new logical j = old logical perm[j]
                 continue
             if isinstance(layer, ElementwiseBijection):
-                item = _elementwise_op(layer, d, pos, D, Dp)
+                if context and not layer.use_global_parameters:
+                    item = _elementwise_ctx_op(layer, d, pos, D, Dp)
+                else:
+                    item = _elementwise_op(layer, d, pos, D, Dp)
             elif isinstance(layer, CouplingBijection):
                 if slots and Dp != D:
                     swap, pos = _plane_swap(layer, pos, Dp)
@@ -816,7 +878,7 @@ def compile_chain(composition, direction: int, device: torch.device,
             return None                          # a single op larger than LDS: not fusable here
         # a launch holds as many ops as fit the LDS budget; a coupling op too big for the budget
         # gets a launch of its own, and the small elementwise ops around it ride along
-        small = kind in (OP_EW_MULADD, OP_EW_SUBDIV, OP_PLANE_SWAP)
+        small = kind in (OP_EW_MULADD, OP_EW_SUBDIV, OP_PLANE_SWAP, OP_EWC_MULADD, OP_EWC_SUBDIV)
         budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0)) if mfma else MAX_PARAM_BYTES
         over = (used + n) * 4 > budget
         if ops and ((over and not (small and (used + n) * 4 <= 150 * 1024)) or len(ops) == MAX_OPS):
@@ -886,10 +948,10 @@ def _live_checksum(module: nn.Module) -> float:
     return acc
 
 
-def get_compiled(composition, direction: int, device: torch.device) -> Optional[CompiledChain]:
+def get_compiled(composition, direction: int, device: torch.device, context: bool = False) -> Optional[CompiledChain]:
     """Cached ``compile_chain``; recompiles when a parameter / buffer was modified in place."""
     cache = composition.__dict__.setdefault("_tfk_compiled", {})
-    key = (direction, str(device), bool(composition.training))
+    key = (direction, str(device), bool(composition.training), bool(context))
     hit = cache.get(key)
     version = _params_version(composition)
     if hit is not None and hit[0] == version:
@@ -903,7 +965,7 @@ def get_compiled(composition, direction: int, device: torch.device) -> Optional[
                     "torchflows_amd: parameters below this composition changed without their version counters "
                     "moving (an in-place edit through .data?): call invalidate_native_caches() after such edits")
         return hit[1]
-    chain = compile_chain(composition, direction, device)
+    chain = compile_chain(composition, direction, device, context=context)
     cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
     if chain is None:
         warn_declined(composition, direction)
@@ -918,6 +980,11 @@ def warn_declined(composition, direction: int) -> None:
     composition.__dict__["_tfk_declined_warned"] = True
     if len(tuple(composition.event_shape)) >= 3:
         return          # image blocks (ConvNet conditioners): one kernel per layer IS their route, nothing was lost
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import MaskedAutoregressiveBijection
+    order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
+    plan = _flatten(order, "forward" if direction == FORWARD else "inverse") or []
+    if any(isinstance(layer, MaskedAutoregressiveBijection) and d == layer._sequential_when for layer, d in plan):
+        return          # the element-by-element map of a MADE layer runs as ONE launch per layer (tfk_made_*_sequential)
     warnings.warn("torchflows_amd: this composition is not compiled to a flow program and runs layer by layer on "
                   "the HIP kernels (about 10x slower): " + _why_declined(composition, direction),
                   NativeRouteWarning, stacklevel=4)
@@ -948,7 +1015,8 @@ def _why_declined(composition, direction: int) -> str:
             what = (f"{name} (transformer {layer.transformer.native_kind or type(layer.transformer).__name__}, "
                     f"conditioner {type(ct).__name__}")
             if layer.context_shape is not None:
-                return what + f", context_shape {tuple(layer.context_shape)}): context-conditioned layers have no op yet"
+                if type(ct).__name__ != "FeedForward" or D > 256:
+                    return what + f", context_shape {tuple(layer.context_shape)})"
             seq = getattr(ct, "sequential", None)
             hidden = getattr(seq[0], "out_features", None) if seq is not None and len(seq) else None
             kind = layer.transformer.native_kind
@@ -962,7 +1030,9 @@ def _why_declined(composition, direction: int) -> str:
             if getattr(layer, "first_training_batch_pass", False) and layer.training:
                 return f"{name} still has to initialise itself from a batch (train mode)"
             if not layer.use_global_parameters:
-                return f"{name} takes its parameters from the context: context-conditioned layers have no op yet"
+                if type(layer.conditioner_transform).__name__ != "Linear":
+                    return f"{name} takes its parameters from the context through a {type(layer.conditioner_transform).__name__}"
+                continue
             if layer.transformer.native_kind not in ("affine", "inverse_affine"):
                 return f"{name} (transformer {type(layer.transformer).__name__})"
             continue
@@ -970,7 +1040,8 @@ def _why_declined(composition, direction: int) -> str:
     return f"event size {D} / layer mix not covered by one kernel"
 
 
-def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False):
+def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False,
+              context: Optional[torch.Tensor] = None):
     """Apply the compiled chain to ``rows`` (N, D).  Returns ``(out_rows or None, logdet or
     None, logprob or None)``; with ``base`` (loc, log_scale in logical order) the final launch
     also evaluates the diagonal-Gaussian log-density and adds the log-det (flows.py:647-648).
@@ -994,7 +1065,7 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     padded = chain.pos_in is not None
     # lean programs read narrower rows themselves (tfk_flow_run_mfma_in): no padding pass over the rows
     narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma
-                 and chain.segments[0].ops[0][0] >= OP_AFFINE_FWD_LEAN and narrow_enabled())
+                 and OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
         wide = rows.new_zeros(N, chain.D)
         if chain.D_log % 2 == 0:                 # each half at the head of its plane: two strided copies
@@ -1039,6 +1110,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
             out = buf                             # in place from the second segment on
         run = native.flow_run_mfma if seg.mfma else native.flow_run
         kw = dict(D=chain.D) if (narrow_in and i == 0) else {}
+        if context is not None:
+            kw["context"] = context
         run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
             loc_p if last else None, ls_p if last else None,
             logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0), **kw)

@@ -33,7 +33,7 @@ SYMBOLS = (
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32", "tfk_sum_f32_ws",
     "tfk_flow_supported", "tfk_flow_run",
-    "tfk_flow_mfma_supported", "tfk_flow_run_mfma", "tfk_flow_run_mfma_in",
+    "tfk_flow_mfma_supported", "tfk_flow_run_mfma", "tfk_flow_run_mfma_in", "tfk_flow_run_mfma_ctx",
     "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
     "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd", "tfk_lrs_coupling_bwd",
     "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
@@ -99,6 +99,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_flow_mfma_supported.argtypes = [_i32]
     L.tfk_flow_run_mfma.argtypes = L.tfk_flow_run.argtypes
     L.tfk_flow_run_mfma_in.argtypes = [_vp, _i32] + L.tfk_flow_run.argtypes[1:]
+    L.tfk_flow_run_mfma_ctx.argtypes = [_vp, _vp, _i32] + L.tfk_flow_run.argtypes[1:]
     L.tfk_affine_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
     L.tfk_shift_coupling_bwd.argtypes = [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
     L.tfk_rqs_coupling_bwd_supported.argtypes = [_i32]
@@ -648,7 +649,7 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
 
 
 def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False,
-                  reverse_out=False, base_of_input=False, D=None):
+                  reverse_out=False, base_of_input=False, D=None, context=None):
     """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
     ops: list of (kind, src_plane, gemm2_steps, offset); params packed by fused._pack_mfma.
     ``D``: the kernel's row width when ``x`` is narrower (lean programs, tfk_flow_run_mfma_in): x (N, x_width) is read
@@ -656,6 +657,24 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
     global calls
     name = "tfk_flow_run_mfma"
     N, xw = _rows(x, name)
+    if context is not None:               # context-conditioned program (tfk_flow_run_mfma_ctx); rows at full width
+        name = "tfk_flow_run_mfma_ctx"
+        Dk = xw
+        ops_arr = _pack_ops(ops)
+        if context.dim() != 2 or context.shape[0] != N:
+            raise NativeError(f"{name}: context must be (N, C), got {tuple(context.shape)}")
+        for t, n in ((z, N * Dk), (logdet, N), (logprob, N), (gauss_loc, Dk), (gauss_log_scale, Dk)):
+            if t is not None and t.numel() != n:
+                raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
+        args = (_f32(x, name), _f32(context, name), int(context.shape[1]), _f32(z, name), _f32(logdet, name),
+                _f32(gauss_loc, name), _f32(gauss_log_scale, name), _f32(logprob, name), N, Dk, ops_arr, _n_ops(ops),
+                _f32(params, name), params.numel(),
+                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0))
+        with _device_guard(x):
+            rc = lib().tfk_flow_run_mfma_ctx(*args, _stream(x))
+        calls += 1
+        _check(rc, name)
+        return
     if D is not None and D != xw:
         name = "tfk_flow_run_mfma_in"
         ops_arr = _pack_ops(ops)
