@@ -110,8 +110,13 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
     }
 }
 
+// (tuning hook: -DTFK_CHAIN_ATTR='__attribute__((amdgpu_waves_per_eu(5, 5)))' for occupancy experiments, tools/variants.sh)
+#ifndef TFK_CHAIN_ATTR
+#define TFK_CHAIN_ATTR
+#endif
+
 template <int EPL, int BLOCK, int STEPS2, int KIND>
-__global__ __launch_bounds__(BLOCK) void k_flow_chain(
+__global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR void k_flow_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
     const float *__restrict__ params, int n_params, ChainProg prog, int flags, int xw)
