@@ -77,18 +77,27 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
     for (int r = 0; r < 4; ++r)                              // tanh, transforms.py:293-304
         hid[r] = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[r]) + 1.0f), 1.0f);
 
-    float a2[NA2];
+    // GEMM 2 in groups of GT tiles whose A-operands fill whole ds_read_b128s (GT * STEPS2 is a multiple of 4): at most 12
+    // operand registers are live, whatever the row width (all T2 * STEPS2 = 48 of them at D = 256 cost the occupancy)
+    constexpr int GT = (STEPS2 == 4) ? 1 : ((STEPS2 == 2) ? 2 : 4);
+    static_assert(T2 % GT == 0 || T2 < GT, "tile groups");
+    constexpr int GTE = T2 < GT ? T2 : GT;                    // (shift couplings at D = 64: T2 = 2)
+    constexpr int GREG = (GTE * STEPS2 + 3) & ~3;
 #pragma unroll
-    for (int g = 0; g < NA2 / 4; ++g) {
-        const cf32x4 w = A2[g * 64 + lane];
-        a2[4 * g] = w[0]; a2[4 * g + 1] = w[1]; a2[4 * g + 2] = w[2]; a2[4 * g + 3] = w[3];
-    }
+    for (int t0 = 0; t0 < T2; t0 += GTE) {
+        float a2[GREG];
 #pragma unroll
-    for (int t = 0; t < T2; ++t) {
+        for (int g = 0; g < GREG / 4; ++g) {
+            const cf32x4 w = A2[((t0 * STEPS2) / 4 + g) * 64 + lane];
+            a2[4 * g] = w[0]; a2[4 * g + 1] = w[1]; a2[4 * g + 2] = w[2]; a2[4 * g + 3] = w[3];
+        }
+#pragma unroll
+      for (int tt = 0; tt < GTE; ++tt) {
+        const int t = t0 + tt;
         cf32x4 o = *reinterpret_cast<const cf32x4 *>(b2 + (t * 4 + q) * 4);
 #pragma unroll
         for (int k = 0; k < STEPS2; ++k)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t * STEPS2 + k], hid[k], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt * STEPS2 + k], hid[k], o, 0, 0, 0);
         if constexpr (affine) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -107,6 +116,7 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
                 else tgt[e] = tgt[e] - o[i];                                         // affine.py:158
             }
         }
+      }
     }
 }
 
@@ -301,13 +311,16 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
                           int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
     const bool big = N >= (int64_t)kCUs * 3 * 128;
+    // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:
+    // 736 us per launch against 389 with 512 threads, measured; the interpreter's trick does not carry over)
+    constexpr int BIG = 512;
 #define TFK_CB(BLOCK_, ST_) \
     launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
     switch (steps2) {
-    case 1: return big ? TFK_CB(512, 1) : TFK_CB(kBlock, 1);
-    case 2: return big ? TFK_CB(512, 2) : TFK_CB(kBlock, 2);
-    case 3: return big ? TFK_CB(512, 3) : TFK_CB(kBlock, 3);
-    case 4: return big ? TFK_CB(512, 4) : TFK_CB(kBlock, 4);
+    case 1: return big ? TFK_CB(BIG, 1) : TFK_CB(kBlock, 1);
+    case 2: return big ? TFK_CB(BIG, 2) : TFK_CB(kBlock, 2);
+    case 3: return big ? TFK_CB(BIG, 3) : TFK_CB(kBlock, 3);
+    case 4: return big ? TFK_CB(BIG, 4) : TFK_CB(kBlock, 4);
     default: return fail(TFK_EINVAL, "%s: lean couplings need 1..4 GEMM-2 steps, got %d", fn, steps2);
     }
 #undef TFK_CB
