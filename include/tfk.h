@@ -226,7 +226,14 @@ enum {
      * (tile 6 e + c of a chunk = parameters 4 c .. 4 c + 3 of the lane-group's target element 8 chunk + e, lane-major
      * over <= 4 k-steps).  Per element 24 parameters: [0, 8) width logits u_x, [8, 16) height logits u_x + u_y / 1000,
      * [16, 23) derivative logits c + u_d / 1000 -- ALL multiplied by log2(e) by the packer -- and one pad; W1 / b1
-     * times 2 log2(e) as for the affine lean ops.  Op record as for TFK_OP_RQS_*: K = 8, boundary, scale, c. */
+     * times 2 log2(e) as for the affine lean ops.  Op record as for TFK_OP_RQS_*: K = 8, boundary, scale, c.
+     * K = 8 + 256 selects the bf16 x 3 operand format: GEMM 2 on the bf16 matrix pipe at fp32 accuracy -- every weight
+     * is split by the packer into three bf16 pieces of 8 mantissa bits (hi = w & 0xffff0000, mid, lo likewise from the
+     * exact remainders), the kernel splits the hidden activations the same way and keeps six of the nine piece products
+     * (three v_mfma_f32_16x16x32_bf16 per tile).  Chunks then hold 4 target elements: A[24][2][64][4 dwords] with, per
+     * tile and lane, the two operands [W_hi | W_mid] and [W_lo | W_hi] (4 bf16 each = hidden units 4 i + (lane >> 4));
+     * no b2: the bias is the weight of hidden unit 15, which the kernel sets to 1 (hidden width <= 15); D/32 chunks
+     * per layer. */
     TFK_OP_RQS_FWD_LEAN = 17,
     TFK_OP_RQS_INV_LEAN = 18,
     /* context-conditioned programs (tfk_flow_run_mfma_ctx): an elementwise affine layer whose (D, 2) parameters are

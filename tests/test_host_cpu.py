@@ -470,13 +470,17 @@ def test_torchflows_import_alias_resolves_to_the_build():
                                                        ("RealNVP", 128, 2, 0), ("RealNVP", 22, 3, 0), ("NICE", 8, 3, 1),
                                                        ("CouplingRQNSF", 64, 3, 0), ("CouplingRQNSF", 64, 2, 1),
                                                        ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1)])
-def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction):
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, bf16x3, monkeypatch):
     """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
     pre-affines, pre-scaled logits, lane-major operands): an fp64 emulator that decodes the packed blocks exactly as
     csrc/tfk_flow_chain.h reads them must reproduce the composition's forward / inverse."""
     from lean_emulator import run_lean
     from torchflows_amd import fused
     import torchflows_amd as tfa
+    if bf16x3 == "0" and "RQ" not in arch:
+        pytest.skip("the operand format only concerns spline chains")
+    monkeypatch.setenv("TORCHFLOWS_AMD_RQS_BF16X3", bf16x3)
     torch.manual_seed(3)
     flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers))
     flow.train()

@@ -662,7 +662,24 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t) -> tor
                       pre_s, pre_t]).float()
 
 
-def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float) -> torch.Tensor:
+def rqs_bf16x3_enabled() -> bool:
+    return os.environ.get("TORCHFLOWS_AMD_RQS_BF16X3", "1") != "0"
+
+
+def _bf16_pieces(w: torch.Tensor):
+    """fp32 -> three bf16 pieces by truncation (hi = w & 0xffff0000, mid and lo likewise from the exact remainders),
+    each returned as the int32 holding its 16 significant bits in the LOW half."""
+    w = w.float().contiguous()
+    mask = torch.tensor(-65536, dtype=torch.int32, device=w.device)             # 0xffff0000
+    hi = (w.view(torch.int32) & mask).view(torch.float32)
+    r1 = w - hi
+    mid = (r1.view(torch.int32) & mask).view(torch.float32)
+    r2 = (r1 - mid).contiguous()
+    lo = (r2.view(torch.int32) & mask).view(torch.float32)
+    return [(t.contiguous().view(torch.int32) >> 16) & 0xFFFF for t in (hi, mid, lo)]
+
+
+def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float, bf16x3: bool = False) -> torch.Tensor:
     """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out:
     head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks A2[48][64][4] | b2[48][4][4].
     Per target element 24 parameters, all times log2(e): [0, 8) u_x, [8, 16) u_x + u_y / 1000 (the reference's height
@@ -698,6 +715,22 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     mb = EPL * qq.view(1, 1, 1, 4, 4) + 8 * ch + e
     b2 = bq[mb, 4 * c + rr.view(1, 1, 1, 4, 4)]                                            # (NC, 8, 6, 4, 4)
     parts = [A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]
+    if bf16x3:
+        # chunks of 4 elements; per tile and lane the operands [W_hi | W_mid] and [W_lo | W_hi], 4 bf16 each: slot i of
+        # lane-group q <-> hidden unit 4 i + q (the k-steps r1 of the fp32 layout)
+        # the bias as the weight of hidden unit 15 (= 1 in the kernel): lane-group 3, slot 3
+        A2 = A2.clone()
+        A2[:, :, :, 48:64, 3] = b2.reshape(NC, 8, 6, 16)          # lane 48 + i <-> D-row i = 4 q2 + r2 = b2's [q][r] order
+        hi, mid, lo = _bf16_pieces(A2.reshape(NC * 8, 6, 64, 4))               # (elements, 6, 64, 4) int32, low halves
+        pack2 = lambda t: (t[..., 0::2] | (t[..., 1::2] << 16))                # two bf16 per dword: (…, 2)
+        a1 = torch.cat([pack2(hi), pack2(mid)], dim=-1)                        # (elements, 6, 64, 4 dwords)
+        a2 = torch.cat([pack2(lo), pack2(hi)], dim=-1)
+        A3 = torch.stack([a1, a2], dim=2).to(torch.int32)                       # (elements, 6, 2, 64, 4)
+        head = torch.cat(parts).float()
+        out = [head]
+        for k in range(EPL // 4):
+            out.append(A3[4 * k:4 * k + 4].reshape(-1).view(torch.float32))
+        return torch.cat(out)
     for k in range(NC):
         parts += [A2[k].reshape(-1), b2[k].reshape(-1)]
     return torch.cat(parts).float()
@@ -754,12 +787,13 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 W1f = W1t * s[src]
                 if lk >= 4:                                  # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
-                    extra = (8, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)),
-                             float(np.float32(tr.boundary_u_delta)))
+                    fmt3 = rqs_bf16x3_enabled() and H <= 15          # (hidden unit 15 carries the bias)
+                    extra = (8 + (256 if fmt3 else 0), float(tr.boundary),
+                             float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)), float(np.float32(tr.boundary_u_delta)))
                     if items and items[-1][4] != extra:
                         return None
                     block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
-                                           float(np.float32(tr.boundary_u_delta)))
+                                           float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3)
                     items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
                 else:
                     block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone())
