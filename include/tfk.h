@@ -212,7 +212,10 @@ enum {
      * Block: A1[D/32][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[D/2] | pre_t[D/2], lane-major
      * A-operands (nA2 = T2 * gemm2_steps rounded up to 4; entry t * gemm2_steps + k = tile t, step k), with W1 / b1
      * multiplied by 2 log2(e) and the scale-logit rows of W2 / b2 by log2(e) / 2 (b2 += log(1 - 1e-10) log2(e)):
-     * tanh = 1 - 2 / (exp2(.) + 1), alpha = exp2(.) + 1e-10, log-det accumulated in base 2. */
+     * tanh = 1 - 2 / (exp2(.) + 1), alpha = exp2(.) + 1e-10, log-det accumulated in base 2.
+     * Op record field K = 256 (D = 64 only): GEMM 2 in the bf16 x 3 operand format described at TFK_OP_RQS_*_LEAN --
+     * block A1 | b1 | A23[T2][2][64][4 dwords] | pre_s | pre_t, A23[t] = {[W_hi | W_mid], [W_lo | W_hi]}, b2 as the
+     * weight of hidden unit 15 (hidden width <= 15). */
     TFK_OP_AFFINE_FWD_LEAN = 12,
     TFK_OP_AFFINE_INV_LEAN = 13,
     TFK_OP_SHIFT_FWD_LEAN = 14,

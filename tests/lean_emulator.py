@@ -66,6 +66,24 @@ def rqs_lean_eval(p, v, C, inverse):
     return torch.where(inb, out, v), torch.where(inb, -l2 if inverse else l2, torch.zeros_like(l2))
 
 
+def _pieces(v32):
+    """fp32 tensor -> (hi, mid, lo) bf16 pieces by truncation, as fp64."""
+    bits = v32.contiguous().view(torch.int32)
+    hi = (bits & -65536).view(torch.float32)
+    r1 = v32 - hi
+    mid = (r1.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    r2 = r1 - mid
+    lo = (r2.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    return hi.double(), mid.double(), lo.double()
+
+
+def _unpack_bf16(d):
+    """(64, 2 dwords) int32 -> (64, 4) fp64 values of the 4 packed bf16."""
+    lo16 = ((d & 0xFFFF) << 16).view(torch.float32).double()
+    hi16 = (d & -65536).view(torch.float32).double()
+    return torch.stack([lo16[:, 0], hi16[:, 0], lo16[:, 1], hi16[:, 1]], dim=1)
+
+
 def run_lean(ops, params, rows, D):
     """rows (N, D) fp64, N a multiple of 16 -> (rows out, logdet) of one lean segment."""
     EPL, HALF = D // 8, D // 2
@@ -182,6 +200,45 @@ def run_lean(ops, params, rows, D):
         lk = kind - 12
         affine = lk < 2
         T2 = EPL // 2 if affine else EPL // 4
+        if (kind, off) in op_extra and int(op_extra[(kind, off)][0]) == 256:      # bf16 x 3 operands (couple_lean3)
+            A1 = prm[off:off + EPL * 64].reshape(EPL // 4, 64, 4)
+            b1 = prm[off + EPL * 64:off + EPL * 64 + 16]
+            o2 = off + EPL * 64 + 16
+            raw = params.contiguous().view(torch.int32)
+            A23 = raw[o2:o2 + T2 * 2 * 64 * 4].reshape(T2, 2, 64, 4)
+            pre = prm[o2 + T2 * 2 * 64 * 4:]
+            src, tgt = (a, b) if plane == 0 else (b, a)
+            acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+            for s_ in range(EPL):
+                acc = _mfma(A1[s_ // 4, :, s_ % 4], src[:, s_], acc)
+            tgt = (pre[idx][:, :, None] * tgt + pre[HALF + idx][:, :, None]).clone()
+            hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)
+            hid[q == 3, 3] = 1.0
+            h_hi, h_mid, h_lo = _pieces(hid.float())
+            for t_ in range(T2):
+                w_hi, w_mid = _unpack_bf16(A23[t_, 0][:, 0:2]), _unpack_bf16(A23[t_, 0][:, 2:4])
+                w_lo = _unpack_bf16(A23[t_, 1][:, 0:2])
+                assert torch.equal(w_hi, _unpack_bf16(A23[t_, 1][:, 2:4]))
+                o = torch.zeros(64, 4, W, dtype=torch.float64)
+                for Wl, Bl in ((w_hi, h_hi), (w_mid, h_hi), (w_hi, h_mid), (w_mid, h_mid), (w_lo, h_hi), (w_hi, h_lo)):
+                    for i in range(4):
+                        o = _mfma(Wl[:, i], Bl[:, i], o)
+                if affine:
+                    for i in range(2):
+                        e = 2 * t_ + i
+                        al = torch.exp2(o[:, 2 * i]) + 1e-10
+                        ld2 = ld2 + torch.log2(al)
+                        tgt[:, e] = al * tgt[:, e] + o[:, 2 * i + 1] if lk == 0 else (tgt[:, e] - o[:, 2 * i + 1]) / al
+                    sign = 1.0 if lk == 0 else -1.0
+                else:
+                    for i in range(4):
+                        e = 4 * t_ + i
+                        tgt[:, e] = tgt[:, e] + o[:, i] if lk == 2 else tgt[:, e] - o[:, i]
+            if plane == 0:
+                b = tgt
+            else:
+                a = tgt
+            continue
         nA2 = (T2 * steps2 + 3) & ~3
         A1 = prm[off:off + EPL * 64].reshape(EPL // 4, 64, 4)
         b1 = prm[off + EPL * 64:off + EPL * 64 + 16]

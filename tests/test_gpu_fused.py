@@ -605,3 +605,28 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
     assert rel(lp1.cpu().numpy(), lp_h.numpy()) < tol
     assert torch.equal(lp1, lp0) and torch.equal(z1, z0)
     assert torch.allclose(xr1.cpu(), x, atol=1e-3)
+
+
+def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):
+    """TORCHFLOWS_AMD_LEAN_BF16X3=1: GEMM 2 of RealNVP-64 chains on the bf16 matrix pipe at fp32 accuracy (opt-in: no
+    faster than fp32 operands for affine chains, fused.lean_bf16x3_enabled) -- same values as the default format to
+    fp32 rounding, and as the host."""
+    import torchflows_amd as tfa
+    torch.manual_seed(2)
+    flow = tfa.Flow(tfa.RealNVP(64, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, 64))
+    flow.eval()
+    x = torch.randn(2000, 64)
+    with torch.no_grad():
+        lp_h = flow.log_prob(x)
+        flow = flow.cuda()
+        lp0 = flow.log_prob(x.cuda())
+        monkeypatch.setenv("TORCHFLOWS_AMD_LEAN_BF16X3", "1")
+        flow.invalidate_native_caches()
+        lp1 = flow.log_prob(x.cuda())
+        z1, ld1 = flow.bijection.forward(x.cuda())
+        xr, _ = flow.bijection.inverse(z1)
+    assert rel(lp1.cpu().numpy(), lp_h.numpy()) < 1e-5 and rel(lp1.cpu().numpy(), lp0.cpu().numpy()) < 2e-6
+    assert torch.allclose(xr.cpu(), x, atol=1e-4)

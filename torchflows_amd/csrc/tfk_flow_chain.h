@@ -120,6 +120,108 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
     }
 }
 
+
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+typedef int li32x4 __attribute__((ext_vector_type(4)));
+
+// The same coupling with GEMM 2 on the bf16 matrix pipe at fp32 accuracy ("bf16 x 3", see tfk_flow_rqs_chain.h): the
+// weights arrive split into three bf16 pieces, the lane's 4 hidden activations are split here (22 vector
+// instructions), and each tile takes three v_mfma_f32_16x16x32_bf16 (~16 cycles each) instead of STEPS2
+// v_mfma_f32_16x16x4_f32 (32 cycles each); b2 rides as the weight of hidden unit 15 = 1 (hidden width <= 15).
+// Block: A1[EPL/4][64][4] | b1[4][4] | A23[T2][2][64][4 dwords] | pre_s[HALF] | pre_t[HALF]
+//   A23[t][0] = [W_hi | W_mid], A23[t][1] = [W_lo | W_hi]: 4 bf16 each = hidden units 4 i + (lane >> 4).
+template <int EPL, int KIND>
+__device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, const float (&src)[EPL],
+                                             float (&tgt)[EPL], float &ld2)
+{
+    constexpr bool affine = KIND < 2;
+    constexpr int HALF = 4 * EPL;
+    constexpr int T2 = affine ? EPL / 2 : EPL / 4;
+    const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(prm);
+    const float *b1 = prm + EPL * 64;
+    const li32x4 *A23 = reinterpret_cast<const li32x4 *>(b1 + 16);
+    const float *pre = b1 + 16 + T2 * 2 * 64 * 4;
+
+    cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+#pragma unroll
+    for (int g = 0; g < EPL / 4; ++g) {
+        const cf32x4 w = A1[g * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+        const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
+    }
+    int hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float h = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[r]) + 1.0f), 1.0f);
+        if (r == 3) h = (q == 3) ? 1.0f : h;                  // hidden unit 15 = 1 carries b2
+        const int hb = __float_as_int(h) & (int)0xffff0000;
+        const float r1 = h - __int_as_float(hb);
+        const int mb = __float_as_int(r1) & (int)0xffff0000;
+        hi[r] = hb; mid[r] = mb; lo[r] = __float_as_int(r1 - __int_as_float(mb));
+    }
+    const int hh01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302), hh23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302);
+    const int mm01 = __builtin_amdgcn_perm(mid[1], mid[0], 0x07060302), mm23 = __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302);
+    const int ll01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302), ll23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302);
+    const li32x4 B1 = {hh01, hh23, hh01, hh23}, B2 = {mm01, mm23, mm01, mm23}, B3 = {hh01, hh23, ll01, ll23};
+
+    // the tiles side by side, product by product (a tile's three MFMAs must not follow each other back to back)
+    cf32x4 o[T2];
+    li32x4 a1[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        o[t] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        a1[t] = A23[(t * 2) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[t]), __builtin_bit_cast(lbf16x8, B1), o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[t]), __builtin_bit_cast(lbf16x8, B2), o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        const li32x4 a2 = A23[(t * 2 + 1) * 64 + lane];
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a2), __builtin_bit_cast(lbf16x8, B3), o[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        if constexpr (affine) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * t + i;
+                const float al = __builtin_amdgcn_exp2f(o[t][2 * i]) + kAffMinScale;
+                ld2 += __builtin_amdgcn_logf(al);
+                if constexpr (KIND == 0) tgt[e] = fmaf(al, tgt[e], o[t][2 * i + 1]);
+                else tgt[e] = (tgt[e] - o[t][2 * i + 1]) * __builtin_amdgcn_rcpf(al);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * t + i;
+                if constexpr (KIND == 2) tgt[e] = tgt[e] + o[t][i];
+                else tgt[e] = tgt[e] - o[t][i];
+            }
+        }
+    }
+}
+
+// one coupling in whichever operand format the kernel was instantiated for (STEPS2 = 0: bf16 x 3)
+template <int EPL, int STEPS2, int KIND>
+__device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, const float (&src)[EPL],
+                                           float (&tgt)[EPL], float &ld2)
+{
+    if constexpr (STEPS2 == 0) couple_lean3<EPL, KIND>(prm, lane, q, src, tgt, ld2);
+    else couple_lean<EPL, STEPS2, KIND>(prm, lane, q, src, tgt, ld2);
+}
+
 // (tuning hook: -DTFK_CHAIN_ATTR='__attribute__((amdgpu_waves_per_eu(5, 5)))' for occupancy experiments, tools/variants.sh)
 #ifndef TFK_CHAIN_ATTR
 #define TFK_CHAIN_ATTR
@@ -212,14 +314,14 @@ __global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR void k_flow_chain(
         float ld2 = 0.0f;                                             // this lane's share, in base 2
         int o = 0;
         if (prog.first_src == 1 && prog.n_c > 0) {
-            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
+            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
             o = 1;
         }
         for (; o + 1 < prog.n_c; o += 2) {
-            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
-            couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
+            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
         }
-        if (o < prog.n_c) couple_lean<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
         if constexpr (KIND == 0) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
         else if constexpr (KIND == 1) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
 
@@ -317,6 +419,9 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
 #define TFK_CB(BLOCK_, ST_) \
     launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
     switch (steps2) {
+    case 0:                         // bf16 x 3 operands: ~85 KB for RealNVP-64, one 1024-thread workgroup per CU
+        if constexpr (EPL == 8) return big ? TFK_CB(1024, 0) : TFK_CB(kBlock, 0);
+        else return fail(TFK_EINVAL, "%s: the bf16 x 3 operand format of lean couplings is built for D = 64", fn);
     case 1: return big ? TFK_CB(BIG, 1) : TFK_CB(kBlock, 1);
     case 2: return big ? TFK_CB(BIG, 2) : TFK_CB(kBlock, 2);
     case 3: return big ? TFK_CB(BIG, 3) : TFK_CB(kBlock, 3);

@@ -104,6 +104,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     prog.ew_offset = -1;
     prog.pad = 0;
     int kind = -1, steps2 = 1;
+    bool fmt3 = false;
     for (int i = 0; i < n_ops; ++i) {
         const int32_t *rec = ops + 8 * i;
         const int k = rec[0], src = rec[1], st = rec[2], off = rec[3];
@@ -128,7 +129,11 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
             }
             const int T2 = (kind < 2) ? EPL / 2 : EPL / 4;
             const int nA2 = (T2 * st + 3) & ~3;
-            need = (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF;
+            const bool f3 = rec[4] == 256;               // K field: 256 = bf16 x 3 operands (no b2, A23[T2][2][64][4])
+            if (prog.n_c == 0) fmt3 = f3;
+            else if (f3 != fmt3) return fail(TFK_EINVAL, "%s: op %d: the ops of a lean program share one operand format", fn, i);
+            need = f3 ? (int64_t)EPL * 64 + 16 + (int64_t)T2 * 2 * 64 * 4 + 2 * HALF
+                      : (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF;
             prog.offset[prog.n_c++] = off;
         } else {
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean ops", fn, i, k);
@@ -138,6 +143,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
                         off, (long long)(off + need), (long long)n_params);
     }
     if (kind < 0) kind = 2;
+    if (fmt3) steps2 = 0;
     if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     return flow_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);

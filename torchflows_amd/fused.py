@@ -616,7 +616,15 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     return lk, plane, H, W1t, b1, W2p, b2p
 
 
-def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t) -> torch.Tensor:
+def lean_bf16x3_enabled() -> bool:
+    """bf16 x 3 operands for GEMM 2 of affine / shift chains at D = 64: OFF by default -- measured on RealNVP-64 (2^20
+    rows): 252.0 us per launch against 255.8 us with fp32 operands.  The 12 f32 MFMAs it removes (384 matrix cycles per
+    wave-layer) come back as 12 bf16 MFMAs (~192) + 22 vector instructions for the split + a 1024-thread workgroup per
+    CU (85 KB of operands).  It pays for spline chains (24 -> 18 MFMAs per element, split amortised over 8 elements)."""
+    return os.environ.get("TORCHFLOWS_AMD_LEAN_BF16X3", "0") == "1"
+
+
+def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3: bool = False) -> torch.Tensor:
     """Parameter block of a lean coupling op (csrc/tfk_flow_chain.h): lane-major MFMA A-operands
     A1[EPL/4][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[hp] | pre_t[hp], with W1 / b1 multiplied by
     2 log2(e) and (affine) the scale-logit rows of W2 / b2 by log2(e) / 2, b2 += c0 log2(e).  Inputs fp64, physical
@@ -655,6 +663,24 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t) -> tor
         for r1 in range(steps2):
             A2.append(W2pad[m_l, p_l, 4 * r1 + ql])
         b2m.append(b2q[m_b, p_b])
+    if bf16x3:
+        # GEMM 2 in the bf16 x 3 operand format (csrc/tfk_flow_chain.h: couple_lean3): per tile and lane
+        # [W_hi | W_mid] and [W_lo | W_hi], 4 bf16 each (slot i <-> hidden unit 4 i + q); b2 = the weight of unit 15
+        W2b = W2pad.clone()
+        W2b[:, :, 15] = b2q
+        Af = []
+        for t in range(T2):
+            if P == 2:
+                m_l, p_l = EPL * q2 + 2 * t + (r2 >> 1), r2 & 1
+            else:
+                m_l, p_l = EPL * q2 + 4 * t + r2, torch.zeros_like(r2)
+            Af.append(torch.stack([W2b[m_l, p_l, 4 * i + ql] for i in range(4)], dim=1))      # (64, 4)
+        hi, mid, lo = _bf16_pieces(torch.stack(Af))                                            # (T2, 64, 4)
+        pack2 = lambda v: (v[..., 0::2] | (v[..., 1::2] << 16))
+        A23 = torch.stack([torch.cat([pack2(hi), pack2(mid)], dim=-1),
+                           torch.cat([pack2(lo), pack2(hi)], dim=-1)], dim=1).to(torch.int32)  # (T2, 2, 64, 4)
+        return torch.cat([A1.reshape(-1).float(), b1m.reshape(-1).float(), A23.reshape(-1).view(torch.float32),
+                          pre_s.float(), pre_t.float()])
     nA2 = (T2 * steps2 + 3) & ~3
     A2 = torch.stack(A2 + [torch.zeros(64, dtype=torch.float64, device=dev)] * (nA2 - T2 * steps2))
     A2 = A2.reshape(nA2 // 4, 4, 64).permute(0, 2, 1)
@@ -751,6 +777,10 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     ld_const = torch.zeros((), dtype=torch.float64, device=device)
     items = []          # (lean kind, plane, steps2, block)
     kind0 = steps0 = None
+    # bf16 x 3 operands for affine / shift chains: D = 64 only, and the whole chain must stay ONE launch (10.6 KB of
+    # operands per coupling instead of 5.7): decided after a dry count of the couplings
+    n_couplings = sum(isinstance(layer, CouplingBijection) for layer, _ in plan)
+    aff3 = lean_bf16x3_enabled() and Dp == 64 and 0 < n_couplings <= 13
     with torch.no_grad():
         for layer, d in plan:
             if isinstance(layer, PermutationMatrix):
@@ -796,8 +826,11 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                                            float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3)
                     items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
                 else:
-                    block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone())
-                    items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block, ()))
+                    use3 = aff3 and H <= 15
+                    if items and bool(items[-1][4]) != use3:
+                        return None
+                    block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(), bf16x3=use3)
+                    items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block, (256,) if use3 else ()))
                 s[tgt] = 1.0
                 t[tgt] = 0.0
             else:
@@ -808,6 +841,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
+    if any(extra == (256,) for *_, extra in items):
+        budget = 150 * 1024          # bf16 x 3 operands: one 1024-thread workgroup per CU holds the whole chain
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
     for kind, plane, steps2, block, extra in items:
