@@ -54,6 +54,7 @@ class KernelTimer:
     byte count of the launch (SURVEY.md 8(d) per-row figures x rows)."""
 
     def __init__(self, native):
+        _heavy_imports()
         self.native = native
         self.active = False
         self.records = []   # (name, bytes, start_event, end_event)
@@ -222,8 +223,18 @@ class KernelTimer:
         return agg
 
 
+def _heavy_imports():
+    """numpy / torch come in on first use: the launcher parent of an N > 1 run must not touch them (see main)."""
+    global np, torch, dist
+    if torch is None:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+
 def make_flow(arch, D, n_layers):
     """seed 0, data-initialised ActNorm (one train-mode forward on 4096 host rows), eval."""
+    _heavy_imports()
     import torchflows_amd as tfa
     from torchflows_amd.bijections.finite.multiscale import AffineGlow
     ctor = AffineGlow if arch == "AffineGlow" else getattr(tfa, arch)
@@ -363,10 +374,7 @@ def main():
         os.environ["TORCHFLOWS_AMD_MFMA"] = "0"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])          # does not return
-    global np, torch, dist
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    _heavy_imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
