@@ -56,16 +56,28 @@ class _OrcLayer(C.Structure):
     ]
 
 
+def _sources_sha256() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for p in (os.path.join(_HERE, "oracle.c"), os.path.join(_HERE, "oracle.h"), os.path.join(_HERE, "oracle_tfk.c"),
+              os.path.join(_HERE, "..", "include", "tfk.h"), os.path.join(_HERE, "Makefile")):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    """Compile liboracle.so with gcc (oracle/Makefile).  Returns its path."""
-    src = os.path.join(_HERE, "oracle.c")
-    hdr = os.path.join(_HERE, "oracle.h")
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH)
-        for p in (src, hdr, os.path.join(_HERE, "oracle_tfk.c"), os.path.join(_HERE, "..", "include", "tfk.h")))
-    if force or stale:
+    """Compile liboracle.so with gcc (oracle/Makefile).  Returns its path.
+    Staleness is judged by a hash of the sources kept beside the library, not by modification times: a copy of the
+    tree (the snapshot sent to the GPU box) does not preserve their order, and a rebuild there would fork a compiler
+    out of a process that may already have initialised the GPU."""
+    stamp = _LIB_PATH + ".sha256"
+    want = _sources_sha256()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if force or not os.path.exists(_LIB_PATH) or have != want:
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return _LIB_PATH
 
 
