@@ -72,6 +72,14 @@ class Bijection(nn.Module):
         self.invalidate_native_caches()
         return super().train(mode)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() ...: the tensors keep their identity and version counters but move -- the packed
+        # copies (and the dtype / device check) are dropped here instead of comparing data pointers on every call
+        out = super()._apply(fn, *args, **kwargs)
+        from torchflows_amd import fused
+        fused.tensors_moved(self)
+        return out
+
     # -- the two maps ------------------------------------------------------
     def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         raise NotImplementedError

@@ -62,6 +62,12 @@ class BaseFlow(nn.Module):
         self.invalidate_native_caches()
         return super().train(mode)
 
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)       # (see Bijection._apply)
+        from torchflows_amd import fused
+        fused.tensors_moved(self)
+        return out
+
     def get_device(self) -> torch.device:
         return self.device_buffer.device
 

@@ -133,10 +133,11 @@ def _tensor_slots(module: nn.Module):
 
 
 def _params_version(module: nn.Module) -> int:
-    """Changes whenever a parameter / buffer below ``module`` is modified in place (version
-    counter), moved or converted (data pointer) or replaced by another tensor (slot identity).
-    The walk over the module tree is done once and cached: per call this is one pass over a flat
-    list (the ``module.parameters()`` traversal alone cost ~150 us per ``log_prob`` call)."""
+    """Changes whenever a parameter / buffer below ``module`` is modified in place (version counter) or replaced by
+    another tensor (slot identity).  Moves and conversions (``.to()``, ``.cuda()``, ``.double()``: the tensor object
+    stays, its storage changes) are caught by ``Bijection._apply`` / ``BaseFlow._apply``, which drop the caches -- so
+    the per-call check is ONE pass over a flat list reading ``_version`` (the ``data_ptr()`` walk this replaces cost
+    ~35 us of the ~57 us a small-batch ``log_prob`` call spent on the host)."""
     slots = module.__dict__.get("_tfk_slots")
     if slots is None:
         slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
@@ -144,45 +145,52 @@ def _params_version(module: nn.Module) -> int:
     for owner, k, t in slots:
         if owner.get(k) is not t:                     # a tensor was replaced: re-walk the tree
             slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
-            v = len(slots)
+            module.__dict__.pop("_tfk_static_ok", None)
+            v = len(slots) + 7
             for _, _, t2 in slots:
-                v = (v * 1000003 + t2._version + (t2.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
-            return v
-        v = (v * 1000003 + t._version + (t.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
-    return v
+                v = v * 1000003 + t2._version
+            return v & 0xFFFFFFFFFFFFFFF
+        v = v * 1000003 + t._version
+    return v & 0xFFFFFFFFFFFFFFF
 
 
 def _layout_version(module: nn.Module) -> int:
-    """Like ``_params_version`` without the in-place version counters: changes only when a tensor
-    is moved, converted or replaced (an optimizer step does not change it)."""
+    """Kept for callers that key on the layout alone: the identity of the slot list (rebuilt when a tensor is replaced;
+    dropped by ``_apply`` when tensors move)."""
     slots = module.__dict__.get("_tfk_slots")
     if slots is None:
         slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
-    v = len(slots)
-    for owner, k, t in slots:
-        if owner.get(k) is not t:
-            slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
-            return _layout_version(module)
-        v = (v * 1000003 + (t.data_ptr() >> 4)) & 0xFFFFFFFFFFFF
-    return v
+    return id(slots)
 
 
 def static_ok(module: nn.Module) -> bool:
-    """Every floating-point parameter / buffer below ``module`` is fp32 on one HIP device (cached
-    until a tensor moves)."""
-    layout = _layout_version(module)
+    """Every floating-point parameter / buffer below ``module`` is fp32 on one HIP device (cached until a tensor moves:
+    ``_apply`` drops the cache)."""
     hit = module.__dict__.get("_tfk_static_ok")
-    if hit is not None and hit[0] == layout:
-        return hit[1]
+    if hit is not None:
+        return hit
+    slots = module.__dict__.get("_tfk_slots")
+    if slots is None:
+        slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
     devices = set()
     ok = True
-    for _, _, t in module.__dict__["_tfk_slots"]:
+    for _, _, t in slots:
         if t.is_floating_point():
             devices.add(t.device)
             ok = ok and t.device.type == "cuda" and t.dtype == torch.float32
     ok = ok and len(devices) <= 1
-    module.__dict__["_tfk_static_ok"] = (layout, ok)
+    module.__dict__["_tfk_static_ok"] = ok
     return ok
+
+
+def tensors_moved(module: nn.Module) -> None:
+    """Called from ``_apply`` (``.to()`` / ``.cuda()`` / ``.float()`` ...): every cache that depends on where the
+    tensors live or on their values is dropped, on this module and -- because a parent's program packs this module's
+    weights -- this is also invoked for every ancestor that is itself being moved (Module._apply recurses)."""
+    for m in module.modules():          # (submodules that are not bijections -- conditioner blocks -- keep caches too)
+        d = m.__dict__
+        for k in [k for k in d if k.startswith("_tfk_") and k != "_tfk_declined_warned"]:
+            del d[k]
 
 
 def any_requires_grad(module: nn.Module) -> bool:
@@ -1001,7 +1009,7 @@ def invalidate(module: nn.Module, compiled_only: bool = False) -> None:
 # device), the flat tensor-slot list and the dtype / device check -- and therefore never go stale through a value
 # edit.  They must survive invalidate(): a captured hipGraph of the training step (Flow.fit, TORCHFLOWS_AMD_GRAPH=1)
 # reads the packs' index tensors on every replay, and fit() invalidates after every epoch of replays.
-_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_static_ok", "_tfk_declined_warned")
+_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_declined_warned")
 
 
 _CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
