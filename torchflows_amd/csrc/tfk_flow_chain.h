@@ -228,7 +228,8 @@ __device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, co
 #endif
 
 template <int EPL, int BLOCK, int STEPS2, int KIND>
-__global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR void k_flow_chain(
+__global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR
+__attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16 && BLOCK == 1024) ? 4 : 1)))) void k_flow_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
     const float *__restrict__ params, int n_params, ChainProg prog, int flags, int xw)
@@ -415,7 +416,12 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:
     // 736 us per launch against 389 with 512 threads, measured; the interpreter's trick does not carry over)
-    constexpr int BIG = 512;
+    // (D = 128: the chain's operands, ~90 KB, allow one workgroup per CU: 768 threads at <= 168 VGPRs put 3 waves on every
+    // SIMD -- RealNVP(128) 1.51e9 -> 1.54e9, RealNVP(100) 1.43e9 -> 1.52e9 evals/s; 1024 threads at 128 VGPRs: 1.38e9)
+#ifndef TFK_CHAIN_BIG16
+#define TFK_CHAIN_BIG16 768
+#endif
+    constexpr int BIG = (EPL == 16) ? TFK_CHAIN_BIG16 : 512;
 #define TFK_CB(BLOCK_, ST_) \
     launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
     switch (steps2) {
