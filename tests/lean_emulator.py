@@ -110,64 +110,47 @@ def run_lean(ops, params, rows, D):
             continue
         if kind in (17, 18):                                  # lean RQ-spline coupling
             K, boundary, scale, cdelta = op_extra[(kind, off)]
-            HEAD = EPL * 64 + 16 + 2 * HALF
-            A1 = prm[off:off + EPL * 64].reshape(EPL // 4, 64, 4)
-            b1 = prm[off + EPL * 64:off + EPL * 64 + 16]
-            pre = prm[off + EPL * 64 + 16:off + HEAD]
+            fmt3 = (int(K) >> 8) == 1
+            HT = 2 if (fmt3 and steps2 > 4) else 1
+            HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF
+            A1 = prm[off:off + EPL * HT * 64].reshape(EPL // 4, HT, 64, 4)
+            b1 = prm[off + EPL * HT * 64:off + EPL * HT * 64 + HT * 16].reshape(HT, 16)
+            pre = prm[off + EPL * HT * 64 + HT * 16:off + HEAD]
             src, tgt = (a, b) if plane == 0 else (b, a)
-            acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
-            for s_ in range(EPL):
-                acc = _mfma(A1[s_ // 4, :, s_ % 4], src[:, s_], acc)
+            hids = []
+            for th in range(HT):
+                acc = b1[th][(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+                for s_ in range(EPL):
+                    acc = _mfma(A1[s_ // 4, th, :, s_ % 4], src[:, s_], acc)
+                hids.append(1.0 - 2.0 / (torch.exp2(acc) + 1.0))
             tgt = pre[idx][:, :, None] * tgt + pre[HALF + idx][:, :, None]
-            hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)
+            hid = hids[0]
             tgt = tgt.clone()
             span = 2.0 * boundary
             C = (-boundary, boundary, span * scale, span * 1e-3, (cdelta + cdelta / 1000.0) * 1.4426950408889634)
-            fmt3 = (int(K) >> 8) == 1
-            if fmt3:                                          # bf16 x 3 operands: chunks of 4 elements
-                import numpy as np
-                def pieces(v32):                              # fp32 tensor -> (hi, mid, lo) as fp64, truncation split
-                    bits = v32.contiguous().view(torch.int32)
-                    hi = (bits & -65536).view(torch.float32)
-                    r1 = v32 - hi
-                    mid = (r1.contiguous().view(torch.int32) & -65536).view(torch.float32)
-                    r2 = r1 - mid
-                    lo = (r2.contiguous().view(torch.int32) & -65536).view(torch.float32)
-                    return hi.double(), mid.double(), lo.double()
-                hid3 = hid.clone()
-                hid3[q == 3, 3] = 1.0                         # hidden unit 15 carries the bias
-                h_hi, h_mid, h_lo = pieces(hid3.float())      # (64, 4, W): slot i = unit 4 i + q
-                CH3 = 24 * 2 * 64 * 4
+            if fmt3:                                          # bf16 x 3 operands: chunks of 4 / HT elements
+                hids[HT - 1] = hids[HT - 1].clone()
+                hids[HT - 1][q == 3, 3] = 1.0                 # the last hidden unit carries the bias
+                hp = [_pieces(h.float()) for h in hids]       # per hidden tile: (hi, mid, lo), each (64, 4, W)
                 raw = params.contiguous().view(torch.int32)
-                def unpack(d):                                # (64, 2 dwords) int32 -> (64, 4) fp64 bf16 values
-                    lo16 = ((d & 0xFFFF) << 16).view(torch.float32).double()
-                    hi16 = (d & -65536).view(torch.float32).double()
-                    return torch.stack([lo16[:, 0], hi16[:, 0], lo16[:, 1], hi16[:, 1]], dim=1)
-                def mm(Wl, Bl, o):
-                    """K = 16 product: Wl (64 lanes, 4 slots) = A[m = l & 15][unit 4 i + (l >> 4)], Bl (64, 4, W) likewise."""
-                    out = o.clone()
-                    for i in range(4):
-                        out = _mfma(Wl[:, i], Bl[:, i], out)
-                    return out
-                for ch in range(EPL // 4):
-                    base = off + HEAD + ch * CH3
-                    A = raw[base:base + 24 * 2 * 64 * 4].reshape(24, 2, 64, 4)
-                    for e in range(4):
-                        pp = []
-                        for c in range(6):
-                            t_ = e * 6 + c
-                            o = torch.zeros(64, 4, W, dtype=torch.float64)
-                            w_hi, w_mid = unpack(A[t_, 0][:, 0:2]), unpack(A[t_, 0][:, 2:4])
-                            w_lo, w_hi2 = unpack(A[t_, 1][:, 0:2]), unpack(A[t_, 1][:, 2:4])
-                            assert torch.equal(w_hi, w_hi2)
-                            o = mm(w_hi, h_hi, o); o = mm(w_mid, h_hi, o)
-                            o = mm(w_hi, h_mid, o); o = mm(w_mid, h_mid, o)
-                            o = mm(w_lo, h_hi, o); o = mm(w_hi, h_lo, o)
-                            pp.append(o)
-                        pvec = torch.cat(pp, 1).permute(0, 2, 1)
-                        out, l2 = rqs_lean_eval(pvec, tgt[:, 4 * ch + e], C, kind == 18)
-                        tgt[:, 4 * ch + e] = out
-                        ld2 = ld2 + l2
+                A = raw[off + HEAD:off + HEAD + EPL * 6 * HT * 2 * 64 * 4].reshape(EPL, 6, HT, 2, 64, 4)
+                for e in range(EPL):
+                    pp = []
+                    for c in range(6):
+                        o = torch.zeros(64, 4, W, dtype=torch.float64)
+                        for th in range(HT):
+                            w_hi, w_mid = _unpack_bf16(A[e, c, th, 0][:, 0:2]), _unpack_bf16(A[e, c, th, 0][:, 2:4])
+                            w_lo = _unpack_bf16(A[e, c, th, 1][:, 0:2])
+                            assert torch.equal(w_hi, _unpack_bf16(A[e, c, th, 1][:, 2:4]))
+                            h_hi, h_mid, h_lo = hp[th]
+                            for Wl, Bl in ((w_hi, h_hi), (w_mid, h_hi), (w_hi, h_mid), (w_mid, h_mid), (w_lo, h_hi), (w_hi, h_lo)):
+                                for i in range(4):
+                                    o = _mfma(Wl[:, i], Bl[:, i], o)
+                        pp.append(o)
+                    pvec = torch.cat(pp, 1).permute(0, 2, 1)
+                    out, l2 = rqs_lean_eval(pvec, tgt[:, e], C, kind == 18)
+                    tgt[:, e] = out
+                    ld2 = ld2 + l2
                 sign = 1.0
                 if plane == 0:
                     b = tgt

@@ -112,11 +112,9 @@ def test_fused_spline_flow_vs_layerwise_vs_oracle(pkg, oracle, monkeypatch, D, n
     got_fused, _, got_layer = run_both(flow, x.cuda(), monkeypatch)
     monkeypatch.setenv("TORCHFLOWS_AMD_FUSED", "1")
     flow.bijection.__dict__.pop("_tfk_compiled", None)
-    if D <= 128:
-        assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is not None
-        assert got_fused["launches"] < got_layer["launches"]
-    else:       # D = 256: one coupling's 17 x 128 x 24 weights (209 KB) exceed the LDS -> layer by layer
-        assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is None
+    # (D = 256, hidden width 17: two hidden tiles, operands streamed chunk by chunk -- round 1 ran it layer by layer)
+    assert fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0)) is not None
+    assert got_fused["launches"] < got_layer["launches"]
     z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
     xr_ref, ldi_ref = ref.inverse(x.numpy())
     for name, got in (("fused", got_fused), ("layerwise", got_layer)):
@@ -630,3 +628,32 @@ def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):
         xr, _ = flow.bijection.inverse(z1)
     assert rel(lp1.cpu().numpy(), lp_h.numpy()) < 1e-5 and rel(lp1.cpu().numpy(), lp0.cpu().numpy()) < 2e-6
     assert torch.allclose(xr.cpu(), x, atol=1e-4)
+
+
+@pytest.mark.parametrize("D,n_hidden", [(64, 24), (64, 31), (128, None), (256, None), (22, 20)])
+def test_spline_chain_two_hidden_tiles(D, n_hidden):
+    """CouplingRQNSF chains whose conditioner is wider than 15 units -- a user-chosen n_hidden, or the default at D = 256
+    (17 units) -- run as ONE single-launch spline chain with two hidden tiles (bf16 x 3 operands); D = 128 (15 units)
+    takes one.  Against the host (ATen, fp32) path; one libtfk launch per log_prob."""
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    torch.manual_seed(6)
+    kw = {} if n_hidden is None else dict(conditioner_kwargs=dict(n_hidden=n_hidden))
+    flow = tfa.Flow(tfa.CouplingRQNSF(D, n_layers=2, **kw))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow.eval()
+    x = torch.randn(700, D) * 1.5
+    with torch.no_grad():
+        lp_h = flow.log_prob(x)
+        z_h, _ = flow.bijection.forward(x)
+        flow = flow.cuda()
+        before = native.calls
+        lp_d = flow.log_prob(x.cuda())
+        assert native.calls - before == 1
+        z_d, ld_d = flow.bijection.forward(x.cuda())
+        xr, ldr = flow.bijection.inverse(z_d)
+    assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 1e-5 * max(1.0, D / 64)
+    assert normwise(z_d.cpu().numpy(), z_h.numpy()) < 2e-5
+    assert torch.allclose(xr.cpu(), x, atol=1e-3) and torch.allclose(ld_d, -ldr, atol=1e-3)

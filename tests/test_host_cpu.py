@@ -469,7 +469,9 @@ def test_torchflows_import_alias_resolves_to_the_build():
 @pytest.mark.parametrize("arch,D,n_layers,direction", [("RealNVP", 64, 8, 0), ("RealNVP", 64, 3, 1), ("NICE", 64, 4, 0),
                                                        ("RealNVP", 128, 2, 0), ("RealNVP", 22, 3, 0), ("NICE", 8, 3, 1),
                                                        ("CouplingRQNSF", 64, 3, 0), ("CouplingRQNSF", 64, 2, 1),
-                                                       ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1)])
+                                                       ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1),
+                                                       ("CouplingRQNSF-h24", 64, 2, 0), ("CouplingRQNSF-h31", 64, 2, 1),
+                                                       ("CouplingRQNSF", 256, 2, 0)])
 @pytest.mark.parametrize("bf16x3", ["1", "0"])
 def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, bf16x3, monkeypatch):
     """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
@@ -483,7 +485,15 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     monkeypatch.setenv("TORCHFLOWS_AMD_RQS_BF16X3", bf16x3)
     monkeypatch.setenv("TORCHFLOWS_AMD_LEAN_BF16X3", bf16x3)
     torch.manual_seed(3)
-    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers))
+    kw = {}
+    if "-h" in arch:                                          # wider conditioner: two hidden tiles (bf16 x 3 format only)
+        arch, h = arch.split("-h")
+        kw = dict(conditioner_kwargs=dict(n_hidden=int(h)))
+        if bf16x3 == "0":
+            pytest.skip("fp32 operands stop at hidden width 16")
+    if D == 256 and bf16x3 == "0":
+        pytest.skip("CouplingRQNSF(256) has hidden width 17: bf16 x 3 operands only")
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers, **kw))
     flow.train()
     with torch.no_grad():
         flow.log_prob(torch.randn(512, D) * 1.5 + 0.3)

@@ -29,8 +29,10 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     const int EPL = D / 8, HALF = D / 2;
     // operand format: K = 8 -> fp32 A-operands (chunks of 8 elements); K = 8 + 256 -> bf16 x 3 (chunks of 4 elements)
     const bool fmt3 = n_ops > 0 && (ops[4] >> 8) == 1;
-    const int64_t block = (int64_t)EPL * 64 + 16 + 2 * HALF +
-                          (fmt3 ? (int64_t)(EPL / 4) * kRqsChunk3Dwords : (int64_t)(EPL / 8) * kRqsChunkFloats);
+    // bf16 x 3: gemm2_steps = ceil((H + 1) / 4) counts the bias unit; more than 4 steps = two hidden tiles
+    const int ht3 = (fmt3 && n_ops > 0 && ops[2] > 4) ? 2 : 1;
+    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (int64_t)(EPL * ht3 / 4) * kRqsChunk3Dwords
+                               : (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
     RqsChainProg prog;
     memset(&prog, 0, sizeof(prog));
     prog.ew_offset = -1;
@@ -55,7 +57,8 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
         if ((rec[4] & 255) != 8) return fail(TFK_EINVAL, "%s: op %d: lean spline ops support n_bins = 8, got %d", fn, i, rec[4] & 255);
         if (((rec[4] >> 8) == 1) != fmt3 || (rec[4] >> 8) > 1)
             return fail(TFK_EINVAL, "%s: op %d: the ops of a lean spline program share one operand format", fn, i);
-        if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
+        if (st < 1 || st > (fmt3 ? 8 : 4))
+            return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, %d]", fn, i, st, fmt3 ? 8 : 4);
         if (src != 0 && src != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, src);
         if (!(bnd > 0.0f)) return fail(TFK_EINVAL, "%s: op %d: boundary must be positive", fn, i);
         if (off < 0 || (off & 3) || off + block > n_params)
@@ -85,7 +88,7 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     prog.C.cmin = (float)(span * 1e-3);
     prog.C.d_edge = (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
     const int inverse = kind == TFK_OP_RQS_INV_LEAN;
-    if (fmt3) steps2 = 0;
+    if (fmt3) steps2 = ht3 == 2 ? 8 : 0;
     if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);

@@ -258,56 +258,66 @@ __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float 
 // carry the first product's 4 hidden units, slots 4..7 the second's), ~17.7 cycles each, instead of four
 // v_mfma_f32_16x16x4_f32 of 32 cycles: 319 instead of 768 matrix cycles per spline element.  The weights are split by
 // the packer; the 4 hidden activations of a lane are split once per layer (16 + 6 vector instructions).
-template <int EPL, int BLOCK, bool INVERSE>
+// HT = 16-unit tiles of the hidden layer (hidden width <= 16 HT - 1: the last unit carries b2); a chunk holds
+// 4 / HT target elements, so its size does not depend on HT.
+// Block: head A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then chunks A[4/HT][6][HT][2][64][4 dwords].
+template <int EPL, int BLOCK, int HT, bool INVERSE>
 __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float *stage, int lane, int q,
                                            const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2)
 {
     constexpr int HALF = 4 * EPL;
-    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
-    constexpr int NC = EPL / 4;
+    constexpr int HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF;
+    constexpr int ELEMS = 4 / HT;
+    constexpr int NC = EPL / ELEMS;
+    constexpr bool STATIC_CH = NC <= 8;                       // chunk loop unrolled: the element index is static
     float *head_s = stage;
     float *chunk_s = stage + HEAD;
-    ci32x4 B1, B2, B3;                                        // [h_hi | h_hi], [h_mid | h_mid], [h_hi | h_lo]
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch) {
+    ci32x4 B1[HT], B2[HT], B3[HT];                            // [h_hi | h_hi], [h_mid | h_mid], [h_hi | h_lo] per hidden tile
+
+    auto stage_in = [&](int ch) {
         __syncthreads();
-        {
-            const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * kRqsChunk3Dwords);
-            float4 *d4 = reinterpret_cast<float4 *>(chunk_s);
-            for (int i = threadIdx.x; i < kRqsChunk3Dwords / 4; i += BLOCK) d4[i] = g4[i];
-            if (ch == 0) {
-                const float4 *h4 = reinterpret_cast<const float4 *>(gprm);
-                float4 *e4 = reinterpret_cast<float4 *>(head_s);
-                for (int i = threadIdx.x; i < HEAD / 4; i += BLOCK) e4[i] = h4[i];
-            }
+        const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * kRqsChunk3Dwords);
+        float4 *d4 = reinterpret_cast<float4 *>(chunk_s);
+        for (int i = threadIdx.x; i < kRqsChunk3Dwords / 4; i += BLOCK) d4[i] = g4[i];
+        if (ch == 0) {
+            const float4 *h4 = reinterpret_cast<const float4 *>(gprm);
+            float4 *e4 = reinterpret_cast<float4 *>(head_s);
+            for (int i = threadIdx.x; i < HEAD / 4; i += BLOCK) e4[i] = h4[i];
         }
         __syncthreads();
-        if (ch == 0) {
-            const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(head_s);
-            const float *b1 = head_s + EPL * 64;
-            const float *pre = b1 + 16;
-            cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+    };
+    auto gemm1 = [&]() {
+        const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(head_s);
+        const float *b1 = head_s + EPL * HT * 64;
+        const float *pre = b1 + HT * 16;
+        cf32x4 acc[HT];
 #pragma unroll
-            for (int g = 0; g < EPL / 4; ++g) {
-                const cf32x4 w = A1[g * 64 + lane];
+        for (int t = 0; t < HT; ++t) acc[t] = *reinterpret_cast<const cf32x4 *>(b1 + t * 16 + 4 * q);
+#pragma unroll
+        for (int g = 0; g < EPL / 4; ++g)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                const cf32x4 w = A1[(g * HT + t) * 64 + lane];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < EPL / 4; ++i) {
-                const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
-                const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+        for (int i = 0; i < EPL / 4; ++i) {
+            const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+            const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
-            }
+            for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
             int hi[4], mid[4], lo[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float h = fmaf(-2.0f, rcp_f(exp2_f(acc[r]) + 1.0f), 1.0f);
-                // hidden unit 15 (lane-group 3, register 3) is the constant 1 that carries b2 through GEMM 2: no bias
-                // reads -- the LDS, not the matrix pipe, bounded the first version (18 ds_read_b128 per element and wave)
-                if (r == 3) h = (q == 3) ? 1.0f : h;
+                float h = fmaf(-2.0f, rcp_f(exp2_f(acc[t][r]) + 1.0f), 1.0f);
+                // the last hidden unit (tile HT - 1, lane-group 3, register 3) is the constant 1 that carries b2 through
+                // GEMM 2: no bias reads
+                if (t == HT - 1 && r == 3) h = (q == 3) ? 1.0f : h;
                 const int hb = __float_as_int(h) & (int)0xffff0000;
                 const float r1 = h - __int_as_float(hb);                      // exact
                 const int mb = __float_as_int(r1) & (int)0xffff0000;
@@ -318,36 +328,40 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
             const int hh01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302), hh23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302);
             const int mm01 = __builtin_amdgcn_perm(mid[1], mid[0], 0x07060302), mm23 = __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302);
             const int ll01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302), ll23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302);
-            B1 = ci32x4{hh01, hh23, hh01, hh23};
-            B2 = ci32x4{mm01, mm23, mm01, mm23};
-            B3 = ci32x4{hh01, hh23, ll01, ll23};
+            B1[t] = ci32x4{hh01, hh23, hh01, hh23};
+            B2[t] = ci32x4{mm01, mm23, mm01, mm23};
+            B3[t] = ci32x4{hh01, hh23, ll01, ll23};
         }
-        const ci32x4 *A = reinterpret_cast<const ci32x4 *>(chunk_s);          // [tile][2][64]
+    };
+    auto chunk = [&](int ch) {
+        const ci32x4 *A = reinterpret_cast<const ci32x4 *>(chunk_s);          // [elem][6][HT][2][64]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // the six tiles of an element side by side, product by product: a bf16 MFMA issues in ~16 cycles but its
-            // result takes longer, so the three MFMAs of ONE tile must not follow each other (back to back they ran at
-            // ~36 cycles each: measured, the first version of this loop)
+        for (int e = 0; e < ELEMS; ++e) {
+            // the tiles of an element side by side, product by product: a bf16 MFMA issues in ~16 cycles but its result
+            // takes longer, so the MFMAs of ONE tile must not follow each other (back to back they ran at ~36 cycles
+            // each: measured, the first version of this loop); groups of three tiles = 36 operand / accumulator registers
             float p[24];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {                      // two groups of three tiles: 36 operand / accumulator registers
+            for (int g = 0; g < 2; ++g) {
                 cf32x4 o[3];
-                ci32x4 a1[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    o[c] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    a1[c] = A[((e * 6 + 3 * g + c) * 2) * 64 + lane];
-                }
+                for (int c = 0; c < 3; ++c) o[c] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B1), o[c], 0, 0, 0);
+                for (int t = 0; t < HT; ++t) {
+                    ci32x4 a1[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B2), o[c], 0, 0, 0);
+                    for (int c = 0; c < 3; ++c) a1[c] = A[(((e * 6 + 3 * g + c) * HT + t) * 2) * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const ci32x4 a2 = A[((e * 6 + 3 * g + c) * 2 + 1) * 64 + lane];
-                    o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a2), __builtin_bit_cast(cbf16x8, B3), o[c], 0, 0, 0);
+                    for (int c = 0; c < 3; ++c)
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B1[t]), o[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B2[t]), o[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const ci32x4 a2 = A[(((e * 6 + 3 * g + c) * HT + t) * 2 + 1) * 64 + lane];
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a2), __builtin_bit_cast(cbf16x8, B3[t]), o[c], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -355,21 +369,47 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
                     p[12 * g + 4 * c + 2] = o[c][2]; p[12 * g + 4 * c + 3] = o[c][3];
                 }
             }
-            const float v = tgt[4 * ch + e];                   // (the chunk loop is unrolled: a static index)
+            float v;
+            if constexpr (STATIC_CH) {
+                v = tgt[ELEMS * ch + e];
+            } else {                                           // run-time chunk index: a select over the chunks
+                v = tgt[e];
+#pragma unroll
+                for (int c2 = 1; c2 < NC; ++c2) v = (ch == c2) ? tgt[ELEMS * c2 + e] : v;
+            }
             float out = v, l = 0.0f;
             if (v > C.minimum && v < C.maximum) rqs_eval_lean<INVERSE>(p, v, C, out, l);
             ld2 += l;
-            tgt[4 * ch + e] = out;
+            if constexpr (STATIC_CH) {
+                tgt[ELEMS * ch + e] = out;
+            } else {
+#pragma unroll
+                for (int c2 = 0; c2 < NC; ++c2) tgt[ELEMS * c2 + e] = (ch == c2) ? out : tgt[ELEMS * c2 + e];
+            }
+        }
+    };
+    if constexpr (STATIC_CH) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(ch);
+            if (ch == 0) gemm1();
+            chunk(ch);
+        }
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(ch);
+            if (ch == 0) gemm1();
+            chunk(ch);
         }
     }
 }
 
-// STEPS2 = 0 selects the bf16 x 3 operand format (rqs_layer3), 1..4 the fp32 one with that many GEMM-2 k-steps
 #ifndef TFK_RQS3_WAVES
 #define TFK_RQS3_WAVES 4
 #endif
 template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(STEPS2 == 0 ? TFK_RQS3_WAVES : 1)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((STEPS2 == 0 || STEPS2 == 8) ? (EPL == 32 ? 2 : TFK_RQS3_WAVES) : 1)))
 void k_flow_rqs_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
@@ -377,11 +417,13 @@ void k_flow_rqs_chain(
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
-    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
+    constexpr bool F3 = STEPS2 == 0 || STEPS2 == 8;
+    constexpr int HT3 = STEPS2 == 8 ? 2 : 1;
+    constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;
     const bool base_of_input = (flags & 4) != 0;
-    constexpr int CHUNK = STEPS2 == 0 ? kRqsChunk3Dwords : kRqsChunkFloats;
+    constexpr int CHUNK = F3 ? kRqsChunk3Dwords : kRqsChunkFloats;
     float *stage = lds;                                      // [HEAD + chunk]
     float *ew_s = lds + HEAD + CHUNK;                        // s[D] | t[D] | ldc, pad[3]
     float *base_s = ew_s + 2 * D + 4;                        // loc[D] | 1/scale[D] | const
@@ -457,9 +499,9 @@ void k_flow_rqs_chain(
 #pragma unroll 1
         for (int l = 0; l < prog.n_layers; ++l) {
             const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
-            if constexpr (STEPS2 == 0) {
-                if (((prog.first_src + l) & 1) == 0) rqs_layer3<EPL, BLOCK, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
-                else rqs_layer3<EPL, BLOCK, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+            if constexpr (F3) {
+                if (((prog.first_src + l) & 1) == 0) rqs_layer3<EPL, BLOCK, HT3, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
+                else rqs_layer3<EPL, BLOCK, HT3, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
             } else {
                 if (((prog.first_src + l) & 1) == 0)
                     rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
@@ -522,8 +564,10 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
                               int xw, hipStream_t s, const char *fn)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
-    constexpr int HEAD = EPL * 64 + 16 + 2 * HALF;
-    const size_t lds = ((size_t)HEAD + (STEPS2 == 0 ? kRqsChunk3Dwords : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float);
+    constexpr bool F3 = STEPS2 == 0 || STEPS2 == 8;
+    constexpr int HT3 = STEPS2 == 8 ? 2 : 1;
+    constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
+    const size_t lds = ((size_t)HEAD + (F3 ? kRqsChunk3Dwords : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float);
     auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -556,7 +600,8 @@ static int launch_rqs_chain(const float *x, float *z, float *logdet, const float
     (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn) \
              : launch_rqs_chain_b<EPL, 512, ST_, false>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn))
     switch (steps2) {
-    case 0: return TFK_RC(0);                                // bf16 x 3 operands
+    case 0: return TFK_RC(0);                                // bf16 x 3 operands, hidden width <= 15
+    case 8: return TFK_RC(8);                                // bf16 x 3 operands, hidden width <= 31
     case 1: return TFK_RC(1);
     case 2: return TFK_RC(2);
     case 3: return TFK_RC(3);

@@ -601,7 +601,7 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     W1, b1 = mods[0].weight.detach().double(), mods[0].bias.detach().double()
     W2, b2 = mods[2].weight.detach().double(), mods[2].bias.detach().double()
     H = W1.shape[0]
-    if H > 16 or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
+    if H > (31 if kind == "rqs" else 16) or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
         return None
     hp = Dp // 2
     src_pos, tgt_pos = pos[:S], pos[S:]
@@ -714,18 +714,21 @@ def _bf16_pieces(w: torch.Tensor):
 
 
 def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float, bf16x3: bool = False) -> torch.Tensor:
-    """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out:
-    head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks A2[48][64][4] | b2[48][4][4].
+    """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out.
+    fp32 operands (hidden width <= 16): head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks
+    A2[48][64][4] | b2[48][4][4].  bf16 x 3 operands (hidden width <= 15, or <= 31 with HT = 2 hidden tiles): head
+    A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then EPL HT / 4 chunks A[4/HT][6][HT][2][64][4 dwords].
     Per target element 24 parameters, all times log2(e): [0, 8) u_x, [8, 16) u_x + u_y / 1000 (the reference's height
     logits, rational_quadratic.py:76), [16, 23) c + u_d / 1000 (:77, c = boundary_u_delta), pad."""
     hp, EPL = Dp // 2, Dp // 8
-    NC = EPL // 8
     dev = W1t.device
-    W1pad = torch.zeros(16, hp, dtype=torch.float64, device=dev)
+    HT = 2 if (bf16x3 and H > 15) else 1
+    HU = 16 * HT                                                   # hidden units the kernel sees
+    W1pad = torch.zeros(HU, hp, dtype=torch.float64, device=dev)
     W1pad[:H] = W1t * (2.0 * LOG2E)
-    b1pad = torch.zeros(16, dtype=torch.float64, device=dev)
+    b1pad = torch.zeros(HU, dtype=torch.float64, device=dev)
     b1pad[:H] = b1 * (2.0 * LOG2E)
-    Q = torch.zeros(hp, 24, 16, dtype=torch.float64, device=dev)
+    Q = torch.zeros(hp, 24, HU, dtype=torch.float64, device=dev)
     Q[:, 0:8, :H] = W2p[:, 0:8] * LOG2E
     Q[:, 8:16, :H] = (W2p[:, 0:8] + W2p[:, 8:16] / 1000.0) * LOG2E
     Q[:, 16:23, :H] = W2p[:, 16:23] / 1000.0 * LOG2E
@@ -736,37 +739,33 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
     unit1 = 4 * (il & 3) + (il >> 2)
-    A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)]).reshape(EPL // 4, 4, 64).permute(0, 2, 1)
+    # A1[g][t][lane][k]: source k-step 4 g + k, hidden tile t, D-row i <-> unit 16 t + unit1(i)
+    A1 = torch.stack([torch.stack([W1pad[16 * t + unit1, EPL * ql + s_] for t in range(HT)]) for s_ in range(EPL)])
+    A1 = A1.reshape(EPL // 4, 4, HT, 64).permute(0, 2, 3, 1)                          # (EPL/4, HT, 64, 4)
     qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
-    b1m = b1pad[4 * rr + qq]
+    b1m = torch.stack([b1pad[16 * t + 4 * rr + qq] for t in range(HT)])                # [t][q][r]
     q2, r2 = il >> 2, il & 3
-    ch = torch.arange(NC, device=dev).view(NC, 1, 1, 1, 1)
-    e = torch.arange(8, device=dev).view(1, 8, 1, 1, 1)
-    c = torch.arange(6, device=dev).view(1, 1, 6, 1, 1)
-    r1 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
-    m = EPL * q2.view(1, 1, 1, 64, 1) + 8 * ch + e
-    A2 = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 4 * r1 + ql.view(1, 1, 1, 64, 1)]          # (NC, 8, 6, 64, 4)
-    mb = EPL * qq.view(1, 1, 1, 4, 4) + 8 * ch + e
-    b2 = bq[mb, 4 * c + rr.view(1, 1, 1, 4, 4)]                                            # (NC, 8, 6, 4, 4)
     parts = [A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]
+    e_all = torch.arange(EPL, device=dev).view(EPL, 1, 1, 1, 1)                        # the lane-group's element index
+    c = torch.arange(6, device=dev).view(1, 6, 1, 1, 1)
+    m = EPL * q2.view(1, 1, 1, 64, 1) + e_all                                          # physical target element
     if bf16x3:
-        # chunks of 4 elements; per tile and lane the operands [W_hi | W_mid] and [W_lo | W_hi], 4 bf16 each: slot i of
-        # lane-group q <-> hidden unit 4 i + q (the k-steps r1 of the fp32 layout)
-        # the bias as the weight of hidden unit 15 (= 1 in the kernel): lane-group 3, slot 3
-        A2 = A2.clone()
-        A2[:, :, :, 48:64, 3] = b2.reshape(NC, 8, 6, 16)          # lane 48 + i <-> D-row i = 4 q2 + r2 = b2's [q][r] order
-        hi, mid, lo = _bf16_pieces(A2.reshape(NC * 8, 6, 64, 4))               # (elements, 6, 64, 4) int32, low halves
-        pack2 = lambda t: (t[..., 0::2] | (t[..., 1::2] << 16))                # two bf16 per dword: (…, 2)
-        a1 = torch.cat([pack2(hi), pack2(mid)], dim=-1)                        # (elements, 6, 64, 4 dwords)
+        Q[:, :, HU - 1] = bq                                   # the bias as the weight of the last hidden unit (= 1)
+        th = torch.arange(HT, device=dev).view(1, 1, HT, 1, 1)
+        i4 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
+        Wf = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 16 * th + 4 * i4 + ql.view(1, 1, 1, 64, 1)]   # (EPL, 6, HT, 64, 4)
+        hi, mid, lo = _bf16_pieces(Wf)
+        pack2 = lambda v: (v[..., 0::2] | (v[..., 1::2] << 16))
+        a1 = torch.cat([pack2(hi), pack2(mid)], dim=-1)
         a2 = torch.cat([pack2(lo), pack2(hi)], dim=-1)
-        A3 = torch.stack([a1, a2], dim=2).to(torch.int32)                       # (elements, 6, 2, 64, 4)
-        head = torch.cat(parts).float()
-        out = [head]
-        for k in range(EPL // 4):
-            out.append(A3[4 * k:4 * k + 4].reshape(-1).view(torch.float32))
-        return torch.cat(out)
-    for k in range(NC):
-        parts += [A2[k].reshape(-1), b2[k].reshape(-1)]
+        A3 = torch.stack([a1, a2], dim=3).to(torch.int32)                              # (EPL, 6, HT, 2, 64, 4)
+        return torch.cat([torch.cat(parts).float(), A3.reshape(-1).view(torch.float32)])
+    r1 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
+    A2 = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 4 * r1 + ql.view(1, 1, 1, 64, 1)][:, :, 0]   # (EPL, 6, 64, 4)
+    mb = EPL * qq.view(1, 1, 4, 4) + torch.arange(EPL, device=dev).view(EPL, 1, 1, 1)
+    b2 = bq[mb, 4 * torch.arange(6, device=dev).view(1, 6, 1, 1) + rr.view(1, 1, 4, 4)]       # (EPL, 6, 4, 4)
+    for k in range(EPL // 8):
+        parts += [A2[8 * k:8 * k + 8].reshape(-1), b2[8 * k:8 * k + 8].reshape(-1)]
     return torch.cat(parts).float()
 
 
@@ -813,19 +812,23 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     return None
                 lk, plane, H, W1t, b1, W2p, b2p = got
                 steps2 = (H + 3) // 4
+                if lk >= 4 and rqs_bf16x3_enabled():
+                    steps2 = (H + 1 + 3) // 4                 # bf16 x 3 operands: counts the bias unit; > 4 = two hidden tiles
                 if kind0 is None:
                     kind0, steps0 = lk, steps2
                 elif (lk, steps2) != (kind0, steps0) or plane != 1 - items[-1][1]:
                     return None
-                if lk >= 4 and Dp > 128 and H > 16:
-                    return None
+
                 src = torch.arange(plane * hp, (plane + 1) * hp, device=device)
                 tgt = torch.arange((1 - plane) * hp, (2 - plane) * hp, device=device)
                 b1f = b1 + W1t @ t[src]                      # W1 (s x + t) + b1 = (W1 s) x + (W1 t + b1)
                 W1f = W1t * s[src]
                 if lk >= 4:                                  # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
-                    fmt3 = rqs_bf16x3_enabled() and H <= 15          # (hidden unit 15 carries the bias)
+                    fmt3 = rqs_bf16x3_enabled()                       # (the last hidden unit carries the bias: H <= 31)
+                    if not fmt3 and H > 16:
+                        return None
+
                     extra = (8 + (256 if fmt3 else 0), float(tr.boundary),
                              float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)), float(np.float32(tr.boundary_u_delta)))
                     if items and items[-1][4] != extra:
