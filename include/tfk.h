@@ -247,7 +247,13 @@ enum {
      * (conditioning/context.py:46-60): src_plane bits 4..7 = cs, and cs further GEMM-1 A-operand steps A1c[cs][64]
      * follow the op's block. */
     TFK_OP_EWC_MULADD = 19,
-    TFK_OP_EWC_SUBDIV = 20
+    TFK_OP_EWC_SUBDIV = 20,
+    /* lean MADE programs (the parallel map of MAF / IAF layers, cf. TFK_OP_MADE_*): a chain of MADE-based affine layers
+     * of one kind and one hidden width (<= 16), optionally ended by one TFK_OP_EW_FMA, on the straight-line kernel.
+     * Block: A1[D/16][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | A2[nA2/4][64][4] | b2[D/8][4][4] |
+     * pre_s[D] | pre_t[D], weights pre-scaled as for the lean couplings; every element takes its pre-affine. */
+    TFK_OP_MADE_FWD_LEAN = 21,
+    TFK_OP_MADE_INV_LEAN = 22
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

@@ -180,6 +180,34 @@ def run_lean(ops, params, rows, D):
             else:
                 a = tgt
             continue
+        if kind in (21, 22):                                  # lean MADE layer (made_lean)
+            nA2 = (EPL * steps2 + 3) & ~3
+            A1 = prm[off:off + 2 * EPL * 64].reshape(2 * EPL // 4, 64, 4)
+            b1 = prm[off + 2 * EPL * 64:off + 2 * EPL * 64 + 16]
+            o2 = off + 2 * EPL * 64 + 16
+            A2 = prm[o2:o2 + nA2 * 64].reshape(nA2 // 4, 64, 4)
+            b2 = prm[o2 + nA2 * 64:o2 + nA2 * 64 + EPL * 16]
+            pre = prm[o2 + nA2 * 64 + EPL * 16:]
+            acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+            for s_ in range(EPL):
+                acc = _mfma(A1[s_ // 4, :, s_ % 4], a[:, s_], acc)
+                acc = _mfma(A1[EPL // 4 + s_ // 4, :, s_ % 4], b[:, s_], acc)
+            a = (pre[idx][:, :, None] * a + pre[D + idx][:, :, None]).clone()
+            b = (pre[HALF + idx][:, :, None] * b + pre[D + HALF + idx][:, :, None]).clone()
+            hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)
+            for t_ in range(EPL):
+                o = b2[((t_ * 4 + q) * 4)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+                for k in range(steps2):
+                    e_ = t_ * steps2 + k
+                    o = _mfma(A2[e_ // 4, :, e_ % 4], hid[:, k], o)
+                plane_t, tt = (a, t_) if t_ < EPL // 2 else (b, t_ - EPL // 2)
+                for i in range(2):
+                    al = torch.exp2(o[:, 2 * i]) + 1e-10
+                    ld2 = ld2 + torch.log2(al)
+                    e = 2 * tt + i
+                    plane_t[:, e] = al * plane_t[:, e] + o[:, 2 * i + 1] if kind == 21 else (plane_t[:, e] - o[:, 2 * i + 1]) / al
+            sign = 1.0 if kind == 21 else -1.0
+            continue
         lk = kind - 12
         affine = lk < 2
         T2 = EPL // 2 if affine else EPL // 4

@@ -471,7 +471,8 @@ def test_torchflows_import_alias_resolves_to_the_build():
                                                        ("CouplingRQNSF", 64, 3, 0), ("CouplingRQNSF", 64, 2, 1),
                                                        ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1),
                                                        ("CouplingRQNSF-h24", 64, 2, 0), ("CouplingRQNSF-h31", 64, 2, 1),
-                                                       ("CouplingRQNSF", 256, 2, 0)])
+                                                       ("CouplingRQNSF", 256, 2, 0),
+                                                       ("MAF", 64, 3, 0), ("IAF", 64, 2, 1), ("MAF", 22, 2, 0), ("MAF", 128, 2, 0)])
 @pytest.mark.parametrize("bf16x3", ["1", "0"])
 def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, bf16x3, monkeypatch):
     """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
@@ -514,7 +515,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     rows[:, pos] = x
     ld = torch.zeros(64, dtype=torch.float64)
     for seg in chain.segments:
-        assert seg.mfma and all(12 <= op[0] <= 18 for op in seg.ops)
+        assert seg.mfma and all(12 <= op[0] <= 22 and op[0] not in (19, 20) for op in seg.ops)
         rows, l = run_lean(seg.ops, seg.params, rows, Dp)
         ld = ld + l
     got = rows[:, chain.pos]

@@ -213,6 +213,82 @@ __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, 
     }
 }
 
+
+// MADE-based affine layer, parallel map (MaskedAutoregressiveBijection.forward, layers_base.py:201-206; MADE = two
+// masked linear layers, transforms.py:184-267, masks folded into the packed weights), in the lean form: the
+// conditioner reads BOTH planes as they are (pending elementwise layers folded into W1 / b1), every element of both
+// planes then takes its pending layers (one fma) and is transformed with parameters that depend on the preceding
+// elements only.  KIND 4: alpha x + beta, 5: (x - beta) / alpha.
+// Block: A1[2 EPL / 4][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | A2[nA2 / 4][64][4] | b2[EPL][4][4] |
+//        pre_s[D] | pre_t[D];  tile t < EPL / 2: this lane's elements 2 t, 2 t + 1 of plane A, else of plane B.
+template <int EPL, int STEPS2, int KIND>
+__device__ __forceinline__ void made_lean(const float *prm, int lane, int q, float (&a)[EPL], float (&b)[EPL], float &ld2)
+{
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    constexpr int T2 = EPL;
+    constexpr int NA2 = (T2 * STEPS2 + 3) & ~3;
+    const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(prm);
+    const float *b1 = prm + 2 * EPL * 64;
+    const cf32x4 *A2 = reinterpret_cast<const cf32x4 *>(b1 + 16);
+    const float *b2 = b1 + 16 + NA2 * 64;
+    const float *pre = b2 + T2 * 16;
+
+    cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+#pragma unroll
+    for (int g = 0; g < EPL / 4; ++g) {
+        const cf32x4 wa = A1[g * 64 + lane], wb = A1[(EPL / 4 + g) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k], a[4 * g + k], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[k], b[4 * g + k], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+        const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+        const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(pre + D + EPL * q + 4 * i);
+        const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(pre + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
+            b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+        }
+    }
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        hid[r] = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[r]) + 1.0f), 1.0f);
+
+    constexpr int GT = (STEPS2 == 4) ? 1 : ((STEPS2 == 2) ? 2 : 4);
+    constexpr int GREG = GT * STEPS2;
+#pragma unroll
+    for (int t0 = 0; t0 < T2; t0 += GT) {
+        float a2[GREG];
+#pragma unroll
+        for (int g = 0; g < GREG / 4; ++g) {
+            const cf32x4 w = A2[((t0 * STEPS2) / 4 + g) * 64 + lane];
+            a2[4 * g] = w[0]; a2[4 * g + 1] = w[1]; a2[4 * g + 2] = w[2]; a2[4 * g + 3] = w[3];
+        }
+#pragma unroll
+        for (int tt = 0; tt < GT; ++tt) {
+            const int t = t0 + tt;
+            cf32x4 o = *reinterpret_cast<const cf32x4 *>(b2 + (t * 4 + q) * 4);
+#pragma unroll
+            for (int k = 0; k < STEPS2; ++k)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt * STEPS2 + k], hid[k], o, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float al = __builtin_amdgcn_exp2f(o[2 * i]) + kAffMinScale;
+                ld2 += __builtin_amdgcn_logf(al);
+                float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
+                if constexpr (KIND == 4) v = fmaf(al, v, o[2 * i + 1]);
+                else v = (v - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al);
+            }
+        }
+    }
+}
+
 // one coupling in whichever operand format the kernel was instantiated for (STEPS2 = 0: bf16 x 3)
 template <int EPL, int STEPS2, int KIND>
 __device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, const float (&src)[EPL],
@@ -314,17 +390,23 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
 
         float ld2 = 0.0f;                                             // this lane's share, in base 2
         int o = 0;
-        if (prog.first_src == 1 && prog.n_c > 0) {
-            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
-            o = 1;
+        if constexpr (KIND >= 4) {                                    // MADE layers: both planes in, both planes out
+#pragma unroll 1
+            for (; o < prog.n_c; ++o)
+                made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+        } else {
+            if (prog.first_src == 1 && prog.n_c > 0) {
+                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
+                o = 1;
+            }
+            for (; o + 1 < prog.n_c; o += 2) {
+                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
+                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
+            }
+            if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
         }
-        for (; o + 1 < prog.n_c; o += 2) {
-            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
-            couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
-        }
-        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
-        if constexpr (KIND == 0) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
-        else if constexpr (KIND == 1) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
+        if constexpr (KIND == 0 || KIND == 4) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
+        else if constexpr (KIND == 1 || KIND == 5) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
 
         if (prog.ew_offset >= 0) {                                    // what is still pending, one fma per element
             const float *ew = lds + prog.ew_offset;
@@ -426,7 +508,7 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
     launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
     switch (steps2) {
     case 0:                         // bf16 x 3 operands: ~85 KB for RealNVP-64, one 1024-thread workgroup per CU
-        if constexpr (EPL == 8) return big ? TFK_CB(1024, 0) : TFK_CB(kBlock, 0);
+        if constexpr (EPL == 8 && KIND < 4) return big ? TFK_CB(1024, 0) : TFK_CB(kBlock, 0);
         else return fail(TFK_EINVAL, "%s: the bf16 x 3 operand format of lean couplings is built for D = 64", fn);
     case 1: return big ? TFK_CB(BIG, 1) : TFK_CB(kBlock, 1);
     case 2: return big ? TFK_CB(BIG, 2) : TFK_CB(kBlock, 2);
@@ -446,7 +528,9 @@ static int launch_chain(const float *x, float *z, float *logdet, const float *lo
     case 0: return launch_chain_k<EPL, 0>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
     case 1: return launch_chain_k<EPL, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
     case 2: return launch_chain_k<EPL, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
-    default: return launch_chain_k<EPL, 3>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+    case 3: return launch_chain_k<EPL, 3>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+    case 4: return launch_chain_k<EPL, 4>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+    default: return launch_chain_k<EPL, 5>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
     }
 }
 

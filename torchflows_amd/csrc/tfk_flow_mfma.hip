@@ -116,7 +116,18 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
             if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
             need = 2 * (int64_t)D + 4;
             prog.ew_offset = off;
+        } else if (k == TFK_OP_MADE_FWD_LEAN || k == TFK_OP_MADE_INV_LEAN) {
+            if (prog.n_c == kMaxChainOps) return fail(TFK_EINVAL, "%s: more than %d lean ops", fn, kMaxChainOps);
+            if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
+            const int mk = 4 + (k - TFK_OP_MADE_FWD_LEAN);
+            if (prog.n_c == 0) { kind = mk; steps2 = st; }
+            else if (mk != kind || st != steps2)
+                return fail(TFK_EINVAL, "%s: op %d: a lean program holds layers of one kind and one hidden width", fn, i);
+            const int nA2 = (EPL * st + 3) & ~3;
+            need = (int64_t)2 * EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)EPL * 16 + 2 * (int64_t)D;
+            prog.offset[prog.n_c++] = off;
         } else if (k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN) {
+            if (kind >= 4) return fail(TFK_EINVAL, "%s: op %d: couplings and MADE layers cannot share a lean program", fn, i);
             if (prog.n_c == kMaxChainOps) return fail(TFK_EINVAL, "%s: more than %d lean couplings", fn, kMaxChainOps);
             if (src != 0 && src != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, src);
             if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
@@ -185,14 +196,16 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
-    const bool lean = n_ops > 0 && ops && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN;
+    const bool lean = n_ops > 0 && ops && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN) ||
+                                           ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN);
     if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
     if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN))
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                              accumulate, x_width, static_cast<hipStream_t>(stream), fn);
-    if (n_ops > 0 && ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA)
+    if (n_ops > 0 && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA) ||
+                      ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN))
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                          accumulate, x_width, static_cast<hipStream_t>(stream), fn);
     const int EPL = D / 8;

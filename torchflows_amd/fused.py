@@ -42,7 +42,7 @@ from torchflows_amd import native
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
     OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
     OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA, \
-    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV = range(21)
+    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN = range(23)
 MAX_CONTEXT = 16      # context elements a flow program takes (4 k-steps of 4, csrc/tfk_flow_mfma.h: kCtxSteps)
 LOG2E = 1.4426950408889634
 AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
@@ -769,6 +769,72 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     return torch.cat(parts).float()
 
 
+def _lean_made(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
+    """Physical-order weights of a MADE-based affine layer's PARALLEL map (the checks of ``_made_op``), fp64:
+    (divide, H, W1p (H, Dp), b1, W2p (Dp, 2, H), b2p (Dp, 2)) or None."""
+    from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import MADE
+    if d == layer._sequential_when or layer.context_shape is not None:
+        return None
+    kind = layer.transformer.native_kind
+    ct = layer.conditioner_transform
+    if kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+        return None
+    if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
+        return None
+    mods = list(ct.sequential)
+    if not (len(mods) == 3 and isinstance(mods[0], MADE.MaskedLinear) and isinstance(mods[1], nn.Tanh)
+            and isinstance(mods[2], MADE.MaskedLinear)):
+        return None
+    H = mods[0].out_features
+    if mods[0].in_features != D or H > 16:
+        return None
+    W1 = (mods[0].weight * mods[0].mask).detach().double()                     # (H, D) logical columns
+    W2 = (mods[2].weight * mods[2].mask).detach().double().view(D, 2, H)       # logical element, parameter, unit
+    W1p = W1.new_zeros(H, Dp)
+    W1p[:, pos] = W1
+    W2p = W2.new_zeros(Dp, 2, H)
+    W2p[pos] = W2
+    b2p = W2.new_zeros(Dp, 2)
+    b2p[pos] = mods[2].bias.detach().double().view(D, 2)
+    return kind == "inverse_affine", H, W1p, mods[0].bias.detach().double(), W2p, b2p
+
+
+def _pack_lean_made(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t) -> torch.Tensor:
+    """Parameter block of a lean MADE op (csrc/tfk_flow_chain.h: made_lean): A1[2 EPL / 4][64][4] (plane A's k-steps,
+    then plane B's) | b1[4][4] | A2[nA2 / 4][64][4] | b2[EPL][4][4] | pre_s[Dp] | pre_t[Dp], weights pre-scaled as
+    for the lean couplings.  Inputs fp64, physical order, pending elementwise maps already folded into W1f / b1f."""
+    hp, EPL = Dp // 2, Dp // 8
+    dev = W1f.device
+    steps2 = (H + 3) // 4
+    W1pad = torch.zeros(16, Dp, dtype=torch.float64, device=dev)
+    W1pad[:H] = W1f * (2.0 * LOG2E)
+    b1pad = torch.zeros(16, dtype=torch.float64, device=dev)
+    b1pad[:H] = b1f * (2.0 * LOG2E)
+    W2pad = torch.zeros(Dp, 2, 16, dtype=torch.float64, device=dev)
+    W2pad[:, :, :H] = W2p
+    W2pad[:, 0, :] *= 0.5 * LOG2E
+    b2q = b2p.clone()
+    b2q[:, 0] = (b2q[:, 0] * 0.5 + AFF_C0) * LOG2E
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    A1 = torch.stack([W1pad[unit1, plane * hp + EPL * ql + s_] for plane in range(2) for s_ in range(EPL)])
+    A1 = A1.reshape(2 * EPL // 4, 4, 64).permute(0, 2, 1)
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    b1m = b1pad[4 * rr + qq]
+    q2, r2 = il >> 2, il & 3
+    A2, b2m = [], []
+    for t in range(EPL):
+        plane, tt = (0, t) if t < EPL // 2 else (1, t - EPL // 2)
+        for r1 in range(steps2):
+            A2.append(W2pad[plane * hp + EPL * q2 + 2 * tt + (r2 >> 1), r2 & 1, 4 * r1 + ql])
+        b2m.append(b2q[plane * hp + EPL * qq + 2 * tt + (rr >> 1), rr & 1])
+    nA2 = (EPL * steps2 + 3) & ~3
+    A2 = torch.stack(A2 + [torch.zeros(64, dtype=torch.float64, device=dev)] * (nA2 - EPL * steps2))
+    A2 = A2.reshape(nA2 // 4, 4, 64).permute(0, 2, 1)
+    return torch.cat([A1.reshape(-1), b1m.reshape(-1), A2.reshape(-1), torch.stack(b2m).reshape(-1), pre_s, pre_t]).float()
+
+
 def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor):
     """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
     folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
@@ -776,7 +842,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     pending map x -> s[c] x + t[c] (fp64 on the host) that is folded into W1 / b1 where c feeds a conditioner,
     applied by the coupling that transforms c (its pre-affine), and flushed by one TFK_OP_EW_FMA at the end together
     with the sum of the constant log-dets."""
-    from torchflows_amd.bijections.finite.autoregressive.layers_base import CouplingBijection, ElementwiseBijection
+    from torchflows_amd.bijections.finite.autoregressive.layers_base import (
+        CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
     hp = Dp // 2
     s = torch.ones(Dp, dtype=torch.float64, device=device)
@@ -806,11 +873,27 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     s[pos] = alpha * s[pos]
                     t[pos] = alpha * t[pos] + beta
                     ld_const = ld_const + torch.log(alpha).sum()
+            elif isinstance(layer, MaskedAutoregressiveBijection):
+                got = _lean_made(layer, d, pos, D, Dp)       # MAF density / IAF sampling: the parallel map
+                if got is None:
+                    return None
+                divide, H, W1p, b1, W2p, b2p = got
+                lk, steps2 = (7 if divide else 6), (H + 3) // 4
+                if kind0 is None:
+                    kind0, steps0 = lk, steps2
+                elif (lk, steps2) != (kind0, steps0):
+                    return None
+                block = _pack_lean_made(H, Dp, W1p * s, b1 + W1p @ t, W2p, b2p, s.clone(), t.clone())
+                s.fill_(1.0)
+                t.fill_(0.0)
+                items.append((OP_MADE_INV_LEAN if divide else OP_MADE_FWD_LEAN, 0, steps2, block, ()))
             elif isinstance(layer, CouplingBijection):
                 got = _lean_coupling(layer, d, pos, D, Dp)
                 if got is None:
                     return None
                 lk, plane, H, W1t, b1, W2p, b2p = got
+                if kind0 is not None and kind0 >= 6:
+                    return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
                 if lk >= 4 and rqs_bf16x3_enabled():
                     steps2 = (H + 1 + 3) // 4                 # bf16 x 3 operands: counts the bias unit; > 4 = two hidden tiles
@@ -847,7 +930,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
             else:
                 return None
     flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
-    streamed = kind0 is not None and kind0 >= 4          # spline chains read their operands from global memory
+    streamed = kind0 in (4, 5)                           # spline chains read their operands from global memory
     if not items and streamed:
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
