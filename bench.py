@@ -59,6 +59,7 @@ class KernelTimer:
         self.active = False
         self.records = []   # (name, bytes, start_event, end_event)
         self.mfma_insts = {}   # kernel -> v_mfma_f32_16x16x4_f32 wave-instructions issued while active
+        self.mfma_bf16_insts = {}   # kernel -> v_mfma_f32_16x16x32_bf16 wave-instructions issued while active
         for fn, byte_fn in (("affine_coupling", self._coupling_bytes(2)),
                             ("shift_coupling", self._coupling_bytes(1)),
                             ("rqs_coupling", self._rqs_bytes),
@@ -155,6 +156,7 @@ class KernelTimer:
                 flops = n_rows * 6 * h_ * (d_ // 2 + d_)
             if name == "flow_run_mfma":
                 self.mfma_insts[variant] = self.mfma_insts.get(variant, 0) + self._flow_mfmas(a)
+                self.mfma_bf16_insts[variant] = self.mfma_bf16_insts.get(variant, 0) + self._flow_mfmas_bf16(a)
             self.records.append((variant, byte_fn(a, k), s, e, flops))
             return r
         setattr(self.native, name, timed)
@@ -176,12 +178,29 @@ class KernelTimer:
                 per_wave += EPL * HT + (EPL // 2) * steps2
             elif kind in (4, 5, 14, 15):
                 per_wave += EPL * HT + (EPL // 4) * steps2
+            elif kind in (17, 18) and len(op) > 4 and (int(op[4]) >> 8) == 1:
+                per_wave += EPL * (2 if steps2 > 4 else 1)      # GEMM 1 only: GEMM 2 runs as bf16 MFMAs (_flow_mfmas_bf16)
             elif kind in (6, 7, 17, 18):
                 per_wave += EPL + 6 * EPL * steps2
             elif kind in (8, 9):
                 per_wave += 2 * EPL * HT + EPL * steps2
             elif kind == 10:
                 per_wave += 2 * EPL + 12 * EPL * steps2
+        return per_wave * ((N + 15) // 16)
+
+    @staticmethod
+    def _flow_mfmas_bf16(a):
+        """v_mfma_f32_16x16x32_bf16 wave-instructions of one launch: lean spline ops in the bf16 x 3 operand format issue
+        3 per tile and hidden tile, 6 tiles per target element."""
+        x, ops = a[0], a[6]
+        N, D = x.shape
+        EPL = D // 8
+        if not isinstance(ops, (list, tuple)):
+            ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
+        per_wave = 0
+        for op in ops:
+            if op[0] in (17, 18) and len(op) > 4 and (int(op[4]) >> 8) == 1:
+                per_wave += 18 * EPL * (2 if op[2] > 4 else 1)
         return per_wave * ((N + 15) // 16)
 
     @staticmethod
@@ -513,10 +532,19 @@ def main():
                 roofline["valu_insts_per_launch"] = valu
                 roofline["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
                 n_mfma = timer.mfma_insts.get(dom_name, 0) / max(dom["launches"], 1)
+                n_bf16 = timer.mfma_bf16_insts.get(dom_name, 0) / max(dom["launches"], 1)
+                roofline["mfma_f32_insts_per_launch_model"] = n_mfma
+                if n_bf16:
+                    roofline["mfma_bf16_insts_per_launch_model"] = n_bf16
                 if mfma_pmc is not None:
-                    # measured: rocprofv3 SQ_INSTS_VALU_MFMA_F32 (tools/profile.sh pass 5); the analytic count must agree
+                    # measured: rocprofv3 SQ_INSTS_VALU_MFMA_F32 / _BF16 (tools/profile.sh pass 5); the analytic counts
+                    # must agree
                     roofline["mfma_insts_per_launch_pmc"] = mfma_pmc
                     roofline["mfma_insts_model_vs_pmc"] = n_mfma / mfma_pmc if mfma_pmc else None
+                    bf16_pmc = traffic_db.get(dom_name + ":mfma_bf16_insts")
+                    if bf16_pmc:
+                        roofline["mfma_bf16_insts_per_launch_pmc"] = bf16_pmc
+                        roofline["mfma_bf16_insts_model_vs_pmc"] = n_bf16 / bf16_pmc
                 gui = traffic_db.get(dom_name + ":grbm_gui_active")
                 busy_mfma = traffic_db.get(dom_name + ":mfma_busy_cycles")
                 if gui and busy_mfma is not None:
@@ -528,7 +556,7 @@ def main():
                     roofline["mfma_util"] = busy_mfma / simd_cycles
                     roofline["mfma_coexec_frac"] = (traffic_db.get(dom_name + ":mfma_coexec_cycles") or 0.0) / simd_cycles
                     trans = traffic_db.get(dom_name + ":trans_insts") or 0.0
-                    vec = valu - (mfma_pmc or 0.0)              # SQ_INSTS_VALU counts the MFMAs too
+                    vec = valu - (mfma_pmc or 0.0) - (traffic_db.get(dom_name + ":mfma_bf16_insts") or 0.0)   # SQ_INSTS_VALU counts the MFMAs too
                     roofline["vector_insts_per_launch"] = vec
                     # SIMD cycles accounted for: 4 per vector instruction (+4 for a transcendental) + the matrix pipe
                     roofline["fp32_datapath_frac"] = (4.0 * vec + 4.0 * trans + busy_mfma) / simd_cycles

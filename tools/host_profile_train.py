@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Host-side profile of the eager maximum-likelihood step (RealNVP-64, 2^18 rows): cProfile over 30 steps."""
+import cProfile
+import pstats
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import bench  # noqa: E402
+
+flow = bench.make_flow("RealNVP", 64, 8).cuda()
+x = torch.randn(1 << 18, 64, device="cuda")
+flow.train()
+opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = -flow.log_prob(x).mean() / flow.event_size + flow.regularization()
+    loss.backward()
+    opt.step()
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    step()
+torch.cuda.synchronize()
+print("ms per step:", 1e3 * (time.perf_counter() - t0) / 20)
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(30):
+    step()
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)

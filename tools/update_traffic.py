@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = [("k_flow_chain", "flow_run_mfma"), ("k_flow_run_mfma", "flow_run_mfma"), ("k_flow_run<", "flow_run"), ("k_affine_half_v4", "affine_coupling[inplace]"),
+KERNELS = [("k_flow_chain", "flow_run_mfma"), ("k_flow_rqs_chain", "flow_run_mfma"), ("k_flow_run_mfma", "flow_run_mfma"), ("k_flow_run<", "flow_run"), ("k_affine_half_v4", "affine_coupling[inplace]"),
            ("k_rqs_coupling_dma", "rqs_coupling[inplace]"), ("k_elementwise_affine<", "elementwise_affine"),
            ("k_permute", "permute"), ("k_diag_gauss<", "diag_gauss_logprob"),
            ("k_conv3x3_relu_pool_affine", "conv3x3_relu_pool_affine")]
@@ -41,7 +41,7 @@ def main():
                 continue
             ent["_n:" + name] = int(r["dispatches"])
             ent[name] = int(float(r["hbm_bytes_per_launch"]))
-            for col, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_VALU_MFMA_F32", "mfma_insts"),
+            for col, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_VALU_MFMA_F32", "mfma_insts"), ("SQ_INSTS_VALU_MFMA_BF16", "mfma_bf16_insts"),
                              ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles"),
                              ("SQ_VALU_MFMA_COEXEC_CYCLES", "mfma_coexec_cycles"), ("SQ_BUSY_CYCLES", "sq_busy_cycles"),
                              ("GRBM_GUI_ACTIVE", "grbm_gui_active"), ("SQ_INSTS_VALU_TRANS_F32", "trans_insts")):
