@@ -43,6 +43,7 @@ WORKLOADS = {
     "nsf64": ("CouplingRQNSF", 64, 8, 1 << 20, 1 << 18),     # configs[2]
     "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
     "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 13),  # configs[4] (3 blocks, 3.2 M params)
+    "lrs64": ("CouplingLRS", 64, 8, 1 << 20, 1 << 18),       # sibling preset (linear rational splines), not a BASELINE config
 }
 
 
@@ -178,7 +179,7 @@ class KernelTimer:
                 per_wave += EPL * HT + (EPL // 2) * steps2
             elif kind in (4, 5, 14, 15):
                 per_wave += EPL * HT + (EPL // 4) * steps2
-            elif kind in (17, 18) and len(op) > 4 and (int(op[4]) >> 8) == 1:
+            elif kind in (17, 18, 23, 24) and len(op) > 4 and (int(op[4]) >> 8) == 1:
                 per_wave += EPL * (2 if steps2 > 4 else 1)      # GEMM 1 only: GEMM 2 runs as bf16 MFMAs (_flow_mfmas_bf16)
             elif kind in (6, 7, 17, 18):
                 per_wave += EPL + 6 * EPL * steps2
@@ -191,7 +192,7 @@ class KernelTimer:
     @staticmethod
     def _flow_mfmas_bf16(a):
         """v_mfma_f32_16x16x32_bf16 wave-instructions of one launch: lean spline ops in the bf16 x 3 operand format issue
-        3 per tile and hidden tile, 6 tiles per target element."""
+        3 per tile and hidden tile, 6 tiles per target element (8 for linear rational splines)."""
         x, ops = a[0], a[6]
         N, D = x.shape
         EPL = D // 8
@@ -199,8 +200,8 @@ class KernelTimer:
             ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         per_wave = 0
         for op in ops:
-            if op[0] in (17, 18) and len(op) > 4 and (int(op[4]) >> 8) == 1:
-                per_wave += 18 * EPL * (2 if op[2] > 4 else 1)
+            if op[0] in (17, 18, 23, 24) and len(op) > 4 and (int(op[4]) >> 8) == 1:
+                per_wave += (24 if op[0] >= 23 else 18) * EPL * (2 if op[2] > 4 else 1)
         return per_wave * ((N + 15) // 16)
 
     @staticmethod
@@ -217,9 +218,9 @@ class KernelTimer:
             ops = [tuple(ops[8 * i:8 * i + 8]) for i in range(len(ops) // 8)]
         for op in ops:
             kind, H = op[0], op[2]
-            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15, 17, 18):
+            if mfma and kind in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15, 17, 18, 23, 24):
                 H = KernelTimer.true_hidden.get(D, 4 * H)       # the matrix-core ops record ceil(H / 4)
-            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23, 12: 2, 13: 2, 14: 1, 15: 1, 17: 23, 18: 23}.get(kind)
+            P = {2: 2, 3: 2, 4: 1, 5: 1, 6: 23, 7: 23, 12: 2, 13: 2, 14: 1, 15: 1, 17: 23, 18: 23, 23: 32, 24: 32}.get(kind)
             if P is not None:
                 per_row += 2 * (half * H + H * half * P)
             elif kind in (8, 9, 10):                            # MADE ops: both planes in, every element a target

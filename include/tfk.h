@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 20
+#define TFK_ABI_VERSION 21
 
 enum {
     TFK_OK = 0,
@@ -253,7 +253,14 @@ enum {
      * Block: A1[D/16][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | A2[nA2/4][64][4] | b2[D/8][4][4] |
      * pre_s[D] | pre_t[D], weights pre-scaled as for the lean couplings; every element takes its pre-affine. */
     TFK_OP_MADE_FWD_LEAN = 21,
-    TFK_OP_MADE_INV_LEAN = 22
+    TFK_OP_MADE_INV_LEAN = 22,
+    /* lean LINEAR rational spline programs (LinearRational, spline/linear_rational.py:9-182; CouplingLRS): as
+     * TFK_OP_RQS_*_LEAN in the bf16 x 3 operand format (K = 8 + 256 only), 32 parameters = 8 tiles per element --
+     * [0, 8) width logits, [8, 16) height logits u_x + u_y / 100, [16, 24) MINUS the lambda logits, [24, 31) derivative
+     * logits c + u_d / 100, [31] the w0 logit, all times log2(e); chunks of 4 / HT elements = 16384 dwords.  Op record:
+     * K = 8 + 256, boundary, scale = 1 - 1e-2 * 8, c = log(exp(1 - 1e-5) - 1). */
+    TFK_OP_LRS_FWD_LEAN = 23,
+    TFK_OP_LRS_INV_LEAN = 24
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,

@@ -66,6 +66,48 @@ def rqs_lean_eval(p, v, C, inverse):
     return torch.where(inb, out, v), torch.where(inb, -l2 if inverse else l2, torch.zeros_like(l2))
 
 
+def lrs_lean_eval(p, v, C, inverse):
+    """The linear-rational-spline element of csrc/tfk_flow_rqs_chain.h (lrs_eval_lean) in fp64: p (..., 32)."""
+    minimum, maximum, g, cmin, d_edge = C
+    ux, uy, nl, ud, uw = p[..., 0:8], p[..., 8:16], p[..., 16:24], p[..., 24:31], p[..., 31]
+    ex = torch.exp2(ux - ux.max(-1, keepdim=True).values)
+    ey = torch.exp2(uy - uy.max(-1, keepdim=True).values)
+    gx, gy = g / ex.sum(-1, keepdim=True), g / ey.sum(-1, keepdim=True)
+    jj = torch.arange(1, 8, dtype=torch.float64)
+    edge = lambda val: torch.full_like(v[..., None], val)
+    X = torch.cat([edge(minimum), torch.cumsum(ex * gx, -1)[..., :7] + minimum + jj * cmin, edge(maximum)], -1)
+    Y = torch.cat([edge(minimum), torch.cumsum(ey * gy, -1)[..., :7] + minimum + jj * cmin, edge(maximum)], -1)
+    Dl = torch.cat([edge(d_edge), ud, edge(d_edge)], -1)
+    S = Y if inverse else X
+    k = ((S[..., 1:8] < v[..., None]).sum(-1, keepdim=True)).clamp(0, 7)
+    pick = lambda t, i: torch.gather(t, -1, i).squeeze(-1)
+    xk, xk1, yk, yk1 = pick(X, k), pick(X, k + 1), pick(Y, k), pick(Y, k + 1)
+    dk = 1e-5 + LN2 * torch.log2(1 + torch.exp2(pick(Dl, k)))
+    dk1 = 1e-5 + LN2 * torch.log2(1 + torch.exp2(pick(Dl, k + 1)))
+    lam = 1.0 / (1.0 + torch.exp2(pick(nl, k)))
+    w0 = LN2 * torch.log2(1 + torch.exp2(uw))
+    wk, wk1 = w0 / torch.sqrt(dk), w0 / torch.sqrt(dk1)
+    ym = ((1 - lam) * wk * yk + lam * wk1 * yk1) / ((1 - lam) * wk + lam * wk1)
+    dx = xk1 - xk
+    wm = (lam * wk * dk + (1 - lam) * wk1 * dk1) * (dx / (yk1 - yk))
+    n_lo, n_hi = lam * wk * wm * (ym - yk), (1 - lam) * wm * wk1 * (yk1 - ym)
+    if not inverse:
+        phi = (v - xk) / dx
+        up = phi > lam
+        den = torch.where(up, wm * (1 - phi) + wk1 * (phi - lam), wk * (lam - phi) + wm * phi)
+        num = torch.where(up, wm * ym * (1 - phi) + wk1 * yk1 * (phi - lam), wk * yk * (lam - phi) + wm * ym * phi)
+        out = num / den
+        l2 = torch.log2(torch.where(up, n_hi, n_lo) / ((den * den + 5e-10) * dx))
+    else:
+        up = v > ym
+        den = torch.where(up, wk1 * (yk1 - v), wk * (yk - v)) + wm * (v - ym)
+        num = torch.where(up, lam * wk1 * (yk1 - v) + wm * (v - ym), lam * wk * (yk - v))
+        out = num / den * dx + xk
+        l2 = torch.log2(torch.where(up, n_hi, n_lo) * dx / (den * den + 5e-10))
+    inb = (v > minimum) & (v < maximum)
+    return torch.where(inb, out, v), torch.where(inb, l2, torch.zeros_like(l2))
+
+
 def _pieces(v32):
     """fp32 tensor -> (hi, mid, lo) bf16 pieces by truncation, as fp64."""
     bits = v32.contiguous().view(torch.int32)
@@ -108,7 +150,9 @@ def run_lean(ops, params, rows, D):
             b = s[HALF + idx][:, :, None] * b + t[HALF + idx][:, :, None]
             ld[q == 0] += prm[off + 2 * D]
             continue
-        if kind in (17, 18):                                  # lean RQ-spline coupling
+        if kind in (17, 18, 23, 24):                          # lean RQ-spline / linear-rational-spline coupling
+            lrs = kind >= 23
+            TPE = 8 if lrs else 6
             K, boundary, scale, cdelta = op_extra[(kind, off)]
             fmt3 = (int(K) >> 8) == 1
             HT = 2 if (fmt3 and steps2 > 4) else 1
@@ -127,16 +171,17 @@ def run_lean(ops, params, rows, D):
             hid = hids[0]
             tgt = tgt.clone()
             span = 2.0 * boundary
-            C = (-boundary, boundary, span * scale, span * 1e-3, (cdelta + cdelta / 1000.0) * 1.4426950408889634)
+            C = (-boundary, boundary, span * scale, span * (1e-2 if lrs else 1e-3),
+                 (cdelta if lrs else cdelta + cdelta / 1000.0) * 1.4426950408889634)
             if fmt3:                                          # bf16 x 3 operands: chunks of 4 / HT elements
                 hids[HT - 1] = hids[HT - 1].clone()
                 hids[HT - 1][q == 3, 3] = 1.0                 # the last hidden unit carries the bias
                 hp = [_pieces(h.float()) for h in hids]       # per hidden tile: (hi, mid, lo), each (64, 4, W)
                 raw = params.contiguous().view(torch.int32)
-                A = raw[off + HEAD:off + HEAD + EPL * 6 * HT * 2 * 64 * 4].reshape(EPL, 6, HT, 2, 64, 4)
+                A = raw[off + HEAD:off + HEAD + EPL * TPE * HT * 2 * 64 * 4].reshape(EPL, TPE, HT, 2, 64, 4)
                 for e in range(EPL):
                     pp = []
-                    for c in range(6):
+                    for c in range(TPE):
                         o = torch.zeros(64, 4, W, dtype=torch.float64)
                         for th in range(HT):
                             w_hi, w_mid = _unpack_bf16(A[e, c, th, 0][:, 0:2]), _unpack_bf16(A[e, c, th, 0][:, 2:4])
@@ -148,7 +193,8 @@ def run_lean(ops, params, rows, D):
                                     o = _mfma(Wl[:, i], Bl[:, i], o)
                         pp.append(o)
                     pvec = torch.cat(pp, 1).permute(0, 2, 1)
-                    out, l2 = rqs_lean_eval(pvec, tgt[:, e], C, kind == 18)
+                    out, l2 = (lrs_lean_eval(pvec, tgt[:, e], C, kind == 24) if lrs
+                               else rqs_lean_eval(pvec, tgt[:, e], C, kind == 18))
                     tgt[:, e] = out
                     ld2 = ld2 + l2
                 sign = 1.0

@@ -657,3 +657,37 @@ def test_spline_chain_two_hidden_tiles(D, n_hidden):
     assert rel(lp_d.cpu().numpy(), lp_h.numpy()) < 1e-5 * max(1.0, D / 64)
     assert normwise(z_d.cpu().numpy(), z_h.numpy()) < 2e-5
     assert torch.allclose(xr.cpu(), x, atol=1e-3) and torch.allclose(ld_d, -ldr, atol=1e-3)
+
+
+@pytest.mark.parametrize("D,n_hidden,n_layers", [(64, None, 8), (64, 24, 2), (128, None, 3), (22, None, 2), (16, None, 3)])
+def test_linear_rational_spline_chain_is_one_launch(D, n_hidden, n_layers):
+    """CouplingLRS chains (linear rational splines, TFK_OP_LRS_*_LEAN) run as ONE single-launch spline chain, one or two
+    hidden tiles, padded event sizes included.  Against the host path in fp64 (the composition in double precision):
+    log_prob within 1e-5; the inverse undoes the forward."""
+    import copy
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    torch.manual_seed(8)
+    kw = {} if n_hidden is None else dict(conditioner_kwargs=dict(n_hidden=n_hidden))
+    flow = tfa.Flow(tfa.CouplingLRS(D, n_layers=n_layers, **kw))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow.eval()
+    x = torch.randn(1500, D) * 1.5
+    x[:200] *= 20.0                                        # rows with elements outside the +-50 box
+    flow64 = copy.deepcopy(flow).double()
+    with torch.no_grad():
+        lp_h = flow64.log_prob(x.double())
+        z_h, _ = flow64.bijection.forward(x.double())
+        flow = flow.cuda()
+        before = native.calls
+        lp_d = flow.log_prob(x.cuda())
+        assert native.calls - before == 1
+        z_d, ld_d = flow.bijection.forward(x.cuda())
+        xr, ldr = flow.bijection.inverse(z_d)
+    e_lp, e_z = rel(lp_d.cpu().numpy(), lp_h.numpy()), normwise(z_d.cpu().numpy(), z_h.numpy())
+    print(f"CouplingLRS({D}, hidden {n_hidden}, {n_layers} layers): log_prob {e_lp:.2e}, z nw {e_z:.2e}")
+    assert e_lp < 1e-5
+    assert e_z < 2e-5
+    assert torch.allclose(xr.cpu(), x, atol=2e-3, rtol=1e-5) and torch.allclose(ld_d, -ldr, atol=1e-3)

@@ -472,6 +472,9 @@ def test_torchflows_import_alias_resolves_to_the_build():
                                                        ("CouplingRQNSF", 128, 2, 0), ("CouplingRQNSF", 22, 2, 1),
                                                        ("CouplingRQNSF-h24", 64, 2, 0), ("CouplingRQNSF-h31", 64, 2, 1),
                                                        ("CouplingRQNSF", 256, 2, 0),
+                                                       ("CouplingLRS", 64, 3, 0), ("CouplingLRS", 64, 2, 1),
+                                                       ("CouplingLRS", 22, 2, 0), ("CouplingLRS-h24", 64, 2, 1),
+                                                       ("CouplingLRS", 128, 2, 0),
                                                        ("MAF", 64, 3, 0), ("IAF", 64, 2, 1), ("MAF", 22, 2, 0), ("MAF", 128, 2, 0)])
 @pytest.mark.parametrize("bf16x3", ["1", "0"])
 def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, bf16x3, monkeypatch):
@@ -481,7 +484,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     from lean_emulator import run_lean
     from torchflows_amd import fused
     import torchflows_amd as tfa
-    if bf16x3 == "0" and "RQ" not in arch and D not in (64, 22, 8):
+    if bf16x3 == "0" and "RQ" not in arch and "LRS" not in arch and D not in (64, 22, 8):
         pytest.skip("the operand format only concerns spline chains and 64-wide affine chains")
     monkeypatch.setenv("TORCHFLOWS_AMD_RQS_BF16X3", bf16x3)
     monkeypatch.setenv("TORCHFLOWS_AMD_LEAN_BF16X3", bf16x3)
@@ -494,6 +497,8 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
             pytest.skip("fp32 operands stop at hidden width 16")
     if D == 256 and bf16x3 == "0":
         pytest.skip("CouplingRQNSF(256) has hidden width 17: bf16 x 3 operands only")
+    if "LRS" in arch and bf16x3 == "0":
+        pytest.skip("lean linear rational splines: bf16 x 3 operands only")
     flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers, **kw))
     flow.train()
     with torch.no_grad():
@@ -515,7 +520,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     rows[:, pos] = x
     ld = torch.zeros(64, dtype=torch.float64)
     for seg in chain.segments:
-        assert seg.mfma and all(12 <= op[0] <= 22 and op[0] not in (19, 20) for op in seg.ops)
+        assert seg.mfma and all(12 <= op[0] <= 24 and op[0] not in (19, 20) for op in seg.ops)
         rows, l = run_lean(seg.ops, seg.params, rows, Dp)
         ld = ld + l
     got = rows[:, chain.pos]

@@ -31,7 +31,9 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     const bool fmt3 = n_ops > 0 && (ops[4] >> 8) == 1;
     // bf16 x 3: gemm2_steps = ceil((H + 1) / 4) counts the bias unit; more than 4 steps = two hidden tiles
     const int ht3 = (fmt3 && n_ops > 0 && ops[2] > 4) ? 2 : 1;
-    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (int64_t)(EPL * ht3 / 4) * kRqsChunk3Dwords
+    const bool lrs = n_ops > 0 && (ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN);
+    if (lrs && !fmt3) return fail(TFK_EINVAL, "%s: lean linear-rational-spline ops use the bf16 x 3 operand format (K = 8 + 256)", fn);
+    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (int64_t)(EPL * ht3 / 4) * (lrs ? 16384 : kRqsChunk3Dwords)
                                : (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
     RqsChainProg prog;
     memset(&prog, 0, sizeof(prog));
@@ -48,7 +50,7 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
             prog.ew_offset = off;
             continue;
         }
-        if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN)
+        if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN && k != TFK_OP_LRS_FWD_LEAN && k != TFK_OP_LRS_INV_LEAN)
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean spline ops", fn, i, k);
         float bnd, sc, cc;
         memcpy(&bnd, rec + 5, 4);
@@ -85,10 +87,11 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     prog.C.minimum = -boundary;
     prog.C.maximum = boundary;
     prog.C.g = (float)(span * (double)scale);
-    prog.C.cmin = (float)(span * 1e-3);
-    prog.C.d_edge = (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
-    const int inverse = kind == TFK_OP_RQS_INV_LEAN;
-    if (fmt3) steps2 = ht3 == 2 ? 8 : 0;
+    prog.C.cmin = (float)(span * (lrs ? 1e-2 : 1e-3));
+    prog.C.d_edge = lrs ? (float)((double)c * 1.4426950408889634)
+                        : (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
+    const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN;
+    if (fmt3) steps2 = (ht3 == 2 ? 8 : 0) + (lrs ? 16 : 0);
     if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
@@ -197,11 +200,12 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
     const bool lean = n_ops > 0 && ops && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN) ||
-                                           ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN);
+                                           (ops[0] >= TFK_OP_MADE_FWD_LEAN && ops[0] <= TFK_OP_LRS_INV_LEAN));
     if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
-    if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN))
+    if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
+                      ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN))
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                              accumulate, x_width, static_cast<hipStream_t>(stream), fn);
     if (n_ops > 0 && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA) ||

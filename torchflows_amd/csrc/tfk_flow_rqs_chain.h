@@ -167,6 +167,104 @@ __device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, con
     l2 = INVERSE ? -l : l;
 }
 
+
+// Linear rational spline element (LinearRational, spline/linear_rational.py:9-182) in the same lean form.  p: 32
+// pre-scaled parameters -- [0, 8) width logits, [8, 16) height logits (u_x + u_y / 100), [16, 24) MINUS the lambda logits,
+// [24, 31) derivative logits (c + u_d / 100), [31] the w0 logit, all times log2(e).  C.d_edge = c log2(e) makes the
+// boundary derivative 1e-5 + softplus(c) = 1 (the reference pads exactly 1).  l2 = log2 of the map's own log-det factor
+// (the reference's inverse_1d returns the inverse's log-det directly: no negation here).
+template <bool INVERSE>
+__device__ __forceinline__ void lrs_eval_lean(const float (&p)[32], float v, const RqsLean &C, float &out, float &l2)
+{
+    float mx = p[0], my = p[8];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { mx = fmaxf(mx, p[j]); my = fmaxf(my, p[8 + j]); }
+    float ex[8], ey[8], sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ex[j] = exp2_f(p[j] - mx);
+        ey[j] = exp2_f(p[8 + j] - my);
+        sx += ex[j];
+        sy += ey[j];
+    }
+    const float gx = C.g * rcp_f(sx), gy = C.g * rcp_f(sy);
+    float X[9], Y[9], Dl[9];
+    X[0] = C.minimum; Y[0] = C.minimum; X[8] = C.maximum; Y[8] = C.maximum;
+    Dl[0] = C.d_edge; Dl[8] = C.d_edge;
+    float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        ax = fmaf(ex[j - 1], gx, ax);
+        ay = fmaf(ey[j - 1], gy, ay);
+        const float cj = C.minimum + (float)j * C.cmin;
+        X[j] = ax + cj;
+        Y[j] = ay + cj;
+        Dl[j] = p[23 + j];
+    }
+    // bin search (:53, searchsorted left), carrying knots, opposite knots, derivative logits and the bins' lambda logits
+    float S5[5], O5[5], D5[5], L4[4];
+    {
+        const bool up = (INVERSE ? Y[4] : X[4]) < v;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            S5[i] = up ? (INVERSE ? Y[4 + i] : X[4 + i]) : (INVERSE ? Y[i] : X[i]);
+            O5[i] = up ? (INVERSE ? X[4 + i] : Y[4 + i]) : (INVERSE ? X[i] : Y[i]);
+            D5[i] = up ? Dl[4 + i] : Dl[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L4[i] = up ? p[20 + i] : p[16 + i];
+    }
+    float S3[3], O3[3], D3[3], L2[2];
+    {
+        const bool up = S5[2] < v;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            S3[i] = up ? S5[2 + i] : S5[i];
+            O3[i] = up ? O5[2 + i] : O5[i];
+            D3[i] = up ? D5[2 + i] : D5[i];
+        }
+        L2[0] = up ? L4[2] : L4[0];
+        L2[1] = up ? L4[3] : L4[1];
+    }
+    const bool up = S3[1] < v;
+    const float s0 = up ? S3[1] : S3[0], s1 = up ? S3[2] : S3[1];
+    const float o0 = up ? O3[1] : O3[0], o1 = up ? O3[2] : O3[1];
+    const float t0 = up ? D3[1] : D3[0], t1 = up ? D3[2] : D3[1];
+    const float ls = up ? L2[1] : L2[0];
+    const float xk = INVERSE ? o0 : s0, xk1 = INVERSE ? o1 : s1;
+    const float yk = INVERSE ? s0 : o0, yk1 = INVERSE ? s1 : o1;
+
+    const float LN2 = __int_as_float(0x3f317218);
+    const float lam = rcp_f(1.0f + exp2_f(ls));                                     // sigmoid, :57
+    const float dk = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t0, 126.0f))), kRqsMinDelta);   // :56
+    const float dk1 = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t1, 126.0f))), kRqsMinDelta);
+    const float w0 = LN2 * log2_f(1.0f + exp2_f(fminf(p[31], 126.0f)));             // softplus(u_w0), :58
+    const float wk = w0 * __builtin_amdgcn_rsqf(dk), wk1 = w0 * __builtin_amdgcn_rsqf(dk1);   // w0 sqrt(d_0 / d_j), d_0 = 1
+    const float one_m = 1.0f - lam;
+    const float a1 = one_m * wk, a2 = lam * wk1;
+    const float ym = fmaf(a1, yk, a2 * yk1) * rcp_f(a1 + a2);                       // :68
+    const float dx = xk1 - xk;
+    const float wm = fmaf(lam * wk, dk, (one_m * wk1) * dk1) * (dx * rcp_f(yk1 - yk));      // :69
+    const float n_lo = ((lam * wk) * wm) * (ym - yk), n_hi = ((one_m * wm) * wk1) * (yk1 - ym);
+    if constexpr (!INVERSE) {
+        const float phi = (v - xk) * rcp_f(dx);                                     // :74 (not clipped)
+        const bool upper = phi > lam;
+        const float wa = upper ? wm : wk, ya = upper ? ym : yk, ta = upper ? 1.0f - phi : lam - phi;
+        const float wb = upper ? wk1 : wm, yb = upper ? yk1 : ym, tb = upper ? phi - lam : phi;
+        const float den = fmaf(wa, ta, wb * tb);
+        out = fmaf(wa * ya, ta, (wb * yb) * tb) * rcp_f(den);                       // :76 / :80
+        l2 = log2_f((upper ? n_hi : n_lo) * rcp_f(fmaf(den, den, 5e-10f) * dx));    // :77 / :81-82
+    } else {
+        const bool upper = v > ym;
+        const float wa = upper ? wk1 : wk, yv = upper ? yk1 - v : yk - v;
+        const float vm = v - ym;
+        const float den = fmaf(wa, yv, wm * vm);
+        const float num = upper ? fmaf(lam * wa, yv, wm * vm) : (lam * wa) * yv;
+        out = fmaf(num * rcp_f(den), dx, xk);                                       // :89 / :93
+        l2 = log2_f(((upper ? n_hi : n_lo) * dx) * rcp_f(fmaf(den, den, 5e-10f)));  // :90 / :94-95
+    }
+}
+
 // one layer with the roles of the planes fixed: src feeds the conditioner, tgt is transformed
 template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
 __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float *stage, int lane, int q,
@@ -261,12 +359,16 @@ __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float 
 // HT = 16-unit tiles of the hidden layer (hidden width <= 16 HT - 1: the last unit carries b2); a chunk holds
 // 4 / HT target elements, so its size does not depend on HT.
 // Block: head A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then chunks A[4/HT][6][HT][2][64][4 dwords].
-template <int EPL, int BLOCK, int HT, bool INVERSE>
+// LRS: linear rational spline elements (32 parameters = 8 tiles per element) instead of rational-quadratic ones (24 = 6).
+template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS = false>
 __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float *stage, int lane, int q,
                                            const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2)
 {
     constexpr int HALF = 4 * EPL;
     constexpr int HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF;
+    constexpr int TPE = LRS ? 8 : 6;                          // tiles of 4 parameters per element
+    constexpr int GRP = LRS ? 4 : 3;                          // tiles side by side (TPE / 2)
+    constexpr int CHUNKD = (LRS ? 4 : 3) * 4096;              // = (4 / HT) * TPE * HT * 2 * 64 * 4 dwords
     constexpr int ELEMS = 4 / HT;
     constexpr int NC = EPL / ELEMS;
     constexpr bool STATIC_CH = NC <= 8;                       // chunk loop unrolled: the element index is static
@@ -276,9 +378,9 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
 
     auto stage_in = [&](int ch) {
         __syncthreads();
-        const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * kRqsChunk3Dwords);
+        const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * CHUNKD);
         float4 *d4 = reinterpret_cast<float4 *>(chunk_s);
-        for (int i = threadIdx.x; i < kRqsChunk3Dwords / 4; i += BLOCK) d4[i] = g4[i];
+        for (int i = threadIdx.x; i < CHUNKD / 4; i += BLOCK) d4[i] = g4[i];
         if (ch == 0) {
             const float4 *h4 = reinterpret_cast<const float4 *>(gprm);
             float4 *e4 = reinterpret_cast<float4 *>(head_s);
@@ -340,33 +442,33 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
             // the tiles of an element side by side, product by product: a bf16 MFMA issues in ~16 cycles but its result
             // takes longer, so the MFMAs of ONE tile must not follow each other (back to back they ran at ~36 cycles
             // each: measured, the first version of this loop); groups of three tiles = 36 operand / accumulator registers
-            float p[24];
+            float p[4 * TPE];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                cf32x4 o[3];
+                cf32x4 o[GRP];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) o[c] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < GRP; ++c) o[c] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
-                    ci32x4 a1[3];
+                    ci32x4 a1[GRP];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) a1[c] = A[(((e * 6 + 3 * g + c) * HT + t) * 2) * 64 + lane];
+                    for (int c = 0; c < GRP; ++c) a1[c] = A[(((e * TPE + GRP * g + c) * HT + t) * 2) * 64 + lane];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < GRP; ++c)
                         o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B1[t]), o[c], 0, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < GRP; ++c)
                         o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B2[t]), o[c], 0, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const ci32x4 a2 = A[(((e * 6 + 3 * g + c) * HT + t) * 2 + 1) * 64 + lane];
+                    for (int c = 0; c < GRP; ++c) {
+                        const ci32x4 a2 = A[(((e * TPE + GRP * g + c) * HT + t) * 2 + 1) * 64 + lane];
                         o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a2), __builtin_bit_cast(cbf16x8, B3[t]), o[c], 0, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    p[12 * g + 4 * c] = o[c][0]; p[12 * g + 4 * c + 1] = o[c][1];
-                    p[12 * g + 4 * c + 2] = o[c][2]; p[12 * g + 4 * c + 3] = o[c][3];
+                for (int c = 0; c < GRP; ++c) {
+                    p[4 * GRP * g + 4 * c] = o[c][0]; p[4 * GRP * g + 4 * c + 1] = o[c][1];
+                    p[4 * GRP * g + 4 * c + 2] = o[c][2]; p[4 * GRP * g + 4 * c + 3] = o[c][3];
                 }
             }
             float v;
@@ -378,7 +480,10 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
                 for (int c2 = 1; c2 < NC; ++c2) v = (ch == c2) ? tgt[ELEMS * c2 + e] : v;
             }
             float out = v, l = 0.0f;
-            if (v > C.minimum && v < C.maximum) rqs_eval_lean<INVERSE>(p, v, C, out, l);
+            if (v > C.minimum && v < C.maximum) {
+                if constexpr (LRS) lrs_eval_lean<INVERSE>(p, v, C, out, l);
+                else rqs_eval_lean<INVERSE>(p, v, C, out, l);
+            }
             ld2 += l;
             if constexpr (STATIC_CH) {
                 tgt[ELEMS * ch + e] = out;
@@ -409,7 +514,7 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
 #define TFK_RQS3_WAVES 4
 #endif
 template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((STEPS2 == 0 || STEPS2 == 8) ? (EPL == 32 ? 2 : TFK_RQS3_WAVES) : 1)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((STEPS2 == 0 || STEPS2 >= 8) ? (EPL == 32 ? 2 : TFK_RQS3_WAVES) : 1)))
 void k_flow_rqs_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
@@ -417,13 +522,14 @@ void k_flow_rqs_chain(
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
-    constexpr bool F3 = STEPS2 == 0 || STEPS2 == 8;
-    constexpr int HT3 = STEPS2 == 8 ? 2 : 1;
+    constexpr bool F3 = STEPS2 == 0 || STEPS2 >= 8;
+    constexpr bool LRS = STEPS2 >= 16;
+    constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
     constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;
     const bool base_of_input = (flags & 4) != 0;
-    constexpr int CHUNK = F3 ? kRqsChunk3Dwords : kRqsChunkFloats;
+    constexpr int CHUNK = F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats;
     float *stage = lds;                                      // [HEAD + chunk]
     float *ew_s = lds + HEAD + CHUNK;                        // s[D] | t[D] | ldc, pad[3]
     float *base_s = ew_s + 2 * D + 4;                        // loc[D] | 1/scale[D] | const
@@ -500,8 +606,8 @@ void k_flow_rqs_chain(
         for (int l = 0; l < prog.n_layers; ++l) {
             const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
             if constexpr (F3) {
-                if (((prog.first_src + l) & 1) == 0) rqs_layer3<EPL, BLOCK, HT3, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
-                else rqs_layer3<EPL, BLOCK, HT3, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+                if (((prog.first_src + l) & 1) == 0) rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS>(gprm, stage, lane, q, C, a, b, ld2);
+                else rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS>(gprm, stage, lane, q, C, b, a, ld2);
             } else {
                 if (((prog.first_src + l) & 1) == 0)
                     rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
@@ -564,10 +670,11 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
                               int xw, hipStream_t s, const char *fn)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
-    constexpr bool F3 = STEPS2 == 0 || STEPS2 == 8;
-    constexpr int HT3 = STEPS2 == 8 ? 2 : 1;
+    constexpr bool F3 = STEPS2 == 0 || STEPS2 >= 8;
+    constexpr bool LRS = STEPS2 >= 16;
+    constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
     constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
-    const size_t lds = ((size_t)HEAD + (F3 ? kRqsChunk3Dwords : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float);
+    const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float);
     auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -602,6 +709,8 @@ static int launch_rqs_chain(const float *x, float *z, float *logdet, const float
     switch (steps2) {
     case 0: return TFK_RC(0);                                // bf16 x 3 operands, hidden width <= 15
     case 8: return TFK_RC(8);                                // bf16 x 3 operands, hidden width <= 31
+    case 16: return TFK_RC(16);                              // linear rational spline, hidden width <= 15
+    case 24: return TFK_RC(24);                              // linear rational spline, hidden width <= 31
     case 1: return TFK_RC(1);
     case 2: return TFK_RC(2);
     case 3: return TFK_RC(3);

@@ -42,7 +42,8 @@ from torchflows_amd import native
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
     OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
     OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA, \
-    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN = range(23)
+    OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN, \
+    OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN = range(25)
 MAX_CONTEXT = 16      # context elements a flow program takes (4 k-steps of 4, csrc/tfk_flow_mfma.h: kCtxSteps)
 LOG2E = 1.4426950408889634
 AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
@@ -316,7 +317,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
             and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
         return None
-    P = {"shift": 1, "rqs": 23}.get(kind, 2)
+    P = {"shift": 1, "rqs": 23, "lrs": 32}.get(kind, 2)
     W1, b1 = mods[0].weight.detach(), mods[0].bias.detach()          # (H, S), (H,)
     W2, b2 = mods[2].weight.detach(), mods[2].bias.detach()          # (T*P, H), (T*P,)
     H = W1.shape[0]
@@ -579,9 +580,9 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     in fp64, or None (the checks of ``_coupling_op``)."""
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
     kind = layer.transformer.native_kind
-    if kind not in ("affine", "inverse_affine", "shift", "rqs") or layer.context_shape is not None:
+    if kind not in ("affine", "inverse_affine", "shift", "rqs", "lrs") or layer.context_shape is not None:
         return None
-    if kind == "rqs" and layer.transformer.n_bins != 8:
+    if kind in ("rqs", "lrs") and layer.transformer.n_bins != 8:
         return None
     half = D // 2
     c = layer.coupling
@@ -597,11 +598,11 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.Tanh)
             and isinstance(mods[2], nn.Linear) and isinstance(mods[3], nn.Unflatten)):
         return None
-    P = {"shift": 1, "rqs": 23}.get(kind, 2)
+    P = {"shift": 1, "rqs": 23, "lrs": 32}.get(kind, 2)
     W1, b1 = mods[0].weight.detach().double(), mods[0].bias.detach().double()
     W2, b2 = mods[2].weight.detach().double(), mods[2].bias.detach().double()
     H = W1.shape[0]
-    if H > (31 if kind == "rqs" else 16) or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
+    if H > (31 if kind in ("rqs", "lrs") else 16) or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
         return None
     hp = Dp // 2
     src_pos, tgt_pos = pos[:S], pos[S:]
@@ -619,6 +620,8 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
         lk = 2 if d == FORWARD else 3
     elif kind == "rqs":
         lk = 4 if d == FORWARD else 5
+    elif kind == "lrs":
+        lk = 8 if d == FORWARD else 9
     else:
         lk = 0 if (d == FORWARD) != (kind == "inverse_affine") else 1
     return lk, plane, H, W1t, b1, W2p, b2p
@@ -713,13 +716,16 @@ def _bf16_pieces(w: torch.Tensor):
     return [(t.contiguous().view(torch.int32) >> 16) & 0xFFFF for t in (hi, mid, lo)]
 
 
-def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float, bf16x3: bool = False) -> torch.Tensor:
+def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float, bf16x3: bool = False,
+                   lrs: bool = False) -> torch.Tensor:
     """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out.
     fp32 operands (hidden width <= 16): head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks
     A2[48][64][4] | b2[48][4][4].  bf16 x 3 operands (hidden width <= 15, or <= 31 with HT = 2 hidden tiles): head
     A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then EPL HT / 4 chunks A[4/HT][6][HT][2][64][4 dwords].
     Per target element 24 parameters, all times log2(e): [0, 8) u_x, [8, 16) u_x + u_y / 1000 (the reference's height
-    logits, rational_quadratic.py:76), [16, 23) c + u_d / 1000 (:77, c = boundary_u_delta), pad."""
+    logits, rational_quadratic.py:76), [16, 23) c + u_d / 1000 (:77, c = boundary_u_delta), pad.
+    ``lrs`` (bf16 x 3 only): linear rational spline, 32 parameters = 8 tiles per element (linear_rational.py:49-58):
+    [0, 8) u_x, [8, 16) u_x + u_y / 100, [16, 24) -u_lambda, [24, 31) c + u_d / 100, [31] u_w0, times log2(e)."""
     hp, EPL = Dp // 2, Dp // 8
     dev = W1t.device
     HT = 2 if (bf16x3 and H > 15) else 1
@@ -728,14 +734,25 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     W1pad[:H] = W1t * (2.0 * LOG2E)
     b1pad = torch.zeros(HU, dtype=torch.float64, device=dev)
     b1pad[:H] = b1 * (2.0 * LOG2E)
-    Q = torch.zeros(hp, 24, HU, dtype=torch.float64, device=dev)
-    Q[:, 0:8, :H] = W2p[:, 0:8] * LOG2E
-    Q[:, 8:16, :H] = (W2p[:, 0:8] + W2p[:, 8:16] / 1000.0) * LOG2E
-    Q[:, 16:23, :H] = W2p[:, 16:23] / 1000.0 * LOG2E
-    bq = torch.zeros(hp, 24, dtype=torch.float64, device=dev)
-    bq[:, 0:8] = b2p[:, 0:8] * LOG2E
-    bq[:, 8:16] = (b2p[:, 0:8] + b2p[:, 8:16] / 1000.0) * LOG2E
-    bq[:, 16:23] = (c_delta + b2p[:, 16:23] / 1000.0) * LOG2E
+    TPE = 8 if lrs else 6                                          # tiles of 4 parameters per element
+    Q = torch.zeros(hp, 4 * TPE, HU, dtype=torch.float64, device=dev)
+    bq = torch.zeros(hp, 4 * TPE, dtype=torch.float64, device=dev)
+    if lrs:
+        assert bf16x3
+        for dst, w in ((Q[:, :, :H], W2p), (bq, b2p)):
+            dst[:, 0:8] = w[:, 0:8] * LOG2E
+            dst[:, 8:16] = (w[:, 0:8] + w[:, 8:16] / 100.0) * LOG2E
+            dst[:, 16:24] = -w[:, 16:24] * LOG2E
+            dst[:, 24:31] = w[:, 24:31] / 100.0 * LOG2E
+            dst[:, 31] = w[:, 31] * LOG2E
+        bq[:, 24:31] += c_delta * LOG2E
+    else:
+        Q[:, 0:8, :H] = W2p[:, 0:8] * LOG2E
+        Q[:, 8:16, :H] = (W2p[:, 0:8] + W2p[:, 8:16] / 1000.0) * LOG2E
+        Q[:, 16:23, :H] = W2p[:, 16:23] / 1000.0 * LOG2E
+        bq[:, 0:8] = b2p[:, 0:8] * LOG2E
+        bq[:, 8:16] = (b2p[:, 0:8] + b2p[:, 8:16] / 1000.0) * LOG2E
+        bq[:, 16:23] = (c_delta + b2p[:, 16:23] / 1000.0) * LOG2E
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
     unit1 = 4 * (il & 3) + (il >> 2)
@@ -747,18 +764,18 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     q2, r2 = il >> 2, il & 3
     parts = [A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]
     e_all = torch.arange(EPL, device=dev).view(EPL, 1, 1, 1, 1)                        # the lane-group's element index
-    c = torch.arange(6, device=dev).view(1, 6, 1, 1, 1)
+    c = torch.arange(TPE, device=dev).view(1, TPE, 1, 1, 1)
     m = EPL * q2.view(1, 1, 1, 64, 1) + e_all                                          # physical target element
     if bf16x3:
         Q[:, :, HU - 1] = bq                                   # the bias as the weight of the last hidden unit (= 1)
         th = torch.arange(HT, device=dev).view(1, 1, HT, 1, 1)
         i4 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
-        Wf = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 16 * th + 4 * i4 + ql.view(1, 1, 1, 64, 1)]   # (EPL, 6, HT, 64, 4)
+        Wf = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 16 * th + 4 * i4 + ql.view(1, 1, 1, 64, 1)]   # (EPL, TPE, HT, 64, 4)
         hi, mid, lo = _bf16_pieces(Wf)
         pack2 = lambda v: (v[..., 0::2] | (v[..., 1::2] << 16))
         a1 = torch.cat([pack2(hi), pack2(mid)], dim=-1)
         a2 = torch.cat([pack2(lo), pack2(hi)], dim=-1)
-        A3 = torch.stack([a1, a2], dim=3).to(torch.int32)                              # (EPL, 6, HT, 2, 64, 4)
+        A3 = torch.stack([a1, a2], dim=3).to(torch.int32)                              # (EPL, TPE, HT, 2, 64, 4)
         return torch.cat([torch.cat(parts).float(), A3.reshape(-1).view(torch.float32)])
     r1 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
     A2 = Q[m, 4 * c + r2.view(1, 1, 1, 64, 1), 4 * r1 + ql.view(1, 1, 1, 64, 1)][:, :, 0]   # (EPL, 6, 64, 4)
@@ -892,9 +909,11 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 if got is None:
                     return None
                 lk, plane, H, W1t, b1, W2p, b2p = got
-                if kind0 is not None and kind0 >= 6:
+                if kind0 is not None and kind0 in (6, 7):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
+                if lk >= 8 and not rqs_bf16x3_enabled():
+                    return None                               # (linear rational splines: bf16 x 3 operands only)
                 if lk >= 4 and rqs_bf16x3_enabled():
                     steps2 = (H + 1 + 3) // 4                 # bf16 x 3 operands: counts the bias unit; > 4 = two hidden tiles
                 if kind0 is None:
@@ -906,7 +925,16 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 tgt = torch.arange((1 - plane) * hp, (2 - plane) * hp, device=device)
                 b1f = b1 + W1t @ t[src]                      # W1 (s x + t) + b1 = (W1 s) x + (W1 t + b1)
                 W1f = W1t * s[src]
-                if lk >= 4:                                  # RQ spline: one launch for the chain, operands streamed
+                if lk >= 8:                                  # linear rational spline: as the RQ spline, 32 parameters
+                    tr = layer.transformer
+                    extra = (8 + 256, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_width * tr.n_bins)),
+                             float(np.float32(tr.const)))
+                    if items and items[-1][4] != extra:
+                        return None
+                    block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
+                                           float(np.float32(tr.const)), bf16x3=True, lrs=True)
+                    items.append((OP_LRS_FWD_LEAN + lk - 8, plane, steps2, block, extra))
+                elif lk >= 4:                                # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
                     fmt3 = rqs_bf16x3_enabled()                       # (the last hidden unit carries the bias: H <= 31)
                     if not fmt3 and H > 16:
@@ -930,7 +958,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
             else:
                 return None
     flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
-    streamed = kind0 in (4, 5)                           # spline chains read their operands from global memory
+    streamed = kind0 in (4, 5, 8, 9)                     # spline chains read their operands from global memory
     if not items and streamed:
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
@@ -1228,7 +1256,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     padded = chain.pos_in is not None
     # lean programs read narrower rows themselves (tfk_flow_run_mfma_in): no padding pass over the rows
     narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma
-                 and OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN and narrow_enabled())
+                 and (OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN
+                      or chain.segments[0].ops[0][0] in (OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN)) and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
         wide = rows.new_zeros(N, chain.D)
         if chain.D_log % 2 == 0:                 # each half at the head of its plane: two strided copies
