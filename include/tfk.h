@@ -290,6 +290,10 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
  * packed by torchflows_amd/fused.py:_pack_mfma). */
 int tfk_flow_mfma_supported(int32_t D);
+/* Row widths the LEAN programs (TFK_OP_*_LEAN) run at: tfk_flow_mfma_supported's and 32 -- event sizes <= 32 are
+ * padded to 32 instead of 64 (the straight-line kernels are instantiated for D / 8 = 4 as well; spline chains at
+ * D = 32 in the bf16 x 3 operand format only). */
+int tfk_flow_lean_supported(int32_t D);
 int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                       const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,

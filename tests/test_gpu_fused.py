@@ -691,3 +691,50 @@ def test_linear_rational_spline_chain_is_one_launch(D, n_hidden, n_layers):
     assert e_lp < 1e-5
     assert e_z < 2e-5
     assert torch.allclose(xr.cpu(), x, atol=2e-3, rtol=1e-5) and torch.allclose(ld_d, -ldr, atol=1e-3)
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("RealNVP", 128), ("RealNVP", 22), ("MAF", 64), ("IAF", 64)])
+def test_affine_scale_logits_far_below_zero(arch, D):
+    """alpha = exp(u / 2 + c0) + 1e-10 (affine.py:33-34) with logits down to -80: the chain kernels take log2(alpha) = u'
+    (and 1 / alpha = 2^-u' in the inverse) only while every lane of the wave holds u' >= -8 (csrc/tfk_flow_chain.h:
+    log2_scales) -- rows whose scales approach the 1e-10 floor must take the full logarithm.  Against the host path in
+    fp64, in the direction(s) that run as a chain kernel (MAF: forward, IAF: inverse, RealNVP: both)."""
+    import copy
+    import torchflows_amd as tfa
+    torch.manual_seed(9)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow.eval()
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if name.endswith("sequential.2.bias"):          # (T, 2) interleaved (scale logit, shift)
+                b = p.view(-1, 2)
+                b[:, 0] += torch.linspace(-80.0, 0.0, b.shape[0])[torch.randperm(b.shape[0])]
+    flow64 = copy.deepcopy(flow).double()
+    flow = flow.cuda()
+    if arch != "IAF":
+        x = torch.randn(3000, D)
+        with torch.no_grad():
+            lp_h = flow64.log_prob(x.double())
+            z_h, ld_h = flow64.bijection.forward(x.double())
+            lp_d = flow.log_prob(x.cuda())
+            z_d, ld_d = flow.bijection.forward(x.cuda())
+        e_lp, e_ld = rel(lp_d.cpu().numpy(), lp_h.numpy()), rel(ld_d.cpu().numpy(), ld_h.numpy())
+        print(f"{arch}({D}) scale logits down to -80: log_prob {e_lp:.2e}, log_det {e_ld:.2e}, "
+              f"mean log_det {float(ld_h.mean()):.1f}")
+        assert e_lp < 1e-5 and e_ld < 1e-5
+        assert normwise(z_d.cpu().numpy(), z_h.numpy()) < 2e-5
+    if arch != "MAF":
+        # the inverse map (Flow.sample's direction; 1 / alpha up to 2e17 per layer)
+        y = torch.randn(3000, D) * 1e-3
+        with torch.no_grad():
+            xi_h, ldi_h = flow64.bijection.inverse(y.double())
+            xi_d, ldi_d = flow.bijection.inverse(y.cuda())
+        e_ldi = rel(ldi_d.cpu().numpy(), ldi_h.numpy())
+        ok = torch.isfinite(xi_h.float()).all(dim=1)                   # (rows that leave fp32's range are not compared)
+        e_xi = normwise(xi_d.cpu()[ok].numpy(), xi_h[ok].numpy())
+        print(f"{arch}({D}) inverse: log_det {e_ldi:.2e}, x nw {e_xi:.2e} on {int(ok.sum())} rows")
+        assert e_ldi < 1e-5
+        assert int(ok.sum()) > 100 and e_xi < 1e-4

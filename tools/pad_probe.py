@@ -25,10 +25,10 @@ for D in sizes:
         with torch.no_grad(), warnings.catch_warnings():
             warnings.simplefilter("ignore")
             from torchflows_amd.distributed import sharded_log_likelihood as sll
-            sll(flow, x, chunk_rows=1 << 18); torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(5): lp = sll(flow, x, chunk_rows=1 << 18)
+            sll(flow, x, chunk_rows=1 << 20); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): lp = sll(flow, x, chunk_rows=1 << 20)
             torch.cuda.synchronize()
-        rate = (1 << 20) * 5 / (time.perf_counter() - t0)
+        rate = (1 << 20) * 20 / (time.perf_counter() - t0)
         if D == 64 and ref_rate is None:
             ref_rate = rate * 64
         extra = f", per-element rate {rate * D / ref_rate:.2f} x D=64's" if ref_rate else ""

@@ -40,10 +40,33 @@ struct ChainProg {
 
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
 
+// log2 of the two scales of one GEMM-2 tile, alpha = exp2(u) + 1e-10 (affine.py:33-42):
+//   log2 alpha = u + log2(1 + 1e-10 * 2^-u),
+// and for u >= -8 (alpha >= 0.0039) the second term is below 3.7e-8 -- under the rounding of v_log_f32's own result
+// there.  FAST: take u, and keep the smallest logit this lane has seen (one v_min3_f32 per tile); the kernel checks it
+// ONCE per 16 rows after the chain and, if any lane of the wave saw a logit below -8, re-runs the chain on those rows
+// with the logarithms (a guard per tile costs more than the 8 quarter-rate v_log_f32 per wave-layer it would save:
+// 267 us per launch against 255 without the shortcut and 241 unguarded, RealNVP-64).
+// -DTFK_LOG_SHORTCUT=0: always take the logarithm.
+#ifndef TFK_LOG_SHORTCUT
+#define TFK_LOG_SHORTCUT 1
+#endif
+constexpr float kLogShortcutMin = -8.0f;
+template <bool FAST>
+__device__ __forceinline__ float log2_scales(float u0, float u1, float al0, float al1, float &umin)
+{
+    if constexpr (FAST) {
+        umin = fminf(fminf(umin, u0), u1);
+        return u0 + u1;
+    } else {
+        return __builtin_amdgcn_logf(al0) + __builtin_amdgcn_logf(al1);
+    }
+}
+
 // KIND: 0 affine fwd, 1 affine inv, 2 shift fwd, 3 shift inv
-template <int EPL, int STEPS2, int KIND>
+template <int EPL, int STEPS2, int KIND, bool FAST>
 __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, const float (&src)[EPL],
-                                            float (&tgt)[EPL], float &ld2)
+                                            float (&tgt)[EPL], float &ld2, float &umin)
 {
     constexpr bool affine = KIND < 2;
     constexpr int HALF = 4 * EPL;
@@ -99,14 +122,20 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
         for (int k = 0; k < STEPS2; ++k)
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt * STEPS2 + k], hid[k], o, 0, 0, 0);
         if constexpr (affine) {
+            // affine.py:33-34 with the logit row pre-scaled: o = (u / 2 + c0) log2 e
+            if constexpr (FAST && KIND == 1) {               // 1 / alpha = 2^-u to 2.6e-8 relative while u >= -8 (log2_scales)
+                ld2 += log2_scales<true>(o[0], o[2], 0.0f, 0.0f, umin);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) tgt[2 * t + i] = (tgt[2 * t + i] - o[2 * i + 1]) * __builtin_amdgcn_exp2f(-o[2 * i]);
+            } else {
+            const float al[2] = {__builtin_amdgcn_exp2f(o[0]) + kAffMinScale, __builtin_amdgcn_exp2f(o[2]) + kAffMinScale};
+            ld2 += log2_scales<FAST>(o[0], o[2], al[0], al[1], umin);               // log2 alpha; affine.py:42
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int e = 2 * t + i;
-                // affine.py:33-34 with the logit row pre-scaled: o = (u / 2 + c0) log2 e
-                const float al = __builtin_amdgcn_exp2f(o[2 * i]) + kAffMinScale;
-                ld2 += __builtin_amdgcn_logf(al);                                    // log2 alpha; affine.py:42
-                if constexpr (KIND == 0) tgt[e] = fmaf(al, tgt[e], o[2 * i + 1]);    // affine.py:48
-                else tgt[e] = (tgt[e] - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al);   // affine.py:59
+                if constexpr (KIND == 0) tgt[e] = fmaf(al[i], tgt[e], o[2 * i + 1]);    // affine.py:48
+                else tgt[e] = (tgt[e] - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al[i]);   // affine.py:59
+            }
             }
         } else {
 #pragma unroll
@@ -130,9 +159,9 @@ typedef int li32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32 (32 cycles each); b2 rides as the weight of hidden unit 15 = 1 (hidden width <= 15).
 // Block: A1[EPL/4][64][4] | b1[4][4] | A23[T2][2][64][4 dwords] | pre_s[HALF] | pre_t[HALF]
 //   A23[t][0] = [W_hi | W_mid], A23[t][1] = [W_lo | W_hi]: 4 bf16 each = hidden units 4 i + (lane >> 4).
-template <int EPL, int KIND>
+template <int EPL, int KIND, bool FAST>
 __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, const float (&src)[EPL],
-                                             float (&tgt)[EPL], float &ld2)
+                                             float (&tgt)[EPL], float &ld2, float &umin)
 {
     constexpr bool affine = KIND < 2;
     constexpr int HALF = 4 * EPL;
@@ -194,13 +223,20 @@ __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, 
 #pragma unroll
     for (int t = 0; t < T2; ++t) {
         if constexpr (affine) {
+            if constexpr (FAST && KIND == 1) {
+                ld2 += log2_scales<true>(o[t][0], o[t][2], 0.0f, 0.0f, umin);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    tgt[2 * t + i] = (tgt[2 * t + i] - o[t][2 * i + 1]) * __builtin_amdgcn_exp2f(-o[t][2 * i]);
+            } else {
+            const float al[2] = {__builtin_amdgcn_exp2f(o[t][0]) + kAffMinScale, __builtin_amdgcn_exp2f(o[t][2]) + kAffMinScale};
+            ld2 += log2_scales<FAST>(o[t][0], o[t][2], al[0], al[1], umin);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int e = 2 * t + i;
-                const float al = __builtin_amdgcn_exp2f(o[t][2 * i]) + kAffMinScale;
-                ld2 += __builtin_amdgcn_logf(al);
-                if constexpr (KIND == 0) tgt[e] = fmaf(al, tgt[e], o[t][2 * i + 1]);
-                else tgt[e] = (tgt[e] - o[t][2 * i + 1]) * __builtin_amdgcn_rcpf(al);
+                if constexpr (KIND == 0) tgt[e] = fmaf(al[i], tgt[e], o[t][2 * i + 1]);
+                else tgt[e] = (tgt[e] - o[t][2 * i + 1]) * __builtin_amdgcn_rcpf(al[i]);
+            }
             }
         } else {
 #pragma unroll
@@ -221,8 +257,9 @@ __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, 
 // elements only.  KIND 4: alpha x + beta, 5: (x - beta) / alpha.
 // Block: A1[2 EPL / 4][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | A2[nA2 / 4][64][4] | b2[EPL][4][4] |
 //        pre_s[D] | pre_t[D];  tile t < EPL / 2: this lane's elements 2 t, 2 t + 1 of plane A, else of plane B.
-template <int EPL, int STEPS2, int KIND>
-__device__ __forceinline__ void made_lean(const float *prm, int lane, int q, float (&a)[EPL], float (&b)[EPL], float &ld2)
+template <int EPL, int STEPS2, int KIND, bool FAST>
+__device__ __forceinline__ void made_lean(const float *prm, int lane, int q, float (&a)[EPL], float (&b)[EPL], float &ld2,
+                                          float &umin)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     constexpr int T2 = EPL;
@@ -277,25 +314,57 @@ __device__ __forceinline__ void made_lean(const float *prm, int lane, int q, flo
 #pragma unroll
             for (int k = 0; k < STEPS2; ++k)
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt * STEPS2 + k], hid[k], o, 0, 0, 0);
+            if constexpr (FAST && KIND == 5) {
+                ld2 += log2_scales<true>(o[0], o[2], 0.0f, 0.0f, umin);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
+                    v = (v - o[2 * i + 1]) * __builtin_amdgcn_exp2f(-o[2 * i]);
+                }
+            } else {
+            const float al[2] = {__builtin_amdgcn_exp2f(o[0]) + kAffMinScale, __builtin_amdgcn_exp2f(o[2]) + kAffMinScale};
+            ld2 += log2_scales<FAST>(o[0], o[2], al[0], al[1], umin);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float al = __builtin_amdgcn_exp2f(o[2 * i]) + kAffMinScale;
-                ld2 += __builtin_amdgcn_logf(al);
                 float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
-                if constexpr (KIND == 4) v = fmaf(al, v, o[2 * i + 1]);
-                else v = (v - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al);
+                if constexpr (KIND == 4) v = fmaf(al[i], v, o[2 * i + 1]);
+                else v = (v - o[2 * i + 1]) * __builtin_amdgcn_rcpf(al[i]);
+            }
             }
         }
     }
 }
 
 // one coupling in whichever operand format the kernel was instantiated for (STEPS2 = 0: bf16 x 3)
-template <int EPL, int STEPS2, int KIND>
+template <int EPL, int STEPS2, int KIND, bool FAST>
 __device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, const float (&src)[EPL],
-                                           float (&tgt)[EPL], float &ld2)
+                                           float (&tgt)[EPL], float &ld2, float &umin)
 {
-    if constexpr (STEPS2 == 0) couple_lean3<EPL, KIND>(prm, lane, q, src, tgt, ld2);
-    else couple_lean<EPL, STEPS2, KIND>(prm, lane, q, src, tgt, ld2);
+    if constexpr (STEPS2 == 0) couple_lean3<EPL, KIND, FAST>(prm, lane, q, src, tgt, ld2, umin);
+    else couple_lean<EPL, STEPS2, KIND, FAST>(prm, lane, q, src, tgt, ld2, umin);
+}
+
+// the couplings (or MADE layers) of the program on the 16 rows a wave holds
+template <int EPL, int STEPS2, int KIND, bool FAST>
+__device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &prog, int lane, int q, float (&a)[EPL],
+                                             float (&b)[EPL], float &ld2, float &umin)
+{
+    int o = 0;
+    if constexpr (KIND >= 4) {                                    // MADE layers: both planes in, both planes out
+#pragma unroll 1
+        for (; o < prog.n_c; ++o)
+            made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
+    } else {
+        if (prog.first_src == 1 && prog.n_c > 0) {
+            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[0], lane, q, b, a, ld2, umin);
+            o = 1;
+        }
+        for (; o + 1 < prog.n_c; o += 2) {
+            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
+            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o + 1], lane, q, b, a, ld2, umin);
+        }
+        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
+    }
 }
 
 // (tuning hook: -DTFK_CHAIN_ATTR='__attribute__((amdgpu_waves_per_eu(5, 5)))' for occupancy experiments, tools/variants.sh)
@@ -345,6 +414,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
         const long long row = row0 + j;
         const long long rr = row < N ? row : N - 1;    // tail: compute a valid row, store nothing
         float a[EPL], b[EPL];
+        auto load_rows = [&]() {
         if (xw == D) {
             const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
             const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
@@ -355,8 +425,8 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
                 b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
             }
         } else {
-            // rows narrower than the kernel's planes (event sizes that are not 64 / 128 / 256): the caller's rows are
-            // read as they are -- first half into the head of plane A, second half into the head of plane B, zeros
+            // rows narrower than the kernel's planes (event sizes that are not 32 / 64 / 128 / 256): the caller's rows
+            // are read as they are -- first half into the head of plane A, second half into the head of plane B, zeros
             // behind them (the padding is an exact identity by construction of the weights, fused.py)
             const int hl = xw >> 1;
             const float *xr = x + rr * xw;
@@ -368,6 +438,8 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
                 b[e] = ok ? xr[hl + col] : 0.0f;
             }
         }
+        };
+        load_rows();
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         float sq = 0.0f;                                              // sum of squared standardised elements
         auto base_terms = [&]() {                                     // gaussian.py:46-54
@@ -389,21 +461,15 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
         if (logprob && base_of_input) base_terms();                   // Flow.sample (flows.py:699-707)
 
         float ld2 = 0.0f;                                             // this lane's share, in base 2
-        int o = 0;
-        if constexpr (KIND >= 4) {                                    // MADE layers: both planes in, both planes out
-#pragma unroll 1
-            for (; o < prog.n_c; ++o)
-                made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
-        } else {
-            if (prog.first_src == 1 && prog.n_c > 0) {
-                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[0], lane, q, b, a, ld2);
-                o = 1;
+        float umin = 0.0f;                                            // smallest scale logit seen (log2_scales)
+        constexpr bool kShortcut = TFK_LOG_SHORTCUT && (KIND < 2 || KIND >= 4);
+        chain_layers<EPL, STEPS2, KIND, kShortcut>(lds, prog, lane, q, a, b, ld2, umin);
+        if constexpr (kShortcut) {
+            if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {   // scales near the 1e-10 floor: with logarithms
+                load_rows();                                          // (x is still intact: z is stored below)
+                ld2 = 0.0f;
+                chain_layers<EPL, STEPS2, KIND, false>(lds, prog, lane, q, a, b, ld2, umin);
             }
-            for (; o + 1 < prog.n_c; o += 2) {
-                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
-                couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o + 1], lane, q, b, a, ld2);
-            }
-            if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND>(lds + prog.offset[o], lane, q, a, b, ld2);
         }
         if constexpr (KIND == 0 || KIND == 4) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
         else if constexpr (KIND == 1 || KIND == 5) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);

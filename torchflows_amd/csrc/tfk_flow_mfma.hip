@@ -5,6 +5,8 @@
 #include "tfk_flow_rqs_chain.h"
 
 namespace tfk {
+int flow_chain_launch_4(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                        const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
                         const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -12,6 +14,8 @@ int flow_chain_launch_16(const float *, float *, float *, const float *, const f
 int flow_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
                          const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 
+int flow_rqs_chain_launch_4(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_rqs_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_rqs_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -92,6 +96,7 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
                         : (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
     const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN;
     if (fmt3) steps2 = (ht3 == 2 ? 8 : 0) + (lrs ? 16 : 0);
+    if (EPL == 4) return flow_rqs_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
     return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
@@ -161,6 +166,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     }
     if (kind < 0) kind = 2;
     if (fmt3) steps2 = 0;
+    if (EPL == 4) return flow_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     return flow_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
@@ -180,6 +186,8 @@ extern "C" {
 
 int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128 || D == 256) ? 1 : 0; }
 
+int tfk_flow_lean_supported(int32_t D) { return (D == 32 || tfk_flow_mfma_supported(D)) ? 1 : 0; }
+
 static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
                               const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                               const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
@@ -190,7 +198,10 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         return fail(TFK_EINVAL, "%s: context size %d must be in [1, %d]", fn, C, 4 * kCtxSteps);
     const int cs_want = context ? (C + 3) / 4 : 0;
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
-    if (!tfk_flow_mfma_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256", fn, D);
+    const bool lean = n_ops > 0 && ops && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN) ||
+                                           (ops[0] >= TFK_OP_MADE_FWD_LEAN && ops[0] <= TFK_OP_LRS_INV_LEAN));
+    if (!(lean ? tfk_flow_lean_supported(D) : tfk_flow_mfma_supported(D)))
+        return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256 (lean programs: 32 as well)", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
     if (n_params < 0 || (n_params & 3)) return fail(TFK_EINVAL, "%s: n_params must be a non-negative multiple of 4", fn);
     if (N == 0) return TFK_OK;
@@ -199,8 +210,6 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
-    const bool lean = n_ops > 0 && ops && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN) ||
-                                           (ops[0] >= TFK_OP_MADE_FWD_LEAN && ops[0] <= TFK_OP_LRS_INV_LEAN));
     if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);

@@ -711,12 +711,18 @@ static int launch_rqs_chain(const float *x, float *z, float *logdet, const float
     case 8: return TFK_RC(8);                                // bf16 x 3 operands, hidden width <= 31
     case 16: return TFK_RC(16);                              // linear rational spline, hidden width <= 15
     case 24: return TFK_RC(24);                              // linear rational spline, hidden width <= 31
-    case 1: return TFK_RC(1);
-    case 2: return TFK_RC(2);
-    case 3: return TFK_RC(3);
-    case 4: return TFK_RC(4);
-    default: return fail(TFK_EINVAL, "%s: lean spline couplings need 1..4 GEMM-2 steps, got %d", fn, steps2);
+    default: break;
     }
+    if constexpr (EPL >= 8) {                                // fp32 operands: chunks of 8 elements per lane group
+        switch (steps2) {
+        case 1: return TFK_RC(1);
+        case 2: return TFK_RC(2);
+        case 3: return TFK_RC(3);
+        case 4: return TFK_RC(4);
+        default: break;
+        }
+    }
+    return fail(TFK_EINVAL, "%s: lean spline couplings: %d GEMM-2 steps (fp32 operands: 1..4, D >= 64)", fn, steps2);
 #undef TFK_RC
 }
 

@@ -937,8 +937,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 elif lk >= 4:                                # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
                     fmt3 = rqs_bf16x3_enabled()                       # (the last hidden unit carries the bias: H <= 31)
-                    if not fmt3 and H > 16:
-                        return None
+                    if not fmt3 and (H > 16 or Dp < 64):
+                        return None                                   # (fp32 operands: chunks of 8 elements per lane group)
 
                     extra = (8 + (256 if fmt3 else 0), float(tr.boundary),
                              float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)), float(np.float32(tr.boundary_u_delta)))
@@ -1025,14 +1025,22 @@ def compile_chain(composition, direction: int, device: torch.device,
     plan = _flatten(order, "forward" if direction == FORWARD else "inverse")
     if plan is None:
         return None
-    pos = torch.arange(D, device=device)
-    if Dp != D and not slots:                    # second half of the row starts at the padded plane boundary
-        pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
-    pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
+    def planes(width):                           # logical element -> physical column of a row of `width`
+        p_ = torch.arange(D, device=device)
+        if width != D and not slots:             # second half of the row starts at the padded plane boundary
+            p_ = torch.where(p_ < D // 2, p_, p_ - D // 2 + width // 2)
+        return p_
     if mfma and not slots and lean_enabled() and not context:
-        chain = _compile_lean(composition, plan, device, D, Dp, pos.clone(), pos_in)
-        if chain is not None:
-            return chain
+        # event sizes <= 32: the straight-line kernels exist at row width 32 as well (half the work of a 64-wide row)
+        widths = ([32] if (D % 2 == 0 and 4 <= D <= 32 and narrow_rows_enabled()) else []) + [Dp]
+        for w in widths:
+            if w != D and not padded_enabled(D, w):
+                continue
+            chain = _compile_lean(composition, plan, device, D, w, planes(w), planes(w))
+            if chain is not None:
+                return chain
+    pos = planes(Dp)
+    pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
     items = []                                   # [(op triple, block)]
     with torch.no_grad():
         for layer, d in plan:
@@ -1089,6 +1097,11 @@ def compile_chain(composition, direction: int, device: torch.device,
 
 def narrow_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_NARROW_IN", "1") != "0"
+
+
+def narrow_rows_enabled() -> bool:
+    """Row width 32 for event sizes <= 32 (TORCHFLOWS_AMD_ROWS32=0: pad them to 64 as before)."""
+    return os.environ.get("TORCHFLOWS_AMD_ROWS32", "1") != "0"
 
 
 def padded_enabled(D: int, Dp: int) -> bool:

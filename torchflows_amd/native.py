@@ -33,7 +33,7 @@ SYMBOLS = (
     "tfk_permute", "tfk_diag_gauss_logprob",
     "tfk_sum_workspace_bytes", "tfk_sum_f32", "tfk_sum_f32_ws",
     "tfk_flow_supported", "tfk_flow_run",
-    "tfk_flow_mfma_supported", "tfk_flow_run_mfma", "tfk_flow_run_mfma_in", "tfk_flow_run_mfma_ctx",
+    "tfk_flow_mfma_supported", "tfk_flow_lean_supported", "tfk_flow_run_mfma", "tfk_flow_run_mfma_in", "tfk_flow_run_mfma_ctx",
     "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
     "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd", "tfk_lrs_coupling_bwd",
     "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
@@ -97,6 +97,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_flow_run.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(_i32), _i32,
                                _vp, _i64, _i32, _vp]
     L.tfk_flow_mfma_supported.argtypes = [_i32]
+    L.tfk_flow_lean_supported.argtypes = [_i32]
     L.tfk_flow_run_mfma.argtypes = L.tfk_flow_run.argtypes
     L.tfk_flow_run_mfma_in.argtypes = [_vp, _i32] + L.tfk_flow_run.argtypes[1:]
     L.tfk_flow_run_mfma_ctx.argtypes = [_vp, _vp, _i32] + L.tfk_flow_run.argtypes[1:]
