@@ -282,7 +282,9 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * accumulate: bit 0 = add to logdet instead of overwriting it; bit 1 = store the rows reversed
  *   (z[n, D-1-c] = column c: a ReversePermutationMatrix that follows the program, folded into the store);
  *   bit 2 = logprob is the base density of the rows as they come IN plus the log-det (Flow.sample with
- *   return_log_prob, flows.py:699-707: base_log_prob(z) + log_det of the inverse) instead of the rows going out.
+ *   return_log_prob, flows.py:699-707: base_log_prob(z) + log_det of the inverse) instead of the rows going out;
+ *   bit 3 = (lean affine / shift programs, D >= 128) stream the operands from `params` even if they fit the LDS -- a
+ *   program whose blocks do NOT fit the 160 KiB LDS together is streamed anyway: one launch, two blocks resident.
  * A MADE op (TFK_OP_MADE_*: MaskedAutoregressiveBijection's parallel map, layers_base.py:201-206,
  * affine transformer, weights pre-multiplied by the MADE masks) reads BOTH halves of the row and
  * transforms both:  A1[2*D/8][HT][64] | b1[HT][4][4] | A2[2*D/16][gemm2_steps][64] | b2[2*D/16][4][4].

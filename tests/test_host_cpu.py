@@ -475,6 +475,7 @@ def test_torchflows_import_alias_resolves_to_the_build():
                                                        ("CouplingLRS", 64, 3, 0), ("CouplingLRS", 64, 2, 1),
                                                        ("CouplingLRS", 22, 2, 0), ("CouplingLRS-h24", 64, 2, 1),
                                                        ("CouplingLRS", 128, 2, 0),
+                                                       ("RealNVP", 256, 8, 0),        # one segment, operands streamed
                                                        ("RealNVP@32", 22, 3, 0), ("NICE@32", 8, 3, 1), ("RealNVP@32", 32, 2, 1),
                                                        ("CouplingRQNSF@32", 22, 2, 0), ("CouplingLRS@32", 16, 2, 1),
                                                        ("MAF@32", 22, 2, 0), ("IAF@32", 32, 2, 1),
@@ -527,6 +528,8 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     rows = torch.zeros(64, Dp, dtype=torch.float64)
     rows[:, pos] = x
     ld = torch.zeros(64, dtype=torch.float64)
+    if D == 256 and n_layers == 8:
+        assert len(chain.segments) == 1 and chain.segments[0].params.numel() * 4 > 160 * 1024
     for seg in chain.segments:
         assert seg.mfma and all(12 <= op[0] <= 24 and op[0] not in (19, 20) for op in seg.ops)
         rows, l = run_lean(seg.ops, seg.params, rows, Dp)

@@ -367,12 +367,83 @@ __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &
     }
 }
 
+// floats of one lean coupling's parameter block (fp32 operand format), see couple_lean
+template <int EPL, int STEPS2, int KIND>
+constexpr int chain_block_floats()
+{
+    constexpr int T2 = KIND < 2 ? EPL / 2 : EPL / 4;
+    constexpr int NA2 = (T2 * (STEPS2 == 0 ? 1 : STEPS2) + 3) & ~3;
+    return EPL * 64 + 16 + NA2 * 64 + T2 * 16 + 8 * EPL;
+}
+
+// STREAMED operands: chains whose blocks do not fit the LDS together (RealNVP at D = 256: 22 KB per coupling) keep them
+// in global memory; the workgroup holds TFK_STREAM_DEPTH + 1 blocks in the LDS and, while its waves compute coupling l
+// out of one, the LDS-DMA (global_load_lds_dwordx4: no registers, 1 KB per wave-instruction) fills the others with the
+// couplings that follow -- after the chain's last coupling, with the first ones for the next 16 rows of every wave.  One
+// barrier per coupling: it publishes the block that has landed (each wave waits for its own share first, by COUNT, so
+// the later blocks stay in flight) and frees the one just computed from.
+// The whole chain is ONE launch: the rows cross HBM once (two half-chain launches wrote and re-read them).
+// blocks in flight ahead of the one being computed from (TFK_STREAM_DEPTH + 1 buffers in the LDS)
+#ifndef TFK_STREAM_DEPTH
+#define TFK_STREAM_DEPTH 1
+#endif
+constexpr int kStreamBufs = TFK_STREAM_DEPTH + 1;
+
+// this wave's share of one coupling's block: global -> LDS, no registers
+template <int BLOCK, int LB>
+__device__ __forceinline__ void stream_block(const float *__restrict__ src_f, float *dst_f, int lane, int wave)
+{
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const char *src = reinterpret_cast<const char *>(src_f);
+    // (measured, RealNVP-256, 2^19 rows: 621 us per launch; 574 without the DMA -- stale operands --, 543 without DMA and
+    // barriers; two or three blocks in flight instead of one: 632 / 634; every workgroup starting at a different 1 KB
+    // piece so the chip's requests spread over the L2 channels: 636; 256-thread workgroups, two per CU: 835)
+    for (int c = wave; c * 1024 < LB * 4; c += BLOCK / 64) {
+        const int off = c * 1024 + lane * 16;
+        if (off < LB * 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(reinterpret_cast<char *>(dst_f) + c * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool FAST>
+__device__ __forceinline__ void chain_layers_stream(float *buf0, const float *__restrict__ params, const ChainProg &prog,
+                                                    int &bufi, int lane, int q, float (&a)[EPL], float (&b)[EPL],
+                                                    float &ld2, float &umin)
+{
+    constexpr int LB = chain_block_floats<EPL, STEPS2, KIND>();
+    // every wave issues at least KMIN LDS-DMA instructions per block, in order: "at most KMIN (DEPTH - 1) outstanding"
+    // means the block for THIS step has landed while the later ones may still be in flight
+    constexpr int KMIN = ((LB * 4) / 1024) / (BLOCK / 64);
+    constexpr int WAIT = KMIN * (TFK_STREAM_DEPTH - 1);
+    const int wave = threadIdx.x >> 6;
+    int ahead = TFK_STREAM_DEPTH % (prog.n_c > 0 ? prog.n_c : 1);     // layer of the block to fetch next
+#pragma unroll 1
+    for (int l = 0; l < prog.n_c; ++l) {
+#ifndef TFK_STREAM_NOBARRIER
+        // this wave's share of the block for this step has landed; the barrier publishes everyone's and frees the buffer
+        // the previous step computed from (no memory access of the compiler's crosses the statement)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAIT) : "memory");
+#endif
+        float *cur = buf0 + bufi * LB;
+        int nb = bufi + TFK_STREAM_DEPTH;
+        nb = nb >= kStreamBufs ? nb - kStreamBufs : nb;
+#ifndef TFK_STREAM_NODMA                                              // (measurement only: compute on stale operands)
+        stream_block<BLOCK, LB>(params + prog.offset[ahead], buf0 + nb * LB, lane, wave);
+#endif
+        ahead = ahead + 1 < prog.n_c ? ahead + 1 : 0;
+        if (((prog.first_src + l) & 1) == 0) couple_fmt<EPL, STEPS2, KIND, FAST>(cur, lane, q, a, b, ld2, umin);
+        else couple_fmt<EPL, STEPS2, KIND, FAST>(cur, lane, q, b, a, ld2, umin);
+        bufi = bufi + 1 < kStreamBufs ? bufi + 1 : 0;
+    }
+}
+
 // (tuning hook: -DTFK_CHAIN_ATTR='__attribute__((amdgpu_waves_per_eu(5, 5)))' for occupancy experiments, tools/variants.sh)
 #ifndef TFK_CHAIN_ATTR
 #define TFK_CHAIN_ATTR
 #endif
 
-template <int EPL, int BLOCK, int STEPS2, int KIND>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false>
 __global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR
 __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16 && BLOCK == 1024) ? 4 : 1)))) void k_flow_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
@@ -384,13 +455,20 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;
     const bool base_of_input = (flags & 4) != 0;
-    {
+    // resident: the whole parameter block; streamed: two coupling blocks | the closing TFK_OP_EW_FMA block
+    constexpr int LB = chain_block_floats<EPL, STEPS2, KIND>();
+    static_assert(!STREAM || (KIND < 4 && STEPS2 != 0), "streamed operands: affine / shift couplings, fp32 format");
+    float *ew_s = STREAM ? lds + kStreamBufs * LB : lds + (prog.ew_offset >= 0 ? prog.ew_offset : 0);
+    if constexpr (STREAM) {
+        if (prog.ew_offset >= 0)
+            for (int i = threadIdx.x; i < 2 * D + 4; i += BLOCK) ew_s[i] = params[prog.ew_offset + i];
+    } else {
         const float4 *src = reinterpret_cast<const float4 *>(params);
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < (n_params >> 2); i += BLOCK) dst[i] = src[i];
     }
     // base density as  -0.5 sum ((z - loc) / scale)^2 - sum (log scale + 0.5 log 2 pi):  loc[D] | 1/scale[D] | const
-    float *base_s = lds + n_params;
+    float *base_s = STREAM ? lds + kStreamBufs * LB + 2 * D + 4 : lds + n_params;
     if (logprob) {
         for (int e = threadIdx.x; e < D; e += BLOCK) {
             base_s[e] = gauss_loc[e];
@@ -410,7 +488,16 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const long long stride = (long long)gridDim.x * rows_per_block;
     const float base_const = logprob ? base_s[2 * D] : 0.0f;
-    for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * 16; row0 < N; row0 += stride) {
+    int bufi = 0;                                                     // (streamed) buffer of the next coupling
+    if constexpr (STREAM) {                                           // the first TFK_STREAM_DEPTH blocks
+#pragma unroll
+        for (int k = 0; k < TFK_STREAM_DEPTH; ++k)
+            stream_block<BLOCK, LB>(params + prog.offset[k % (prog.n_c > 0 ? prog.n_c : 1)], lds + k * LB, lane, wave);
+    }
+    // (streamed: the barriers inside the chain need every wave of the workgroup in every iteration -- the loop runs on
+    // the workgroup's first row, and waves past the end compute row N - 1 again and store nothing)
+    for (long long blk0 = (long long)blockIdx.x * rows_per_block; blk0 < (STREAM ? N : N - wave * 16); blk0 += stride) {
+        const long long row0 = blk0 + wave * 16;
         const long long row = row0 + j;
         const long long rr = row < N ? row : N - 1;    // tail: compute a valid row, store nothing
         float a[EPL], b[EPL];
@@ -463,6 +550,16 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
         float ld2 = 0.0f;                                             // this lane's share, in base 2
         float umin = 0.0f;                                            // smallest scale logit seen (log2_scales)
         constexpr bool kShortcut = TFK_LOG_SHORTCUT && (KIND < 2 || KIND >= 4);
+        if constexpr (STREAM) {
+            chain_layers_stream<EPL, BLOCK, STEPS2, KIND, kShortcut>(lds, params, prog, bufi, lane, q, a, b, ld2, umin);
+            if constexpr (kShortcut) {
+                if (__syncthreads_or(umin < kLogShortcutMin)) {       // (workgroup-wide: the re-run streams the blocks again)
+                    load_rows();
+                    ld2 = 0.0f;
+                    chain_layers_stream<EPL, BLOCK, STEPS2, KIND, false>(lds, params, prog, bufi, lane, q, a, b, ld2, umin);
+                }
+            }
+        } else {
         chain_layers<EPL, STEPS2, KIND, kShortcut>(lds, prog, lane, q, a, b, ld2, umin);
         if constexpr (kShortcut) {
             if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {   // scales near the 1e-10 floor: with logarithms
@@ -471,11 +568,12 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
                 chain_layers<EPL, STEPS2, KIND, false>(lds, prog, lane, q, a, b, ld2, umin);
             }
         }
+        }
         if constexpr (KIND == 0 || KIND == 4) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
         else if constexpr (KIND == 1 || KIND == 5) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
 
         if (prog.ew_offset >= 0) {                                    // what is still pending, one fma per element
-            const float *ew = lds + prog.ew_offset;
+            const float *ew = ew_s;
 #pragma unroll
             for (int i = 0; i < EPL / 4; ++i) {
                 const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
@@ -522,18 +620,20 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
             }
         }
     }
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the block prefetched for a step that never came)
 }
 
-template <int EPL, int BLOCK, int STEPS2, int KIND>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false>
 static int launch_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                           float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
                           int flags, int xw, hipStream_t s, const char *fn)
 {
     constexpr int D = 8 * EPL;
-    const size_t lds = ((size_t)n_params + 2 * D + 4) * sizeof(float);
+    const size_t lds = STREAM ? ((size_t)kStreamBufs * chain_block_floats<EPL, STEPS2, KIND>() + 2 * (2 * D + 4)) * sizeof(float)
+                              : ((size_t)n_params + 2 * D + 4) * sizeof(float);
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
-    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND>;
+    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -561,6 +661,26 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
                           float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
                           int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
+    // operands that do not fit the LDS beside each other are streamed (chain_layers_stream): D >= 128, fp32 format
+    if ((size_t)n_params + 16 * EPL + 4 > 160 * 1024 / sizeof(float) || ((flags & 8) && EPL >= 16 && KIND < 4 && steps2 != 0)) {
+        if constexpr (EPL >= 16 && KIND < 4) {
+#ifndef TFK_STREAM_BLOCK
+#define TFK_STREAM_BLOCK 512
+#endif
+#define TFK_CS(ST_) \
+    launch_chain_b<EPL, TFK_STREAM_BLOCK, ST_, KIND, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
+            switch (steps2) {
+            case 1: return TFK_CS(1);
+            case 2: return TFK_CS(2);
+            case 3: return TFK_CS(3);
+            case 4: return TFK_CS(4);
+            default: break;
+            }
+#undef TFK_CS
+        }
+        return fail(TFK_EINVAL, "%s: %d floats of parameters do not fit the 160 KiB LDS, and streamed operands exist for "
+                    "affine / shift couplings at D >= 128 with fp32 operands; split the program", fn, n_params);
+    }
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:
     // 736 us per launch against 389 with 512 threads, measured; the interpreter's trick does not carry over)

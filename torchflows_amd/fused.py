@@ -965,6 +965,12 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
     if any(extra == (256,) for *_, extra in items):
         budget = 150 * 1024          # bf16 x 3 operands: one 1024-thread workgroup per CU holds the whole chain
+    # affine / shift chains whose blocks do not fit the LDS together (D = 256: 22 KB per coupling): ONE launch with the
+    # operands streamed block by block (csrc/tfk_flow_chain.h: chain_layers_stream) instead of one launch per LDS-full
+    total = sum(block.numel() for _, _, _, block, _ in items) * 4
+    if (not streamed and kind0 in (0, 1, 2, 3) and Dp >= 128 and stream_chain_enabled() and len(items) <= 61
+            and total > 158 * 1024 and not any(extra for *_, extra in items)):
+        streamed = True
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
     for kind, plane, steps2, block, extra in items:
@@ -1097,6 +1103,12 @@ def compile_chain(composition, direction: int, device: torch.device,
 
 def narrow_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_NARROW_IN", "1") != "0"
+
+
+def stream_chain_enabled() -> bool:
+    """One launch with streamed operands for affine / shift chains that do not fit the LDS (TORCHFLOWS_AMD_STREAM_CHAIN=0:
+    one launch per LDS-full of couplings, as before)."""
+    return os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") != "0"
 
 
 def narrow_rows_enabled() -> bool:

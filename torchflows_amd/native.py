@@ -656,6 +656,12 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
     _check(rc, name)
 
 
+def _stream_flag() -> int:
+    """Flag bit 3 of tfk_flow_run_mfma: stream the operands of an affine / shift chain (D >= 128) even if they fit the LDS
+    (tuning: TORCHFLOWS_AMD_STREAM_CHAIN=force)."""
+    return 8 if os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") == "force" else 0
+
+
 def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False,
                   reverse_out=False, base_of_input=False, D=None, context=None):
     """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
@@ -677,7 +683,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
         args = (_f32(x, name), _f32(context, name), int(context.shape[1]), _f32(z, name), _f32(logdet, name),
                 _f32(gauss_loc, name), _f32(gauss_log_scale, name), _f32(logprob, name), N, Dk, ops_arr, _n_ops(ops),
                 _f32(params, name), params.numel(),
-                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0))
+                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0) | _stream_flag())
         with _device_guard(x):
             rc = lib().tfk_flow_run_mfma_ctx(*args, _stream(x))
         calls += 1
@@ -692,7 +698,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
         args = (_f32(x, name), xw, _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
                 _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, _n_ops(ops),
                 _f32(params, name), params.numel(),
-                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0))
+                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0) | _stream_flag())
         with _device_guard(x):
             rc = lib().tfk_flow_run_mfma_in(*args, _stream(x))
         calls += 1
@@ -706,7 +712,7 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
     args = (_f32(x, name), _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
             _f32(gauss_log_scale, name), _f32(logprob, name), N, D, ops_arr, _n_ops(ops),
             _f32(params, name), params.numel(),
-            (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0))
+            (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0) | _stream_flag())
     with _device_guard(x):
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
