@@ -738,3 +738,40 @@ def test_affine_scale_logits_far_below_zero(arch, D):
         print(f"{arch}({D}) inverse: log_det {e_ldi:.2e}, x nw {e_xi:.2e} on {int(ok.sum())} rows")
         assert e_ldi < 1e-5
         assert int(ok.sum()) > 100 and e_xi < 1e-4
+
+
+@pytest.mark.parametrize("arch,D", [("CouplingRQNSF", 64), ("CouplingLRS", 64), ("CouplingRQNSF", 22)])
+def test_spline_logits_beyond_the_fast_softmax_range(arch, D):
+    """The spline chain kernels form the bin softmax WITHOUT subtracting the maximum while every logit of the workgroup's
+    rows stays within +-64 / log2(e) (csrc/tfk_flow_rqs_chain.h: spline_knots); rows beyond that are re-run with the
+    maximum subtracted.  Logits up to +-150 on a quarter of the elements, against the host path in fp64."""
+    import copy
+    import torchflows_amd as tfa
+    torch.manual_seed(10)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=3))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow.eval()
+    P = 23 if arch == "CouplingRQNSF" else 32
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if name.endswith("sequential.2.bias"):
+                b = p.view(-1, P)
+                T = b.shape[0]
+                pick = torch.randperm(T)[: max(1, T // 4)]
+                b[pick, 0:8] += torch.empty(len(pick), 8).uniform_(-150.0, 150.0)
+    flow64 = copy.deepcopy(flow).double()
+    flow = flow.cuda()
+    x = torch.randn(2000, D) * 2.0
+    with torch.no_grad():
+        lp_h = flow64.log_prob(x.double())
+        z_h, _ = flow64.bijection.forward(x.double())
+        lp_d = flow.log_prob(x.cuda())
+        z_d, ld_d = flow.bijection.forward(x.cuda())
+        xr, ldr = flow.bijection.inverse(z_d)
+    e_lp, e_z = rel(lp_d.cpu().numpy(), lp_h.numpy()), normwise(z_d.cpu().numpy(), z_h.numpy())
+    print(f"{arch}({D}) softmax logits up to +-150: log_prob {e_lp:.2e}, z nw {e_z:.2e}")
+    assert torch.isfinite(lp_d).all()
+    assert e_lp < 4e-5 and e_z < 4e-5
+    assert torch.allclose(ld_d, -ldr, atol=2e-3)

@@ -92,6 +92,7 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     prog.C.maximum = boundary;
     prog.C.g = (float)(span * (double)scale);
     prog.C.cmin = (float)(span * (lrs ? 1e-2 : 1e-3));
+    for (int j = 1; j < 8; ++j) prog.C.knot_c[j - 1] = (float)(-(double)boundary + j * span * (lrs ? 1e-2 : 1e-3));
     prog.C.d_edge = lrs ? (float)((double)c * 1.4426950408889634)
                         : (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
     const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN;

@@ -29,6 +29,7 @@
 //   logits (c + u_d / 1000), all times log2(e); 23 = padding.
 #pragma once
 #include "tfk_common.h"
+#include <type_traits>
 #include "tfk_flow_chain.h"
 
 namespace tfk {
@@ -38,6 +39,7 @@ struct RqsLean {
     float g;                  // span * (1 - min_bin * K)
     float cmin;               // span * min_bin
     float d_edge;             // (c + c / 1000) * log2(e): the padded derivative logits (rational_quadratic.py:127)
+    float knot_c[7];          // minimum + j * span * min_bin, j = 1..7: the constant part of inner knot j
 };
 
 struct RqsChainProg {
@@ -63,37 +65,55 @@ __device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v
 __device__ __forceinline__ float exp2_f(float v) { return __builtin_amdgcn_exp2f(v); }
 __device__ __forceinline__ float log2_f(float v) { return __builtin_amdgcn_logf(v); }
 
-// One in-box element.  p: its 24 pre-scaled parameters (registers).  l2 = log2 |dz/dx| (forward) or of dx/dz (inverse).
-template <bool INVERSE>
-__device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, const RqsLean &C, float &out, float &l2)
+// The 7 inner knots of one axis from its 8 pre-scaled logits (rational_quadratic.py:46-52, linear_rational.py:44-47):
+//   knot_j = minimum + span * sum_{i<j} (min_bin + scale * softmax_i) = knot_c[j-1] + (g / sum) * prefix_j,
+// prefix sums of the softmax numerators (the last one is the normaliser), then one fma per knot.
+// FAST: no maximum is subtracted -- exact to rounding while the logits stay within +-kSoftmaxFastMax (the sums cannot
+// leave fp32's range, terms 2^-128 below the largest are lost either way); the lane keeps the largest |logit| it has
+// seen in `amax` and the kernel re-runs the 16 rows with FAST = false if any lane of the workgroup saw a larger one
+// (22 of an element's ~150 vector instructions).  -DTFK_SOFTMAX_FAST=0: always subtract the maximum.
+#ifndef TFK_SOFTMAX_FAST
+#define TFK_SOFTMAX_FAST 1
+#endif
+constexpr float kSoftmaxFastMax = 64.0f;
+template <bool FAST>
+__device__ __forceinline__ void spline_knots(const float *u, const RqsLean &C, float (&K)[9], float &amax)
 {
-    // softmax numerators, rational_quadratic.py:46 (logits arrive times log2 e)
-    float mx = p[0], my = p[8];
+    float pre[8];
+    if constexpr (FAST) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) { mx = fmaxf(mx, p[j]); my = fmaxf(my, p[8 + j]); }
-    float ex[8], ey[8], sx = 0.0f, sy = 0.0f;
+        for (int j = 0; j < 8; j += 2) amax = fmaxf(fmaxf(amax, __builtin_fabsf(u[j])), __builtin_fabsf(u[j + 1]));
+        pre[0] = exp2_f(u[0]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        ex[j] = exp2_f(p[j] - mx);
-        ey[j] = exp2_f(p[8 + j] - my);
-        sx += ex[j];
-        sy += ey[j];
+        for (int j = 1; j < 8; ++j) pre[j] = pre[j - 1] + exp2_f(u[j]);
+    } else {
+        // (plain fmaxf: the compiler folds the chain into v_max3_f32; hand-placed v_max3_f32 through inline asm is NOT an
+        // option on matrix-core results -- the hazard recognizer inserts no wait states for asm operands, measured as
+        // last-bit differences between runs)
+        float m = u[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) m = fmaxf(m, u[j]);
+        pre[0] = exp2_f(u[0] - m);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) pre[j] = pre[j - 1] + exp2_f(u[j] - m);
     }
-    const float gx = C.g * rcp_f(sx), gy = C.g * rcp_f(sy);
-    // knots :47-52:  span * cumsum(min_bin + scale * softmax) + minimum, ends pinned
+    const float g = C.g * rcp_f(pre[7]);
+    K[0] = C.minimum;
+    K[8] = C.maximum;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) K[j] = fmaf(pre[j - 1], g, C.knot_c[j - 1]);
+}
+
+// One in-box element.  p: its 24 pre-scaled parameters (registers).  l2 = log2 |dz/dx| (forward) or of dx/dz (inverse).
+template <bool INVERSE, bool FAST = false>
+__device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, const RqsLean &C, float &out, float &l2, float &amax)
+{
     float X[9], Y[9], Dl[9];
-    X[0] = C.minimum; Y[0] = C.minimum; X[8] = C.maximum; Y[8] = C.maximum;
+    spline_knots<FAST>(p, C, X, amax);
+    spline_knots<FAST>(p + 8, C, Y, amax);
     Dl[0] = C.d_edge; Dl[8] = C.d_edge;
-    float ax = 0.0f, ay = 0.0f;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-        ax = fmaf(ex[j - 1], gx, ax);
-        ay = fmaf(ey[j - 1], gy, ay);
-        const float cj = C.minimum + (float)j * C.cmin;       // uniform: scalar unit
-        X[j] = ax + cj;
-        Y[j] = ay + cj;
-        Dl[j] = p[15 + j];
-    }
+    for (int j = 1; j < 8; ++j) Dl[j] = p[15 + j];
     // bin = number of knots strictly below v, minus one (:82 / :147); three halvings that carry the searched knots,
     // the opposite knots and the derivative logits along
     float S5[5], O5[5], D5[5];
@@ -173,34 +193,15 @@ __device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, con
 // [24, 31) derivative logits (c + u_d / 100), [31] the w0 logit, all times log2(e).  C.d_edge = c log2(e) makes the
 // boundary derivative 1e-5 + softplus(c) = 1 (the reference pads exactly 1).  l2 = log2 of the map's own log-det factor
 // (the reference's inverse_1d returns the inverse's log-det directly: no negation here).
-template <bool INVERSE>
-__device__ __forceinline__ void lrs_eval_lean(const float (&p)[32], float v, const RqsLean &C, float &out, float &l2)
+template <bool INVERSE, bool FAST = false>
+__device__ __forceinline__ void lrs_eval_lean(const float (&p)[32], float v, const RqsLean &C, float &out, float &l2, float &amax)
 {
-    float mx = p[0], my = p[8];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) { mx = fmaxf(mx, p[j]); my = fmaxf(my, p[8 + j]); }
-    float ex[8], ey[8], sx = 0.0f, sy = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        ex[j] = exp2_f(p[j] - mx);
-        ey[j] = exp2_f(p[8 + j] - my);
-        sx += ex[j];
-        sy += ey[j];
-    }
-    const float gx = C.g * rcp_f(sx), gy = C.g * rcp_f(sy);
     float X[9], Y[9], Dl[9];
-    X[0] = C.minimum; Y[0] = C.minimum; X[8] = C.maximum; Y[8] = C.maximum;
+    spline_knots<FAST>(p, C, X, amax);
+    spline_knots<FAST>(p + 8, C, Y, amax);
     Dl[0] = C.d_edge; Dl[8] = C.d_edge;
-    float ax = 0.0f, ay = 0.0f;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-        ax = fmaf(ex[j - 1], gx, ax);
-        ay = fmaf(ey[j - 1], gy, ay);
-        const float cj = C.minimum + (float)j * C.cmin;
-        X[j] = ax + cj;
-        Y[j] = ay + cj;
-        Dl[j] = p[23 + j];
-    }
+    for (int j = 1; j < 8; ++j) Dl[j] = p[23 + j];
     // bin search (:53, searchsorted left), carrying knots, opposite knots, derivative logits and the bins' lambda logits
     float S5[5], O5[5], D5[5], L4[4];
     {
@@ -335,7 +336,7 @@ __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float 
             }
             float out = v, l = 0.0f;                           // spline/base.py:54-55
             if (v > C.minimum && v < C.maximum)                // strict box, base.py:29-33
-                rqs_eval_lean<INVERSE>(p, v, C, out, l);
+                { float unused = 0.0f; rqs_eval_lean<INVERSE, false>(p, v, C, out, l, unused); }
             ld2 += l;
             if constexpr (NC > 1) {
 #pragma unroll
@@ -360,9 +361,10 @@ __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float 
 // 4 / HT target elements, so its size does not depend on HT.
 // Block: head A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then chunks A[4/HT][6][HT][2][64][4 dwords].
 // LRS: linear rational spline elements (32 parameters = 8 tiles per element) instead of rational-quadratic ones (24 = 6).
-template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS = false>
+template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS, bool FAST>
 __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float *stage, int lane, int q,
-                                           const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2)
+                                           const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2,
+                                           float &amax)
 {
     constexpr int HALF = 4 * EPL;
     constexpr int HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF;
@@ -481,8 +483,8 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
             }
             float out = v, l = 0.0f;
             if (v > C.minimum && v < C.maximum) {
-                if constexpr (LRS) lrs_eval_lean<INVERSE>(p, v, C, out, l);
-                else rqs_eval_lean<INVERSE>(p, v, C, out, l);
+                if constexpr (LRS) lrs_eval_lean<INVERSE, FAST>(p, v, C, out, l, amax);
+                else rqs_eval_lean<INVERSE, FAST>(p, v, C, out, l, amax);
             }
             ld2 += l;
             if constexpr (STATIC_CH) {
@@ -559,6 +561,7 @@ void k_flow_rqs_chain(
         const long long row = blk0 + wave * 16 + j;
         const long long rr = row < N ? row : N - 1;
         float a[EPL], b[EPL];
+        auto load_rows = [&]() {
         if (xw == D) {
             const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
             const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
@@ -582,6 +585,8 @@ void k_flow_rqs_chain(
                 b[e] = ok ? xr[hl + col] : 0.0f;
             }
         }
+        };
+        load_rows();
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         float sq = 0.0f;
         auto base_terms = [&]() {
@@ -602,18 +607,34 @@ void k_flow_rqs_chain(
         };
         if (logprob && base_of_input) base_terms();
         float ld2 = 0.0f;
+        float amax = 0.0f;                                            // largest |softmax logit| seen (spline_knots)
+        auto layers = [&](auto fast) {
+            constexpr bool FAST = decltype(fast)::value;
 #pragma unroll 1
-        for (int l = 0; l < prog.n_layers; ++l) {
-            const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
-            if constexpr (F3) {
-                if (((prog.first_src + l) & 1) == 0) rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS>(gprm, stage, lane, q, C, a, b, ld2);
-                else rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS>(gprm, stage, lane, q, C, b, a, ld2);
-            } else {
-                if (((prog.first_src + l) & 1) == 0)
-                    rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
-                else
-                    rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+            for (int l = 0; l < prog.n_layers; ++l) {
+                const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
+                if constexpr (F3) {
+                    if (((prog.first_src + l) & 1) == 0)
+                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, a, b, ld2, amax);
+                    else
+                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, b, a, ld2, amax);
+                } else {
+                    if (((prog.first_src + l) & 1) == 0)
+                        rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
+                    else
+                        rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+                }
             }
+        };
+        if constexpr (F3 && TFK_SOFTMAX_FAST) {
+            layers(std::true_type{});
+            if (__syncthreads_or(!(amax <= kSoftmaxFastMax))) {       // (also catches a NaN logit)
+                load_rows();                                          // x is intact: z is stored below
+                ld2 = 0.0f;
+                layers(std::false_type{});
+            }
+        } else {
+            layers(std::false_type{});
         }
         ld = fmaf(ld2, __int_as_float(0x3f317218), ld);             // ln 2
         if (prog.ew_offset >= 0) {
