@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--total-rows", type=int, default=None,
                     help="strong scaling: this many rows in total, split evenly over the ranks "
                          "(config 4: --workload realnvp256 --total-rows 4194304 --gpus 8)")
+    ap.add_argument("--priming", type=int, default=PRIMING_STEPS,
+                    help="untimed steps before the requested warm-ups (clock ramp after idle; reported in the JSON)")
     ap.add_argument("--stats-steps", type=int, default=100,
                     help="extra steps, timed one by one with HIP events AFTER the K timed steps (median / min / max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -452,7 +454,7 @@ def main():
     with torch.no_grad():
         step()                      # module load, LDS attributes, RCCL communicator: never inside the timed region,
         drain()                     # whatever --warmup says
-        n_prime = PRIMING_STEPS if not isinstance(D, tuple) else 0      # (a config-5 step is 0.25 s: no ramp to hide)
+        n_prime = args.priming if not isinstance(D, tuple) else 0      # (a config-5 step is 0.25 s: no ramp to hide)
         for _ in range(n_prime):        # ... and the clocks: the first ~20 launches after idle run 7 % slower (r02 step_stats)
             step()
         drain()
