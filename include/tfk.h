@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 21
+#define TFK_ABI_VERSION 22
 
 enum {
     TFK_OK = 0,
@@ -305,6 +305,18 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
  * of plane B, zeros behind them -- the layout the packer pads such flows to (zero weights make the padding an exact
  * identity), without a host-side padding pass over the rows.  Lean programs only; z / logdet / logprob as above
  * (z in the kernel's D-wide physical layout). */
+/* tfk_flow_run_mfma_in for a LEAN program that ends in the base density, plus the fp64 sum of the launch's N
+ * log-probabilities in sum_out[0] (device) -- the per-rank term of SURVEY.md 8(e)'s one all-reduce -- without further
+ * launches: every workgroup leaves the fp64 sum of its rows in the workspace, the last one to finish adds them in index
+ * order (deterministic) and resets the workspace.  sum_workspace: tfk_flow_sum_workspace_bytes() bytes, ZERO before its
+ * first use and not shared by launches that may overlap (one per stream).  Replaces: Flow.log_prob(x).sum() over a batch
+ * (flows.py:646-658 + the reduction of the caller). */
+int64_t tfk_flow_sum_workspace_bytes(void);
+int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
+                          const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                          const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                          int32_t accumulate, void *sum_workspace, double *sum_out, void *stream);
+
 /* The same for context-conditioned flows: context (N, C) fp32, 1 <= C <= 16, one row per data row (Flow.log_prob(x,
  * context=...), flows.py:628-658).  Programs of elementwise ops, TFK_OP_EWC_* and couplings only (no MADE / lean ops). */
 int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,

@@ -775,3 +775,43 @@ def test_spline_logits_beyond_the_fast_softmax_range(arch, D):
     assert torch.isfinite(lp_d).all()
     assert e_lp < 4e-5 and e_z < 4e-5
     assert torch.allclose(ld_d, -ldr, atol=2e-3)
+
+
+@pytest.mark.parametrize("arch,D,N", [("RealNVP", 64, 100003), ("RealNVP", 64, 17), ("CouplingRQNSF", 64, 40001),
+                                      ("RealNVP", 256, 30011), ("RealNVP", 22, 70001), ("MAF", 64, 50021),
+                                      ("CouplingLRS", 16, 9001)])
+def test_log_likelihood_sum_rides_in_the_log_prob_launch(arch, D, N, monkeypatch):
+    """Flow.log_prob_and_sum: the fp64 sum of the log-probabilities comes out of the SAME launch (tfk_flow_run_mfma_sum:
+    one partial per workgroup, the last workgroup adds them in index order and resets the workspace) -- equal to the
+    fp64 sum of the returned vector to rounding, bitwise reproducible, and correct call after call.  (Opt-in:
+    TORCHFLOWS_AMD_SUM_IN_KERNEL=1; by default log_prob_and_sum is log_prob + tfk_sum_f32.)"""
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    monkeypatch.setenv("TORCHFLOWS_AMD_SUM_IN_KERNEL", "1")
+    torch.manual_seed(11)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D))
+    flow = flow.eval().cuda()
+    x = torch.randn(N, D, device="cuda")
+    with torch.no_grad():
+        before = native.calls
+        lp, total = flow.log_prob_and_sum(x)
+        assert native.calls - before == 1                       # ONE launch: no separate reduction
+        lp_ref = flow.log_prob(x)
+        want = lp.double().sum()
+        assert torch.equal(lp, lp_ref)
+        assert total.dtype == torch.float64 and total.shape == (1,)
+        assert abs(float(total) - float(want)) <= 1e-12 * abs(float(want)) + 1e-9
+        for n in (N, max(1, N // 3), 1, N):                     # the workspace resets itself; other sizes in between
+            lp2, t2 = flow.log_prob_and_sum(x[:n])
+            w2 = lp2.double().sum()
+            assert abs(float(t2) - float(w2)) <= 1e-12 * abs(float(w2)) + 1e-9
+        assert float(t2) == float(total)                        # same rows, same order of additions
+    # a second stream has its own workspace
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), torch.no_grad():
+        lp3, t3 = flow.log_prob_and_sum(x)
+    s.synchronize()
+    assert float(t3) == float(total)

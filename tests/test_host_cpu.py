@@ -538,3 +538,16 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     # the blocks are stored in fp32: agreement at fp32 resolution of the weights
     assert float((got - want).abs().max() / want.abs().max()) < 2e-5
     assert float((ld - ld_want).abs().max() / max(1.0, float(ld_want.abs().max()))) < 2e-5
+
+
+def test_log_prob_and_sum_on_host():
+    """Flow.log_prob_and_sum off the HIP path: log_prob followed by an fp64 reduction (1-element float64 tensor)."""
+    import torchflows_amd as tfa
+    torch.manual_seed(0)
+    flow = tfa.Flow(tfa.RealNVP(6)).eval()
+    x = torch.randn(100, 6)
+    with torch.no_grad():
+        lp, total = flow.log_prob_and_sum(x)
+        assert torch.equal(lp, flow.log_prob(x))
+    assert total.dtype == torch.float64 and total.shape == (1,)
+    assert abs(float(total) - float(lp.double().sum())) < 1e-9

@@ -118,6 +118,54 @@ __device__ __forceinline__ float log1p_pos(float y) {
 }
 
 // sum over the G (power of two, <= 64) consecutive lanes that share a row
+// Sum of the log-probabilities a launch produced, in fp64 and in a fixed order, without further launches (feeds the
+// all-reduce of SURVEY.md 8(e)): every lane hands in the fp64 sum of the rows it wrote; the workgroup's total goes to
+// ws[1 + blockIdx.x]; the LAST workgroup to finish (ticket from the counter in ws[0]) adds the partials in index order,
+// writes out[0] and resets the counter for the next launch.
+// Visibility across the 8 XCDs' L2s WITHOUT release / acquire fences (an agent-scope release writes the whole L2 back:
+// +24 us on a 242 us launch when 3 072 workgroups each do it, measured): the partial is an agent-scope ATOMIC store
+// (written through), its completion is awaited (vmcnt) before the agent-scope ticket increment, and the last workgroup
+// reads the partials with agent-scope atomic loads.
+// `scratch`: >= BLOCK / 64 + 2 doubles of LDS nobody else touches any more.
+template <int BLOCK>
+__device__ __forceinline__ void finish_sum_f64(double acc, double *scratch, double *ws, double *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = BLOCK / 64;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+    __syncthreads();                                             // the LDS is free from here on
+    if (lane == 0) scratch[wave] = acc;
+    __syncthreads();
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(ws);
+    double *partials = ws + 1;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += scratch[w];
+        __hip_atomic_store(partials + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partial is at the coherence point
+        const unsigned long long ticket =
+            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scratch[NW] = (ticket == (unsigned long long)gridDim.x - 1ull) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (scratch[NW] == 0.0) return;
+    double a = 0.0;                                              // (last workgroup: every partial has been written)
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK)
+        a += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, kWave);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += scratch[w];
+        out[0] = t;
+        __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ float group_sum(float v, int G) {
     for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
     return v;

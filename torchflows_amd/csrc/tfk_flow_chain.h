@@ -36,6 +36,8 @@ struct ChainProg {
     int ew_offset;    // TFK_OP_EW_FMA that ends the program (-1: none)
     int pad;
     int offset[kMaxChainOps];
+    double *sum_ws;   // tfk_flow_run_mfma_sum: counter + one partial per workgroup (finish_sum_f64), or null
+    double *sum_out;  // ... and the fp64 sum of the launch's log-probabilities
 };
 
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
@@ -488,6 +490,10 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const long long stride = (long long)gridDim.x * rows_per_block;
     const float base_const = logprob ? base_s[2 * D] : 0.0f;
+    // (tfk_flow_run_mfma_sum) fp64 sum of the log-probabilities this thread wrote: in the LDS, not in two registers that
+    // would be live across the whole chain (130 VGPRs = 3 waves per SIMD instead of 124 = 4: 254 -> 293 us, measured)
+    double *lp_slot = reinterpret_cast<double *>(base_s + 2 * D + 4) + threadIdx.x;
+    if (prog.sum_ws) *lp_slot = 0.0;
     int bufi = 0;                                                     // (streamed) buffer of the next coupling
     if constexpr (STREAM) {                                           // the first TFK_STREAM_DEPTH blocks
 #pragma unroll
@@ -616,11 +622,19 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
             }
             if (q == 0) {
                 if (logdet) logdet[row] = ld;
-                if (logprob) logprob[row] = (fmaf(-0.5f, sq, -base_const)) + ld;          // flows.py:648
+                if (logprob) {
+                    const float lp = (fmaf(-0.5f, sq, -base_const)) + ld;                 // flows.py:648
+                    logprob[row] = lp;
+                    if (prog.sum_ws) *lp_slot += (double)lp;
+                }
             }
         }
     }
     if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the block prefetched for a step that never came)
+    if (prog.sum_ws) {
+        const double mine = (q == 0) ? *lp_slot : 0.0;
+        finish_sum_f64<BLOCK>(mine, reinterpret_cast<double *>(lds), prog.sum_ws, prog.sum_out);
+    }
 }
 
 template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false>
@@ -629,8 +643,9 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
                           int flags, int xw, hipStream_t s, const char *fn)
 {
     constexpr int D = 8 * EPL;
-    const size_t lds = STREAM ? ((size_t)kStreamBufs * chain_block_floats<EPL, STEPS2, KIND>() + 2 * (2 * D + 4)) * sizeof(float)
-                              : ((size_t)n_params + 2 * D + 4) * sizeof(float);
+    const size_t lds = (STREAM ? ((size_t)kStreamBufs * chain_block_floats<EPL, STEPS2, KIND>() + 2 * (2 * D + 4)) * sizeof(float)
+                               : ((size_t)n_params + 2 * D + 4) * sizeof(float))
+                       + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);       // one fp64 slot per thread
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
     auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM>;
@@ -647,6 +662,7 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
         (void)hipGetLastError();
         per_cu = 1;
     }
+    if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;

@@ -28,7 +28,8 @@ int flow_rqs_chain_launch_32(const float *, float *, float *, const float *, con
 // tfk_flow_rqs_chain.h, the operands streamed layer by layer from `params` (global memory).
 static int run_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                          float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
-                         int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn)
+                         int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn,
+                         double *sum_ws, double *sum_out)
 {
     const int EPL = D / 8, HALF = D / 2;
     // operand format: K = 8 -> fp32 A-operands (chunks of 8 elements); K = 8 + 256 -> bf16 x 3 (chunks of 4 elements)
@@ -42,6 +43,8 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     RqsChainProg prog;
     memset(&prog, 0, sizeof(prog));
     prog.ew_offset = -1;
+    prog.sum_ws = sum_ws;
+    prog.sum_out = sum_out;
     int kind = -1, steps2 = 0;
     float boundary = 0.0f, scale = 0.0f, c = 0.0f;
     for (int i = 0; i < n_ops; ++i) {
@@ -107,7 +110,8 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
 // plane alternates, optionally ended by one TFK_OP_EW_FMA) runs on the straight-line kernel of tfk_flow_chain.h.
 static int run_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
-                     int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn)
+                     int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn,
+                     double *sum_ws, double *sum_out)
 {
     const int EPL = D / 8, HALF = D / 2;
     ChainProg prog;
@@ -115,6 +119,8 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     prog.first_src = 0;
     prog.ew_offset = -1;
     prog.pad = 0;
+    prog.sum_ws = sum_ws;
+    prog.sum_out = sum_out;
     int kind = -1, steps2 = 1;
     bool fmt3 = false;
     for (int i = 0; i < n_ops; ++i) {
@@ -193,7 +199,8 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
                               const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                               const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
                               int32_t accumulate, void *stream, const char *fn,
-                              const float *context = nullptr, int32_t C = 0)
+                              const float *context = nullptr, int32_t C = 0,
+                              double *sum_ws = nullptr, double *sum_out = nullptr)
 {
     if (context && (C < 1 || C > 4 * kCtxSteps))
         return fail(TFK_EINVAL, "%s: context size %d must be in [1, %d]", fn, C, 4 * kCtxSteps);
@@ -212,16 +219,18 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
     if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
+    if (sum_ws && (!lean || !logprob || !sum_out))
+        return fail(TFK_EINVAL, "%s: the in-kernel sum needs a lean program, logprob and sum_out", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
     if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
                       ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN))
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                             accumulate, x_width, static_cast<hipStream_t>(stream), fn);
+                             accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out);
     if (n_ops > 0 && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA) ||
                       ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN))
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                         accumulate, x_width, static_cast<hipStream_t>(stream), fn);
+                         accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out);
     const int EPL = D / 8;
     MProgram prog;
     prog.n_ops = n_ops;
@@ -312,6 +321,20 @@ int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logde
 {
     return flow_run_mfma_impl(x, x_width, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params,
                               n_params, accumulate, stream, "tfk_flow_run_mfma_in");
+}
+
+int64_t tfk_flow_sum_workspace_bytes(void) { return (int64_t)(1 + kCUs * 8 * kGridOversubscribe) * (int64_t)sizeof(double); }
+
+int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
+                          const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
+                          const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
+                          int32_t accumulate, void *sum_workspace, double *sum_out, void *stream)
+{
+    const char *fn = "tfk_flow_run_mfma_sum";
+    if (!sum_workspace || !sum_out) return fail(TFK_EINVAL, "%s: null sum_workspace / sum_out", fn);
+    if (N <= 0) return fail(TFK_EINVAL, "%s: N = %lld: the in-kernel sum needs at least one row", fn, (long long)N);
+    return flow_run_mfma_impl(x, x_width, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params,
+                              n_params, accumulate, stream, fn, nullptr, 0, static_cast<double *>(sum_workspace), sum_out);
 }
 
 int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,

@@ -50,6 +50,8 @@ struct RqsChainProg {
     int offset0;              // first layer's block
     int pad[3];
     RqsLean C;
+    double *sum_ws;           // tfk_flow_run_mfma_sum (see ChainProg)
+    double *sum_out;
 };
 
 constexpr int kRqsChunkFloats = 48 * 256 + 48 * 16;
@@ -556,6 +558,9 @@ void k_flow_rqs_chain(
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const long long stride = (long long)gridDim.x * rows_per_block;
     const float base_const = logprob ? base_s[2 * D] : 0.0f;
+    // (tfk_flow_run_mfma_sum) fp64 sum of the log-probabilities this thread wrote, kept in the LDS (see tfk_flow_chain.h)
+    double *lp_slot = reinterpret_cast<double *>(base_s + 2 * D + 4) + threadIdx.x;
+    if (prog.sum_ws) *lp_slot = 0.0;
     // the trip count is the same for every wave of a workgroup (barriers inside): loop on the workgroup's first row
     for (long long blk0 = (long long)blockIdx.x * rows_per_block; blk0 < N; blk0 += stride) {
         const long long row = blk0 + wave * 16 + j;
@@ -679,9 +684,17 @@ void k_flow_rqs_chain(
             }
             if (q == 0) {
                 if (logdet) logdet[row] = ld;
-                if (logprob) logprob[row] = (fmaf(-0.5f, sq, -base_const)) + ld;
+                if (logprob) {
+                    const float lp = (fmaf(-0.5f, sq, -base_const)) + ld;
+                    logprob[row] = lp;
+                    if (prog.sum_ws) *lp_slot += (double)lp;
+                }
             }
         }
+    }
+    if (prog.sum_ws) {
+        const double mine = (q == 0) ? *lp_slot : 0.0;
+        finish_sum_f64<BLOCK>(mine, reinterpret_cast<double *>(lds), prog.sum_ws, prog.sum_out);
     }
 }
 
@@ -695,7 +708,8 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     constexpr bool LRS = STEPS2 >= 16;
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
     constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
-    const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float);
+    const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float)
+                       + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);
     auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -710,6 +724,7 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
         (void)hipGetLastError();
         per_cu = 1;
     }
+    if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
     const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;

@@ -36,6 +36,8 @@ def _local_log_likelihood(flow, x_local, context, chunk_rows):
     n = x_local.shape[0]
     step = chunk_rows or n
     if step >= n:
+        if hasattr(flow, "log_prob_and_sum"):        # the sum rides in the log_prob launch where it can
+            return flow.log_prob_and_sum(x_local, context=context)
         lp = flow.log_prob(x_local, context=context)
     else:
         lp = torch.empty(n, dtype=x_local.dtype, device=x_local.device)

@@ -101,9 +101,10 @@ class Flow(BaseFlow):
             raise AssertionError("x and context must share their batch shape")
         return context.to(self.get_device())
 
-    def _fused_log_prob(self, x: torch.Tensor, want_z: bool, context: torch.Tensor = None):
+    def _fused_log_prob(self, x: torch.Tensor, want_z: bool, context: torch.Tensor = None, want_sum: bool = False):
         """log_prob (and z) as flow programs ending in the base log-density: 4*D + 4 bytes of
-        HBM traffic per evaluation.  None when the chain is not compilable."""
+        HBM traffic per evaluation.  None when the chain is not compilable.  ``want_sum``: a third value, the fp64
+        sum of the log-probabilities from the same launch (1-element tensor) or None if the chain cannot carry it."""
         from torchflows_amd import fused, native
         from torchflows_amd.bijections.base import (BijectiveComposition, _params_ok,
                                                     method_direction)
@@ -120,8 +121,14 @@ class Flow(BaseFlow):
             return None
         rows, batch = as_rows(x, self.event_shape)
         crows = None if context is None else context.reshape(rows.shape[0], -1).contiguous()
+        total = None
+        if want_sum and crows is None and fused.sum_ready(chain) and rows.shape[0] > 0:
+            total = torch.empty(1, dtype=torch.float64, device=rows.device)
         z, _, lp = fused.run_chain(chain, rows, want_rows=want_z,
-                                   base=(self.base.loc.detach(), self.base.log_scale.detach()), context=crows)
+                                   base=(self.base.loc.detach(), self.base.log_scale.detach()), context=crows,
+                                   sum_out=total)
+        if want_sum:
+            return (z.view(x.shape) if want_z else None), lp.view(batch), total
         return (z.view(x.shape) if want_z else None), lp.view(batch)
 
     def _fused_sample(self, z: torch.Tensor):
@@ -144,6 +151,21 @@ class Flow(BaseFlow):
             x, _, lp = fused.run_chain(chain, rows, want_rows=True, base_of_input=True,
                                        base=(self.base.loc.detach(), self.base.log_scale.detach()))
         return x.view(z.shape), lp.view(batch)
+
+    def log_prob_and_sum(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``(log_prob(x), its sum in fp64 as a 1-element tensor)``: on the HIP path the sum comes out of the same
+        launch as the log-probabilities (tfk_flow_run_mfma_sum) -- the per-rank term of the sharded log-likelihood
+        (torchflows_amd.distributed); otherwise ``log_prob`` (flows.py:650-658) followed by a reduction."""
+        from torchflows_amd.distributed import local_sum_f64
+        if not torch.is_grad_enabled() or not x.requires_grad:
+            ctx = self._checked_context(x, context)
+            got = self._fused_log_prob(x.to(self.get_device()), want_z=False, context=ctx, want_sum=True)
+            if got is not None and got[2] is not None:
+                return got[1], got[2]
+            if got is not None:
+                return got[1], local_sum_f64(got[1])
+        lp = self.log_prob(x, context=context)
+        return lp, local_sum_f64(lp)
 
     def forward_with_log_prob(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         context = self._checked_context(x, context)

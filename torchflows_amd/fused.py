@@ -1256,13 +1256,31 @@ def _why_declined(composition, direction: int) -> str:
     return f"event size {D} / layer mix not covered by one kernel"
 
 
+_LEAN_KINDS = frozenset((OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA,
+                         OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN,
+                         OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN))
+
+
+def sum_ready(chain: Optional[CompiledChain]) -> bool:
+    """One LEAN launch: the fp64 sum of the log-probabilities can ride along (tfk_flow_run_mfma_sum).  Opt-in
+    (TORCHFLOWS_AMD_SUM_IN_KERNEL=1): measured on RealNVP-64, 2^20 rows, it removes the reduction's two launches (~8 us
+    of a 261 us step) and adds ~6 us to the kernel (one agent-scope ticket per workgroup, 3 072 of them): 263.7 against
+    261.2 us per step over 20 steps, 239.3 against 241.3 us at the median of 100 -- a wash."""
+    return (chain is not None and len(chain.segments) == 1 and chain.segments[0].mfma
+            and chain.segments[0].ops[0][0] in _LEAN_KINDS
+            and os.environ.get("TORCHFLOWS_AMD_SUM_IN_KERNEL", "0") == "1")
+
+
 def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False,
-              context: Optional[torch.Tensor] = None):
+              context: Optional[torch.Tensor] = None, sum_out: Optional[torch.Tensor] = None):
     """Apply the compiled chain to ``rows`` (N, D).  Returns ``(out_rows or None, logdet or
     None, logprob or None)``; with ``base`` (loc, log_scale in logical order) the final launch
     also evaluates the diagonal-Gaussian log-density and adds the log-det (flows.py:647-648).
     ``base_of_input`` (single-launch matrix-core programs only, see ``sample_ready``): the density is that
-    of the rows as they come in -- ``Flow.sample``'s ``base_log_prob(z) + log_det`` in the same launch."""
+    of the rows as they come in -- ``Flow.sample``'s ``base_log_prob(z) + log_det`` in the same launch.
+    ``sum_out`` (1-element float64, ``sum_ready`` chains with ``base``): receives the fp64 sum of the log-probabilities
+    from the same launch."""
+    assert sum_out is None or (sum_ready(chain) and base is not None and not base_of_input and context is None)
     if base_of_input:
         assert sample_ready(chain) and base is not None
         N, D = rows.shape
@@ -1329,6 +1347,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         kw = dict(D=chain.D) if (narrow_in and i == 0) else {}
         if context is not None:
             kw["context"] = context
+        if sum_out is not None:
+            kw["sum_out"] = sum_out
         run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
             loc_p if last else None, ls_p if last else None,
             logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0), **kw)

@@ -34,6 +34,7 @@ SYMBOLS = (
     "tfk_sum_workspace_bytes", "tfk_sum_f32", "tfk_sum_f32_ws",
     "tfk_flow_supported", "tfk_flow_run",
     "tfk_flow_mfma_supported", "tfk_flow_lean_supported", "tfk_flow_run_mfma", "tfk_flow_run_mfma_in", "tfk_flow_run_mfma_ctx",
+    "tfk_flow_sum_workspace_bytes", "tfk_flow_run_mfma_sum",
     "tfk_affine_coupling_bwd", "tfk_shift_coupling_bwd",
     "tfk_rqs_coupling_bwd_supported", "tfk_rqs_coupling_bwd", "tfk_lrs_coupling_bwd",
     "tfk_elementwise_affine_bwd_workspace_bytes", "tfk_elementwise_affine_bwd",
@@ -46,7 +47,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class NativeError(RuntimeError):
@@ -101,6 +102,9 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_flow_run_mfma.argtypes = L.tfk_flow_run.argtypes
     L.tfk_flow_run_mfma_in.argtypes = [_vp, _i32] + L.tfk_flow_run.argtypes[1:]
     L.tfk_flow_run_mfma_ctx.argtypes = [_vp, _vp, _i32] + L.tfk_flow_run.argtypes[1:]
+    L.tfk_flow_sum_workspace_bytes.argtypes = []
+    L.tfk_flow_sum_workspace_bytes.restype = _i64
+    L.tfk_flow_run_mfma_sum.argtypes = [_vp, _i32] + L.tfk_flow_run.argtypes[1:-1] + [_vp, _vp, _vp]
     L.tfk_affine_coupling_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
     L.tfk_shift_coupling_bwd.argtypes = [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]
     L.tfk_rqs_coupling_bwd_supported.argtypes = [_i32]
@@ -662,8 +666,19 @@ def _stream_flag() -> int:
     return 8 if os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") == "force" else 0
 
 
+_sum_ws = {}      # (device index, stream handle) -> zero-initialised workspace of tfk_flow_run_mfma_sum (resets itself)
+
+
+def flow_sum_workspace(t: torch.Tensor) -> torch.Tensor:
+    key = (t.device.index, _stream(t))
+    ws = _sum_ws.get(key)
+    if ws is None:
+        ws = _sum_ws[key] = torch.zeros(int(lib().tfk_flow_sum_workspace_bytes()) // 8, dtype=torch.float64, device=t.device)
+    return ws
+
+
 def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, accumulate=False,
-                  reverse_out=False, base_of_input=False, D=None, context=None):
+                  reverse_out=False, base_of_input=False, D=None, context=None, sum_out=None):
     """Fused flow program with the conditioner GEMMs on the matrix cores (tfk_flow_run_mfma).
     ops: list of (kind, src_plane, gemm2_steps, offset); params packed by fused._pack_mfma.
     ``D``: the kernel's row width when ``x`` is narrower (lean programs, tfk_flow_run_mfma_in): x (N, x_width) is read
@@ -671,6 +686,26 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
     global calls
     name = "tfk_flow_run_mfma"
     N, xw = _rows(x, name)
+    if sum_out is not None:               # lean program + the fp64 sum of its log-probabilities (tfk_flow_run_mfma_sum)
+        name = "tfk_flow_run_mfma_sum"
+        Dk = xw if D is None else D
+        ops_arr = _pack_ops(ops)
+        if context is not None or logprob is None or sum_out.dtype != torch.float64 or sum_out.numel() != 1:
+            raise NativeError(f"{name}: needs logprob, a 1-element float64 sum_out and no context")
+        for t, n in ((z, N * Dk), (logdet, N), (logprob, N), (gauss_loc, Dk), (gauss_log_scale, Dk)):
+            if t is not None and t.numel() != n:
+                raise NativeError(f"{name}: tensor with {t.numel()} elements, expected {n}")
+        ws = flow_sum_workspace(x)
+        args = (_f32(x, name), xw, _f32(z, name), _f32(logdet, name), _f32(gauss_loc, name),
+                _f32(gauss_log_scale, name), _f32(logprob, name), N, Dk, ops_arr, _n_ops(ops),
+                _f32(params, name), params.numel(),
+                (1 if accumulate else 0) | (2 if reverse_out else 0) | (4 if base_of_input else 0) | _stream_flag(),
+                ws.data_ptr(), sum_out.data_ptr())
+        with _device_guard(x):
+            rc = lib().tfk_flow_run_mfma_sum(*args, _stream(x))
+        calls += 1
+        _check(rc, name)
+        return
     if context is not None:               # context-conditioned program (tfk_flow_run_mfma_ctx); rows at full width
         name = "tfk_flow_run_mfma_ctx"
         Dk = xw
