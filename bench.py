@@ -44,6 +44,7 @@ WORKLOADS = {
     "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
     "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 13),  # configs[4] (3 blocks, 3.2 M params)
     "lrs64": ("CouplingLRS", 64, 8, 1 << 20, 1 << 18),       # sibling preset (linear rational splines), not a BASELINE config
+    "realnvp128": ("RealNVP", 128, 8, 1 << 20, None),        # between configs 2 and 4 (tuning the 128-wide kernel)
 }
 
 

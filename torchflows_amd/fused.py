@@ -965,6 +965,11 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
     if any(extra == (256,) for *_, extra in items):
         budget = 150 * 1024          # bf16 x 3 operands: one 1024-thread workgroup per CU holds the whole chain
+    if Dp == 128:
+        # the 128-wide chain kernel runs one 768-thread workgroup per CU whatever the block's size: RealNVP(128, 8 layers)
+        # = 90.6 KB is ONE launch (at the interpreter's 76 KB budget it was two, and the rows' trip through HBM between
+        # them -- 0.9 GB per launch at 2.8 TB/s -- bound both: 2 x 316 us)
+        budget = 150 * 1024
     # affine / shift chains whose blocks do not fit the LDS together (D = 256: 22 KB per coupling): ONE launch with the
     # operands streamed block by block (csrc/tfk_flow_chain.h: chain_layers_stream) instead of one launch per LDS-full
     total = sum(block.numel() for _, _, _, block, _ in items) * 4
