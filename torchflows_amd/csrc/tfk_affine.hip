@@ -10,6 +10,20 @@
 // with -ffp-contract=off); reference lines are cited at each kernel.
 #include "tfk_common.h"
 
+// whole-row streams of the permutation / base-density kernels: non-temporal (-DTFK_NT_EW=0: plain; same-call A/B at 2^20
+// rows x 64: permute 105 -> 100 us, the coupling that follows 109.6 -> 106; the elementwise-affine kernel 87 -> 91, so it
+// keeps plain accesses)
+#ifndef TFK_NT_EW
+#define TFK_NT_EW 1
+#endif
+#if TFK_NT_EW
+#define TFK_EW_LOAD4(p) nt_load4(p)
+#define TFK_EW_STORE4(p, v) nt_store4(p, v)
+#else
+#define TFK_EW_LOAD4(p) (*(p))
+#define TFK_EW_STORE4(p, v) (*(p) = (v))
+#endif
+
 namespace tfk {
 
 // ---------------------------------------------------------------------------
@@ -38,8 +52,8 @@ __global__ __launch_bounds__(kBlock) void k_affine_half_v4(
             float4 xs;
             if (!INPLACE) xs = xr[j];
             const float4 xt = xr[Sv + j];
-            const float4 h0 = hr[2 * j];       // (u0, b0, u1, b1)
-            const float4 h1 = hr[2 * j + 1];   // (u2, b2, u3, b3)
+            const float4 h0 = nt_load4(hr + 2 * j);       // (u0, b0, u1, b1); read once: non-temporal
+            const float4 h1 = nt_load4(hr + 2 * j + 1);   // (u2, b2, u3, b3)
             const float a0 = aff_alpha(h0.x), a1 = aff_alpha(h0.z);
             const float a2 = aff_alpha(h1.x), a3 = aff_alpha(h1.z);
             float4 o;
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_affine_half_v4(
             acc += log_normal(a2);
             acc += log_normal(a3);
             if (!INPLACE) zr[j] = xs;
-            zr[Sv + j] = o;
+            nt_store4(zr + Sv + j, o);
         }
         acc = group_sum(acc, G);
         if (lane == 0) {
@@ -109,12 +123,13 @@ __global__ __launch_bounds__(kBlock) void k_coupling_generic(
             const float v = xr[idx];
             float o;
             if (MODE < 2) {
-                const float a = aff_alpha(hr[2 * t]);
-                const float b = hr[2 * t + 1];
+                const float a = aff_alpha(nt_load(hr + 2 * t));
+                const float b = nt_load(hr + 2 * t + 1);
                 o = (MODE == 0) ? a * v + b : (v - b) / a;
                 acc += log_normal(a);
             } else {
-                o = (MODE == 2) ? v + hr[t] : v - hr[t];     // affine.py:150,158
+                const float sh = nt_load(hr + t);
+                o = (MODE == 2) ? v + sh : v - sh;           // affine.py:150,158
             }
             zr[idx] = o;
         }
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_elementwise_affine(
             const float4 *a4 = reinterpret_cast<const float4 *>(alpha_s);
             const float4 *b4 = reinterpret_cast<const float4 *>(beta_s);
             for (int v = lane; v < Dv; v += G) {
-                const float4 xv = xr[v], a = a4[v], b = b4[v];
+                const float4 xv = xr[v], a = a4[v], b = b4[v];    // (plain: non-temporal measured 3.5 % slower here)
                 float4 o;
                 if (!DIVIDE) {
                     o.x = a.x * xv.x + b.x; o.y = a.y * xv.y + b.y;
@@ -286,8 +301,8 @@ __global__ __launch_bounds__(kBlock) void k_permute(
             const float4 *xr = reinterpret_cast<const float4 *>(x + row * D);
             float4 *zr = reinterpret_cast<float4 *>(z + row * D);
             for (int v = lane; v < Dv; v += G) {
-                const float4 s = xr[Dv - 1 - v];
-                zr[v] = make_float4(s.w, s.z, s.y, s.x);
+                const float4 s = TFK_EW_LOAD4(xr + (Dv - 1 - v));
+                TFK_EW_STORE4(zr + v, make_float4(s.w, s.z, s.y, s.x));
             }
         } else {
             const float *xr = x + row * D;
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_diag_gauss(
             const int Dv = D >> 2;
             const float4 *zr = reinterpret_cast<const float4 *>(z + row * D);
             for (int v = lane; v < Dv; v += G) {
-                const float4 q = zr[v];
+                const float4 q = TFK_EW_LOAD4(zr + v);          // last reader of the rows
                 term(q.x, 4 * v); term(q.y, 4 * v + 1); term(q.z, 4 * v + 2); term(q.w, 4 * v + 3);
             }
         } else {

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling_bwd(
         const float4 *src = reinterpret_cast<const float4 *>(h + e0 * P);
         float4 *dst = reinterpret_cast<float4 *>(rec);
         __syncthreads();                       // previous tile's stores have read rec
-        for (int i = tid; i < nv; i += kBlock) dst[i] = src[i];
-        for (int i = (nv << 2) + tid; i < nfl; i += kBlock) rec[i] = h[e0 * P + i];
+        for (int i = tid; i < nv; i += kBlock) dst[i] = nt_load4(src + i);          // h: touched once per pass
+        for (int i = (nv << 2) + tid; i < nfl; i += kBlock) rec[i] = nt_load(h + e0 * P + i);
         __syncthreads();
         if (tid < E) {
             const long long e = e0 + tid;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling_bwd(
         }
         __syncthreads();
         float4 *out = reinterpret_cast<float4 *>(gh + e0 * P);
-        for (int i = tid; i < nv; i += kBlock) out[i] = dst[i];
+        for (int i = tid; i < nv; i += kBlock) nt_store4(out + i, dst[i]);         // 2.9 KB per row: no cache holds it
         for (int i = (nv << 2) + tid; i < nfl; i += kBlock) gh[e0 * P + i] = rec[i];
     }
 }

@@ -118,6 +118,24 @@ __device__ __forceinline__ float log1p_pos(float y) {
 }
 
 // sum over the G (power of two, <= 64) consecutive lanes that share a row
+// Non-temporal access for streams that are touched once (the conditioner's output h: 2 T or 23 T floats per row, written
+// by a GEMM and read by exactly one transform kernel; the transformed rows of a 2^20-row batch: 268 MB, gone from every
+// cache before the next kernel asks for them): the lines bypass the L2's retention and leave it to the data that is
+// reused.  Measured at 2^20 rows (profiles/r02, bench.py --no-fused): tfk_affine_coupling_fwd 121.2 -> 105.7 us
+// (4.50 -> 5.16 TB/s), tfk_rqs_coupling_fwd 213.1 -> 157.9 us (3.95 -> 5.32 TB/s).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4 *p)
+{
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float nt_load(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void nt_store4(float4 *p, const float4 &v)
+{
+    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4 *>(p));
+}
+constexpr int kDmaNonTemporal = 2;      // aux operand of global_load_lds: the NT bit of the gfx940+ cache policy
+
 // Sum of the log-probabilities a launch produced, in fp64 and in a fixed order, without further launches (feeds the
 // all-reduce of SURVEY.md 8(e)): every lane hands in the fp64 sum of the rows it wrote; the workgroup's total goes to
 // ws[1 + blockIdx.x]; the LAST workgroup to finish (ticket from the counter in ws[0]) adds the partials in index order,

@@ -25,6 +25,9 @@
 // TFK_OP_EW_FMA: s[D] | t[D] | logdet_const | pad[3]      z = fma(s, x, t)
 #pragma once
 #include "tfk_common.h"
+#ifndef TFK_CHAIN_OVERSUB
+#define TFK_CHAIN_OVERSUB kGridOversubscribe   // resident sets of workgroups a launch is cut into (tuning: tools/variants.sh)
+#endif
 
 namespace tfk {
 
@@ -665,7 +668,7 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
     if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int64_t cap = (int64_t)kCUs * per_cu * TFK_CHAIN_OVERSUB;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
                        params, n_params, prog, flags, xw);

@@ -29,6 +29,9 @@
 //   logits (c + u_d / 1000), all times log2(e); 23 = padding.
 #pragma once
 #include "tfk_common.h"
+#ifndef TFK_CHAIN_OVERSUB
+#define TFK_CHAIN_OVERSUB kGridOversubscribe   // resident sets of workgroups a launch is cut into (tuning: tools/variants.sh)
+#endif
 #include <type_traits>
 #include "tfk_flow_chain.h"
 
@@ -727,7 +730,7 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int64_t cap = (int64_t)kCUs * per_cu * TFK_CHAIN_OVERSUB;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
                        params, prog, flags, xw);

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_lrs_coupling(
             const float4 *src = reinterpret_cast<const float4 *>(h + (row0 * (long long)T + cbase) * P);
             __syncthreads();                    // previous tile's readers are done
             for (int i = tid; i < E * (P / 4); i += kBlock) {
-                const float4 v4 = src[i];
+                const float4 v4 = nt_load4(src + i);                // h is read once
                 const int r = i / (P / 4), j = (i - r * (P / 4)) * 4;
                 float *dst = rec + r * PS + j;
                 dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;

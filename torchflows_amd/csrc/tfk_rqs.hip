@@ -75,10 +75,10 @@ __global__ __launch_bounds__(TILE) void k_rqs_coupling(
                 const float4 *src = reinterpret_cast<const float4 *>(h + hoff);
                 float4 *dst = reinterpret_cast<float4 *>(rec);
                 const int nv = nfl >> 2;
-                for (int i = tid; i < nv; i += TILE) dst[i] = src[i];
-                for (int i = (nv << 2) + tid; i < nfl; i += TILE) rec[i] = h[hoff + i];
+                for (int i = tid; i < nv; i += TILE) dst[i] = nt_load4(src + i);
+                for (int i = (nv << 2) + tid; i < nfl; i += TILE) rec[i] = nt_load(h + hoff + i);
             } else {
-                for (int i = tid; i < nfl; i += TILE) rec[i] = h[hoff + i];
+                for (int i = tid; i < nfl; i += TILE) rec[i] = nt_load(h + hoff + i);
             }
             __syncthreads();
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_rqs_coupling_dma(
             if (off < nbytes)
                 __builtin_amdgcn_global_load_lds((gptr_t)(src + off),
                                                  (lptr_t)(reinterpret_cast<char *>(lds) + c * 1024),
-                                                 16, 0, 0);
+                                                 16, 0, kDmaNonTemporal);           // h is read once
         }
     };
 
