@@ -543,8 +543,9 @@ def test_declined_composition_warns_once():
 @pytest.mark.parametrize("variant", ["fresh", "init"])
 def test_context_conditioned_flows_run_as_flow_programs(name, arch, n_layers, ctx_shape, variant):
     """Context-conditioned flows (VERDICT r1 missing 5): couplings whose conditioner sees [x_A || context] and elementwise
-    layers whose parameters are a Linear map of the context run as ONE flow program (tfk_flow_run_mfma_ctx) -- against
-    the reference's golden outputs; the number of libtfk launches is the number of program launches."""
+    layers whose parameters are a Linear map of the context run as flow programs (tfk_flow_run_mfma_ctx; spline chains:
+    the lean single-launch chain between two small elementwise launches) -- against the reference's golden outputs; the
+    number of libtfk launches is the number of program launches."""
     import warnings
     import torchflows_amd as tfa
     from torchflows_amd import native, fused
@@ -561,12 +562,13 @@ def test_context_conditioned_flows_run_as_flow_programs(name, arch, n_layers, ct
         warnings.simplefilter("error", fused.NativeRouteWarning)      # nothing may fall to the layer-by-layer route
         before = native.calls
         lp = flow.log_prob(x, context=ctx)
-        # program launches only: ONE for the affine flow, one per spline coupling for the NSF (54 KB of operands each)
-        assert native.calls - before == (1 if arch == "RealNVP" else n_layers)
+        # program launches only: ONE for the affine flow; the NSF: the context-conditioned elementwise layer in front, the
+        # lean spline chain (the context as further GEMM-1 k-steps), the elementwise layers behind it
+        assert native.calls - before == (1 if arch == "RealNVP" else 3)
         before = native.calls
         z, lp2 = flow.forward_with_log_prob(x, context=ctx)
         xr, ldr = flow.bijection.inverse(z_in, context=ctx)
-        assert native.calls - before <= 2 * n_layers
+        assert native.calls - before <= 6
     tol = 4e-5 if "RQ" in arch else 1e-5
     assert rel(lp.cpu().numpy(), g("log_prob")) < 1e-5 and torch.equal(lp, lp2)
     assert normwise(z.cpu().numpy(), g("z")) < tol
@@ -815,3 +817,37 @@ def test_log_likelihood_sum_rides_in_the_log_prob_launch(arch, D, N, monkeypatch
         lp3, t3 = flow.log_prob_and_sum(x)
     s.synchronize()
     assert float(t3) == float(total)
+
+
+@pytest.mark.parametrize("arch,D,C,n_hidden", [("CouplingRQNSF", 64, 8, None), ("CouplingRQNSF", 64, 16, 24),
+                                               ("CouplingLRS", 64, 5, None), ("CouplingRQNSF", 128, 3, None),
+                                               ("CouplingRQNSF", 22, 8, None)])
+def test_conditional_spline_chain_is_three_launches(arch, D, C, n_hidden):
+    """Conditional spline flows (log_prob(x, context=c)): [context-conditioned elementwise layer] + ONE lean chain launch
+    whose GEMM 1 takes the context's columns of W1 as further k-steps + [the elementwise layers behind the chain].
+    Against the host path in fp64; forward and inverse."""
+    import copy
+    import torchflows_amd as tfa
+    from torchflows_amd import native
+    torch.manual_seed(12)
+    kw = {} if n_hidden is None else dict(conditioner_kwargs=dict(n_hidden=n_hidden))
+    flow = tfa.Flow(getattr(tfa, arch)(D, context_shape=(C,), n_layers=4, **kw))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(1024, D), context=torch.randn(1024, C))
+    flow.eval()
+    x, c = torch.randn(1500, D) * 1.5, torch.randn(1500, C)
+    flow64 = copy.deepcopy(flow).double()
+    with torch.no_grad():
+        lp_h = flow64.log_prob(x.double(), context=c.double())
+        z_h, _ = flow64.bijection.forward(x.double(), context=c.double())
+        flow = flow.cuda()
+        before = native.calls
+        lp_d = flow.log_prob(x.cuda(), context=c.cuda())
+        assert native.calls - before == 3
+        z_d, ld_d = flow.bijection.forward(x.cuda(), context=c.cuda())
+        xr, ldr = flow.bijection.inverse(z_d, context=c.cuda())
+    e_lp, e_z = rel(lp_d.cpu().numpy(), lp_h.numpy()), normwise(z_d.cpu().numpy(), z_h.numpy())
+    print(f"{arch}({D}) context {C}: log_prob {e_lp:.2e}, z nw {e_z:.2e}")
+    assert e_lp < 1e-5 and e_z < 2e-5
+    assert torch.allclose(xr.cpu(), x, atol=2e-3, rtol=1e-5) and torch.allclose(ld_d, -ldr, atol=1e-3)

@@ -15,13 +15,13 @@ int flow_chain_launch_32(const float *, float *, float *, const float *, const f
                          const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 
 int flow_rqs_chain_launch_4(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
+                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *, const float *, int);
 int flow_rqs_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
+                            const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *, const float *, int);
 int flow_rqs_chain_launch_16(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
+                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *, const float *, int);
 int flow_rqs_chain_launch_32(const float *, float *, float *, const float *, const float *, float *, int64_t,
-                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *);
+                             const float *, const RqsChainProg &, int, int, int, int, hipStream_t, const char *, const float *, int);
 
 // A program of lean spline couplings (TFK_OP_RQS_*_LEAN of one direction, one hidden width, one spline box, blocks
 // at a constant stride, source plane alternating; optionally ended by one TFK_OP_EW_FMA): ONE launch of
@@ -29,16 +29,19 @@ int flow_rqs_chain_launch_32(const float *, float *, float *, const float *, con
 static int run_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                          float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
                          int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn,
-                         double *sum_ws, double *sum_out)
+                         double *sum_ws, double *sum_out, const float *context = nullptr, int32_t Cn = 0)
 {
     const int EPL = D / 8, HALF = D / 2;
+    const int cs_want = context ? (Cn + 3) / 4 : 0;
     // operand format: K = 8 -> fp32 A-operands (chunks of 8 elements); K = 8 + 256 -> bf16 x 3 (chunks of 4 elements)
     const bool fmt3 = n_ops > 0 && (ops[4] >> 8) == 1;
     // bf16 x 3: gemm2_steps = ceil((H + 1) / 4) counts the bias unit; more than 4 steps = two hidden tiles
     const int ht3 = (fmt3 && n_ops > 0 && ops[2] > 4) ? 2 : 1;
     const bool lrs = n_ops > 0 && (ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN);
     if (lrs && !fmt3) return fail(TFK_EINVAL, "%s: lean linear-rational-spline ops use the bf16 x 3 operand format (K = 8 + 256)", fn);
-    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (int64_t)(EPL * ht3 / 4) * (lrs ? 16384 : kRqsChunk3Dwords)
+    if (context && !fmt3) return fail(TFK_EINVAL, "%s: context-conditioned lean spline chains use the bf16 x 3 operand format", fn);
+    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (cs_want ? ht3 * 256 : 0)
+                                     + (int64_t)(EPL * ht3 / 4) * (lrs ? 16384 : kRqsChunk3Dwords)
                                : (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
     RqsChainProg prog;
     memset(&prog, 0, sizeof(prog));
@@ -49,7 +52,8 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     float boundary = 0.0f, scale = 0.0f, c = 0.0f;
     for (int i = 0; i < n_ops; ++i) {
         const int32_t *rec = ops + 8 * i;
-        const int k = rec[0], src = rec[1], st = rec[2], off = rec[3];
+        const int k = rec[0], st = rec[2], off = rec[3];
+        int src = rec[1];
         if (k == TFK_OP_EW_FMA) {
             if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
             if (off < 0 || (off & 3) || off + 2 * (int64_t)D + 4 > n_params)
@@ -57,6 +61,9 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
             prog.ew_offset = off;
             continue;
         }
+        if ((src >> 4) != cs_want)                           // src_plane bits 4..7: k-steps of context in GEMM 1
+            return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
+        src &= 15;
         if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN && k != TFK_OP_LRS_FWD_LEAN && k != TFK_OP_LRS_INV_LEAN)
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean spline ops", fn, i, k);
         float bnd, sc, cc;
@@ -100,10 +107,11 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
                         : (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
     const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN;
     if (fmt3) steps2 = (ht3 == 2 ? 8 : 0) + (lrs ? 16 : 0);
-    if (EPL == 4) return flow_rqs_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
-    if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
-    if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
-    return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
+    prog.ctx_steps = cs_want;
+    if (EPL == 4) return flow_rqs_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
+    if (EPL == 8) return flow_rqs_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
+    if (EPL == 32) return flow_rqs_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
+    return flow_rqs_chain_launch_16(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
 }
 
 // A program made of lean ops only (TFK_OP_*_LEAN couplings of one kind and one GEMM-2 step count whose source
@@ -218,7 +226,10 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
-    if (lean && context) return fail(TFK_EINVAL, "%s: lean programs take no context", fn);
+    const bool lean_spline = lean && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
+                                      ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN);
+    if (lean && context && !lean_spline)
+        return fail(TFK_EINVAL, "%s: of the lean programs only spline chains take a context", fn);
     if (sum_ws && (!lean || !logprob || !sum_out))
         return fail(TFK_EINVAL, "%s: the in-kernel sum needs a lean program, logprob and sum_out", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
@@ -226,7 +237,7 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
                       ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN))
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                             accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out);
+                             accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out, context, C);
     if (n_ops > 0 && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA) ||
                       ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN))
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,

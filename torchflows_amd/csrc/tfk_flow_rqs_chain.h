@@ -51,7 +51,8 @@ struct RqsChainProg {
     int ew_offset;            // TFK_OP_EW_FMA (global offset), -1: none
     int layer_stride;         // floats between consecutive layers' blocks
     int offset0;              // first layer's block
-    int pad[3];
+    int ctx_steps;            // k-steps of context in GEMM 1 (0: none; the head then ends with A1c[HT][64][4])
+    int pad[2];
     RqsLean C;
     double *sum_ws;           // tfk_flow_run_mfma_sum (see ChainProg)
     double *sum_out;
@@ -366,13 +367,15 @@ __device__ __forceinline__ void rqs_layer(const float *__restrict__ gprm, float 
 // 4 / HT target elements, so its size does not depend on HT.
 // Block: head A1[EPL/4][HT][64][4] | b1[HT][4][4] | pre_s | pre_t, then chunks A[4/HT][6][HT][2][64][4 dwords].
 // LRS: linear rational spline elements (32 parameters = 8 tiles per element) instead of rational-quadratic ones (24 = 6).
-template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS, bool FAST>
+// CTX: the conditioner also reads the context (Concatenation, conditioning/context.py:38-64: [x_A | context]): its columns
+// of W1 are up to 4 further k-steps of GEMM 1 -- A1c[HT][64][4] behind the head, the lane's context elements 4 s + q in cx.
+template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS, bool FAST, bool CTX = false>
 __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float *stage, int lane, int q,
                                            const RqsLean &C, const float (&src)[EPL], float (&tgt)[EPL], float &ld2,
-                                           float &amax)
+                                           float &amax, const float (&cx)[4] = {0.0f, 0.0f, 0.0f, 0.0f}, int cs = 0)
 {
     constexpr int HALF = 4 * EPL;
-    constexpr int HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF;
+    constexpr int HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF + (CTX ? HT * 256 : 0);
     constexpr int TPE = LRS ? 8 : 6;                          // tiles of 4 parameters per element
     constexpr int GRP = LRS ? 4 : 3;                          // tiles side by side (TPE / 2)
     constexpr int CHUNKD = (LRS ? 4 : 3) * 4096;              // = (4 / HT) * TPE * HT * 2 * 64 * 4 dwords
@@ -411,6 +414,16 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
                 for (int k = 0; k < 4; ++k)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc[t], 0, 0, 0);
             }
+        if constexpr (CTX) {
+            const cf32x4 *A1c = reinterpret_cast<const cf32x4 *>(pre + 2 * HALF);
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                const cf32x4 w = A1c[t * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cs) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], cx[k], acc[t], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < EPL / 4; ++i) {
             const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
@@ -520,19 +533,21 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
 #ifndef TFK_RQS3_WAVES
 #define TFK_RQS3_WAVES 4
 #endif
-template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((STEPS2 == 0 || STEPS2 >= 8) ? (EPL == 32 ? 2 : TFK_RQS3_WAVES) : 1)))
 void k_flow_rqs_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
-    const float *__restrict__ params, RqsChainProg prog, int flags, int xw)
+    const float *__restrict__ params, RqsChainProg prog, int flags, int xw,
+    const float *__restrict__ context = nullptr, int Cn = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     constexpr bool F3 = STEPS2 == 0 || STEPS2 >= 8;
     constexpr bool LRS = STEPS2 >= 16;
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
-    constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
+    static_assert(!CTX || (STEPS2 == 0 || STEPS2 >= 8), "context-conditioned spline chains: bf16 x 3 operand format");
+    constexpr int HEAD = (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;
     const bool base_of_input = (flags & 4) != 0;
@@ -595,6 +610,11 @@ void k_flow_rqs_chain(
         }
         };
         load_rows();
+        float cx[4] = {0.0f, 0.0f, 0.0f, 0.0f};                      // this lane's context elements 4 s + q of row j
+        if constexpr (CTX) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) cx[s] = (4 * s + q < Cn) ? context[rr * Cn + 4 * s + q] : 0.0f;
+        }
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         float sq = 0.0f;
         auto base_terms = [&]() {
@@ -623,9 +643,9 @@ void k_flow_rqs_chain(
                 const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
                 if constexpr (F3) {
                     if (((prog.first_src + l) & 1) == 0)
-                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, a, b, ld2, amax);
+                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST, CTX>(gprm, stage, lane, q, C, a, b, ld2, amax, cx, prog.ctx_steps);
                     else
-                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, b, a, ld2, amax);
+                        rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST, CTX>(gprm, stage, lane, q, C, b, a, ld2, amax, cx, prog.ctx_steps);
                 } else {
                     if (((prog.first_src + l) & 1) == 0)
                         rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
@@ -701,19 +721,19 @@ void k_flow_rqs_chain(
     }
 }
 
-template <int EPL, int BLOCK, int STEPS2, bool INVERSE>
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false>
 static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                               float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int flags,
-                              int xw, hipStream_t s, const char *fn)
+                              int xw, hipStream_t s, const char *fn, const float *context = nullptr, int Cn = 0)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
     constexpr bool F3 = STEPS2 == 0 || STEPS2 >= 8;
     constexpr bool LRS = STEPS2 >= 16;
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
-    constexpr int HEAD = F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF;
+    constexpr int HEAD = (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
     const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float)
                        + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);
-    auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE>;
+    auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE, CTX>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -733,15 +753,32 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     const int64_t cap = (int64_t)kCUs * per_cu * TFK_CHAIN_OVERSUB;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
-                       params, prog, flags, xw);
+                       params, prog, flags, xw, context, Cn);
     return check_launch(fn);
 }
 
 template <int EPL>
 static int launch_rqs_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                             float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int inverse,
-                            int steps2, int flags, int xw, hipStream_t s, const char *fn)
+                            int steps2, int flags, int xw, hipStream_t s, const char *fn,
+                            const float *context = nullptr, int Cn = 0)
 {
+    if (context) {                                           // context-conditioned chains: bf16 x 3 operands, D >= 64
+        if constexpr (EPL >= 8) {
+#define TFK_RCC(ST_) \
+    (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn, context, Cn) \
+             : launch_rqs_chain_b<EPL, 512, ST_, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn, context, Cn))
+            switch (steps2) {
+            case 0: return TFK_RCC(0);
+            case 8: return TFK_RCC(8);
+            case 16: return TFK_RCC(16);
+            case 24: return TFK_RCC(24);
+            default: break;
+            }
+#undef TFK_RCC
+        }
+        return fail(TFK_EINVAL, "%s: context-conditioned lean spline chains need D >= 64 and the bf16 x 3 operand format", fn);
+    }
 #define TFK_RC(ST_) \
     (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn) \
              : launch_rqs_chain_b<EPL, 512, ST_, false>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn))

@@ -5,9 +5,10 @@ namespace tfk {
 
 int flow_rqs_chain_launch_16(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                              float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int inverse,
-                             int steps2, int flags, int xw, hipStream_t s, const char *fn)
+                             int steps2, int flags, int xw, hipStream_t s, const char *fn,
+                             const float *context, int Cn)
 {
-    return launch_rqs_chain<16>(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn);
+    return launch_rqs_chain<16>(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
 }
 
 }  // namespace tfk

@@ -574,14 +574,18 @@ def _lean_elementwise(layer, d: int, D: int):
     return alpha, beta, (d == INVERSE) != (kind == "inverse_affine")
 
 
-def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
+def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int, allow_ctx: bool = False):
     """Physical-order conditioner weights of an affine / shift HalfSplit coupling with the default FeedForward(tanh)
     conditioner of hidden width <= 16: (lean kind 0..3, source plane, H, W1t (H, hp), b1, W2p (hp, P, H), b2p (hp, P))
     in fp64, or None (the checks of ``_coupling_op``)."""
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import FeedForward
+    from torchflows_amd.utils import event_size as _esize
     kind = layer.transformer.native_kind
-    if kind not in ("affine", "inverse_affine", "shift", "rqs", "lrs") or layer.context_shape is not None:
+    if kind not in ("affine", "inverse_affine", "shift", "rqs", "lrs"):
         return None
+    C = _esize(layer.context_shape) if layer.context_shape is not None else 0
+    if C and not (allow_ctx and kind in ("rqs", "lrs") and C <= MAX_CONTEXT):
+        return None                                           # (a context: spline chains only, as further GEMM-1 k-steps)
     if kind in ("rqs", "lrs") and layer.transformer.n_bins != 8:
         return None
     half = D // 2
@@ -602,8 +606,10 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     W1, b1 = mods[0].weight.detach().double(), mods[0].bias.detach().double()
     W2, b2 = mods[2].weight.detach().double(), mods[2].bias.detach().double()
     H = W1.shape[0]
-    if H > (31 if kind in ("rqs", "lrs") else 16) or W1.shape[1] != S or W2.shape[0] != T * P or W2.shape[1] != H:
+    if H > (31 if kind in ("rqs", "lrs") else 16) or W1.shape[1] != S + C or W2.shape[0] != T * P or W2.shape[1] != H:
         return None
+    W1c = W1[:, S:] if C else None                            # [x_A || context] (conditioning/context.py:46-60)
+    W1 = W1[:, :S]
     hp = Dp // 2
     src_pos, tgt_pos = pos[:S], pos[S:]
     plane = int(src_pos[0].item()) // hp
@@ -624,6 +630,8 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
         lk = 8 if d == FORWARD else 9
     else:
         lk = 0 if (d == FORWARD) != (kind == "inverse_affine") else 1
+    if allow_ctx:
+        return lk, plane, H, W1t, b1, W2p, b2p, W1c
     return lk, plane, H, W1t, b1, W2p, b2p
 
 
@@ -717,7 +725,7 @@ def _bf16_pieces(w: torch.Tensor):
 
 
 def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: float, bf16x3: bool = False,
-                   lrs: bool = False) -> torch.Tensor:
+                   lrs: bool = False, W1c=None) -> torch.Tensor:
     """Parameter block of a lean RQ-spline coupling op (csrc/tfk_flow_rqs_chain.h), fp64 in, fp32 out.
     fp32 operands (hidden width <= 16): head A1[EPL/4][64][4] | b1[4][4] | pre_s[hp] | pre_t[hp], then EPL/8 chunks
     A2[48][64][4] | b2[48][4][4].  bf16 x 3 operands (hidden width <= 15, or <= 31 with HT = 2 hidden tiles): head
@@ -763,6 +771,13 @@ def _pack_lean_rqs(H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, c_delta: fl
     b1m = torch.stack([b1pad[16 * t + 4 * rr + qq] for t in range(HT)])                # [t][q][r]
     q2, r2 = il >> 2, il & 3
     parts = [A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]
+    if W1c is not None:            # the context's columns of W1: A1c[t][lane][k] = W1c[unit 16 t + unit1(i), context 4 k + q]
+        assert bf16x3
+        W1cp = torch.zeros(HU, 16, dtype=torch.float64, device=dev)
+        W1cp[:H, :W1c.shape[1]] = W1c * (2.0 * LOG2E)
+        kk = torch.arange(4, device=dev)
+        A1c = torch.stack([W1cp[(16 * t + unit1).view(64, 1), 4 * kk.view(1, 4) + ql.view(64, 1)] for t in range(HT)])
+        parts.append(A1c.reshape(-1))
     e_all = torch.arange(EPL, device=dev).view(EPL, 1, 1, 1, 1)                        # the lane-group's element index
     c = torch.arange(TPE, device=dev).view(1, TPE, 1, 1, 1)
     m = EPL * q2.view(1, 1, 1, 64, 1) + e_all                                          # physical target element
@@ -852,13 +867,18 @@ def _pack_lean_made(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t) -> torch.
     return torch.cat([A1.reshape(-1), b1m.reshape(-1), A2.reshape(-1), torch.stack(b2m).reshape(-1), pre_s, pre_t]).float()
 
 
-def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor):
+def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor,
+                  context: bool = False):
     """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
     folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
     alternates -- every RealNVP / NICE preset.  The elementwise layers are deferred: physical column c carries a
     pending map x -> s[c] x + t[c] (fp64 on the host) that is folded into W1 / b1 where c feeds a conditioner,
     applied by the coupling that transforms c (its pre-affine), and flushed by one TFK_OP_EW_FMA at the end together
-    with the sum of the constant log-dets."""
+    with the sum of the constant log-dets.
+    ``context`` (conditional flows; spline chains only): the couplings' conditioners read [x_A | context] -- the
+    context's columns of W1 are further k-steps of GEMM 1 --, and the elementwise layers whose parameters are a Linear map
+    of the context (the presets' first and second-to-last layer) run as interpreter ops (TFK_OP_EWC_*) in a launch of
+    their own before / after the lean chain: 3 launches for a conditional CouplingRQNSF instead of one per coupling."""
     from torchflows_amd.bijections.finite.autoregressive.layers_base import (
         CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
@@ -867,17 +887,50 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     t = torch.zeros(Dp, dtype=torch.float64, device=device)
     ld_const = torch.zeros((), dtype=torch.float64, device=device)
     items = []          # (lean kind, plane, steps2, block)
+    head, tail, closed_flush = [], [], None                  # (context) interpreter ops around the chain
+    ctx_bits = 0
     kind0 = steps0 = None
     # bf16 x 3 operands for affine / shift chains: D = 64 only, and the whole chain must stay ONE launch (10.6 KB of
     # operands per coupling instead of 5.7): decided after a dry count of the couplings
     n_couplings = sum(isinstance(layer, CouplingBijection) for layer, _ in plan)
     aff3 = lean_bf16x3_enabled() and Dp == 64 and 0 < n_couplings <= 13
+    # (context) if a context-conditioned elementwise layer precedes the first coupling, every elementwise layer before
+    # that coupling is an interpreter op of the launch in front of the chain (the inverse direction starts with a
+    # constant ActNorm followed by the context-conditioned layer)
+    first_c = next((i for i, (layer, _) in enumerate(plan) if isinstance(layer, (CouplingBijection, MaskedAutoregressiveBijection))), len(plan))
+    head_mode = context and any(isinstance(layer, ElementwiseBijection) and not layer.use_global_parameters
+                                for layer, _ in plan[:first_c])
     with torch.no_grad():
-        for layer, d in plan:
+        for li, (layer, d) in enumerate(plan):
             if isinstance(layer, PermutationMatrix):
                 perm = (layer._fwd_index if d == FORWARD else layer._inv_index).to(device)
                 pos = pos[perm]
+            elif isinstance(layer, ElementwiseBijection) and head_mode and li < first_c:
+                item = (_elementwise_ctx_op(layer, d, pos, D, Dp) if not layer.use_global_parameters
+                        else _elementwise_op(layer, d, pos, D, Dp))
+                if item is None:
+                    return None
+                head.append(item)
             elif isinstance(layer, ElementwiseBijection):
+                if context and not layer.use_global_parameters:
+                    item = _elementwise_ctx_op(layer, d, pos, D, Dp)
+                    if item is None:
+                        return None
+                    if not items and closed_flush is None:   # before the chain: nothing may be pending
+                        if not (bool((s == 1).all()) and bool((t == 0).all())):
+                            return None
+                        head.append(item)
+                    else:                                    # after it: the chain ends here, pending maps flushed
+                        if closed_flush is None:
+                            closed_flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
+                        tail.append(item)
+                    continue
+                if closed_flush is not None:                 # constant elementwise layers behind the chain: interpreter ops
+                    item = _elementwise_op(layer, d, pos, D, Dp)
+                    if item is None:
+                        return None
+                    tail.append(item)
+                    continue
                 got = _lean_elementwise(layer, d, D)
                 if got is None:
                     return None
@@ -891,6 +944,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     t[pos] = alpha * t[pos] + beta
                     ld_const = ld_const + torch.log(alpha).sum()
             elif isinstance(layer, MaskedAutoregressiveBijection):
+                if context:
+                    return None
                 got = _lean_made(layer, d, pos, D, Dp)       # MAF density / IAF sampling: the parallel map
                 if got is None:
                     return None
@@ -905,10 +960,22 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 t.fill_(0.0)
                 items.append((OP_MADE_INV_LEAN if divide else OP_MADE_FWD_LEAN, 0, steps2, block, ()))
             elif isinstance(layer, CouplingBijection):
-                got = _lean_coupling(layer, d, pos, D, Dp)
+                if closed_flush is not None:
+                    return None                               # (a coupling behind a context-conditioned elementwise layer)
+                got = _lean_coupling(layer, d, pos, D, Dp, allow_ctx=context)
                 if got is None:
                     return None
-                lk, plane, H, W1t, b1, W2p, b2p = got
+                W1c = None
+                if context:
+                    lk, plane, H, W1t, b1, W2p, b2p, W1c = got
+                    if lk not in (4, 5, 8, 9) or not rqs_bf16x3_enabled():
+                        return None                           # (lean context programs: spline chains, bf16 x 3 operands)
+                    cs_l = 0 if W1c is None else (W1c.shape[1] + 3) // 4
+                    if items and (cs_l << 4) != ctx_bits:
+                        return None
+                    ctx_bits = cs_l << 4
+                else:
+                    lk, plane, H, W1t, b1, W2p, b2p = got
                 if kind0 is not None and kind0 in (6, 7):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
@@ -932,7 +999,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     if items and items[-1][4] != extra:
                         return None
                     block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
-                                           float(np.float32(tr.const)), bf16x3=True, lrs=True)
+                                           float(np.float32(tr.const)), bf16x3=True, lrs=True, W1c=W1c)
                     items.append((OP_LRS_FWD_LEAN + lk - 8, plane, steps2, block, extra))
                 elif lk >= 4:                                # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
@@ -945,7 +1012,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     if items and items[-1][4] != extra:
                         return None
                     block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
-                                           float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3)
+                                           float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3, W1c=W1c)
                     items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
                 else:
                     use3 = aff3 and H <= 15
@@ -957,9 +1024,9 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 t[tgt] = 0.0
             else:
                 return None
-    flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
+    flush = closed_flush if closed_flush is not None else torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
     streamed = kind0 in (4, 5, 8, 9)                     # spline chains read their operands from global memory
-    if not items and streamed:
+    if (not items and streamed) or (context and not items):
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
@@ -987,10 +1054,22 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
             if ops and kind != OP_EW_FMA and (over or len(ops) >= 60):
                 segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
                 ops, blocks, used = [], [], 0
-        ops.append((kind, plane, steps2, used) + tuple(extra))
+        ops.append((kind, plane | (ctx_bits if kind != OP_EW_FMA else 0), steps2, used) + tuple(extra))
         blocks.append(block)
         used += n
     segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
+
+    def small_segment(its):                              # a few interpreter ops (elementwise layers) as one launch
+        o, b, u = [], [], 0
+        for head_, block_ in its:
+            o.append((head_[0], head_[1], head_[2], u) + tuple(head_[3:]))
+            b.append(block_.float())
+            u += block_.numel()
+        return Segment(o, torch.cat(b).contiguous(), True)
+    if head:
+        segments.insert(0, small_segment(head))
+    if tail:
+        segments.append(small_segment(tail))
     identity = bool(torch.equal(pos, pos_in))
     return CompiledChain(Dp, segments, pos, identity, _params_version(composition), D_log=D,
                          pos_in=pos_in if Dp != D else None)
@@ -1041,13 +1120,14 @@ def compile_chain(composition, direction: int, device: torch.device,
         if width != D and not slots:             # second half of the row starts at the padded plane boundary
             p_ = torch.where(p_ < D // 2, p_, p_ - D // 2 + width // 2)
         return p_
-    if mfma and not slots and lean_enabled() and not context:
+    if mfma and not slots and lean_enabled():
         # event sizes <= 32: the straight-line kernels exist at row width 32 as well (half the work of a 64-wide row)
-        widths = ([32] if (D % 2 == 0 and 4 <= D <= 32 and narrow_rows_enabled()) else []) + [Dp]
+        # (conditional flows: the elementwise layers around the chain are interpreter launches -- 64 columns at least)
+        widths = ([32] if (D % 2 == 0 and 4 <= D <= 32 and narrow_rows_enabled() and not context) else []) + [Dp]
         for w in widths:
             if w != D and not padded_enabled(D, w):
                 continue
-            chain = _compile_lean(composition, plan, device, D, w, planes(w), planes(w))
+            chain = _compile_lean(composition, plan, device, D, w, planes(w), planes(w), context=context)
             if chain is not None:
                 return chain
     pos = planes(Dp)
@@ -1303,7 +1383,7 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     n_seg = len(chain.segments)
     padded = chain.pos_in is not None
     # lean programs read narrower rows themselves (tfk_flow_run_mfma_in): no padding pass over the rows
-    narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma
+    narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma and context is None
                  and (OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN
                       or chain.segments[0].ops[0][0] in (OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN)) and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
