@@ -32,6 +32,7 @@
 namespace tfk {
 
 constexpr int kMaxChainOps = 64;
+constexpr int kChainSideOps = 3;
 
 struct ChainProg {
     int n_c;          // couplings
@@ -41,6 +42,12 @@ struct ChainProg {
     int offset[kMaxChainOps];
     double *sum_ws;   // tfk_flow_run_mfma_sum: counter + one partial per workgroup (finish_sum_f64), or null
     double *sum_out;  // ... and the fp64 sum of the launch's log-probabilities
+    const float *context;   // (N, ctx_n) rows of context, or null: the couplings' conditioners read [x_A | context]
+    int ctx_n, ctx_steps;   // context elements; k-steps of 4 they take in GEMM 1 (A1c[64][4] ends each coupling's block)
+    // (context programs) elementwise ops in front of the couplings and behind the closing TFK_OP_EW_FMA:
+    // kind 0 none, 1 constant x -> s x + t (an EW_FMA block), 2 / 3 context-conditioned multiply-add / subtract-divide
+    int pre_kind[kChainSideOps], pre_off[kChainSideOps];
+    int post_kind[kChainSideOps], post_off[kChainSideOps];
 };
 
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
@@ -69,9 +76,10 @@ __device__ __forceinline__ float log2_scales(float u0, float u1, float al0, floa
 }
 
 // KIND: 0 affine fwd, 1 affine inv, 2 shift fwd, 3 shift inv
-template <int EPL, int STEPS2, int KIND, bool FAST>
+template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false>
 __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, const float (&src)[EPL],
-                                            float (&tgt)[EPL], float &ld2, float &umin)
+                                            float (&tgt)[EPL], float &ld2, float &umin,
+                                            const float (&cx)[4] = {0.0f, 0.0f, 0.0f, 0.0f}, int cs = 0)
 {
     constexpr bool affine = KIND < 2;
     constexpr int HALF = 4 * EPL;
@@ -91,6 +99,12 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+    }
+    if constexpr (CTX) {                                     // [x_A | context] (conditioning/context.py:38-64)
+        const cf32x4 w = *reinterpret_cast<const cf32x4 *>(pre + 2 * HALF + 4 * lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < cs) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], cx[k], acc, 0, 0, 0);
     }
     // the elements about to be transformed take their pending elementwise layers now (one fma)
 #pragma unroll
@@ -341,19 +355,22 @@ __device__ __forceinline__ void made_lean(const float *prm, int lane, int q, flo
 }
 
 // one coupling in whichever operand format the kernel was instantiated for (STEPS2 = 0: bf16 x 3)
-template <int EPL, int STEPS2, int KIND, bool FAST>
+template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false>
 __device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, const float (&src)[EPL],
-                                           float (&tgt)[EPL], float &ld2, float &umin)
+                                           float (&tgt)[EPL], float &ld2, float &umin,
+                                           const float (&cx)[4] = {0.0f, 0.0f, 0.0f, 0.0f}, int cs = 0)
 {
     if constexpr (STEPS2 == 0) couple_lean3<EPL, KIND, FAST>(prm, lane, q, src, tgt, ld2, umin);
-    else couple_lean<EPL, STEPS2, KIND, FAST>(prm, lane, q, src, tgt, ld2, umin);
+    else couple_lean<EPL, STEPS2, KIND, FAST, CTX>(prm, lane, q, src, tgt, ld2, umin, cx, cs);
 }
 
 // the couplings (or MADE layers) of the program on the 16 rows a wave holds
-template <int EPL, int STEPS2, int KIND, bool FAST>
+template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false>
 __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &prog, int lane, int q, float (&a)[EPL],
-                                             float (&b)[EPL], float &ld2, float &umin)
+                                             float (&b)[EPL], float &ld2, float &umin,
+                                             const float (&cx)[4] = {0.0f, 0.0f, 0.0f, 0.0f})
 {
+    const int cs = CTX ? prog.ctx_steps : 0;
     int o = 0;
     if constexpr (KIND >= 4) {                                    // MADE layers: both planes in, both planes out
 #pragma unroll 1
@@ -361,15 +378,74 @@ __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &
             made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
     } else {
         if (prog.first_src == 1 && prog.n_c > 0) {
-            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[0], lane, q, b, a, ld2, umin);
+            couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[0], lane, q, b, a, ld2, umin, cx, cs);
             o = 1;
         }
         for (; o + 1 < prog.n_c; o += 2) {
-            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
-            couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o + 1], lane, q, b, a, ld2, umin);
+            couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o], lane, q, a, b, ld2, umin, cx, cs);
+            couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o + 1], lane, q, b, a, ld2, umin, cx, cs);
         }
-        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
+        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o], lane, q, a, b, ld2, umin, cx, cs);
     }
+}
+
+// x -> s x + t on this lane's elements of both planes (block: s[D] | t[D] | constant log-det, pad[3])
+template <int EPL>
+__device__ __forceinline__ void ew_fma_apply(const float *ew, int q, float (&a)[EPL], float (&b)[EPL], float &ld)
+{
+    constexpr int D = 8 * EPL, HALF = 4 * EPL;
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
+        const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(ew + HALF + EPL * q + 4 * i);
+        const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(ew + D + EPL * q + 4 * i);
+        const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(ew + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
+            b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+        }
+    }
+    if (q == 0) ld = ld + ew[2 * D];
+}
+
+// An elementwise affine layer whose parameters are a Linear map of the CONTEXT (ElementwiseBijection with a
+// context_shape, layers_base.py:300-318) inside a lean context program: one GEMM context -> (D, 2), then the affine
+// transform of every element of both planes -- the interpreter's TFK_OP_EWC_* op (tfk_flow_mfma.h: ewc_m), same block:
+// Ac[EPL][cs][64] | bc[EPL][4][4]; tile t < EPL / 2: this lane's elements 2 t, 2 t + 1 of plane A, else of plane B.
+template <int EPL, bool DIVIDE>
+__device__ __forceinline__ void ewc_lean(const float *prm, int cs, int lane, int q, float (&a)[EPL], float (&b)[EPL],
+                                         float &ld, const float (&cx)[4])
+{
+    const float *Ac = prm;
+    const float *bc = prm + EPL * cs * 64;
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        cf32x4 o = *reinterpret_cast<const cf32x4 *>(bc + (t * 4 + q) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < cs) o = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[(t * cs + k) * 64 + lane], cx[k], o, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float al = aff_alpha_lean(o[2 * i]);
+            const float be = o[2 * i + 1];
+            part += log_lean(al);
+            float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
+            if (!DIVIDE) v = al * v + be;                                   // affine.py:48
+            else v = (v - be) * __builtin_amdgcn_rcpf(al);                  // affine.py:59
+        }
+    }
+    ld = ld + (DIVIDE ? -part : part);
+}
+
+template <int EPL>
+__device__ __forceinline__ void side_op(int kind, const float *prm, int cs, int lane, int q, float (&a)[EPL],
+                                        float (&b)[EPL], float &ld, const float (&cx)[4])
+{
+    if (kind == 1) ew_fma_apply<EPL>(prm, q, a, b, ld);
+    else if (kind == 2) ewc_lean<EPL, false>(prm, cs, lane, q, a, b, ld, cx);
+    else if (kind == 3) ewc_lean<EPL, true>(prm, cs, lane, q, a, b, ld, cx);
 }
 
 // floats of one lean coupling's parameter block (fp32 operand format), see couple_lean
@@ -448,9 +524,9 @@ __device__ __forceinline__ void chain_layers_stream(float *buf0, const float *__
 #define TFK_CHAIN_ATTR
 #endif
 
-template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false>
 __global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR
-__attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16 && BLOCK == 1024) ? 4 : 1)))) void k_flow_chain(
+__attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 16 && BLOCK == 1024) || (EPL == 8 && CTX)) ? 4 : 1)))) void k_flow_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
     const float *__restrict__ gauss_log_scale, float *logprob, long long N,
     const float *__restrict__ params, int n_params, ChainProg prog, int flags, int xw)
@@ -463,6 +539,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
     // resident: the whole parameter block; streamed: two coupling blocks | the closing TFK_OP_EW_FMA block
     constexpr int LB = chain_block_floats<EPL, STEPS2, KIND>();
     static_assert(!STREAM || (KIND < 4 && STEPS2 != 0), "streamed operands: affine / shift couplings, fp32 format");
+    static_assert(!CTX || (KIND < 4 && STEPS2 != 0 && !STREAM), "context: affine / shift couplings, fp32 format, resident");
     float *ew_s = STREAM ? lds + kStreamBufs * LB : lds + (prog.ew_offset >= 0 ? prog.ew_offset : 0);
     if constexpr (STREAM) {
         if (prog.ew_offset >= 0)
@@ -556,7 +633,14 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
         };
         if (logprob && base_of_input) base_terms();                   // Flow.sample (flows.py:699-707)
 
+        float cx[4] = {0.0f, 0.0f, 0.0f, 0.0f};                       // this lane's context elements 4 s + q of row j
+        if constexpr (CTX) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                cx[s4] = (4 * s4 + q < prog.ctx_n) ? prog.context[rr * prog.ctx_n + 4 * s4 + q] : 0.0f;
+        }
         float ld2 = 0.0f;                                             // this lane's share, in base 2
+        float ld_pre = 0.0f;                                          // (context programs) log-det of the ops in front
         float umin = 0.0f;                                            // smallest scale logit seen (log2_scales)
         constexpr bool kShortcut = TFK_LOG_SHORTCUT && (KIND < 2 || KIND >= 4);
         if constexpr (STREAM) {
@@ -569,33 +653,34 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
                 }
             }
         } else {
-        chain_layers<EPL, STEPS2, KIND, kShortcut>(lds, prog, lane, q, a, b, ld2, umin);
+        auto pre_ops = [&]() {
+            if constexpr (CTX) {
+                ld_pre = 0.0f;
+#pragma unroll 1
+                for (int i = 0; i < kChainSideOps; ++i)
+                    if (prog.pre_kind[i]) side_op<EPL>(prog.pre_kind[i], lds + prog.pre_off[i], prog.ctx_steps, lane, q, a, b, ld_pre, cx);
+            }
+        };
+        pre_ops();
+        chain_layers<EPL, STEPS2, KIND, kShortcut, CTX>(lds, prog, lane, q, a, b, ld2, umin, cx);
         if constexpr (kShortcut) {
             if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {   // scales near the 1e-10 floor: with logarithms
                 load_rows();                                          // (x is still intact: z is stored below)
                 ld2 = 0.0f;
-                chain_layers<EPL, STEPS2, KIND, false>(lds, prog, lane, q, a, b, ld2, umin);
+                pre_ops();
+                chain_layers<EPL, STEPS2, KIND, false, CTX>(lds, prog, lane, q, a, b, ld2, umin, cx);
             }
         }
         }
         if constexpr (KIND == 0 || KIND == 4) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
         else if constexpr (KIND == 1 || KIND == 5) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
 
-        if (prog.ew_offset >= 0) {                                    // what is still pending, one fma per element
-            const float *ew = ew_s;
-#pragma unroll
-            for (int i = 0; i < EPL / 4; ++i) {
-                const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
-                const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(ew + HALF + EPL * q + 4 * i);
-                const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(ew + D + EPL * q + 4 * i);
-                const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(ew + D + HALF + EPL * q + 4 * i);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
-                    b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
-                }
-            }
-            if (q == 0) ld = ld + ew[2 * D];
+        if (prog.ew_offset >= 0) ew_fma_apply<EPL>(ew_s, q, a, b, ld);   // what is still pending, one fma per element
+        if constexpr (CTX) {                                          // the elementwise layers behind the couplings
+            ld += ld_pre;
+#pragma unroll 1
+            for (int i = 0; i < kChainSideOps; ++i)
+                if (prog.post_kind[i]) side_op<EPL>(prog.post_kind[i], lds + prog.post_off[i], prog.ctx_steps, lane, q, a, b, ld, cx);
         }
         if (logprob && !base_of_input) base_terms();
 
@@ -640,7 +725,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : ((EPL == 16
     }
 }
 
-template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false>
 static int launch_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                           float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
                           int flags, int xw, hipStream_t s, const char *fn)
@@ -651,7 +736,7 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
                        + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);       // one fp64 slot per thread
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
-    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM>;
+    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM, CTX>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -699,6 +784,22 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
         }
         return fail(TFK_EINVAL, "%s: %d floats of parameters do not fit the 160 KiB LDS, and streamed operands exist for "
                     "affine / shift couplings at D >= 128 with fp32 operands; split the program", fn, n_params);
+    }
+    if (prog.context) {                                      // conditional flows: one workgroup size, fp32 operands, D >= 64
+        if constexpr (EPL >= 8 && KIND < 4) {
+            constexpr int BC = (EPL == 16) ? 768 : 512;
+#define TFK_CC(ST_) \
+    launch_chain_b<EPL, BC, ST_, KIND, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
+            switch (steps2) {
+            case 1: return TFK_CC(1);
+            case 2: return TFK_CC(2);
+            case 3: return TFK_CC(3);
+            case 4: return TFK_CC(4);
+            default: break;
+            }
+#undef TFK_CC
+        }
+        return fail(TFK_EINVAL, "%s: context-conditioned lean chains: affine / shift couplings, fp32 operands, D >= 64", fn);
     }
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:

@@ -119,9 +119,10 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
 static int run_chain(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                      float *logprob, int64_t N, int32_t D, const int32_t *ops, int32_t n_ops, const float *params,
                      int64_t n_params, int32_t flags, int32_t xw, hipStream_t s, const char *fn,
-                     double *sum_ws, double *sum_out)
+                     double *sum_ws, double *sum_out, const float *context = nullptr, int32_t Cn = 0)
 {
     const int EPL = D / 8, HALF = D / 2;
+    const int cs_want = context ? (Cn + 3) / 4 : 0;
     ChainProg prog;
     prog.n_c = 0;
     prog.first_src = 0;
@@ -129,17 +130,44 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     prog.pad = 0;
     prog.sum_ws = sum_ws;
     prog.sum_out = sum_out;
+    prog.context = context;
+    prog.ctx_n = Cn;
+    prog.ctx_steps = cs_want;
+    for (int i = 0; i < kChainSideOps; ++i) prog.pre_kind[i] = prog.post_kind[i] = prog.pre_off[i] = prog.post_off[i] = 0;
+    int phase = 0;                                           // 0 before the couplings, 1 in them, 2 behind the closing EW_FMA
     int kind = -1, steps2 = 1;
     bool fmt3 = false;
     for (int i = 0; i < n_ops; ++i) {
         const int32_t *rec = ops + 8 * i;
-        const int k = rec[0], src = rec[1], st = rec[2], off = rec[3];
+        const int k = rec[0], st = rec[2], off = rec[3];
+        int src = rec[1];
         int64_t need;
-        if (k == TFK_OP_EW_FMA) {
-            if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
-            need = 2 * (int64_t)D + 4;
-            prog.ew_offset = off;
+        const bool ewc = (k == TFK_OP_EWC_MULADD || k == TFK_OP_EWC_SUBDIV);
+        if (k != TFK_OP_EW_FMA && (src >> 4) != (((k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN) || ewc) ? cs_want : 0))
+            return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
+        src &= 15;
+        if (k == TFK_OP_EW_FMA || ewc) {
+            // plain programs: one TFK_OP_EW_FMA, last.  Context programs: elementwise ops (constant or context-conditioned)
+            // may also stand in front of the couplings and behind the closing TFK_OP_EW_FMA
+            if (ewc && !context) return fail(TFK_EINVAL, "%s: op %d: a context-conditioned elementwise op needs a context", fn, i);
+            need = ewc ? (int64_t)EPL * cs_want * 64 + (int64_t)EPL * 16 : 2 * (int64_t)D + 4;
+            const int sk = ewc ? (k == TFK_OP_EWC_MULADD ? 2 : 3) : 1;
+            if (phase == 1 && !ewc) { prog.ew_offset = off; phase = 2; }
+            else if (phase == 1) return fail(TFK_EINVAL, "%s: op %d: a TFK_OP_EW_FMA closes the couplings before this op", fn, i);
+            else if (!context) {
+                if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
+                prog.ew_offset = off;
+            } else {
+                int *kinds = phase == 0 ? prog.pre_kind : prog.post_kind, *offs = phase == 0 ? prog.pre_off : prog.post_off;
+                int n = 0;
+                while (n < kChainSideOps && kinds[n]) ++n;
+                if (n == kChainSideOps) return fail(TFK_EINVAL, "%s: op %d: more than %d elementwise ops on one side of the couplings", fn, i, kChainSideOps);
+                kinds[n] = sk;
+                offs[n] = off;
+            }
         } else if (k == TFK_OP_MADE_FWD_LEAN || k == TFK_OP_MADE_INV_LEAN) {
+            if (context) return fail(TFK_EINVAL, "%s: op %d: lean MADE layers take no context", fn, i);
+            phase = 1;
             if (prog.n_c == kMaxChainOps) return fail(TFK_EINVAL, "%s: more than %d lean ops", fn, kMaxChainOps);
             if (st < 1 || st > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, st);
             const int mk = 4 + (k - TFK_OP_MADE_FWD_LEAN);
@@ -150,6 +178,8 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
             need = (int64_t)2 * EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)EPL * 16 + 2 * (int64_t)D;
             prog.offset[prog.n_c++] = off;
         } else if (k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN) {
+            if (phase == 2) return fail(TFK_EINVAL, "%s: op %d: a coupling behind the closing TFK_OP_EW_FMA", fn, i);
+            phase = 1;
             if (kind >= 4) return fail(TFK_EINVAL, "%s: op %d: couplings and MADE layers cannot share a lean program", fn, i);
             if (prog.n_c == kMaxChainOps) return fail(TFK_EINVAL, "%s: more than %d lean couplings", fn, kMaxChainOps);
             if (src != 0 && src != 1) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, src);
@@ -169,8 +199,9 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
             const bool f3 = rec[4] == 256;               // K field: 256 = bf16 x 3 operands (no b2, A23[T2][2][64][4])
             if (prog.n_c == 0) fmt3 = f3;
             else if (f3 != fmt3) return fail(TFK_EINVAL, "%s: op %d: the ops of a lean program share one operand format", fn, i);
+            if (f3 && context) return fail(TFK_EINVAL, "%s: op %d: context-conditioned lean couplings use fp32 operands", fn, i);
             need = f3 ? (int64_t)EPL * 64 + 16 + (int64_t)T2 * 2 * 64 * 4 + 2 * HALF
-                      : (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF;
+                      : (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF + (cs_want ? 256 : 0);
             prog.offset[prog.n_c++] = off;
         } else {
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean ops", fn, i, k);
@@ -214,8 +245,20 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         return fail(TFK_EINVAL, "%s: context size %d must be in [1, %d]", fn, C, 4 * kCtxSteps);
     const int cs_want = context ? (C + 3) / 4 : 0;
     if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
-    const bool lean = n_ops > 0 && ops && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_RQS_INV_LEAN) ||
-                                           (ops[0] >= TFK_OP_MADE_FWD_LEAN && ops[0] <= TFK_OP_LRS_INV_LEAN));
+    // a LEAN program: its first coupling / MADE op is of a lean kind (elementwise ops may stand in front of it in a context
+    // program), or it consists of TFK_OP_EW_FMA alone
+    int first_kind = -1;
+    for (int i = 0; ops && i < n_ops && first_kind < 0; ++i) {
+        const int k = ops[8 * i];
+        if (k != TFK_OP_EW_FMA && k != TFK_OP_EWC_MULADD && k != TFK_OP_EWC_SUBDIV && k != TFK_OP_EW_MULADD &&
+            k != TFK_OP_EW_SUBDIV && k != TFK_OP_PLANE_SWAP)
+            first_kind = k;
+    }
+    const bool lean = n_ops > 0 && ops &&
+                      (first_kind < 0 ? ops[0] == TFK_OP_EW_FMA
+                                      : ((first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_RQS_INV_LEAN &&
+                                          first_kind != TFK_OP_EW_FMA) ||
+                                         (first_kind >= TFK_OP_MADE_FWD_LEAN && first_kind <= TFK_OP_LRS_INV_LEAN)));
     if (!(lean ? tfk_flow_lean_supported(D) : tfk_flow_mfma_supported(D)))
         return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256 (lean programs: 32 as well)", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
@@ -226,22 +269,20 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (logprob && (!gauss_loc || !gauss_log_scale)) return fail(TFK_EINVAL, "%s: logprob needs the base parameters", fn);
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
-    const bool lean_spline = lean && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
-                                      ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN);
-    if (lean && context && !lean_spline)
-        return fail(TFK_EINVAL, "%s: of the lean programs only spline chains take a context", fn);
+    const bool lean_spline = lean && (first_kind == TFK_OP_RQS_FWD_LEAN || first_kind == TFK_OP_RQS_INV_LEAN ||
+                                      first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN);
+    if (lean && context && !lean_spline && !(first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN))
+        return fail(TFK_EINVAL, "%s: of the lean programs only coupling chains take a context", fn);
     if (sum_ws && (!lean || !logprob || !sum_out))
         return fail(TFK_EINVAL, "%s: the in-kernel sum needs a lean program, logprob and sum_out", fn);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
-    if (n_ops > 0 && (ops[0] == TFK_OP_RQS_FWD_LEAN || ops[0] == TFK_OP_RQS_INV_LEAN ||
-                      ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN))
+    if (lean_spline)
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                              accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out, context, C);
-    if (n_ops > 0 && ((ops[0] >= TFK_OP_AFFINE_FWD_LEAN && ops[0] <= TFK_OP_EW_FMA) ||
-                      ops[0] == TFK_OP_MADE_FWD_LEAN || ops[0] == TFK_OP_MADE_INV_LEAN))
+    if (lean)
         return run_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
-                         accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out);
+                         accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out, context, C);
     const int EPL = D / 8;
     MProgram prog;
     prog.n_ops = n_ops;

@@ -584,8 +584,8 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int, allow_ctx:
     if kind not in ("affine", "inverse_affine", "shift", "rqs", "lrs"):
         return None
     C = _esize(layer.context_shape) if layer.context_shape is not None else 0
-    if C and not (allow_ctx and kind in ("rqs", "lrs") and C <= MAX_CONTEXT):
-        return None                                           # (a context: spline chains only, as further GEMM-1 k-steps)
+    if C and not (allow_ctx and C <= MAX_CONTEXT):
+        return None                                           # (a context: further GEMM-1 k-steps, lean context programs)
     if kind in ("rqs", "lrs") and layer.transformer.n_bins != 8:
         return None
     half = D // 2
@@ -643,7 +643,7 @@ def lean_bf16x3_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_LEAN_BF16X3", "0") == "1"
 
 
-def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3: bool = False) -> torch.Tensor:
+def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3: bool = False, W1c=None) -> torch.Tensor:
     """Parameter block of a lean coupling op (csrc/tfk_flow_chain.h): lane-major MFMA A-operands
     A1[EPL/4][64][4] | b1[4][4] | A2[nA2/4][64][4] | b2[T2][4][4] | pre_s[hp] | pre_t[hp], with W1 / b1 multiplied by
     2 log2(e) and (affine) the scale-logit rows of W2 / b2 by log2(e) / 2, b2 += c0 log2(e).  Inputs fp64, physical
@@ -703,8 +703,14 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3
     nA2 = (T2 * steps2 + 3) & ~3
     A2 = torch.stack(A2 + [torch.zeros(64, dtype=torch.float64, device=dev)] * (nA2 - T2 * steps2))
     A2 = A2.reshape(nA2 // 4, 4, 64).permute(0, 2, 1)
+    tail_ = []
+    if W1c is not None:            # the context's columns of W1: A1c[lane][k] = W1c[unit1(i), context element 4 k + q]
+        W1cp = torch.zeros(16, 16, dtype=torch.float64, device=dev)
+        W1cp[:H, :W1c.shape[1]] = W1c * (2.0 * LOG2E)
+        kk = torch.arange(4, device=dev)
+        tail_.append(W1cp[unit1.view(64, 1), 4 * kk.view(1, 4) + ql.view(64, 1)].reshape(-1))
     return torch.cat([A1.reshape(-1), b1m.reshape(-1), A2.reshape(-1), torch.stack(b2m).reshape(-1),
-                      pre_s, pre_t]).float()
+                      pre_s, pre_t] + tail_).float()
 
 
 def rqs_bf16x3_enabled() -> bool:
@@ -900,12 +906,46 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     first_c = next((i for i, (layer, _) in enumerate(plan) if isinstance(layer, (CouplingBijection, MaskedAutoregressiveBijection))), len(plan))
     head_mode = context and any(isinstance(layer, ElementwiseBijection) and not layer.use_global_parameters
                                 for layer, _ in plan[:first_c])
+    # affine / shift chains take those elementwise layers INSIDE the lean launch (csrc/tfk_flow_chain.h: side_op): in front
+    # of the couplings and behind the closing TFK_OP_EW_FMA, up to 3 ops per side -- one launch per conditional log_prob
+    inline = (context and first_c < len(plan) and isinstance(plan[first_c][0], CouplingBijection)
+              and plan[first_c][0].transformer.native_kind in ("affine", "inverse_affine", "shift")
+              and os.environ.get("TORCHFLOWS_AMD_CTX_INLINE", "1") != "0")
+    pre_items, post_items = [], []
+
+    def pending_block():                                     # the pending maps as an EW_FMA block, then reset
+        nonlocal ld_const
+        blk = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
+        s.fill_(1.0)
+        t.fill_(0.0)
+        ld_const = torch.zeros((), dtype=torch.float64, device=device)
+        return blk
+
+    def pending_is_identity():
+        return bool((s == 1).all()) and bool((t == 0).all()) and float(ld_const) == 0.0
     with torch.no_grad():
         for li, (layer, d) in enumerate(plan):
             if isinstance(layer, PermutationMatrix):
                 perm = (layer._fwd_index if d == FORWARD else layer._inv_index).to(device)
                 pos = pos[perm]
-            elif isinstance(layer, ElementwiseBijection) and head_mode and li < first_c:
+            elif inline and isinstance(layer, ElementwiseBijection) and not layer.use_global_parameters:
+                item = _elementwise_ctx_op(layer, d, pos, D, Dp)
+                if item is None:
+                    return None
+                ewc = (item[0][0], item[0][1], 0, item[1].float(), ())
+                if not items and closed_flush is None:       # in front of the couplings: what is pending goes first
+                    if not pending_is_identity():
+                        pre_items.append((OP_EW_FMA, 0, 0, pending_block(), ()))
+                    pre_items.append(ewc)
+                else:                                        # behind them: close the chain (once), then the op
+                    if closed_flush is None:
+                        closed_flush = pending_block()
+                    elif not pending_is_identity():
+                        post_items.append((OP_EW_FMA, 0, 0, pending_block(), ()))
+                    post_items.append(ewc)
+                if len(pre_items) > 3 or len(post_items) > 2:
+                    return None
+            elif not inline and isinstance(layer, ElementwiseBijection) and head_mode and li < first_c:
                 item = (_elementwise_ctx_op(layer, d, pos, D, Dp) if not layer.use_global_parameters
                         else _elementwise_op(layer, d, pos, D, Dp))
                 if item is None:
@@ -925,7 +965,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                             closed_flush = torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
                         tail.append(item)
                     continue
-                if closed_flush is not None:                 # constant elementwise layers behind the chain: interpreter ops
+                if closed_flush is not None and not inline:  # constant elementwise layers behind the chain: interpreter ops
                     item = _elementwise_op(layer, d, pos, D, Dp)
                     if item is None:
                         return None
@@ -968,8 +1008,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 W1c = None
                 if context:
                     lk, plane, H, W1t, b1, W2p, b2p, W1c = got
-                    if lk not in (4, 5, 8, 9) or not rqs_bf16x3_enabled():
-                        return None                           # (lean context programs: spline chains, bf16 x 3 operands)
+                    if lk in (4, 5, 8, 9) and not rqs_bf16x3_enabled():
+                        return None                           # (lean context spline programs: bf16 x 3 operands)
                     cs_l = 0 if W1c is None else (W1c.shape[1] + 3) // 4
                     if items and (cs_l << 4) != ctx_bits:
                         return None
@@ -1015,23 +1055,31 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                                            float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3, W1c=W1c)
                     items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
                 else:
-                    use3 = aff3 and H <= 15
+                    use3 = aff3 and H <= 15 and not context
                     if items and bool(items[-1][4]) != use3:
                         return None
-                    block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(), bf16x3=use3)
+                    block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(), bf16x3=use3, W1c=W1c)
                     items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block, (256,) if use3 else ()))
                 s[tgt] = 1.0
                 t[tgt] = 0.0
             else:
                 return None
+    if inline and closed_flush is not None and not pending_is_identity():
+        post_items.append((OP_EW_FMA, 0, 0, pending_block(), ()))        # constant layers behind the last context op
     flush = closed_flush if closed_flush is not None else torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
     streamed = kind0 in (4, 5, 8, 9)                     # spline chains read their operands from global memory
     if (not items and streamed) or (context and not items):
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
+    n_pre = len(pre_items)
+    items = pre_items + items + post_items
     budget = max(MAX_PARAM_BYTES_MFMA, MFMA_BUDGET_WIDE.get(Dp, 0))
     if any(extra == (256,) for *_, extra in items):
         budget = 150 * 1024          # bf16 x 3 operands: one 1024-thread workgroup per CU holds the whole chain
+    if Dp == 64 and kind0 in (0, 1, 2, 3):
+        # the 64-wide chain kernel is register-bound at 4 waves per SIMD = TWO 512-thread workgroups per CU: up to
+        # 76 KB of operands per launch cost no occupancy (12 couplings, or 8 with their context columns)
+        budget = max(budget, 76 * 1024)
     if Dp == 128:
         # the 128-wide chain kernel runs one 768-thread workgroup per CU whatever the block's size: RealNVP(128, 8 layers)
         # = 90.6 KB is ONE launch (at the interpreter's 76 KB budget it was two, and the rows' trip through HBM between
@@ -1040,7 +1088,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     # affine / shift chains whose blocks do not fit the LDS together (D = 256: 22 KB per coupling): ONE launch with the
     # operands streamed block by block (csrc/tfk_flow_chain.h: chain_layers_stream) instead of one launch per LDS-full
     total = sum(block.numel() for _, _, _, block, _ in items) * 4
-    if (not streamed and kind0 in (0, 1, 2, 3) and Dp >= 128 and stream_chain_enabled() and len(items) <= 61
+    if (not streamed and not context and kind0 in (0, 1, 2, 3) and Dp >= 128 and stream_chain_enabled() and len(items) <= 61
             and total > 158 * 1024 and not any(extra for *_, extra in items)):
         streamed = True
     segments: List[Segment] = []
@@ -1051,10 +1099,11 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
             if n * 4 > 150 * 1024:
                 return None
             over = (used + n) * 4 > budget
-            if ops and kind != OP_EW_FMA and (over or len(ops) >= 60):
+            if ops and kind not in (OP_EW_FMA, OP_EWC_MULADD, OP_EWC_SUBDIV) and len(ops) > n_pre and (over or len(ops) >= 60):
                 segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
                 ops, blocks, used = [], [], 0
-        ops.append((kind, plane | (ctx_bits if kind != OP_EW_FMA else 0), steps2, used) + tuple(extra))
+        ops.append((kind, plane | (ctx_bits if kind not in (OP_EW_FMA, OP_EWC_MULADD, OP_EWC_SUBDIV) else 0), steps2, used)
+                   + tuple(extra))
         blocks.append(block)
         used += n
     segments.append(Segment(ops, torch.cat(blocks).contiguous(), True))
