@@ -201,6 +201,7 @@ def test_segmented_program_matches_single_launch(pkg, monkeypatch):
     res_m = []
     for budget in (52 * 1024, 12 * 1024):
         monkeypatch.setattr(fused, "MAX_PARAM_BYTES_MFMA", budget)
+        monkeypatch.setattr(fused, "LEAN_BUDGET_64", budget)
         flow.bijection.__dict__.pop("_tfk_compiled", None)
         chain = fused.get_compiled(flow.bijection, 0, x.device)
         assert all(seg.mfma for seg in chain.segments)

@@ -61,6 +61,7 @@ MAX_PARAM_BYTES_MFMA = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS_MFMA", 52 * 
 # D = 128 (120 VGPRs) runs 2 x 512 threads per CU, D = 256 (179 VGPRs) one -- their launches may
 # stage more of the program (each extra launch re-reads and re-writes all the rows)
 MFMA_BUDGET_WIDE = {128: 76 * 1024, 256: 150 * 1024}
+LEAN_BUDGET_64 = 76 * 1024        # lean affine / shift chains at D = 64 (two 512-thread workgroups per CU either way)
 MAX_OPS = 96
 
 
@@ -1079,7 +1080,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     if Dp == 64 and kind0 in (0, 1, 2, 3):
         # the 64-wide chain kernel is register-bound at 4 waves per SIMD = TWO 512-thread workgroups per CU: up to
         # 76 KB of operands per launch cost no occupancy (12 couplings, or 8 with their context columns)
-        budget = max(budget, 76 * 1024)
+        budget = max(budget, LEAN_BUDGET_64)
     if Dp == 128:
         # the 128-wide chain kernel runs one 768-thread workgroup per CU whatever the block's size: RealNVP(128, 8 layers)
         # = 90.6 KB is ONE launch (at the interpreter's 76 KB budget it was two, and the rows' trip through HBM between
