@@ -633,14 +633,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
         };
         if (logprob && base_of_input) base_terms();                   // Flow.sample (flows.py:699-707)
 
-        float cx[4] = {0.0f, 0.0f, 0.0f, 0.0f};                       // this lane's context elements 4 s + q of row j
-        if constexpr (CTX) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-                cx[s4] = (4 * s4 + q < prog.ctx_n) ? prog.context[rr * prog.ctx_n + 4 * s4 + q] : 0.0f;
-        }
         float ld2 = 0.0f;                                             // this lane's share, in base 2
-        float ld_pre = 0.0f;                                          // (context programs) log-det of the ops in front
         float umin = 0.0f;                                            // smallest scale logit seen (log2_scales)
         constexpr bool kShortcut = TFK_LOG_SHORTCUT && (KIND < 2 || KIND >= 4);
         if constexpr (STREAM) {
@@ -652,35 +645,65 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
                     chain_layers_stream<EPL, BLOCK, STEPS2, KIND, false>(lds, params, prog, bufi, lane, q, a, b, ld2, umin);
                 }
             }
-        } else {
-        auto pre_ops = [&]() {
-            if constexpr (CTX) {
+        } else if constexpr (CTX) {
+            // conditional flows: this lane's context elements 4 s + q of row j; the elementwise ops in front of the couplings
+            float cx[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                cx[s4] = (4 * s4 + q < prog.ctx_n) ? prog.context[rr * prog.ctx_n + 4 * s4 + q] : 0.0f;
+            float ld_pre = 0.0f;
+            auto pre_ops = [&]() {
                 ld_pre = 0.0f;
 #pragma unroll 1
                 for (int i = 0; i < kChainSideOps; ++i)
                     if (prog.pre_kind[i]) side_op<EPL>(prog.pre_kind[i], lds + prog.pre_off[i], prog.ctx_steps, lane, q, a, b, ld_pre, cx);
+            };
+            pre_ops();
+            chain_layers<EPL, STEPS2, KIND, kShortcut, true>(lds, prog, lane, q, a, b, ld2, umin, cx);
+            if constexpr (kShortcut) {
+                if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {
+                    load_rows();
+                    ld2 = 0.0f;
+                    pre_ops();
+                    chain_layers<EPL, STEPS2, KIND, false, true>(lds, prog, lane, q, a, b, ld2, umin, cx);
+                }
             }
-        };
-        pre_ops();
-        chain_layers<EPL, STEPS2, KIND, kShortcut, CTX>(lds, prog, lane, q, a, b, ld2, umin, cx);
+            if constexpr (KIND == 0) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
+            else if constexpr (KIND == 1) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
+            ld2 = 0.0f;
+            if (prog.ew_offset >= 0) ew_fma_apply<EPL>(ew_s, q, a, b, ld);
+            ld += ld_pre;
+#pragma unroll 1
+            for (int i = 0; i < kChainSideOps; ++i)                   // the elementwise layers behind the couplings
+                if (prog.post_kind[i]) side_op<EPL>(prog.post_kind[i], lds + prog.post_off[i], prog.ctx_steps, lane, q, a, b, ld, cx);
+        } else {
+        chain_layers<EPL, STEPS2, KIND, kShortcut>(lds, prog, lane, q, a, b, ld2, umin);
         if constexpr (kShortcut) {
             if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {   // scales near the 1e-10 floor: with logarithms
                 load_rows();                                          // (x is still intact: z is stored below)
                 ld2 = 0.0f;
-                pre_ops();
-                chain_layers<EPL, STEPS2, KIND, false, CTX>(lds, prog, lane, q, a, b, ld2, umin, cx);
+                chain_layers<EPL, STEPS2, KIND, false>(lds, prog, lane, q, a, b, ld2, umin);
             }
         }
         }
         if constexpr (KIND == 0 || KIND == 4) ld = fmaf(ld2, __int_as_float(0x3f317218), ld);          // ln 2
         else if constexpr (KIND == 1 || KIND == 5) ld = fmaf(ld2, -__int_as_float(0x3f317218), ld);
 
-        if (prog.ew_offset >= 0) ew_fma_apply<EPL>(ew_s, q, a, b, ld);   // what is still pending, one fma per element
-        if constexpr (CTX) {                                          // the elementwise layers behind the couplings
-            ld += ld_pre;
-#pragma unroll 1
-            for (int i = 0; i < kChainSideOps; ++i)
-                if (prog.post_kind[i]) side_op<EPL>(prog.post_kind[i], lds + prog.post_off[i], prog.ctx_steps, lane, q, a, b, ld, cx);
+        if (!CTX && prog.ew_offset >= 0) {                            // what is still pending, one fma per element
+            const float *ew = ew_s;
+#pragma unroll
+            for (int i = 0; i < EPL / 4; ++i) {
+                const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
+                const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(ew + HALF + EPL * q + 4 * i);
+                const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(ew + D + EPL * q + 4 * i);
+                const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(ew + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
+                    b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+                }
+            }
+            if (q == 0) ld = ld + ew[2 * D];
         }
         if (logprob && !base_of_input) base_terms();
 
