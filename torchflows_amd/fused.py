@@ -912,6 +912,10 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     inline = (context and first_c < len(plan) and isinstance(plan[first_c][0], CouplingBijection)
               and plan[first_c][0].transformer.native_kind in ("affine", "inverse_affine", "shift")
               and os.environ.get("TORCHFLOWS_AMD_CTX_INLINE", "1") != "0")
+    if inline and Dp == 256:
+        # the context variant of the 256-wide chain kernel spills (660 B of scratch at the 256-VGPR cap): measured
+        # 1.8e8 evals/s against the interpreter's 3.5e8 on a conditional RealNVP(256) -- the interpreter keeps that size
+        return None
     pre_items, post_items = [], []
 
     def pending_block():                                     # the pending maps as an EW_FMA block, then reset
