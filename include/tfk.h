@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 22
+#define TFK_ABI_VERSION 23
 
 enum {
     TFK_OK = 0,
@@ -260,7 +260,16 @@ enum {
      * logits c + u_d / 100, [31] the w0 logit, all times log2(e); chunks of 4 / HT elements = 16384 dwords.  Op record:
      * K = 8 + 256, boundary, scale = 1 - 1e-2 * 8, c = log(exp(1 - 1e-5) - 1). */
     TFK_OP_LRS_FWD_LEAN = 23,
-    TFK_OP_LRS_INV_LEAN = 24
+    TFK_OP_LRS_INV_LEAN = 24,
+    /* lean MADE SPLINE programs (the parallel map of MaskedAutoregressive / InverseAutoregressive RQNSF and LRS layers, cf.
+     * TFK_OP_MADE_RQS): as the lean spline couplings in the bf16 x 3 operand format (K = 8 + 256, hidden width <= 15,
+     * D = 64 or 128), but GEMM 1 reads both planes and every element of both planes is a target -- head
+     * A1[D/16][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | pre_s[D] | pre_t[D], then D/16 chunks (plane A's
+     * elements first); MADE masks folded into the packed weights; src_plane = 0. */
+    TFK_OP_MADE_RQS_FWD_LEAN = 25,
+    TFK_OP_MADE_RQS_INV_LEAN = 26,
+    TFK_OP_MADE_LRS_FWD_LEAN = 27,
+    TFK_OP_MADE_LRS_INV_LEAN = 28
 };
 int tfk_flow_supported(int32_t D);
 int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc,
@@ -318,7 +327,16 @@ int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logd
                           int32_t accumulate, void *sum_workspace, double *sum_out, void *stream);
 
 /* The same for context-conditioned flows: context (N, C) fp32, 1 <= C <= 16, one row per data row (Flow.log_prob(x,
- * context=...), flows.py:628-658).  Programs of elementwise ops, TFK_OP_EWC_* and couplings only (no MADE / lean ops). */
+ * context=...), flows.py:628-658).  Interpreter programs of elementwise ops, TFK_OP_EWC_* and couplings (no MADE ops), or
+ * LEAN context programs (ABI v22, D >= 64):
+ *  - spline chains (TFK_OP_RQS_*_LEAN / TFK_OP_LRS_*_LEAN, bf16 x 3 operand format): src_plane bits 4..7 = cs = ceil(C / 4)
+ *    on every coupling, and every coupling's head ends with A1c[HT][64][4] -- lane (q, i), slot k: the weight of hidden
+ *    unit 16 t + unit(i) for context element 4 k + q, times 2 log2(e) (zero beyond C) -- behind pre_t;
+ *  - affine / shift chains (TFK_OP_AFFINE_*_LEAN / TFK_OP_SHIFT_*_LEAN, fp32 operands, D <= 128 from the packer): the
+ *    same bits, A1c[64][4] behind each coupling's pre_t, AND elementwise ops inside the program: up to 3 in front of
+ *    the first coupling and up to 3 behind the closing TFK_OP_EW_FMA, each either a TFK_OP_EW_FMA block (a constant
+ *    x -> s x + t with its log-det) or a TFK_OP_EWC_* op (block as in the interpreter, src_plane = cs << 4).  A lean
+ *    program is recognised by its first coupling op, not by its first op. */
 int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,
                           const float *gauss_loc, const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                           const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,

@@ -226,6 +226,46 @@ def run_lean(ops, params, rows, D):
             else:
                 a = tgt
             continue
+        if kind in (25, 27):                                  # lean MADE spline layer (rqs_made_layer3), bf16 x 3, HT = 1
+            lrs = kind == 27
+            TPE = 8 if lrs else 6
+            K, boundary, scale, cdelta = op_extra[(kind, off)]
+            HEAD = 2 * EPL * 64 + 16 + 2 * D
+            A1 = prm[off:off + 2 * EPL * 64].reshape(2 * EPL // 4, 64, 4)
+            b1 = prm[off + 2 * EPL * 64:off + 2 * EPL * 64 + 16]
+            pre = prm[off + 2 * EPL * 64 + 16:off + HEAD]
+            acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
+            for s_ in range(EPL):
+                acc = _mfma(A1[s_ // 4, :, s_ % 4], a[:, s_], acc)
+                acc = _mfma(A1[EPL // 4 + s_ // 4, :, s_ % 4], b[:, s_], acc)
+            a = (pre[idx][:, :, None] * a + pre[D + idx][:, :, None]).clone()
+            b = (pre[HALF + idx][:, :, None] * b + pre[D + HALF + idx][:, :, None]).clone()
+            hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)
+            hid[q == 3, 3] = 1.0
+            h_hi, h_mid, h_lo = _pieces(hid.float())
+            span = 2.0 * boundary
+            C = (-boundary, boundary, span * scale, span * (1e-2 if lrs else 1e-3),
+                 (cdelta if lrs else cdelta + cdelta / 1000.0) * 1.4426950408889634)
+            raw = params.contiguous().view(torch.int32)
+            per_plane = EPL * TPE * 2 * 64 * 4
+            for plane_i, tgt in enumerate((a, b)):
+                A = raw[off + HEAD + plane_i * per_plane:off + HEAD + (plane_i + 1) * per_plane].reshape(EPL, TPE, 1, 2, 64, 4)
+                for e in range(EPL):
+                    pp = []
+                    for c in range(TPE):
+                        o = torch.zeros(64, 4, W, dtype=torch.float64)
+                        w_hi, w_mid = _unpack_bf16(A[e, c, 0, 0][:, 0:2]), _unpack_bf16(A[e, c, 0, 0][:, 2:4])
+                        w_lo = _unpack_bf16(A[e, c, 0, 1][:, 0:2])
+                        for Wl, Bl in ((w_hi, h_hi), (w_mid, h_hi), (w_hi, h_mid), (w_mid, h_mid), (w_lo, h_hi), (w_hi, h_lo)):
+                            for i in range(4):
+                                o = _mfma(Wl[:, i], Bl[:, i], o)
+                        pp.append(o)
+                    pvec = torch.cat(pp, 1).permute(0, 2, 1)
+                    out, l2 = (lrs_lean_eval(pvec, tgt[:, e], C, False) if lrs else rqs_lean_eval(pvec, tgt[:, e], C, False))
+                    tgt[:, e] = out
+                    ld2 = ld2 + l2
+            sign = 1.0
+            continue
         if kind in (21, 22):                                  # lean MADE layer (made_lean)
             nA2 = (EPL * steps2 + 3) & ~3
             A1 = prm[off:off + 2 * EPL * 64].reshape(2 * EPL // 4, 64, 4)

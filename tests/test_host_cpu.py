@@ -479,7 +479,9 @@ def test_torchflows_import_alias_resolves_to_the_build():
                                                        ("RealNVP@32", 22, 3, 0), ("NICE@32", 8, 3, 1), ("RealNVP@32", 32, 2, 1),
                                                        ("CouplingRQNSF@32", 22, 2, 0), ("CouplingLRS@32", 16, 2, 1),
                                                        ("MAF@32", 22, 2, 0), ("IAF@32", 32, 2, 1),
-                                                       ("MAF", 64, 3, 0), ("IAF", 64, 2, 1), ("MAF", 22, 2, 0), ("MAF", 128, 2, 0)])
+                                                       ("MAF", 64, 3, 0), ("IAF", 64, 2, 1), ("MAF", 22, 2, 0), ("MAF", 128, 2, 0),
+                                                       ("MaskedAutoregressiveRQNSF", 64, 2, 0), ("InverseAutoregressiveRQNSF", 64, 2, 1),
+                                                       ("MaskedAutoregressiveLRS", 64, 2, 0), ("MaskedAutoregressiveRQNSF", 22, 2, 0)])
 @pytest.mark.parametrize("bf16x3", ["1", "0"])
 def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, bf16x3, monkeypatch):
     """Host logic of the lean flow programs (fused._compile_lean: elementwise layers deferred and folded into W1 / b1,
@@ -503,8 +505,8 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
             pytest.skip("fp32 operands stop at hidden width 16")
     if D == 256 and bf16x3 == "0":
         pytest.skip("CouplingRQNSF(256) has hidden width 17: bf16 x 3 operands only")
-    if "LRS" in arch and bf16x3 == "0":
-        pytest.skip("lean linear rational splines: bf16 x 3 operands only")
+    if ("LRS" in arch or "Autoregressive" in arch) and bf16x3 == "0":
+        pytest.skip("lean linear rational splines and MADE spline layers: bf16 x 3 operands only")
     Dp = D if D in (64, 128, 256) else (64 if D < 64 else 128)
     if "@" in arch:                                           # row width 32 for event sizes <= 32
         arch, w = arch.split("@")
@@ -531,7 +533,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     if D == 256 and n_layers == 8:
         assert len(chain.segments) == 1 and chain.segments[0].params.numel() * 4 > 160 * 1024
     for seg in chain.segments:
-        assert seg.mfma and all(12 <= op[0] <= 24 and op[0] not in (19, 20) for op in seg.ops)
+        assert seg.mfma and all(12 <= op[0] <= 28 and op[0] not in (19, 20) for op in seg.ops)
         rows, l = run_lean(seg.ops, seg.params, rows, Dp)
         ld = ld + l
     got = rows[:, chain.pos]

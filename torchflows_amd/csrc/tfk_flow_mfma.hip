@@ -37,10 +37,18 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     const bool fmt3 = n_ops > 0 && (ops[4] >> 8) == 1;
     // bf16 x 3: gemm2_steps = ceil((H + 1) / 4) counts the bias unit; more than 4 steps = two hidden tiles
     const int ht3 = (fmt3 && n_ops > 0 && ops[2] > 4) ? 2 : 1;
-    const bool lrs = n_ops > 0 && (ops[0] == TFK_OP_LRS_FWD_LEAN || ops[0] == TFK_OP_LRS_INV_LEAN);
+    int k0 = -1;                                             // the first spline op (context programs: never the first op? it is)
+    for (int i = 0; i < n_ops && k0 < 0; ++i)
+        if (ops[8 * i] != TFK_OP_EW_FMA) k0 = ops[8 * i];
+    const bool made = k0 >= TFK_OP_MADE_RQS_FWD_LEAN && k0 <= TFK_OP_MADE_LRS_INV_LEAN;
+    const bool lrs = k0 == TFK_OP_LRS_FWD_LEAN || k0 == TFK_OP_LRS_INV_LEAN || k0 == TFK_OP_MADE_LRS_FWD_LEAN ||
+                     k0 == TFK_OP_MADE_LRS_INV_LEAN;
+    if (made && (context || !fmt3 || ht3 != 1 || (EPL != 8 && EPL != 16)))
+        return fail(TFK_EINVAL, "%s: lean MADE spline layers: bf16 x 3 operands, hidden width <= 15, D = 64 or 128, no context", fn);
     if (lrs && !fmt3) return fail(TFK_EINVAL, "%s: lean linear-rational-spline ops use the bf16 x 3 operand format (K = 8 + 256)", fn);
     if (context && !fmt3) return fail(TFK_EINVAL, "%s: context-conditioned lean spline chains use the bf16 x 3 operand format", fn);
-    const int64_t block = fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (cs_want ? ht3 * 256 : 0)
+    const int64_t block = made ? (int64_t)2 * EPL * 64 + 16 + 2 * D + (int64_t)(2 * EPL / 4) * (lrs ? 16384 : kRqsChunk3Dwords)
+                        : fmt3 ? (int64_t)EPL * ht3 * 64 + ht3 * 16 + 2 * HALF + (cs_want ? ht3 * 256 : 0)
                                      + (int64_t)(EPL * ht3 / 4) * (lrs ? 16384 : kRqsChunk3Dwords)
                                : (int64_t)EPL * 64 + 16 + 2 * HALF + (int64_t)(EPL / 8) * kRqsChunkFloats;
     RqsChainProg prog;
@@ -64,7 +72,8 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
         if ((src >> 4) != cs_want)                           // src_plane bits 4..7: k-steps of context in GEMM 1
             return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
         src &= 15;
-        if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN && k != TFK_OP_LRS_FWD_LEAN && k != TFK_OP_LRS_INV_LEAN)
+        if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN && k != TFK_OP_LRS_FWD_LEAN && k != TFK_OP_LRS_INV_LEAN &&
+            !(k >= TFK_OP_MADE_RQS_FWD_LEAN && k <= TFK_OP_MADE_LRS_INV_LEAN))
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean spline ops", fn, i, k);
         float bnd, sc, cc;
         memcpy(&bnd, rec + 5, 4);
@@ -87,7 +96,7 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
         } else {
             if (k != kind || st != steps2 || bnd != boundary || sc != scale || cc != c)
                 return fail(TFK_EINVAL, "%s: op %d: a lean spline program holds couplings of one direction, hidden width and box", fn, i);
-            if (src != ((prog.first_src + prog.n_layers) & 1))
+            if (!made && src != ((prog.first_src + prog.n_layers) & 1))
                 return fail(TFK_EINVAL, "%s: op %d: the source plane of lean couplings must alternate", fn, i);
             const int64_t stride = (int64_t)off - (prog.offset0 + (int64_t)(prog.n_layers - 1) * prog.layer_stride);
             if (prog.n_layers == 1) prog.layer_stride = (int)stride;
@@ -105,7 +114,9 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     for (int j = 1; j < 8; ++j) prog.C.knot_c[j - 1] = (float)(-(double)boundary + j * span * (lrs ? 1e-2 : 1e-3));
     prog.C.d_edge = lrs ? (float)((double)c * 1.4426950408889634)
                         : (float)(((double)c + (double)c / 1000.0) * 1.4426950408889634);
-    const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN;
+    const int inverse = kind == TFK_OP_RQS_INV_LEAN || kind == TFK_OP_LRS_INV_LEAN || kind == TFK_OP_MADE_RQS_INV_LEAN ||
+                        kind == TFK_OP_MADE_LRS_INV_LEAN;
+    prog.made = made ? 1 : 0;
     if (fmt3) steps2 = (ht3 == 2 ? 8 : 0) + (lrs ? 16 : 0);
     prog.ctx_steps = cs_want;
     if (EPL == 4) return flow_rqs_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, prog, inverse, steps2, flags, xw, s, fn, context, Cn);
@@ -258,7 +269,7 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
                       (first_kind < 0 ? ops[0] == TFK_OP_EW_FMA
                                       : ((first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_RQS_INV_LEAN &&
                                           first_kind != TFK_OP_EW_FMA) ||
-                                         (first_kind >= TFK_OP_MADE_FWD_LEAN && first_kind <= TFK_OP_LRS_INV_LEAN)));
+                                         (first_kind >= TFK_OP_MADE_FWD_LEAN && first_kind <= TFK_OP_MADE_LRS_INV_LEAN)));
     if (!(lean ? tfk_flow_lean_supported(D) : tfk_flow_mfma_supported(D)))
         return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256 (lean programs: 32 as well)", fn, D);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
@@ -270,7 +281,8 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if ((x_width == D && !aligned16(x)) || (z && !aligned16(z)) || !aligned16(params))
         return fail(TFK_EINVAL, "%s: x, z and params must be 16-byte aligned", fn);
     const bool lean_spline = lean && (first_kind == TFK_OP_RQS_FWD_LEAN || first_kind == TFK_OP_RQS_INV_LEAN ||
-                                      first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN);
+                                      first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN ||
+                                      (first_kind >= TFK_OP_MADE_RQS_FWD_LEAN && first_kind <= TFK_OP_MADE_LRS_INV_LEAN));
     if (lean && context && !lean_spline && !(first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN))
         return fail(TFK_EINVAL, "%s: of the lean programs only coupling chains take a context", fn);
     if (sum_ws && (!lean || !logprob || !sum_out))

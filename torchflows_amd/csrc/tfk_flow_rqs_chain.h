@@ -52,7 +52,8 @@ struct RqsChainProg {
     int layer_stride;         // floats between consecutive layers' blocks
     int offset0;              // first layer's block
     int ctx_steps;            // k-steps of context in GEMM 1 (0: none; the head then ends with A1c[HT][64][4])
-    int pad[2];
+    int made;                 // MADE-based spline layers (TFK_OP_MADE_*_LEAN spline kinds): both planes in, both planes out
+    int pad[1];
     RqsLean C;
     double *sum_ws;           // tfk_flow_run_mfma_sum (see ChainProg)
     double *sum_out;
@@ -530,10 +531,183 @@ __device__ __forceinline__ void rqs_layer3(const float *__restrict__ gprm, float
     }
 }
 
+// MADE-based spline layer, parallel map (MaskedAutoregressiveBijection.forward with a spline transformer,
+// layers_base.py:201-206; MADE = two masked linear layers, transforms.py:184-267, masks folded into the packed weights):
+// GEMM 1 reads BOTH planes as they are, every element of both planes then takes its pending elementwise layers and is
+// transformed with parameters that depend on the preceding elements only.  Head: A1[2 EPL / 4][HT][64][4] (plane A's
+// k-steps, then plane B's) | b1[HT][4][4] | pre_s[D] | pre_t[D]; then 2 EPL HT / 4 chunks, plane A's elements first.
+template <int EPL, int BLOCK, int HT, bool INVERSE, bool LRS, bool FAST>
+__device__ __forceinline__ void rqs_made_layer3(const float *__restrict__ gprm, float *stage, int lane, int q,
+                                                const RqsLean &C, float (&pa)[EPL], float (&pb)[EPL], float &ld2,
+                                                float &amax)
+{
+    constexpr int HALF = 4 * EPL, D = 8 * EPL;
+    constexpr int HEAD = 2 * EPL * HT * 64 + HT * 16 + 2 * D;
+    constexpr int TPE = LRS ? 8 : 6;                          // tiles of 4 parameters per element
+    constexpr int GRP = LRS ? 4 : 3;                          // tiles side by side (TPE / 2)
+    constexpr int CHUNKD = (LRS ? 4 : 3) * 4096;              // = (4 / HT) * TPE * HT * 2 * 64 * 4 dwords
+    constexpr int ELEMS = 4 / HT;
+    constexpr int NC = EPL / ELEMS;
+    constexpr bool STATIC_CH = NC <= 8;                       // chunk loop unrolled: the element index is static
+    float *head_s = stage;
+    float *chunk_s = stage + HEAD;
+    ci32x4 B1[HT], B2[HT], B3[HT];                            // [h_hi | h_hi], [h_mid | h_mid], [h_hi | h_lo] per hidden tile
+
+    auto stage_in = [&](int ch) {
+        __syncthreads();
+        const float4 *g4 = reinterpret_cast<const float4 *>(gprm + HEAD + (size_t)ch * CHUNKD);
+        float4 *d4 = reinterpret_cast<float4 *>(chunk_s);
+        for (int i = threadIdx.x; i < CHUNKD / 4; i += BLOCK) d4[i] = g4[i];
+        if (ch == 0) {
+            const float4 *h4 = reinterpret_cast<const float4 *>(gprm);
+            float4 *e4 = reinterpret_cast<float4 *>(head_s);
+            for (int i = threadIdx.x; i < HEAD / 4; i += BLOCK) e4[i] = h4[i];
+        }
+        __syncthreads();
+    };
+    auto gemm1 = [&]() {
+        const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(head_s);
+        const float *b1 = head_s + 2 * EPL * HT * 64;
+        const float *pre = b1 + HT * 16;
+        cf32x4 acc[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] = *reinterpret_cast<const cf32x4 *>(b1 + t * 16 + 4 * q);
+#pragma unroll
+        for (int g = 0; g < EPL / 4; ++g)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                const cf32x4 wa = A1[(g * HT + t) * 64 + lane], wb = A1[((EPL / 4 + g) * HT + t) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k], pa[4 * g + k], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[k], pb[4 * g + k], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
+            const cf32x4 sb = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
+            const cf32x4 ta = *reinterpret_cast<const cf32x4 *>(pre + D + EPL * q + 4 * i);
+            const cf32x4 tb = *reinterpret_cast<const cf32x4 *>(pre + D + HALF + EPL * q + 4 * i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pa[4 * i + k] = fmaf(sa[k], pa[4 * i + k], ta[k]);
+                pb[4 * i + k] = fmaf(sb[k], pb[4 * i + k], tb[k]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            int hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h = fmaf(-2.0f, rcp_f(exp2_f(acc[t][r]) + 1.0f), 1.0f);
+                // the last hidden unit (tile HT - 1, lane-group 3, register 3) is the constant 1 that carries b2 through
+                // GEMM 2: no bias reads
+                if (t == HT - 1 && r == 3) h = (q == 3) ? 1.0f : h;
+                const int hb = __float_as_int(h) & (int)0xffff0000;
+                const float r1 = h - __int_as_float(hb);                      // exact
+                const int mb = __float_as_int(r1) & (int)0xffff0000;
+                const float r2 = r1 - __int_as_float(mb);                     // exact; its top 16 bits are the third piece
+                hi[r] = hb; mid[r] = mb; lo[r] = __float_as_int(r2);
+            }
+            // two bf16 (= the upper halves) per dword: bytes {src1[2], src1[3], src0[2], src0[3]}
+            const int hh01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302), hh23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302);
+            const int mm01 = __builtin_amdgcn_perm(mid[1], mid[0], 0x07060302), mm23 = __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302);
+            const int ll01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302), ll23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302);
+            B1[t] = ci32x4{hh01, hh23, hh01, hh23};
+            B2[t] = ci32x4{mm01, mm23, mm01, mm23};
+            B3[t] = ci32x4{hh01, hh23, ll01, ll23};
+        }
+    };
+    auto chunk = [&](float (&tgt)[EPL], int ch) {
+        const ci32x4 *A = reinterpret_cast<const ci32x4 *>(chunk_s);          // [elem][6][HT][2][64]
+#pragma unroll
+        for (int e = 0; e < ELEMS; ++e) {
+            // the tiles of an element side by side, product by product: a bf16 MFMA issues in ~16 cycles but its result
+            // takes longer, so the MFMAs of ONE tile must not follow each other (back to back they ran at ~36 cycles
+            // each: measured, the first version of this loop); groups of three tiles = 36 operand / accumulator registers
+            float p[4 * TPE];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                cf32x4 o[GRP];
+#pragma unroll
+                for (int c = 0; c < GRP; ++c) o[c] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    ci32x4 a1[GRP];
+#pragma unroll
+                    for (int c = 0; c < GRP; ++c) a1[c] = A[(((e * TPE + GRP * g + c) * HT + t) * 2) * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < GRP; ++c)
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B1[t]), o[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < GRP; ++c)
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a1[c]), __builtin_bit_cast(cbf16x8, B2[t]), o[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < GRP; ++c) {
+                        const ci32x4 a2 = A[(((e * TPE + GRP * g + c) * HT + t) * 2 + 1) * 64 + lane];
+                        o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, a2), __builtin_bit_cast(cbf16x8, B3[t]), o[c], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < GRP; ++c) {
+                    p[4 * GRP * g + 4 * c] = o[c][0]; p[4 * GRP * g + 4 * c + 1] = o[c][1];
+                    p[4 * GRP * g + 4 * c + 2] = o[c][2]; p[4 * GRP * g + 4 * c + 3] = o[c][3];
+                }
+            }
+            float v;
+            if constexpr (STATIC_CH) {
+                v = tgt[ELEMS * ch + e];
+            } else {                                           // run-time chunk index: a select over the chunks
+                v = tgt[e];
+#pragma unroll
+                for (int c2 = 1; c2 < NC; ++c2) v = (ch == c2) ? tgt[ELEMS * c2 + e] : v;
+            }
+            float out = v, l = 0.0f;
+            if (v > C.minimum && v < C.maximum) {
+                if constexpr (LRS) lrs_eval_lean<INVERSE, FAST>(p, v, C, out, l, amax);
+                else rqs_eval_lean<INVERSE, FAST>(p, v, C, out, l, amax);
+            }
+            ld2 += l;
+            if constexpr (STATIC_CH) {
+                tgt[ELEMS * ch + e] = out;
+            } else {
+#pragma unroll
+                for (int c2 = 0; c2 < NC; ++c2) tgt[ELEMS * c2 + e] = (ch == c2) ? out : tgt[ELEMS * c2 + e];
+            }
+        }
+    };
+    if constexpr (STATIC_CH) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(ch);
+            if (ch == 0) gemm1();
+            chunk(pa, ch);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(NC + ch);
+            chunk(pb, ch);
+        }
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(ch);
+            if (ch == 0) gemm1();
+            chunk(pa, ch);
+        }
+#pragma unroll 1
+        for (int ch = 0; ch < NC; ++ch) {
+            stage_in(NC + ch);
+            chunk(pb, ch);
+        }
+    }
+}
+
 #ifndef TFK_RQS3_WAVES
 #define TFK_RQS3_WAVES 4
 #endif
-template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false>
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false, bool MADE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((STEPS2 == 0 || STEPS2 >= 8) ? (EPL == 32 ? 2 : TFK_RQS3_WAVES) : 1)))
 void k_flow_rqs_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
@@ -547,7 +721,9 @@ void k_flow_rqs_chain(
     constexpr bool LRS = STEPS2 >= 16;
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
     static_assert(!CTX || (STEPS2 == 0 || STEPS2 >= 8), "context-conditioned spline chains: bf16 x 3 operand format");
-    constexpr int HEAD = (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
+    static_assert(!MADE || ((STEPS2 == 0 || STEPS2 >= 8) && !CTX), "MADE spline layers: bf16 x 3 operand format, no context");
+    constexpr int HEAD = MADE ? 2 * EPL * HT3 * 64 + HT3 * 16 + 2 * D
+                              : (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
     const int accumulate = flags & 1;
     const bool reverse_out = (flags & 2) != 0;
     const bool base_of_input = (flags & 4) != 0;
@@ -641,7 +817,9 @@ void k_flow_rqs_chain(
 #pragma unroll 1
             for (int l = 0; l < prog.n_layers; ++l) {
                 const float *gprm = params + prog.offset0 + (size_t)l * prog.layer_stride;
-                if constexpr (F3) {
+                if constexpr (MADE) {
+                    rqs_made_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, a, b, ld2, amax);
+                } else if constexpr (F3) {
                     if (((prog.first_src + l) & 1) == 0)
                         rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST, CTX>(gprm, stage, lane, q, C, a, b, ld2, amax, cx, prog.ctx_steps);
                     else
@@ -721,7 +899,7 @@ void k_flow_rqs_chain(
     }
 }
 
-template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false>
+template <int EPL, int BLOCK, int STEPS2, bool INVERSE, bool CTX = false, bool MADE = false>
 static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                               float *logprob, int64_t N, const float *params, const RqsChainProg &prog, int flags,
                               int xw, hipStream_t s, const char *fn, const float *context = nullptr, int Cn = 0)
@@ -730,10 +908,11 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     constexpr bool F3 = STEPS2 == 0 || STEPS2 >= 8;
     constexpr bool LRS = STEPS2 >= 16;
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
-    constexpr int HEAD = (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
+    constexpr int HEAD = MADE ? 2 * EPL * HT3 * 64 + HT3 * 16 + 2 * D
+                              : (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
     const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float)
                        + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);
-    auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE, CTX>;
+    auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE, CTX, MADE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -763,6 +942,20 @@ static int launch_rqs_chain(const float *x, float *z, float *logdet, const float
                             int steps2, int flags, int xw, hipStream_t s, const char *fn,
                             const float *context = nullptr, int Cn = 0)
 {
+    if (prog.made) {                                         // MADE spline layers: bf16 x 3 operands, hidden <= 15, D = 64 / 128
+        if constexpr (EPL == 8 || EPL == 16) {
+#define TFK_RCM(ST_) \
+    (inverse ? launch_rqs_chain_b<EPL, 512, ST_, true, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn) \
+             : launch_rqs_chain_b<EPL, 512, ST_, false, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, prog, flags, xw, s, fn))
+            switch (steps2) {
+            case 0: return TFK_RCM(0);
+            case 16: return TFK_RCM(16);
+            default: break;
+            }
+#undef TFK_RCM
+        }
+        return fail(TFK_EINVAL, "%s: lean MADE spline layers need D = 64 or 128 and hidden width <= 15", fn);
+    }
     if (context) {                                           // context-conditioned chains: bf16 x 3 operands, D >= 64
         if constexpr (EPL >= 8) {
 #define TFK_RCC(ST_) \

@@ -43,7 +43,8 @@ OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT
     OP_RQS_FWD, OP_RQS_INV, OP_MADE_FWD, OP_MADE_INV, OP_MADE_RQS, OP_PLANE_SWAP, \
     OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA, \
     OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_EWC_MULADD, OP_EWC_SUBDIV, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN, \
-    OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN = range(25)
+    OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN, OP_MADE_RQS_FWD_LEAN, OP_MADE_RQS_INV_LEAN, OP_MADE_LRS_FWD_LEAN, \
+    OP_MADE_LRS_INV_LEAN = range(29)
 MAX_CONTEXT = 16      # context elements a flow program takes (4 k-steps of 4, csrc/tfk_flow_mfma.h: kCtxSteps)
 LOG2E = 1.4426950408889634
 AFF_C0 = -1.000000082790371e-10       # float32(log(1 - 1e-10)), affine.py:19-23
@@ -816,8 +817,11 @@ def _lean_made(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
         return None
     kind = layer.transformer.native_kind
     ct = layer.conditioner_transform
-    if kind not in ("affine", "inverse_affine") or ct.n_global_parameters != 0:
+    if kind not in ("affine", "inverse_affine", "rqs", "lrs") or ct.n_global_parameters != 0:
         return None
+    if kind in ("rqs", "lrs") and layer.transformer.n_bins != 8:
+        return None
+    P = {"rqs": 23, "lrs": 32}.get(kind, 2)
     if ct.output_lower_bound != float("-inf") or ct.output_upper_bound != float("inf"):
         return None
     mods = list(ct.sequential)
@@ -825,17 +829,45 @@ def _lean_made(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
             and isinstance(mods[2], MADE.MaskedLinear)):
         return None
     H = mods[0].out_features
-    if mods[0].in_features != D or H > 16:
+    if mods[0].in_features != D or H > (15 if P != 2 else 16):
         return None
     W1 = (mods[0].weight * mods[0].mask).detach().double()                     # (H, D) logical columns
-    W2 = (mods[2].weight * mods[2].mask).detach().double().view(D, 2, H)       # logical element, parameter, unit
+    W2 = (mods[2].weight * mods[2].mask).detach().double().view(D, P, H)       # logical element, parameter, unit
     W1p = W1.new_zeros(H, Dp)
     W1p[:, pos] = W1
-    W2p = W2.new_zeros(Dp, 2, H)
+    W2p = W2.new_zeros(Dp, P, H)
     W2p[pos] = W2
-    b2p = W2.new_zeros(Dp, 2)
-    b2p[pos] = mods[2].bias.detach().double().view(D, 2)
-    return kind == "inverse_affine", H, W1p, mods[0].bias.detach().double(), W2p, b2p
+    b2p = W2.new_zeros(Dp, P)
+    b2p[pos] = mods[2].bias.detach().double().view(D, P)
+    return (kind if P != 2 else kind == "inverse_affine"), H, W1p, mods[0].bias.detach().double(), W2p, b2p
+
+
+def _pack_lean_made_spline(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t, c_delta: float, lrs: bool) -> torch.Tensor:
+    """Parameter block of a lean MADE spline op (csrc/tfk_flow_rqs_chain.h: rqs_made_layer3), bf16 x 3 operands, hidden
+    width <= 15: head A1[2 EPL / 4][64][4] (plane A's k-steps, then plane B's) | b1[4][4] | pre_s[Dp] | pre_t[Dp], then the
+    chunks of plane A's elements and of plane B's, each exactly as a lean spline coupling's (``_pack_lean_rqs``)."""
+    hp, EPL = Dp // 2, Dp // 8
+    dev = W1f.device
+    W1pad = torch.zeros(16, Dp, dtype=torch.float64, device=dev)
+    W1pad[:H] = W1f * (2.0 * LOG2E)
+    b1pad = torch.zeros(16, dtype=torch.float64, device=dev)
+    b1pad[:H] = b1f * (2.0 * LOG2E)
+    lane = torch.arange(64, device=dev)
+    ql, il = lane >> 4, lane & 15
+    unit1 = 4 * (il & 3) + (il >> 2)
+    A1 = torch.stack([W1pad[unit1, (s_ // EPL) * hp + EPL * ql + (s_ % EPL)] for s_ in range(2 * EPL)])   # (2 EPL, 64)
+    A1 = A1.reshape(2 * EPL // 4, 4, 64).permute(0, 2, 1)
+    qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
+    b1m = b1pad[4 * rr + qq]
+    head_len = EPL * 64 + 16 + 2 * hp                    # a coupling block's head (dropped below)
+    zero_w1 = torch.zeros(H, hp, dtype=torch.float64, device=dev)
+    chunks = []
+    for plane in (0, 1):
+        sl = slice(plane * hp, (plane + 1) * hp)
+        blk = _pack_lean_rqs(H, Dp, zero_w1, b1f, W2p[sl], b2p[sl], pre_s[sl], pre_t[sl], c_delta, bf16x3=True, lrs=lrs)
+        chunks.append(blk[head_len:])
+    head = torch.cat([A1.reshape(-1), b1m.reshape(-1), pre_s, pre_t]).float()
+    return torch.cat([head] + chunks)
 
 
 def _pack_lean_made(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t) -> torch.Tensor:
@@ -995,6 +1027,29 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 if got is None:
                     return None
                 divide, H, W1p, b1, W2p, b2p = got
+                if divide in ("rqs", "lrs"):                 # MADE spline layers: the single-launch spline chain kernel
+                    if not rqs_bf16x3_enabled() or Dp not in (64, 128):
+                        return None
+                    tr = layer.transformer
+                    lrs_ = divide == "lrs"
+                    lk, steps2 = (12 if lrs_ else 10), (H + 1 + 3) // 4
+                    if lrs_:
+                        extra = (8 + 256, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_width * tr.n_bins)),
+                                 float(np.float32(tr.const)))
+                        c_delta = float(np.float32(tr.const))
+                    else:
+                        extra = (8 + 256, float(tr.boundary), float(np.float32(1.0 - tr.min_bin_size * tr.n_bins)),
+                                 float(np.float32(tr.boundary_u_delta)))
+                        c_delta = float(np.float32(tr.boundary_u_delta))
+                    if kind0 is None:
+                        kind0, steps0 = lk, steps2
+                    elif (lk, steps2) != (kind0, steps0) or items[-1][4] != extra:
+                        return None
+                    block = _pack_lean_made_spline(H, Dp, W1p * s, b1 + W1p @ t, W2p, b2p, s.clone(), t.clone(), c_delta, lrs_)
+                    s.fill_(1.0)
+                    t.fill_(0.0)
+                    items.append((OP_MADE_LRS_FWD_LEAN if lrs_ else OP_MADE_RQS_FWD_LEAN, 0, steps2, block, extra))
+                    continue
                 lk, steps2 = (7 if divide else 6), (H + 3) // 4
                 if kind0 is None:
                     kind0, steps0 = lk, steps2
@@ -1021,7 +1076,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     ctx_bits = cs_l << 4
                 else:
                     lk, plane, H, W1t, b1, W2p, b2p = got
-                if kind0 is not None and kind0 in (6, 7):
+                if kind0 is not None and kind0 in (6, 7, 10, 12):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
                 if lk >= 8 and not rqs_bf16x3_enabled():
@@ -1072,7 +1127,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     if inline and closed_flush is not None and not pending_is_identity():
         post_items.append((OP_EW_FMA, 0, 0, pending_block(), ()))        # constant layers behind the last context op
     flush = closed_flush if closed_flush is not None else torch.cat([s, t, ld_const.reshape(1), ld_const.new_zeros(3)]).float()
-    streamed = kind0 in (4, 5, 8, 9)                     # spline chains read their operands from global memory
+    streamed = kind0 in (4, 5, 8, 9, 10, 12)             # spline chains read their operands from global memory
     if (not items and streamed) or (context and not items):
         return None
     items.append((OP_EW_FMA, 0, 0, flush, ()))
@@ -1397,7 +1452,7 @@ def _why_declined(composition, direction: int) -> str:
 
 _LEAN_KINDS = frozenset((OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LEAN, OP_SHIFT_INV_LEAN, OP_EW_FMA,
                          OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN,
-                         OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN))
+                         OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN, OP_MADE_RQS_FWD_LEAN, OP_MADE_LRS_FWD_LEAN))
 
 
 def sum_ready(chain: Optional[CompiledChain]) -> bool:

@@ -47,7 +47,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
 )
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class NativeError(RuntimeError):
