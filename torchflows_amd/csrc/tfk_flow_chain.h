@@ -411,8 +411,9 @@ __device__ __forceinline__ void ew_fma_apply(const float *ew, int q, float (&a)[
 
 // An elementwise affine layer whose parameters are a Linear map of the CONTEXT (ElementwiseBijection with a
 // context_shape, layers_base.py:300-318) inside a lean context program: one GEMM context -> (D, 2), then the affine
-// transform of every element of both planes -- the interpreter's TFK_OP_EWC_* op (tfk_flow_mfma.h: ewc_m), same block:
-// Ac[EPL][cs][64] | bc[EPL][4][4]; tile t < EPL / 2: this lane's elements 2 t, 2 t + 1 of plane A, else of plane B.
+// transform of every element of both planes -- the interpreter's TFK_OP_EWC_* op (tfk_flow_mfma.h: ewc_m), same block
+// layout: Ac[EPL][cs][64] | bc[EPL][4][4]; tile t < EPL / 2: this lane's elements 2 t, 2 t + 1 of plane A, else of plane
+// B -- but with the scale-logit rows pre-multiplied by log2(e) / 2 (bias += log(1 - 1e-10) log2 e) as in the lean couplings.
 template <int EPL, bool DIVIDE>
 __device__ __forceinline__ void ewc_lean(const float *prm, int cs, int lane, int q, float (&a)[EPL], float (&b)[EPL],
                                          float &ld, const float (&cx)[4])
@@ -428,15 +429,16 @@ __device__ __forceinline__ void ewc_lean(const float *prm, int cs, int lane, int
             if (k < cs) o = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[(t * cs + k) * 64 + lane], cx[k], o, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float al = aff_alpha_lean(o[2 * i]);
+            // the logit rows arrive pre-scaled like a lean coupling's: o = (u / 2 + c0) log2 e (fused.py: lean=True)
+            const float al = __builtin_amdgcn_exp2f(o[2 * i]) + kAffMinScale;
             const float be = o[2 * i + 1];
-            part += log_lean(al);
+            part += __builtin_amdgcn_logf(al);                              // log2 alpha
             float &v = (t < EPL / 2) ? a[2 * t + i] : b[2 * (t - EPL / 2) + i];
-            if (!DIVIDE) v = al * v + be;                                   // affine.py:48
+            if (!DIVIDE) v = fmaf(al, v, be);                               // affine.py:48
             else v = (v - be) * __builtin_amdgcn_rcpf(al);                  // affine.py:59
         }
     }
-    ld = ld + (DIVIDE ? -part : part);
+    ld = fmaf(part, DIVIDE ? -__int_as_float(0x3f317218) : __int_as_float(0x3f317218), ld);        // ln 2
 }
 
 template <int EPL>

@@ -34,12 +34,16 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
     const int EPL = D / 8, HALF = D / 2;
     const int cs_want = context ? (Cn + 3) / 4 : 0;
     // operand format: K = 8 -> fp32 A-operands (chunks of 8 elements); K = 8 + 256 -> bf16 x 3 (chunks of 4 elements)
-    const bool fmt3 = n_ops > 0 && (ops[4] >> 8) == 1;
+    int first = 0;                                           // the first spline op (elementwise ops may precede it)
+    while (first < n_ops - 1 && (ops[8 * first] == TFK_OP_EW_FMA || ops[8 * first] == TFK_OP_EWC_MULADD ||
+                                 ops[8 * first] == TFK_OP_EWC_SUBDIV))
+        ++first;
+    const bool fmt3 = n_ops > 0 && (ops[8 * first + 4] >> 8) == 1;
     // bf16 x 3: gemm2_steps = ceil((H + 1) / 4) counts the bias unit; more than 4 steps = two hidden tiles
-    const int ht3 = (fmt3 && n_ops > 0 && ops[2] > 4) ? 2 : 1;
+    const int ht3 = (fmt3 && n_ops > 0 && ops[8 * first + 2] > 4) ? 2 : 1;
     int k0 = -1;                                             // the first spline op (context programs: never the first op? it is)
     for (int i = 0; i < n_ops && k0 < 0; ++i)
-        if (ops[8 * i] != TFK_OP_EW_FMA) k0 = ops[8 * i];
+        if (ops[8 * i] != TFK_OP_EW_FMA && ops[8 * i] != TFK_OP_EWC_MULADD && ops[8 * i] != TFK_OP_EWC_SUBDIV) k0 = ops[8 * i];
     const bool made = k0 >= TFK_OP_MADE_RQS_FWD_LEAN && k0 <= TFK_OP_MADE_LRS_INV_LEAN;
     const bool lrs = k0 == TFK_OP_LRS_FWD_LEAN || k0 == TFK_OP_LRS_INV_LEAN || k0 == TFK_OP_MADE_LRS_FWD_LEAN ||
                      k0 == TFK_OP_MADE_LRS_INV_LEAN;
@@ -62,13 +66,35 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
         const int32_t *rec = ops + 8 * i;
         const int k = rec[0], st = rec[2], off = rec[3];
         int src = rec[1];
-        if (k == TFK_OP_EW_FMA) {
-            if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
-            if (off < 0 || (off & 3) || off + 2 * (int64_t)D + 4 > n_params)
+        const bool ewc = (k == TFK_OP_EWC_MULADD || k == TFK_OP_EWC_SUBDIV);
+        if (k == TFK_OP_EW_FMA || ewc) {
+            // plain programs: one TFK_OP_EW_FMA, last.  Context programs: elementwise ops (constant or context-conditioned)
+            // may also stand in front of the couplings and behind the closing TFK_OP_EW_FMA (staged in the LDS)
+            if (ewc && (!context || (src >> 4) != cs_want))
+                return fail(TFK_EINVAL, "%s: op %d: a context-conditioned elementwise op needs the call's context", fn, i);
+            const int64_t need = ewc ? (int64_t)EPL * cs_want * 64 + (int64_t)EPL * 16 : 2 * (int64_t)D + 4;
+            if (off < 0 || (off & 3) || off + need > n_params)
                 return fail(TFK_EINVAL, "%s: op %d: parameters outside the block", fn, i);
-            prog.ew_offset = off;
+            const int phase = prog.n_layers == 0 ? 0 : (prog.ew_offset < 0 ? 1 : 2);
+            if (phase == 1 && !ewc) { prog.ew_offset = off; continue; }
+            if (phase == 1) return fail(TFK_EINVAL, "%s: op %d: a TFK_OP_EW_FMA closes the couplings before this op", fn, i);
+            if (!context) {
+                if (i != n_ops - 1) return fail(TFK_EINVAL, "%s: op %d: TFK_OP_EW_FMA must end a lean program", fn, i);
+                prog.ew_offset = off;
+                continue;
+            }
+            int *kinds = phase == 0 ? prog.pre_kind : prog.post_kind, *offs = phase == 0 ? prog.pre_off : prog.post_off;
+            int n = 0;
+            while (n < kChainSideOps && kinds[n]) ++n;
+            if (n == kChainSideOps) return fail(TFK_EINVAL, "%s: op %d: more than %d elementwise ops on one side of the couplings", fn, i, kChainSideOps);
+            if (EPL > 16) return fail(TFK_EINVAL, "%s: op %d: elementwise ops inside a lean spline program need D <= 128", fn, i);
+            kinds[n] = ewc ? (k == TFK_OP_EWC_MULADD ? 2 : 3) : 1;
+            offs[n] = off;
+            (phase == 0 ? prog.pre_lds : prog.post_lds)[n] = prog.side_floats;
+            prog.side_floats += (int)need;
             continue;
         }
+        if (prog.ew_offset >= 0) return fail(TFK_EINVAL, "%s: op %d: a coupling behind the closing TFK_OP_EW_FMA", fn, i);
         if ((src >> 4) != cs_want)                           // src_plane bits 4..7: k-steps of context in GEMM 1
             return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
         src &= 15;

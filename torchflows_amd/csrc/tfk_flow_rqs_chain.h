@@ -53,7 +53,10 @@ struct RqsChainProg {
     int offset0;              // first layer's block
     int ctx_steps;            // k-steps of context in GEMM 1 (0: none; the head then ends with A1c[HT][64][4])
     int made;                 // MADE-based spline layers (TFK_OP_MADE_*_LEAN spline kinds): both planes in, both planes out
-    int pad[1];
+    int side_floats;          // (context programs) floats of the elementwise ops' blocks, staged in the LDS behind the chunk
+    // elementwise ops in front of the couplings / behind the closing TFK_OP_EW_FMA (see ChainProg): kind, offset in params
+    int pre_kind[kChainSideOps], pre_off[kChainSideOps], pre_lds[kChainSideOps];      // (..._lds: float offset in the LDS)
+    int post_kind[kChainSideOps], post_off[kChainSideOps], post_lds[kChainSideOps];
     RqsLean C;
     double *sum_ws;           // tfk_flow_run_mfma_sum (see ChainProg)
     double *sum_out;
@@ -729,8 +732,20 @@ void k_flow_rqs_chain(
     const bool base_of_input = (flags & 4) != 0;
     constexpr int CHUNK = F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats;
     float *stage = lds;                                      // [HEAD + chunk]
-    float *ew_s = lds + HEAD + CHUNK;                        // s[D] | t[D] | ldc, pad[3]
+    float *side_s = lds + HEAD + CHUNK;                      // (context programs) the elementwise ops' blocks, in op order
+    float *ew_s = side_s + (CTX ? prog.side_floats : 0);     // s[D] | t[D] | ldc, pad[3]
     float *base_s = ew_s + 2 * D + 4;                        // loc[D] | 1/scale[D] | const
+    constexpr bool SIDE = CTX && EPL <= 16;                  // elementwise ops inside the launch (D <= 128)
+    if constexpr (SIDE) {
+#pragma unroll 1
+        for (int i = 0; i < 2 * kChainSideOps; ++i) {
+            const int kind = i < kChainSideOps ? prog.pre_kind[i] : prog.post_kind[i - kChainSideOps];
+            const int off = i < kChainSideOps ? prog.pre_off[i] : prog.post_off[i - kChainSideOps];
+            const int at = i < kChainSideOps ? prog.pre_lds[i] : prog.post_lds[i - kChainSideOps];
+            const int len = kind == 0 ? 0 : (kind == 1 ? 2 * D + 4 : EPL * prog.ctx_steps * 64 + EPL * 16);
+            for (int e = threadIdx.x; e < len; e += BLOCK) side_s[at + e] = params[off + e];
+        }
+    }
     if (prog.ew_offset >= 0)
         for (int e = threadIdx.x; e < 2 * D + 4; e += BLOCK) ew_s[e] = params[prog.ew_offset + e];
     if (logprob) {
@@ -832,17 +847,29 @@ void k_flow_rqs_chain(
                 }
             }
         };
+        float ld_pre = 0.0f;                                          // (context programs) log-det of the ops in front
+        auto pre_ops = [&]() {
+            if constexpr (SIDE) {
+                ld_pre = 0.0f;
+#pragma unroll 1
+                for (int i = 0; i < kChainSideOps; ++i)
+                    if (prog.pre_kind[i]) side_op<EPL>(prog.pre_kind[i], side_s + prog.pre_lds[i], prog.ctx_steps, lane, q, a, b, ld_pre, cx);
+            }
+        };
+        pre_ops();
         if constexpr (F3 && TFK_SOFTMAX_FAST) {
             layers(std::true_type{});
             if (__syncthreads_or(!(amax <= kSoftmaxFastMax))) {       // (also catches a NaN logit)
                 load_rows();                                          // x is intact: z is stored below
                 ld2 = 0.0f;
+                pre_ops();
                 layers(std::false_type{});
             }
         } else {
             layers(std::false_type{});
         }
         ld = fmaf(ld2, __int_as_float(0x3f317218), ld);             // ln 2
+        if constexpr (SIDE) ld += ld_pre;
         if (prog.ew_offset >= 0) {
 #pragma unroll
             for (int i = 0; i < EPL / 4; ++i) {
@@ -857,6 +884,12 @@ void k_flow_rqs_chain(
                 }
             }
             if (q == 0) ld = ld + ew_s[2 * D];
+        }
+        if constexpr (SIDE) {                                         // the elementwise layers behind the couplings
+#pragma unroll 1
+            for (int i = 0; i < kChainSideOps; ++i)
+                if (prog.post_kind[i])
+                    side_op<EPL>(prog.post_kind[i], side_s + prog.post_lds[i], prog.ctx_steps, lane, q, a, b, ld, cx);
         }
         if (logprob && !base_of_input) base_terms();
         ld += __shfl_xor(ld, 16, kWave);
@@ -910,7 +943,8 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     constexpr int HT3 = (STEPS2 == 8 || STEPS2 == 24) ? 2 : 1;
     constexpr int HEAD = MADE ? 2 * EPL * HT3 * 64 + HT3 * 16 + 2 * D
                               : (F3 ? EPL * HT3 * 64 + HT3 * 16 + 2 * HALF : EPL * 64 + 16 + 2 * HALF) + (CTX ? HT3 * 256 : 0);
-    const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)) * sizeof(float)
+    const size_t lds = ((size_t)HEAD + (F3 ? (LRS ? 16384 : kRqsChunk3Dwords) : kRqsChunkFloats) + 2 * (2 * D + 4)
+                        + (CTX ? prog.side_floats : 0)) * sizeof(float)
                        + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);
     auto kern = &k_flow_rqs_chain<EPL, BLOCK, STEPS2, INVERSE, CTX, MADE>;
     if (lds > 64 * 1024) {

@@ -395,7 +395,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     return (op, plane, H), block
 
 
-def _elementwise_ctx_op(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
+def _elementwise_ctx_op(layer, d: int, pos: torch.Tensor, D: int, Dp: int, lean: bool = False):
     """An elementwise affine layer whose parameters come from the CONTEXT through the default Linear conditioner
     (layers_base.py:300-318) as a TFK_OP_EWC_* op: Ac[EPL][cs][64] | bc[EPL][4][4] (csrc/tfk_flow_mfma.h: ewc_m)."""
     from torchflows_amd.bijections.finite.autoregressive.conditioning.transforms import Linear
@@ -417,6 +417,10 @@ def _elementwise_ctx_op(layer, d: int, pos: torch.Tensor, D: int, Dp: int):
     W[pos, :, :C] = lin.weight.detach().view(D, 2, C)
     bq = torch.zeros(Dp, 2, dtype=lin.bias.dtype, device=dev)               # padding: zero logits = the identity
     bq[pos] = lin.bias.detach().view(D, 2)
+    if lean:      # inside a lean program (csrc/tfk_flow_chain.h: ewc_lean): alpha = exp2(.) + 1e-10, as the lean couplings
+        W, bq = W.double(), bq.double()
+        W[:, 0] = W[:, 0] * (0.5 * LOG2E)
+        bq[:, 0] = (bq[:, 0] * 0.5 + AFF_C0) * LOG2E
     lane = torch.arange(64, device=dev)
     ql, il = lane >> 4, lane & 15
     q2, r2 = il >> 2, il & 3
@@ -941,10 +945,12 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                                 for layer, _ in plan[:first_c])
     # affine / shift chains take those elementwise layers INSIDE the lean launch (csrc/tfk_flow_chain.h: side_op): in front
     # of the couplings and behind the closing TFK_OP_EW_FMA, up to 3 ops per side -- one launch per conditional log_prob
-    inline = (context and first_c < len(plan) and isinstance(plan[first_c][0], CouplingBijection)
-              and plan[first_c][0].transformer.native_kind in ("affine", "inverse_affine", "shift")
+    kind_c = (plan[first_c][0].transformer.native_kind
+              if first_c < len(plan) and isinstance(plan[first_c][0], CouplingBijection) else None)
+    inline = (context and (kind_c in ("affine", "inverse_affine", "shift")
+                           or (kind_c in ("rqs", "lrs") and Dp <= 128 and rqs_bf16x3_enabled()))
               and os.environ.get("TORCHFLOWS_AMD_CTX_INLINE", "1") != "0")
-    if inline and Dp == 256:
+    if inline and Dp == 256 and kind_c not in ("rqs", "lrs"):
         # the context variant of the 256-wide chain kernel spills (660 B of scratch at the 256-VGPR cap): measured
         # 1.8e8 evals/s against the interpreter's 3.5e8 on a conditional RealNVP(256) -- the interpreter keeps that size
         return None
@@ -966,7 +972,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 perm = (layer._fwd_index if d == FORWARD else layer._inv_index).to(device)
                 pos = pos[perm]
             elif inline and isinstance(layer, ElementwiseBijection) and not layer.use_global_parameters:
-                item = _elementwise_ctx_op(layer, d, pos, D, Dp)
+                item = _elementwise_ctx_op(layer, d, pos, D, Dp, lean=True)
                 if item is None:
                     return None
                 ewc = (item[0][0], item[0][1], 0, item[1].float(), ())
