@@ -331,12 +331,14 @@ int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logd
  * LEAN context programs (ABI v22, D >= 64):
  *  - spline chains (TFK_OP_RQS_*_LEAN / TFK_OP_LRS_*_LEAN, bf16 x 3 operand format): src_plane bits 4..7 = cs = ceil(C / 4)
  *    on every coupling, and every coupling's head ends with A1c[HT][64][4] -- lane (q, i), slot k: the weight of hidden
- *    unit 16 t + unit(i) for context element 4 k + q, times 2 log2(e) (zero beyond C) -- behind pre_t;
+ *    unit 16 t + unit(i) for context element 4 k + q, times 2 log2(e) (zero beyond C) -- behind pre_t; at D <= 128 also the
+ *    elementwise ops inside the program described for the affine chains below;
  *  - affine / shift chains (TFK_OP_AFFINE_*_LEAN / TFK_OP_SHIFT_*_LEAN, fp32 operands, D <= 128 from the packer): the
  *    same bits, A1c[64][4] behind each coupling's pre_t, AND elementwise ops inside the program: up to 3 in front of
  *    the first coupling and up to 3 behind the closing TFK_OP_EW_FMA, each either a TFK_OP_EW_FMA block (a constant
- *    x -> s x + t with its log-det) or a TFK_OP_EWC_* op (block as in the interpreter, src_plane = cs << 4).  A lean
- *    program is recognised by its first coupling op, not by its first op. */
+ *    x -> s x + t with its log-det) or a TFK_OP_EWC_* op (block laid out as in the interpreter, src_plane = cs << 4, but
+ *    with the scale-logit rows times log2(e) / 2 and their bias (b / 2 + log(1 - 1e-10)) log2(e), as in the lean
+ *    couplings).  A lean program is recognised by its first coupling op, not by its first op. */
 int tfk_flow_run_mfma_ctx(const float *x, const float *context, int32_t C, float *z, float *logdet,
                           const float *gauss_loc, const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
                           const int32_t *ops, int32_t n_ops, const float *params, int64_t n_params,
