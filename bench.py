@@ -674,7 +674,8 @@ def main():
             trows = min(rows, chunk or rows, 1 << 18)
             xt = x[:trows]
             flow.train()
-            opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+            from torchflows_amd.utils import make_adamw
+            opt = make_adamw(flow.parameters(), 1e-4)
 
             def train_step():
                 opt.zero_grad(set_to_none=True)

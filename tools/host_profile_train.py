@@ -12,7 +12,8 @@ import bench  # noqa: E402
 flow = bench.make_flow("RealNVP", 64, 8).cuda()
 x = torch.randn(1 << 18, 64, device="cuda")
 flow.train()
-opt = torch.optim.AdamW(flow.parameters(), lr=1e-4)
+from torchflows_amd.utils import make_adamw
+opt = make_adamw(flow.parameters(), 1e-4)
 
 
 def step():

@@ -56,7 +56,15 @@ class AutoregressiveBijection(Bijection):
         if type(self).regularization is not AutoregressiveBijection.regularization:
             return None
         if self.l2_regularization and self.l2_coef > 0:
-            return float(self.l2_coef), [p for p in self.parameters() if p.requires_grad]
+            # (module, name) slots of the parameters, walked once (named_modules over 27 layers cost 0.4 ms of a 3 ms
+            # training step); looked up by name every step, so a replaced Parameter or a flipped requires_grad is seen.
+            # Dropped with the other structural caches (fused.invalidate / load_state_dict / .to()).
+            slots = self.__dict__.get("_tfk_l2_slots")
+            if slots is None:
+                slots = [(m, n) for m in self.modules() for n in m._parameters]
+                self.__dict__["_tfk_l2_slots"] = slots
+            params = [m._parameters[n] for m, n in slots]
+            return float(self.l2_coef), [p for p in params if p is not None and p.requires_grad]
         return 0.0, []
 
     # run a single layer natively when it is called on its own (outside a composition)

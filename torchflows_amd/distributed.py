@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from torchflows_amd import native
+from torchflows_amd.utils import make_adamw
 
 
 def shard_bounds(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -166,7 +167,7 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
     else:
         sizes = [n_local]
     steps_per_epoch = max(-(-n // local_bs) for n in sizes)
-    opt = (optimizer or (lambda ps, lr_: torch.optim.AdamW(ps, lr=lr_)))(flow.parameters(), lr)
+    opt = (optimizer or make_adamw)(flow.parameters(), lr)
     gen = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
     flow.train()
     losses = []

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from torchflows_amd.base_distributions.gaussian import DiagonalGaussian
 from torchflows_amd.bijections.base import Bijection
-from torchflows_amd.utils import event_size, flatten_event, get_batch_shape, unflatten_event
+from torchflows_amd.utils import make_adamw, event_size, flatten_event, get_batch_shape, unflatten_event
 
 
 def _drop_native_caches(module, incompatible_keys=None) -> None:
@@ -290,7 +290,7 @@ class Flow(BaseFlow):
         use_graph = (dev.type == "cuda" and os.environ.get("TORCHFLOWS_AMD_GRAPH", "0") == "1"
                      and context_train is None and self._graph_safe())
         if self._optimizer is None or reset_optimizer:
-            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr, capturable=use_graph)
+            self._optimizer = make_adamw(self.parameters(), lr, capturable=use_graph)
         graphed = None               # (batch size, graph, static x, static w, static loss)
         stats = {"eager_steps": 0, "graph_replays": 0, "graph_captures": 0}
         self._fit_stats = stats
@@ -432,7 +432,7 @@ class Flow(BaseFlow):
             return
         self.train()
         if self._optimizer is None or reset_optimizer:
-            self._optimizer = torch.optim.AdamW(self.parameters(), lr=lr)
+            self._optimizer = make_adamw(self.parameters(), lr)
 
         def snapshot():
             return {k: v.detach().clone() for k, v in self.state_dict().items()}
