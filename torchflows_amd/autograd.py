@@ -114,11 +114,27 @@ def applicable(composition, x: torch.Tensor, context) -> bool:
     return x.requires_grad or fused.any_requires_grad(composition)
 
 
+def _module_params(module) -> List[torch.Tensor]:
+    """``list(module.parameters())`` without the module walk on every call (27 layers x forward + backward = 0.3 ms of a
+    3 ms training step): the (submodule, name) slots are walked once and looked up by name afterwards, so a replaced
+    Parameter is seen; dropped with the other structural caches (fused.invalidate / load_state_dict / .to())."""
+    slots = module.__dict__.get("_tfk_param_slots")
+    if slots is None:
+        seen, slots = set(), []
+        for m in module.modules():
+            for n, p in m._parameters.items():
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    slots.append((m, n))
+        module.__dict__["_tfk_param_slots"] = slots
+    return [m._parameters[n] for m, n in slots]
+
+
 def _layer_params(layer, kind: str) -> List[torch.Tensor]:
     if kind == "elementwise":
         return [layer.value]
     if kind in ("coupling", "made", "elementwise_ctx"):
-        return list(layer.conditioner_transform.parameters())
+        return _module_params(layer.conditioner_transform)
     return []
 
 
@@ -678,7 +694,7 @@ class ChainFunction(torch.autograd.Function):
                                                    gld, want, inverse=_affine_form_is_inverse(layer, d))
                 grads_per_step[i] = [gv.view_as(layer.value) if want else None]
             elif kind == "elementwise_ctx":
-                cparams = list(layer.conditioner_transform.parameters())
+                cparams = _module_params(layer.conditioner_transform)
                 with torch.enable_grad():
                     h2 = layer.conditioner_transform(x=None, context=plan.context).reshape(N, -1)
                 hc = h2.detach().contiguous()
@@ -693,7 +709,7 @@ class ChainFunction(torch.autograd.Function):
             elif kind == "made":
                 # h depends on every input position (through the masks): re-evaluate MADE with a graph,
                 # the transformer's reverse-mode kernel gives dL/dh and the direct dL/dx, autograd the rest
-                cparams = list(layer.conditioner_transform.parameters())
+                cparams = _module_params(layer.conditioner_transform)
                 tk, tr = layer.transformer.native_kind, layer.transformer
                 mlp = _made_mlp(layer)
                 if mlp is not None:             # masked MLP written out (weight-gradient GEMMs split over rows)
@@ -734,7 +750,7 @@ class ChainFunction(torch.autograd.Function):
                 S = layer.coupling.source_event_size
                 tgt = None if layer._target_is_tail else layer._target_index32
                 tk = layer.transformer.native_kind
-                cparams = list(layer.conditioner_transform.parameters())
+                cparams = _module_params(layer.conditioner_transform)
                 if i in packs.slot:         # one launch: conditioner, transform and MLP backward
                     k = packs.slot[i]
                     pack = packs.layers[k][3]
@@ -830,7 +846,7 @@ class ChainFunction(torch.autograd.Function):
                                       zip(pieces[lo:lo + sum(pack.sizes)].split(pack.sizes), pack.shapes))
                 lo += sum(pack.sizes)
                 by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
-                cparams = list(plan[i][0].conditioner_transform.parameters())
+                cparams = _module_params(plan[i][0].conditioner_transform)
                 grads_per_step[i] = [
                     (by_param[id(p)] if id(p) in by_param else torch.zeros_like(p)) if p.requires_grad else None
                     for p in cparams]
