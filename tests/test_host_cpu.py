@@ -553,3 +553,32 @@ def test_log_prob_and_sum_on_host():
         assert torch.equal(lp, flow.log_prob(x))
     assert total.dtype == torch.float64 and total.shape == (1,)
     assert abs(float(total) - float(lp.double().sum())) < 1e-9
+
+
+def test_cached_parameter_slots_follow_module_edits():
+    """The L2 term and the autograd node keep (module, name) slots instead of walking named_modules every step: a
+    replaced Parameter and a flipped requires_grad are seen at once; structural edits after invalidate_native_caches()."""
+    import torchflows_amd as tfa
+    from torchflows_amd import autograd as A
+    torch.manual_seed(0)
+    flow = tfa.Flow(tfa.RealNVP(6))
+    comp = flow.bijection
+    want = sum(float((p.detach() ** 2).sum()) * 0.0 for p in comp.parameters())      # (touch every parameter once)
+    r0 = float(comp.regularization())
+    lin = [m for m in comp.modules() if isinstance(m, torch.nn.Linear)][0]
+    with torch.no_grad():
+        lin.weight = torch.nn.Parameter(lin.weight.detach() * 3.0)                     # replaced, same slot
+    r1 = float(comp.regularization())
+    assert r1 > r0 and want == 0.0
+    ref = sum(float(layer.l2_coef) * sum(float((p.detach() ** 2).sum()) for p in layer.parameters() if p.requires_grad)
+              for layer in comp.layers if getattr(layer, "l2_regularization", False) and hasattr(layer, "l2_coef"))
+    assert abs(r1 - ref) <= 1e-5 * max(1.0, abs(ref))
+    lin.weight.requires_grad_(False)                                                   # leaves the L2 term
+    r2 = float(comp.regularization())
+    assert r2 < r1
+    ct = [layer.conditioner_transform for layer in comp.layers
+          if getattr(layer, "conditioner_transform", None) is not None and list(layer.conditioner_transform.parameters())][0]
+    assert [id(p) for p in A._module_params(ct)] == [id(p) for p in ct.parameters()]
+    ct.extra = torch.nn.Linear(2, 2)                                                   # structural edit
+    comp.invalidate_native_caches()
+    assert [id(p) for p in A._module_params(ct)] == [id(p) for p in ct.parameters()]
