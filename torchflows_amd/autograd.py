@@ -117,7 +117,7 @@ def applicable(composition, x: torch.Tensor, context) -> bool:
 def _module_params(module) -> List[torch.Tensor]:
     """``list(module.parameters())`` without the module walk on every call (27 layers x forward + backward = 0.3 ms of a
     3 ms training step): the (submodule, name) slots are walked once and looked up by name afterwards, so a replaced
-    Parameter is seen; dropped with the other structural caches (fused.invalidate / load_state_dict / .to())."""
+    Parameter is seen; dropped by fused.invalidate (train() / eval() / load_state_dict / invalidate_native_caches)."""
     slots = module.__dict__.get("_tfk_param_slots")
     if slots is None:
         seen, slots = set(), []

@@ -58,7 +58,7 @@ class AutoregressiveBijection(Bijection):
         if self.l2_regularization and self.l2_coef > 0:
             # (module, name) slots of the parameters, walked once (named_modules over 27 layers cost 0.4 ms of a 3 ms
             # training step); looked up by name every step, so a replaced Parameter or a flipped requires_grad is seen.
-            # Dropped with the other structural caches (fused.invalidate / load_state_dict / .to()).
+            # Dropped by fused.invalidate (train() / eval() / load_state_dict / invalidate_native_caches).
             slots = self.__dict__.get("_tfk_l2_slots")
             if slots is None:
                 slots = [(m, n) for m in self.modules() for n in m._parameters]

@@ -1348,7 +1348,9 @@ def invalidate(module: nn.Module, compiled_only: bool = False) -> None:
 # device), the flat tensor-slot list and the dtype / device check -- and therefore never go stale through a value
 # edit.  They must survive invalidate(): a captured hipGraph of the training step (Flow.fit, TORCHFLOWS_AMD_GRAPH=1)
 # reads the packs' index tensors on every replay, and fit() invalidates after every epoch of replays.
-_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_declined_warned", "_tfk_l2_slots", "_tfk_param_slots")
+_STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_declined_warned")
+# (the (module, name) slot lists of the L2 term and of the autograd node -- "_tfk_l2_slots", "_tfk_param_slots" -- hold no
+# tensors and are rebuilt in microseconds: invalidate() drops them like any other cache)
 
 
 _CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
