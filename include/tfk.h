@@ -333,7 +333,7 @@ int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logd
  *    on every coupling, and every coupling's head ends with A1c[HT][64][4] -- lane (q, i), slot k: the weight of hidden
  *    unit 16 t + unit(i) for context element 4 k + q, times 2 log2(e) (zero beyond C) -- behind pre_t; at D <= 128 also the
  *    elementwise ops inside the program described for the affine chains below;
- *  - affine / shift chains (TFK_OP_AFFINE_*_LEAN / TFK_OP_SHIFT_*_LEAN, fp32 operands, D <= 128 from the packer): the
+ *  - affine / shift chains (TFK_OP_AFFINE_*_LEAN / TFK_OP_SHIFT_*_LEAN, fp32 operands, D = 64 or 128): the
  *    same bits, A1c[64][4] behind each coupling's pre_t, AND elementwise ops inside the program: up to 3 in front of
  *    the first coupling and up to 3 behind the closing TFK_OP_EW_FMA, each either a TFK_OP_EW_FMA block (a constant
  *    x -> s x + t with its log-det) or a TFK_OP_EWC_* op (block laid out as in the interpreter, src_plane = cs << 4, but

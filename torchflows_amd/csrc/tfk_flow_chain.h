@@ -810,8 +810,10 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
         return fail(TFK_EINVAL, "%s: %d floats of parameters do not fit the 160 KiB LDS, and streamed operands exist for "
                     "affine / shift couplings at D >= 128 with fp32 operands; split the program", fn, n_params);
     }
-    if (prog.context) {                                      // conditional flows: one workgroup size, fp32 operands, D >= 64
-        if constexpr (EPL >= 8 && KIND < 4) {
+    if (prog.context) {                                      // conditional flows: one workgroup size, fp32 operands
+        // (D = 64 / 128: at D = 256 the context variant spills -- 660 B of scratch at the 256-VGPR cap, half the
+        // interpreter's rate -- and is not built; the packer leaves conditional affine chains of that size to the interpreter)
+        if constexpr (EPL >= 8 && EPL <= 16 && KIND < 4) {
             constexpr int BC = (EPL == 16) ? 768 : 512;
 #define TFK_CC(ST_) \
     launch_chain_b<EPL, BC, ST_, KIND, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
@@ -824,7 +826,7 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
             }
 #undef TFK_CC
         }
-        return fail(TFK_EINVAL, "%s: context-conditioned lean chains: affine / shift couplings, fp32 operands, D >= 64", fn);
+        return fail(TFK_EINVAL, "%s: context-conditioned lean chains: affine / shift couplings, fp32 operands, D = 64 or 128", fn);
     }
     const bool big = N >= (int64_t)kCUs * 3 * 128;
     // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:
