@@ -126,14 +126,23 @@ def _unpack_bf16(d):
     return torch.stack([lo16[:, 0], hi16[:, 0], lo16[:, 1], hi16[:, 1]], dim=1)
 
 
-def run_lean(ops, params, rows, D):
-    """rows (N, D) fp64, N a multiple of 16 -> (rows out, logdet) of one lean segment."""
+def run_lean(ops, params, rows, D, context=None):
+    """rows (N, D) fp64, N a multiple of 16 -> (rows out, logdet) of one lean segment.  ``context`` (N, C) fp64 for
+    context programs: src_plane bits 4..7 of the couplings = k-steps of context in GEMM 1 (A1c behind the block's pre_t),
+    TFK_OP_EWC_* ops (lean format: scale logits pre-scaled for exp2) in front of / behind the couplings."""
     EPL, HALF = D // 8, D // 2
     N = rows.shape[0]
     W = N // 16
     lane = torch.arange(64)
     q, j = lane >> 4, lane & 15
     x = rows.reshape(W, 16, D)
+    cx = None
+    if context is not None:                                   # cx[s][lane, w] = context element 4 s + q of row j of wave w
+        C_ = context.shape[1]
+        cpad = torch.zeros(N, 16, dtype=torch.float64)
+        cpad[:, :C_] = context
+        cw = cpad.reshape(W, 16, 16)
+        cx = [cw[:, j, 4 * s_ + q].t().contiguous() for s_ in range(4)]         # each (64, W)
     # lane registers: a[l, e, w] = row j of wave w, element EPL q + e of plane A
     idx = (EPL * q)[:, None] + torch.arange(EPL)[None, :]                      # (64, EPL)
     a = x[:, j][:, torch.arange(64)[:, None], idx].permute(1, 2, 0).clone()   # (64, EPL, W)
@@ -144,6 +153,25 @@ def run_lean(ops, params, rows, D):
     sign = 0.0
     op_extra = {(op[0], op[3]): op[4:8] for op in ops if len(op) > 4}
     for kind, plane, steps2, off in [op[:4] for op in ops]:
+        cs = plane >> 4                                       # k-steps of context (context programs)
+        plane = plane & 15
+        if kind in (19, 20):                                  # TFK_OP_EWC_* inside a lean program (ewc_lean)
+            Ac = prm[off:off + EPL * cs * 64].reshape(EPL, cs, 64)
+            bc = prm[off + EPL * cs * 64:off + EPL * cs * 64 + EPL * 16].reshape(EPL, 4, 4)
+            part = torch.zeros(64, W, dtype=torch.float64)
+            a, b = a.clone(), b.clone()
+            for t_ in range(EPL):
+                o = bc[t_][q][:, :, None].expand(64, 4, W).clone()
+                for s_ in range(cs):
+                    o = _mfma(Ac[t_, s_], cx[s_], o)
+                pl, tt = (a, t_) if t_ < EPL // 2 else (b, t_ - EPL // 2)
+                for i in range(2):
+                    al = torch.exp2(o[:, 2 * i]) + 1e-10
+                    part = part + torch.log2(al)
+                    e = 2 * tt + i
+                    pl[:, e] = al * pl[:, e] + o[:, 2 * i + 1] if kind == 19 else (pl[:, e] - o[:, 2 * i + 1]) / al
+            ld = ld + (LN2 if kind == 19 else -LN2) * part
+            continue
         if kind == 16:                                        # TFK_OP_EW_FMA
             s, t = prm[off:off + D], prm[off + D:off + 2 * D]
             a = s[idx][:, :, None] * a + t[idx][:, :, None]
@@ -156,16 +184,19 @@ def run_lean(ops, params, rows, D):
             K, boundary, scale, cdelta = op_extra[(kind, off)]
             fmt3 = (int(K) >> 8) == 1
             HT = 2 if (fmt3 and steps2 > 4) else 1
-            HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF
+            HEAD = EPL * HT * 64 + HT * 16 + 2 * HALF + (HT * 256 if cs else 0)
             A1 = prm[off:off + EPL * HT * 64].reshape(EPL // 4, HT, 64, 4)
             b1 = prm[off + EPL * HT * 64:off + EPL * HT * 64 + HT * 16].reshape(HT, 16)
-            pre = prm[off + EPL * HT * 64 + HT * 16:off + HEAD]
+            pre = prm[off + EPL * HT * 64 + HT * 16:off + EPL * HT * 64 + HT * 16 + 2 * HALF]
+            A1c = prm[off + EPL * HT * 64 + HT * 16 + 2 * HALF:off + HEAD].reshape(HT, 64, 4) if cs else None
             src, tgt = (a, b) if plane == 0 else (b, a)
             hids = []
             for th in range(HT):
                 acc = b1[th][(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
                 for s_ in range(EPL):
                     acc = _mfma(A1[s_ // 4, th, :, s_ % 4], src[:, s_], acc)
+                for s_ in range(cs):
+                    acc = _mfma(A1c[th, :, s_], cx[s_], acc)
                 hids.append(1.0 - 2.0 / (torch.exp2(acc) + 1.0))
             tgt = pre[idx][:, :, None] * tgt + pre[HALF + idx][:, :, None]
             hid = hids[0]
@@ -347,6 +378,10 @@ def run_lean(ops, params, rows, D):
         acc = b1[(4 * q)[:, None] + torch.arange(4)[None, :]][:, :, None].expand(64, 4, W).clone()
         for s_ in range(EPL):
             acc = _mfma(A1[s_ // 4, :, s_ % 4], src[:, s_], acc)
+        if cs:                                                # the context's columns of W1: A1c[64][4] behind pre_t
+            A1c = pre[2 * HALF:2 * HALF + 256].reshape(64, 4)
+            for s_ in range(cs):
+                acc = _mfma(A1c[:, s_], cx[s_], acc)
         tgt = pre[idx][:, :, None] * tgt + pre[HALF + idx][:, :, None]
         hid = 1.0 - 2.0 / (torch.exp2(acc) + 1.0)             # (64, 4, W)
         tgt = tgt.clone()

@@ -582,3 +582,43 @@ def test_cached_parameter_slots_follow_module_edits():
     ct.extra = torch.nn.Linear(2, 2)                                                   # structural edit
     comp.invalidate_native_caches()
     assert [id(p) for p in A._module_params(ct)] == [id(p) for p in ct.parameters()]
+
+
+@pytest.mark.parametrize("arch,D,C,direction", [("RealNVP", 64, 8, 0), ("RealNVP", 64, 3, 1), ("NICE", 64, 5, 0),
+                                                ("CouplingRQNSF", 64, 8, 0), ("CouplingRQNSF", 64, 2, 1),
+                                                ("CouplingLRS", 64, 16, 0), ("RealNVP", 22, 4, 0), ("RealNVP", 128, 6, 0)])
+def test_lean_context_programs_against_fp64_emulator(arch, D, C, direction):
+    """Conditional flows as ONE lean program (fused._compile_lean(context=True)): the context's columns of W1 as further
+    GEMM-1 k-steps (A1c), the context-conditioned elementwise layers (TFK_OP_EWC_*, scale logits pre-scaled for exp2) and
+    constant ones (TFK_OP_EW_FMA) in front of / behind the couplings -- decoded by the fp64 emulator exactly as
+    csrc/tfk_flow_chain.h / tfk_flow_rqs_chain.h read them, against the composition's forward / inverse with context."""
+    from lean_emulator import run_lean
+    from torchflows_amd import fused
+    import torchflows_amd as tfa
+    torch.manual_seed(4)
+    flow = tfa.Flow(getattr(tfa, arch)(D, context_shape=(C,), n_layers=3))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(512, D) * 1.5 + 0.3, context=torch.randn(512, C))
+    flow.eval()
+    comp = flow.bijection.double()
+    Dp = D if D in (64, 128, 256) else (64 if D < 64 else 128)
+    order = comp.layers if direction == 0 else list(comp.layers)[::-1]
+    plan = fused._flatten(order, "forward" if direction == 0 else "inverse")
+    pos = torch.arange(D)
+    if Dp != D:
+        pos = torch.where(pos < D // 2, pos, pos - D // 2 + Dp // 2)
+    chain = fused._compile_lean(comp, plan, torch.device("cpu"), D, Dp, pos.clone(), pos.clone(), context=True)
+    assert chain is not None and len(chain.segments) == 1 and chain.D == Dp
+    x, c = torch.randn(64, D, dtype=torch.float64), torch.randn(64, C, dtype=torch.float64)
+    with torch.no_grad():
+        want, ld_want = (comp.forward if direction == 0 else comp.inverse)(x, context=c)
+    rows = torch.zeros(64, Dp, dtype=torch.float64)
+    rows[:, pos] = x
+    seg = chain.segments[0]
+    kinds = [op[0] for op in seg.ops]
+    assert any(k in (19, 20) for k in kinds) and any((op[1] >> 4) == (C + 3) // 4 for op in seg.ops)
+    rows, ld = run_lean(seg.ops, seg.params, rows, Dp, context=c)
+    got = rows[:, chain.pos]
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+    assert float((ld - ld_want).abs().max() / max(1.0, float(ld_want.abs().max()))) < 2e-5
