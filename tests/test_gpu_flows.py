@@ -351,7 +351,7 @@ def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch
     flow.eval()
     sd = {k: v.numpy() for k, v in flow.state_dict().items()}
     ref = oracle.preset_from_state_dict(arch, D, 2, sd)
-    x = torch.randn(160, D) * 1.5
+    x = torch.randn(160 if D < 64 else 48, D) * 1.5        # (the host's fp64 D-pass loop is the slow part of this test)
     seq = "inverse" if arch.startswith("Masked") else "forward"
     import copy
     with torch.no_grad():                      # the ATen composite path on the host: fp64 truth, fp32 floor
