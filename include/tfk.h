@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 23
+#define TFK_ABI_VERSION 24
 
 enum {
     TFK_OK = 0,
@@ -410,6 +410,57 @@ int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, con
 /* Bounded conditioner output (conditioning/transforms.py:107-113, used by ConvNetConditioner with (-2, 2)):
  * out = lo + (hi - lo) * sigmoid(h) over n floats, the three roundings of the reference kept; h may alias out. */
 int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float hi, void *stream);
+
+/* ---- a whole convolutional coupling of the image / multiscale flows in ONE launch (config 5) -----------------
+ * Replaces, for one coupling of multiscale/base.py:19-114 (CheckerboardCoupling, ChannelWiseCoupling,
+ * Invertible1x1ConvolutionalCoupling with the ConvNet conditioner), IN PLACE on the rows:
+ *   x_A = x[..., source_mask].view(constant_shape); h = ConvNetConditioner(x_A)   (multiscale/conditioning/
+ *   classic.py:8-145: ConvModifier, 3 x [conv3x3, ReLU, MaxPool2d(2), BatchNorm2d], ConvModifier, Linear, and the
+ *   (-2, 2) sigmoid bound of conditioning/transforms.py:107-113);  z[..., target_mask] = transformer(x_B, h)
+ *   (Affine, transformers/linear/affine.py:33-59, or Invertible1x1ConvolutionTransformer, linear/convolution.py:
+ *   33-64 + linear/matrix.py:11-99);  logdet[n] += the layer's log-det   (layers_base.py:145-163).
+ * The rows keep ONE physical layout (N, D) through all layers: `src_idx` lists the physical positions of the
+ * conditioner's input image (c_in, hi, wi) in its own row-major order, `tgt_idx` those of the transformer's targets in
+ * the order of h -- so Squeeze / chunk (multiscale/base.py:117-175, 271-280) and the masks (multiscale/coupling.py:
+ * 6-63) are folded into the two tables by the caller.  `src_st` / `tgt_st` hold a pending map per listed element,
+ * (s, t) interleaved: the value the layer sees is s * rows[n, idx] + t (the deferred ActNorm layers in front of it;
+ * (1, 0) = none); targets are stored in final form.
+ * The caller evaluates everything that does not depend on the sample (see torchflows_amd/image_program.py):
+ *   weights  tfk_glow_weight_floats(c_in) floats: first ConvModifier W (4, c_in), b (4) | conv1 W as [ci=4][co=8][3][3],
+ *            b1 (8), BatchNorm-1 scale (8), shift (8) | conv2 W as [ci=8][co=8][3][3], b2, scale, shift (8 each) |
+ *            conv3 W as [ci=8][co=4][3][3], b3 (4) | second ConvModifier's 4 weights times BatchNorm-3's scales, then its
+ *            bias + sum_c weight_c shift_c   (BatchNorm in inference form: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
+ *   bg1, bg2 (8, 16, 16) and (8, 8, 8): the outputs of conv blocks 1 and 2 for the all-bias image (every pixel of the
+ *            (4, 32, 32) frame = the first ConvModifier's bias), i.e. what the blocks produce wherever the source image's
+ *            receptive field does not reach; only the window it does reach is computed per sample
+ *   w_eff    ceil(n_params / 16) tiles of [64 lanes][4] floats: tile t, lane l, k-step ks = W_eff[16 t + (l & 15)][4 ks + (l >> 4)]
+ *            where W_eff (n_params, 16) are the Linear layer's columns of the 4x4 interior of the (1, 10, 10) image
+ *   b_eff    16 * tiles floats: Linear bias + its 84 frame columns times the second ConvModifier's bias (zero padded)
+ * Supported: first ConvModifier with a 1x1 kernel (hi, wi <= 32 with 32 - hi, 32 - wi even: it sits at (oy, ox) =
+ * ((32 - hi) / 2, (32 - wi) / 2)), ConvNet kernels (8, 8, 4), 1x1 convolutions of <= 16 channels.
+ * slots / block / cg1 / cg2 / grid = 0 let the library choose the launch shape (tfk_glow_plan reports it). */
+typedef struct tfk_glow_layer {
+    int32_t kind;              /* 0 affine, 1 invertible 1x1 convolution */
+    int32_t c_in, hi, wi;      /* conditioner input image */
+    int32_t oy, ox;            /* its position in ConvModifier's 32x32 frame */
+    int32_t T;                 /* target elements */
+    int32_t n_params;          /* 2 T (affine) or n + n (n - 1) (1x1 convolution of n channels) */
+    int32_t n_ch, hw;          /* 1x1 convolution: target channels, pixels per channel (T = n_ch * hw); else 0 */
+    int32_t slots, block, cg1, cg2, grid;   /* launch shape overrides, 0 = default */
+    const int32_t *src_idx;    /* device int32[c_in * hi * wi] */
+    const float *src_st;       /* device float[2 * c_in * hi * wi] */
+    const int32_t *tgt_idx;    /* device int32[T] */
+    const float *tgt_st;       /* device float[2 * T] */
+    const float *weights, *bg1, *bg2, *w_eff, *b_eff;
+} tfk_glow_layer;
+int64_t tfk_glow_weight_floats(int32_t c_in);
+int tfk_glow_plan(const tfk_glow_layer *layer, int32_t D, int32_t *slots, int32_t *block, int32_t *cg1, int32_t *cg2,
+                  int32_t *lds_bytes, int32_t *tile_rows);
+int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tfk_glow_layer *layer, int32_t inverse,
+                      void *stream);
+
+/* rows[n, d] = st[2 d] * rows[n, d] + st[2 d + 1] in place: the flush of the pending maps behind the last coupling. */
+int tfk_rows_fma(float *rows, const float *st, int64_t N, int32_t D, void *stream);
 
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from

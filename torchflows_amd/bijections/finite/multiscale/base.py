@@ -21,8 +21,8 @@ import torch
 import torch.nn as nn
 
 from torchflows_amd import native
-from torchflows_amd.bijections.base import (Bijection, BijectiveComposition, forward_method,
-                                            inverse_method)
+from torchflows_amd.bijections.base import (Bijection, BijectiveComposition, FORWARD, INVERSE, _params_ok,
+                                            forward_method, inverse_method)
 from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
 from torchflows_amd.bijections.finite.autoregressive.layers_base import CouplingBijection
 from torchflows_amd.bijections.finite.autoregressive.transformers.base import TensorTransformer
@@ -177,8 +177,20 @@ class MultiscaleBijection(Bijection):
                 event_shape=(c4 // 2, h2, w2), transformer_class=transformer_class,
                 n_blocks=n_blocks - 1, first_layer=False, **kwargs)
 
+    def _run_program(self, x: torch.Tensor, context, d: int):
+        """The whole recursion as one libtfk launch per coupling, in place on one row buffer (image_program.py:
+        squeeze / chunk as index tables, ActNorm layers deferred); None when the compiler does not cover this model."""
+        if context is not None or x.numel() == 0 or not native.eligible(x) or not _params_ok(self):
+            return None
+        from torchflows_amd import image_program
+        prog = image_program.get_program(self, d, x.device)
+        return None if prog is None else image_program.run(prog, x, self.event_shape)
+
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        fused_out = self._run_program(x, context, FORWARD)
+        if fused_out is not None:
+            return fused_out
         log_det = torch.zeros(get_batch_shape(x, self.event_shape), dtype=x.dtype, device=x.device)
         for layer in self.checkerboard_layers:
             x, ld = layer.forward(x, context=context)
@@ -198,6 +210,9 @@ class MultiscaleBijection(Bijection):
 
     @inverse_method
     def inverse(self, z: torch.Tensor, context: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        fused_out = self._run_program(z, context, INVERSE)
+        if fused_out is not None:
+            return fused_out
         log_det = torch.zeros(get_batch_shape(z, self.event_shape), dtype=z.dtype, device=z.device)
         if self.n_blocks > 1:
             z, _ = self.alt_squeeze.forward(z, context=context)

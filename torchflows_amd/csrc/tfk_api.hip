@@ -1,4 +1,5 @@
 // tfk_api.hip -- error plumbing, version and device query of libtfk.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +22,22 @@ int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TFK_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     return TFK_OK;
+}
+
+int cu_count() {
+    static std::atomic<int> cached{0};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0) {
+        v = prop.multiProcessorCount;
+        cached.store(v, std::memory_order_relaxed);
+        return v;
+    }
+    (void)hipGetLastError();
+    return 256;
 }
 
 }  // namespace tfk

@@ -470,7 +470,7 @@ static int launch_rqs_bwd(const float *x, const float *h, float *g, const float 
                           int inverse, hipStream_t s, const char *fn)
 {
     const int64_t tiles = (N * (int64_t)T + kBlock - 1) / kBlock;
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    const int grid = (int)(tiles < max_grid() ? tiles : max_grid());
     if (inverse)
         hipLaunchKernelGGL((k_rqs_coupling_bwd<KT, true>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld,
                            gh, (long long)N, D, tgt_idx, T, C);
@@ -549,7 +549,7 @@ int tfk_rqs_coupling_bwd(const float *x, const float *h, float *g, const float *
 int64_t tfk_elementwise_affine_bwd_workspace_bytes(int64_t N, int32_t D)
 {
     if (N <= 0 || D <= 0) return 0;
-    return (int64_t)kMaxGrid * 2 * D * (int64_t)sizeof(float);
+    return (int64_t)max_grid() * 2 * D * (int64_t)sizeof(float);
 }
 
 int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, const float *gld,
@@ -576,7 +576,7 @@ int tfk_elementwise_affine_bwd(const float *x, const float *value, float *g, con
     if (CW > kBlock) CW = kBlock;
     const int RY = kBlock / CW;
     // slabs of rows: enough workgroups to fill the chip, at least RY * 8 rows each
-    int64_t blocks = kMaxGrid;
+    int64_t blocks = max_grid();
     int64_t rpb = (N + blocks - 1) / blocks;
     const int64_t min_rows = (int64_t)RY * 8;
     if (rpb < min_rows) rpb = min_rows;
@@ -934,10 +934,10 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
         (void)hipGetLastError();
         per_cu = 1;
     }
-    if (per_cu > 8) per_cu = 8;                          // the workspace holds kCUs * 8 partial rows
+    if (per_cu > 8) per_cu = 8;                          // the workspace holds cu_count() * 8 partial rows
     constexpr int rows_per_block = (kBlock / 64) * 16;  // (tfk_coupling_train_bwd_workspace_bytes)
     int64_t grid = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu;          // one resident set: few partial rows to add
+    const int64_t cap = (int64_t)cu_count() * per_cu;          // one resident set: few partial rows to add
     if (grid > cap) grid = cap;
     if (inverse_form)
         hipLaunchKernelGGL((k_affine_coupling_train_bwd<EPL, true>), dim3((int)grid), dim3(kBlock), lds, s, x, g,
@@ -963,7 +963,7 @@ int64_t tfk_coupling_train_bwd_out_floats(int32_t D)
 
 int64_t tfk_coupling_train_bwd_workspace_bytes(int32_t D)
 {
-    return tfk_coupling_train_bwd_out_floats(D) * (int64_t)kCUs * 8 * (int64_t)sizeof(float);
+    return tfk_coupling_train_bwd_out_floats(D) * (int64_t)cu_count() * 8 * (int64_t)sizeof(float);
 }
 
 int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
@@ -1213,7 +1213,7 @@ int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const
     }
     constexpr int rows_per_block = (512 / 64) * 16;
     int64_t grid = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * kGridOversubscribe;      // one workgroup per CU resident
+    const int64_t cap = (int64_t)cu_count() * kGridOversubscribe;      // one workgroup per CU resident
     if (grid > cap) grid = cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (inverse)

@@ -10,13 +10,15 @@ namespace tfk {
 
 constexpr int kWave = 64;         // CDNA4 wavefront
 constexpr int kBlock = 256;       // 4 waves, one per SIMD
-constexpr int kCUs = 256;         // MI355X
+// compute units of the device the calling thread is on, asked once per process (256 on MI355X; the same
+// 256 when no device answers, so that the size queries stay usable without a GPU)
+int cu_count();
 // Grid of the compute-bound flow-program kernels, in resident sets of workgroups.  With exactly
 // one resident set every CU gets the same share and the launch ends with the slowest CU; measured
 // on MI355X (RealNVP D=64, 2^20 rows): 1 set 557 us, 1.5 sets 543, 2 sets 531, 4 sets 511,
 // 8 sets 504, 16 sets 511 (each workgroup re-stages its parameter block from L2).
 constexpr int kGridOversubscribe = 4;
-constexpr int kMaxGrid = kCUs * 8;  // memory-bound kernels: <= 8 resident blocks per CU, grid-stride the rest
+inline int max_grid() { return cu_count() * 8; }  // memory-bound kernels: <= 8 resident blocks per CU, grid-stride the rest
 
 // affine.py:19-23 -- python doubles rounded once to fp32, as ATen does when a python
 // scalar meets an fp32 tensor: m = 1e-10, c0 = log(1 - 1e-10) = -1.000000082790371e-10
@@ -202,7 +204,7 @@ inline int pow2_ceil(int v) {
 inline int grid_for(int64_t units_of_work, int per_block) {
     int64_t b = (units_of_work + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    if (b > kMaxGrid) b = kMaxGrid;
+    if (b > max_grid()) b = max_grid();
     return (int)b;
 }
 

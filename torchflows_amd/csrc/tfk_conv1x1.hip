@@ -330,7 +330,7 @@ int tfk_conv1x1_coupling_bwd(const float *x, const float *h, float *g, const flo
     if (N == 0) return TFK_OK;
     if (!x || !h || !g || !gld || !gh) return fail(TFK_EINVAL, "%s: null pointer", fn);
     const int HW = T / n_channels;
-    const int grid = (int)(N < (int64_t)kMaxGrid * 4 ? N : (int64_t)kMaxGrid * 4);
+    const int grid = (int)(N < (int64_t)max_grid() * 4 ? N : (int64_t)max_grid() * 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (inverse)
         hipLaunchKernelGGL((k_conv1x1_coupling_bwd<true>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld, gh,

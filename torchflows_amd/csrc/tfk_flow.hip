@@ -388,7 +388,7 @@ static int launch_flow_b(const float *x, float *z, float *logdet, const float *l
     if (per_cu < 1) per_cu = 1;
     constexpr int rows_per_block = R * (BLOCK / G);
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int64_t cap = (int64_t)cu_count() * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((k_flow_run<G, BLOCK, R>), dim3(grid), dim3(BLOCK), lds, s,
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(z), logdet,
@@ -407,14 +407,14 @@ static int launch_flow(const float *x, float *z, float *logdet, const float *loc
     // element): 512-thread workgroups, one row per thread
     for (int i = 0; i < prog.n_ops; ++i)
         if (prog.op[i].kind == TFK_OP_RQS_FWD || prog.op[i].kind == TFK_OP_RQS_INV) {
-            if (N * G >= (int64_t)kCUs * 512)
+            if (N * G >= (int64_t)cu_count() * 512)
                 return launch_flow_b<G, 512, 1>(x, z, logdet, loc, log_scale, logprob, N, params,
                                                 n_params, prog, accumulate, s, fn);
             return launch_flow_b<G, kBlock, 1>(x, z, logdet, loc, log_scale, logprob, N, params,
                                                n_params, prog, accumulate, s, fn);
         }
     // (each thread then carries two rows: the weights come out of LDS once for both)
-    if (N * G >= (int64_t)kCUs * 2 * 1024 * 2)
+    if (N * G >= (int64_t)cu_count() * 2 * 1024 * 2)
         return launch_flow_b<G, 1024, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
                                          prog, accumulate, s, fn);
     return launch_flow_b<G, kBlock, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,

@@ -778,7 +778,7 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
     if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * TFK_CHAIN_OVERSUB;
+    const int64_t cap = (int64_t)cu_count() * per_cu * TFK_CHAIN_OVERSUB;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
                        params, n_params, prog, flags, xw);
@@ -828,7 +828,7 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
         }
         return fail(TFK_EINVAL, "%s: context-conditioned lean chains: affine / shift couplings, fp32 operands, D = 64 or 128", fn);
     }
-    const bool big = N >= (int64_t)kCUs * 3 * 128;
+    const bool big = N >= (int64_t)cu_count() * 3 * 128;
     // (D = 256: 768-thread workgroups capped at 168 VGPRs -- 3 waves per SIMD -- spill inside the coupling loop here:
     // 736 us per launch against 389 with 512 threads, measured; the interpreter's trick does not carry over)
     // (D = 128: the chain's operands, ~90 KB, allow one workgroup per CU: 768 threads at <= 168 VGPRs put 3 waves on every

@@ -615,7 +615,7 @@ static int launch_mb(const float *x, float *z, float *logdet, const float *loc, 
     }
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * kGridOversubscribe;
+    const int64_t cap = (int64_t)cu_count() * per_cu * kGridOversubscribe;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((k_flow_run_mfma<EPL, BLOCK, HTMAX, MADE, CTX>), dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc,
                        log_scale, logprob, (long long)N, params, n_params, prog, accumulate, context, C);
@@ -634,7 +634,7 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
     if (context) {
         // context-conditioned programs: their own instantiation (hidden width <= 16, no MADE ops) so that the
         // others keep their registers
-        const bool big_c = N >= (int64_t)kCUs * 3 * 128;
+        const bool big_c = N >= (int64_t)cu_count() * 3 * 128;
         return big_c ? launch_mb<EPL, 512, 1, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog,
                                                           accumulate, s, fn, context, C)
                      : launch_mb<EPL, kBlock, 1, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
@@ -644,7 +644,7 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
     for (int i = 0; i < prog.n_ops; ++i)
         wide = wide || (((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||
                          (prog.op[i].kind == TFK_OP_MADE_FWD || prog.op[i].kind == TFK_OP_MADE_INV)) && prog.op[i].steps2 > 4);
-    const bool big = N >= (int64_t)kCUs * 3 * 128;
+    const bool big = N >= (int64_t)cu_count() * 3 * 128;
     bool made = false;
     for (int i = 0; i < prog.n_ops; ++i)      // (TFK_OP_PLANE_SWAP = 11 lies above the MADE kinds: not a MADE op)
         made = made || (prog.op[i].kind >= TFK_OP_MADE_FWD && prog.op[i].kind <= TFK_OP_MADE_RQS);

@@ -413,7 +413,7 @@ int tfk_flow_run_mfma_in(const float *x, int32_t x_width, float *z, float *logde
                               n_params, accumulate, stream, "tfk_flow_run_mfma_in");
 }
 
-int64_t tfk_flow_sum_workspace_bytes(void) { return (int64_t)(1 + kCUs * 8 * kGridOversubscribe) * (int64_t)sizeof(double); }
+int64_t tfk_flow_sum_workspace_bytes(void) { return (int64_t)(1 + cu_count() * 8 * kGridOversubscribe) * (int64_t)sizeof(double); }
 
 int tfk_flow_run_mfma_sum(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
                           const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,

@@ -963,7 +963,7 @@ static int launch_rqs_chain_b(const float *x, float *z, float *logdet, const flo
     if (per_cu > 8) per_cu = 8;                              // (tfk_flow_sum_workspace_bytes counts on it)
     constexpr int rows_per_block = (BLOCK / 64) * 16;
     const int64_t want = (N + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = (int64_t)kCUs * per_cu * TFK_CHAIN_OVERSUB;
+    const int64_t cap = (int64_t)cu_count() * per_cu * TFK_CHAIN_OVERSUB;
     const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, x, z, logdet, loc, log_scale, logprob, (long long)N,
                        params, prog, flags, xw, context, Cn);

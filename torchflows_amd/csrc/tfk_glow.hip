@@ -1,0 +1,623 @@
+// tfk_glow.hip -- one launch per coupling layer of the image / multiscale flows (config 5, AffineGlow).
+//
+// Replaces, for ONE convolutional coupling (multiscale/base.py:19-114), the whole chain
+//   [ActNorm in front of it, layers.py:39-69, as a pending per-element map]
+//   x_A = x[..., source_mask].view(constant_shape)                         layers_base.py:145-150
+//   ConvModifier -> 3 x (conv3x3, ReLU, MaxPool2d(2), BatchNorm2d) -> ConvModifier -> Linear(100 -> n_params)
+//                                                                          multiscale/conditioning/classic.py:8-122
+//   h = lo + (hi - lo) * sigmoid(h)    (lo, hi) = (-2, 2)                  conditioning/transforms.py:107-113
+//   Affine.forward / inverse (transformers/linear/affine.py:33-59)  or
+//   Invertible1x1ConvolutionTransformer + LUTransformer (linear/convolution.py:33-64, linear/matrix.py:11-99)
+//   z[..., target_mask] = ...                                              layers_base.py:151-152
+// with every activation of the conditioner in the LDS and nothing but the rows crossing HBM: the source part is
+// read once, the target part is read and written once, in place.
+//
+// What makes it cheap (all exact up to fp32 summation order):
+//  * ConvModifier pads the (c, h, w) source image to (4, 32, 32) with a 1x1 convolution whose padding exceeds
+//    kernel - 1: every output pixel outside the image's own rectangle is the modifier's bias, for every sample.
+//    The three conv blocks therefore only differ from a per-layer constant BACKGROUND image (bg1: 8x16x16, bg2: 8x8x8,
+//    evaluated once on the host) inside the window that the rectangle's receptive field reaches; only that window is
+//    computed per sample (AffineGlow (3,32,32): 3.3 M of the reference's 8.7 M multiply-adds per sample and coupling).
+//  * The second modifier pads (4, 4, 4) to (1, 10, 10): 84 of the Linear layer's 100 inputs are its bias; the host
+//    folds them (and BatchNorm 3) into the Linear layer: h = W_eff (n_params x 16) v + b_eff.
+//  * Squeeze / unsqueeze / chunk (multiscale/base.py:117-175, 271-280) are index arithmetic: the rows keep their
+//    (c, h, w) layout from the first to the last layer and every coupling addresses them through two int32 tables
+//    (source and target elements in the order the conditioner / transformer expect them).
+//  * ActNorm layers are deferred by the host: every row element carries a pending map v = s * raw + t (composed in
+//    double), applied where the element is read; a transformed element is stored in final form.
+//
+// Work split: a workgroup owns `tile_rows` <= 16 samples at a time; `slots` of them have their activations resident
+// (LDS bytes per slot depend on the window), so the convolution stages run in tile_rows / slots rounds, lanes over
+// (slot, pooled pixel) with the weights of the wave's output-channel group in SGPRs (scalar loads; every lane of
+// a wave works on the same channels).  The 16 numbers per sample that feed the Linear layer are collected for the
+// whole tile; then the Linear layer runs as v_mfma_f32_16x16x4_f32 tiles (16 parameters x 16 samples, K = 16), each
+// lane receiving the 4 parameters = 2 affine targets of one sample, transforms them and accumulates the log-det.
+#include "tfk_common.h"
+
+namespace tfk {
+
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGlowMaxRows = 16;        // samples per tile = MFMA N
+constexpr int kGlowMaxCh = 16;          // 1x1 convolution: target channels kept in registers
+constexpr int kGlowFrame = 32;          // ConvModifier's target height / width (classic.py:13-16)
+
+struct GlowGeom {
+    int c_in, hi, wi, oy, ox;           // source image and where it sits in the 32x32 frame
+    int a0h, a0w, a0y0, a0x0;           // modifier output buffer (4 channels): dims, frame coordinates of its origin
+    int p1h, p1w, p1y0, p1x0;           // pooled-1 window computed per sample (16x16 frame)
+    int b1h, b1w, b1y0, b1x0;           // pooled-1 buffer (8 channels)
+    int p2h, p2w, p2y0, p2x0;           // pooled-2 window (8x8 frame); its buffer is always 10x10 at (-1,-1)
+    int off_p1, off_p2, off_p3, slot_floats;   // float offsets inside a slot
+    int fixed_floats;                   // LDS floats in front of the slots
+    int slots, tile_rows;               // G, NS
+    int T, n_params, n_tiles, D;
+    int kind, n_ch, hw;                 // 1x1 convolution: channels, pixels
+    int cg1, cg2;                       // output channels per lane task in conv block 1 / 2
+    int h_stride;                       // kind 1: floats per sample in the parameter buffer
+};
+
+// offsets into the packed fp32 weights of a layer (see tfk.h: tfk_glow_layer.weights)
+__host__ __device__ inline int gw_bm(int c_in) { return 4 * c_in; }
+__host__ __device__ inline int gw_w1(int c_in) { return 4 * c_in + 4; }
+__host__ __device__ inline int gw_b1(int c_in) { return gw_w1(c_in) + 4 * 8 * 9; }
+__host__ __device__ inline int gw_w2(int c_in) { return gw_b1(c_in) + 24; }
+__host__ __device__ inline int gw_b2(int c_in) { return gw_w2(c_in) + 8 * 8 * 9; }
+__host__ __device__ inline int gw_w3(int c_in) { return gw_b2(c_in) + 24; }
+__host__ __device__ inline int gw_b3(int c_in) { return gw_w3(c_in) + 8 * 4 * 9; }
+__host__ __device__ inline int gw_m2(int c_in) { return gw_b3(c_in) + 4; }
+__host__ __device__ inline int gw_total(int c_in) { return gw_m2(c_in) + 5; }
+
+// conv3x3(pad 1) -> ReLU -> MaxPool2d(2) -> per-channel scale / shift for one window of pooled pixels, all resident
+// slots at once.  Lane task = one pooled pixel x CG output channels; a wave's 64 tasks share the channel group, so its
+// weights are wave-uniform (scalar loads).  Input buffer: origin = (first conv row - 1, first conv column - 1), so the
+// 4x4 patch of pooled pixel (ly, lx) of the window starts at buffer (2 ly, 2 lx); even row width: aligned float2 reads.
+template <int CI, int CO, int CG, bool AFFINE>
+__device__ __forceinline__ void conv_stage(float *slot0, int slot_floats, int in_off, int ih, int iw, int out_off,
+                                           int oh, int ow, int oy0, int ox0, int ph, int pw, int G,
+                                           const float *__restrict__ w, const float *__restrict__ bias,
+                                           const float *__restrict__ sc, const float *__restrict__ sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int per_slot = ph * pw, n = G * per_slot;
+    const int chunks = (n + 63) >> 6;
+    constexpr int NG = CO / CG;
+    const int plane_in = ih * iw, plane_out = oh * ow;
+    for (int c = wave; c < chunks * NG; c += nw) {
+        const int cgi = __builtin_amdgcn_readfirstlane(c / chunks);
+        const int t = (c - cgi * chunks) * 64 + lane;
+        const bool active = t < n;
+        const int tt = active ? t : n - 1;
+        const int slot = tt / per_slot, rem = tt - slot * per_slot;
+        const int ly = rem / pw, lx = rem - ly * pw;
+        const float *ip = slot0 + slot * slot_floats + in_off + (2 * ly) * iw + 2 * lx;
+        float acc[CG][4];
+#pragma unroll
+        for (int co = 0; co < CG; ++co) acc[co][0] = acc[co][1] = acc[co][2] = acc[co][3] = 0.0f;
+        const float *wg = w + cgi * (CG * 9);
+#pragma unroll 1
+        for (int ci = 0; ci < CI; ++ci) {
+            float p[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 a = *reinterpret_cast<const float2 *>(ip + r * iw);
+                const float2 b = *reinterpret_cast<const float2 *>(ip + r * iw + 2);
+                p[r][0] = a.x, p[r][1] = a.y, p[r][2] = b.x, p[r][3] = b.y;
+            }
+            const float *wc = wg + ci * (CO * 9);
+#pragma unroll
+            for (int co = 0; co < CG; ++co)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wc[co * 9 + ky * 3 + kx];
+                        acc[co][0] = fmaf(wv, p[ky][kx], acc[co][0]);
+                        acc[co][1] = fmaf(wv, p[ky][kx + 1], acc[co][1]);
+                        acc[co][2] = fmaf(wv, p[ky + 1][kx], acc[co][2]);
+                        acc[co][3] = fmaf(wv, p[ky + 1][kx + 1], acc[co][3]);
+                    }
+            ip += plane_in;
+        }
+        if (active) {
+            float *op = slot0 + slot * slot_floats + out_off + (cgi * CG) * plane_out + (oy0 + ly) * ow + ox0 + lx;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) {
+                const int ch = cgi * CG + co;
+                float m = fmaxf(fmaxf(acc[co][0], acc[co][1]), fmaxf(acc[co][2], acc[co][3])) + bias[ch];
+                m = fmaxf(m, 0.0f);                       // max of ReLUs = ReLU of the max (bias shared by the window)
+                if (AFFINE) m = fmaf(sc[ch], m, sh[ch]);
+                op[co * plane_out] = m;
+            }
+        }
+    }
+}
+
+template <int CI, int CO, bool AFFINE>
+__device__ __forceinline__ void conv_stage_cg(int cg, float *slot0, int slot_floats, int in_off, int ih, int iw,
+                                              int out_off, int oh, int ow, int oy0, int ox0, int ph, int pw, int G,
+                                              const float *__restrict__ w, const float *__restrict__ bias,
+                                              const float *__restrict__ sc, const float *__restrict__ sh)
+{
+    if (cg == 8) conv_stage<CI, CO, 8, AFFINE>(slot0, slot_floats, in_off, ih, iw, out_off, oh, ow, oy0, ox0, ph, pw, G, w, bias, sc, sh);
+    else if (cg == 4) conv_stage<CI, CO, 4, AFFINE>(slot0, slot_floats, in_off, ih, iw, out_off, oh, ow, oy0, ox0, ph, pw, G, w, bias, sc, sh);
+    else conv_stage<CI, CO, 2, AFFINE>(slot0, slot_floats, in_off, ih, iw, out_off, oh, ow, oy0, ox0, ph, pw, G, w, bias, sc, sh);
+}
+
+// lo + (hi - lo) * sigmoid(h) with (lo, hi) = (-2, 2): s * 4 is exact, so the reference's multiply-then-add is one fma
+__device__ __forceinline__ float bounded4(float h)
+{
+    const float e = exp_lean(-h);
+    return fmaf(__builtin_amdgcn_rcpf(1.0f + e), 4.0f, -2.0f);
+}
+
+template <int KIND, bool INV>
+__global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logdet, long long N, GlowGeom g,
+                                                        const int *__restrict__ src_idx,
+                                                        const float2 *__restrict__ src_st,
+                                                        const int *__restrict__ tgt_idx,
+                                                        const float2 *__restrict__ tgt_st,
+                                                        const float *__restrict__ wts, const float *__restrict__ bg1,
+                                                        const float *__restrict__ bg2, const float4 *__restrict__ w_eff,
+                                                        const float4 *__restrict__ b_eff)
+{
+    extern __shared__ float4 lds4[];
+    float *lds = reinterpret_cast<float *>(lds4);
+    float *V = lds;                                   // [16 samples][16]
+    float *ldpart = lds + 256;                        // [16 waves][16 samples]
+    float *Hs = lds + 512;                            // kind 1: [16 samples][h_stride]
+    float *slot0 = lds + g.fixed_floats;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int G = g.slots;
+    const int D = g.D;
+    const float *bm = wts + gw_bm(g.c_in);
+
+    // ---- once per workgroup: everything of the buffers that no sample changes ----
+    {
+        const int a0 = 4 * g.a0h * g.a0w, b1 = 8 * g.b1h * g.b1w;
+        for (int i = tid; i < G * a0; i += nthr) {
+            const int slot = i / a0, e = i - slot * a0;
+            const int ch = e / (g.a0h * g.a0w), r = (e / g.a0w) % g.a0h, c = e % g.a0w;
+            const int y = g.a0y0 + r, x = g.a0x0 + c;
+            const bool in = y >= 0 && y < kGlowFrame && x >= 0 && x < kGlowFrame;
+            slot0[slot * g.slot_floats + e] = in ? bm[ch] : 0.0f;
+        }
+        for (int i = tid; i < G * b1; i += nthr) {
+            const int slot = i / b1, e = i - slot * b1;
+            const int ch = e / (g.b1h * g.b1w), r = (e / g.b1w) % g.b1h, c = e % g.b1w;
+            const int y = g.b1y0 + r, x = g.b1x0 + c;
+            const bool in = y >= 0 && y < 16 && x >= 0 && x < 16;
+            slot0[slot * g.slot_floats + g.off_p1 + e] = in ? bg1[(ch * 16 + y) * 16 + x] : 0.0f;
+        }
+        for (int i = tid; i < G * 800; i += nthr) {
+            const int slot = i / 800, e = i - slot * 800;
+            const int ch = e / 100, r = (e / 10) % 10, c = e % 10;
+            const int y = r - 1, x = c - 1;
+            const bool in = y >= 0 && y < 8 && x >= 0 && x < 8;
+            slot0[slot * g.slot_floats + g.off_p2 + e] = in ? bg2[(ch * 8 + y) * 8 + x] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const long long n_tiles_rows = (N + g.tile_rows - 1) / g.tile_rows;
+    const int npix = g.hi * g.wi;
+    for (long long tile = blockIdx.x; tile < n_tiles_rows; tile += gridDim.x) {
+        const long long row_base = tile * g.tile_rows;
+        const int nrows = (int)((N - row_base) < (long long)g.tile_rows ? (N - row_base) : (long long)g.tile_rows);
+
+        for (int s0 = 0; s0 < g.tile_rows; s0 += G) {
+            // ---- S0: pending map + ConvModifier (1x1 convolution c_in -> 4) into the image's rectangle ----
+            for (int t = tid; t < G * npix; t += nthr) {
+                const int slot = t / npix, pix = t - slot * npix;
+                const int iy = pix / g.wi, ix = pix - iy * g.wi;
+                long long row = row_base + s0 + slot;
+                if (row > N - 1) row = N - 1;
+                const float *xr = rows + row * D;
+                float o0 = bm[0], o1 = bm[1], o2 = bm[2], o3 = bm[3];
+                for (int c = 0; c < g.c_in; ++c) {
+                    const int e = c * npix + pix;
+                    const float2 st = src_st[e];
+                    const float v = fmaf(st.x, xr[src_idx[e]], st.y);
+                    o0 = fmaf(wts[c], v, o0);
+                    o1 = fmaf(wts[g.c_in + c], v, o1);
+                    o2 = fmaf(wts[2 * g.c_in + c], v, o2);
+                    o3 = fmaf(wts[3 * g.c_in + c], v, o3);
+                }
+                float *a = slot0 + slot * g.slot_floats + (g.oy + iy - g.a0y0) * g.a0w + (g.ox + ix - g.a0x0);
+                const int plane = g.a0h * g.a0w;
+                a[0] = o0, a[plane] = o1, a[2 * plane] = o2, a[3 * plane] = o3;
+            }
+            __syncthreads();
+            // ---- S1 .. S3: the three conv blocks on their windows ----
+            const int ci = g.c_in;
+            conv_stage_cg<4, 8, true>(g.cg1, slot0, g.slot_floats, 0, g.a0h, g.a0w, g.off_p1, g.b1h, g.b1w,
+                                      g.p1y0 - g.b1y0, g.p1x0 - g.b1x0, g.p1h, g.p1w, G, wts + gw_w1(ci),
+                                      wts + gw_b1(ci), wts + gw_b1(ci) + 8, wts + gw_b1(ci) + 16);
+            __syncthreads();
+            conv_stage_cg<8, 8, true>(g.cg2, slot0, g.slot_floats, g.off_p1, g.b1h, g.b1w, g.off_p2, 10, 10,
+                                      g.p2y0 + 1, g.p2x0 + 1, g.p2h, g.p2w, G, wts + gw_w2(ci), wts + gw_b2(ci),
+                                      wts + gw_b2(ci) + 8, wts + gw_b2(ci) + 16);
+            __syncthreads();
+            conv_stage<8, 4, 1, false>(slot0, g.slot_floats, g.off_p2, 10, 10, g.off_p3, 4, 4, 0, 0, 4, 4, G,
+                                       wts + gw_w3(ci), wts + gw_b3(ci), nullptr, nullptr);
+            __syncthreads();
+            // ---- S4: BatchNorm 3 + second ConvModifier (4 -> 1 channel), folded on the host ----
+            for (int t = tid; t < G * 16; t += nthr) {
+                const int slot = t >> 4, p = t & 15;
+                const float *p3 = slot0 + slot * g.slot_floats + g.off_p3 + p;
+                const float *m2 = wts + gw_m2(ci);
+                float v = m2[4];
+                v = fmaf(m2[0], p3[0], v);
+                v = fmaf(m2[1], p3[16], v);
+                v = fmaf(m2[2], p3[32], v);
+                v = fmaf(m2[3], p3[48], v);
+                V[(s0 + slot) * 16 + p] = v;
+            }
+            // (the next round's S0 writes A0, last read before two barriers; P3 is rewritten after three more)
+        }
+        __syncthreads();
+
+        // ---- Linear layer on the matrix cores + bounded output + transform ----
+        const int j = lane & 15, q = lane >> 4;
+        const bool row_ok = j < nrows;
+        const long long row = row_base + (row_ok ? j : 0);
+        float bq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bq[ks] = V[j * 16 + 4 * ks + q];
+        float ld = 0.0f;
+        if (KIND == 0) {
+            float *xr = rows + row * D;
+            for (int tl = wave; tl < g.n_tiles; tl += nw) {
+                const float4 a = w_eff[tl * 64 + lane];
+                const float4 b = b_eff[tl * 4 + q];
+                gf32x4 acc = {b.x, b.y, b.z, b.w};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[3], acc, 0, 0, 0);
+                const int t0 = 8 * tl + 2 * q;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int t = t0 + k;
+                    if (t < g.T && row_ok) {
+                        const float u = bounded4(k ? acc[2] : acc[0]), beta = bounded4(k ? acc[3] : acc[1]);
+                        const int phys = tgt_idx[t];
+                        const float2 st = tgt_st[t];
+                        const float v = fmaf(st.x, xr[phys], st.y);
+                        const float wl = fmaf(u, 0.5f, kAffC0);           // affine.py:33-34, log(alpha) up to 1e-10
+                        const float alpha = exp_lean(wl) + kAffMinScale;
+                        if (!INV) {
+                            xr[phys] = alpha * v + beta;
+                            ld += wl;
+                        } else {
+                            xr[phys] = (v - beta) * __builtin_amdgcn_rcpf(alpha);
+                            ld -= wl;
+                        }
+                    }
+                }
+            }
+            ld += __shfl_xor(ld, 16, kWave);
+            ld += __shfl_xor(ld, 32, kWave);
+            if (q == 0) ldpart[wave * 16 + j] = ld;
+            __syncthreads();
+            if (tid < nrows) {
+                float s = 0.0f;
+                for (int w = 0; w < nw; ++w) s += ldpart[w * 16 + tid];
+                logdet[row_base + tid] += s;
+            }
+        } else {
+            // parameters of the LU factors per sample into the LDS: [diag logits | U above | L below] (matrix.py:22-51)
+            for (int tl = wave; tl < g.n_tiles; tl += nw) {
+                const float4 a = w_eff[tl * 64 + lane];
+                const float4 b = b_eff[tl * 4 + q];
+                gf32x4 acc = {b.x, b.y, b.z, b.w};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[3], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 16 * tl + 4 * q + r;
+                    float hv = bounded4(acc[r]);
+                    hv = e < g.n_ch ? expf(hv) / 10.0f + 1.0f : hv / 10.0f;      // matrix.py:31-36
+                    Hs[j * g.h_stride + e] = hv;
+                }
+            }
+            __syncthreads();
+            const int n = g.n_ch, HW = g.hw;
+            const int n_off = n * (n - 1) / 2;
+            for (int t = tid; t < nrows * HW; t += nthr) {
+                const int s = t / HW, p = t - s * HW;
+                float *xr = rows + (row_base + s) * D;
+                const float *hr = Hs + s * g.h_stride;
+                float v[kGlowMaxCh];
+#pragma unroll
+                for (int c = 0; c < kGlowMaxCh; ++c)
+                    if (c < n) {
+                        const int e = c * HW + p;
+                        const float2 st = tgt_st[e];
+                        v[c] = fmaf(st.x, xr[tgt_idx[e]], st.y);
+                    }
+                // U entry (r, c), r < c: hr[n + r n - r (r + 1) / 2 + (c - r - 1)];  L entry (r, c), c < r:
+                // hr[n + n_off + r (r - 1) / 2 + c]   (triu_indices / tril_indices order, matrix.py:40-48)
+                if (!INV) {
+#pragma unroll
+                    for (int r = 0; r < kGlowMaxCh; ++r)
+                        if (r < n) {
+                            float acc = hr[r] * v[r];
+                            const int base = n + r * n - (r * (r + 1)) / 2 - r - 1;
+#pragma unroll
+                            for (int c = 0; c < kGlowMaxCh; ++c)
+                                if (c > r && c < n) acc = fmaf(hr[base + c], v[c], acc);
+                            v[r] = acc;
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < kGlowMaxCh; ++rr) {
+                        const int r = kGlowMaxCh - 1 - rr;
+                        if (r < n) {
+                            float acc = v[r];
+                            const int base = n + n_off + (r * (r - 1)) / 2;
+#pragma unroll
+                            for (int c = 0; c < kGlowMaxCh; ++c)
+                                if (c < r) acc = fmaf(hr[base + c], v[c], acc);
+                            v[r] = acc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < kGlowMaxCh; ++r)
+                        if (r < n) {
+                            float acc = v[r];
+                            const int base = n + n_off + (r * (r - 1)) / 2;
+#pragma unroll
+                            for (int c = 0; c < kGlowMaxCh; ++c)
+                                if (c < r) acc = fmaf(-hr[base + c], v[c], acc);
+                            v[r] = acc;
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < kGlowMaxCh; ++rr) {
+                        const int r = kGlowMaxCh - 1 - rr;
+                        if (r < n) {
+                            float acc = v[r];
+                            const int base = n + r * n - (r * (r + 1)) / 2 - r - 1;
+#pragma unroll
+                            for (int c = 0; c < kGlowMaxCh; ++c)
+                                if (c > r && c < n) acc = fmaf(-hr[base + c], v[c], acc);
+                            v[r] = acc / hr[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kGlowMaxCh; ++c)
+                    if (c < n) xr[tgt_idx[c * HW + p]] = v[c];
+                if (p == 0) {                                   // sum_r log U_rr, ONCE per sample
+                    float s_ld = 0.0f;
+                    for (int r = 0; r < n; ++r) s_ld += logf(hr[r]);
+                    logdet[row_base + s] += INV ? -s_ld : s_ld;
+                }
+            }
+        }
+        __syncthreads();                                        // V, ldpart, Hs are free again
+    }
+}
+
+// z = s * raw + t per column, in place: the flush of the pending maps behind the last coupling
+__global__ __launch_bounds__(kBlock) void k_rows_fma(float *rows, const float2 *__restrict__ st, long long N, int D4)
+{
+    const long long total = N * D4;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int c = (int)(i % D4);
+        float4 v = reinterpret_cast<float4 *>(rows)[i];
+        const float4 a = reinterpret_cast<const float4 *>(st)[2 * c], b = reinterpret_cast<const float4 *>(st)[2 * c + 1];
+        v.x = fmaf(a.x, v.x, a.y), v.y = fmaf(a.z, v.y, a.w);
+        v.z = fmaf(b.x, v.z, b.y), v.w = fmaf(b.z, v.w, b.w);
+        reinterpret_cast<float4 *>(rows)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rows_fma1(float *rows, const float2 *__restrict__ st, long long N, int D)
+{
+    const long long total = N * D;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const float2 a = st[(int)(i % D)];
+        rows[i] = fmaf(a.x, rows[i], a.y);
+    }
+}
+
+static inline int floor2(int v) { return v & ~1; }
+static inline int ceil2(int v) { return (v + 1) & ~1; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+// windows and buffers from the image's rectangle (rows [oy, oy + hi), columns [ox, ox + wi) of the 32x32 frame)
+static void glow_windows(GlowGeom &g)
+{
+    const int y0 = imax(g.oy - 1, 0), y1 = imin(g.oy + g.hi + 1, kGlowFrame);
+    const int x0 = imax(g.ox - 1, 0), x1 = imin(g.ox + g.wi + 1, kGlowFrame);
+    const int c1y0 = floor2(y0), c1y1 = ceil2(y1), c1x0 = floor2(x0), c1x1 = ceil2(x1);
+    g.a0y0 = c1y0 - 1, g.a0x0 = c1x0 - 1, g.a0h = c1y1 - c1y0 + 2, g.a0w = c1x1 - c1x0 + 2;
+    g.p1y0 = c1y0 / 2, g.p1x0 = c1x0 / 2, g.p1h = (c1y1 - c1y0) / 2, g.p1w = (c1x1 - c1x0) / 2;
+    const int qy0 = imax(g.p1y0 - 1, 0), qy1 = imin(g.p1y0 + g.p1h + 1, 16);
+    const int qx0 = imax(g.p1x0 - 1, 0), qx1 = imin(g.p1x0 + g.p1w + 1, 16);
+    const int c2y0 = floor2(qy0), c2y1 = ceil2(qy1), c2x0 = floor2(qx0), c2x1 = ceil2(qx1);
+    g.b1y0 = c2y0 - 1, g.b1x0 = c2x0 - 1, g.b1h = c2y1 - c2y0 + 2, g.b1w = c2x1 - c2x0 + 2;
+    g.p2y0 = c2y0 / 2, g.p2x0 = c2x0 / 2, g.p2h = (c2y1 - c2y0) / 2, g.p2w = (c2x1 - c2x0) / 2;
+    g.off_p1 = 4 * g.a0h * g.a0w;
+    g.off_p2 = g.off_p1 + 8 * g.b1h * g.b1w;
+    g.off_p3 = g.off_p2 + 800;
+    g.slot_floats = g.off_p3 + 64;
+}
+
+constexpr int kGlowLdsBytes = 160 * 1024;
+
+static int stage_rounds(int tasks_per_slot, int G, int groups, int nw)
+{
+    const int chunks = ((G * tasks_per_slot + 63) / 64) * groups;
+    return (chunks + nw - 1) / nw;
+}
+
+// Pick slots / block / channel groups: the largest modelled throughput (lane work that is useful / lane slots spent,
+// times how well the resident waves can cover each other's issue gaps), unless the caller fixed them.
+static bool glow_plan(GlowGeom &g, int want_slots, int want_block, int want_cg1, int want_cg2, int *block_out)
+{
+    const int fixed_bytes = 4 * g.fixed_floats, slot_bytes = 4 * g.slot_floats;
+    double best = -1.0;
+    int bs = 1, bb = 256, b1 = 8, b2 = 8;
+    const int blocks[3] = {1024, 512, 256};
+    const int cgs[3] = {8, 4, 2};
+    for (int bi = 0; bi < 3; ++bi) {
+        const int block = blocks[bi];
+        if (want_block && block != want_block) continue;
+        const int nw = block / 64;
+        for (int G = 1; G <= kGlowMaxRows; ++G) {
+            if (want_slots && G != want_slots) continue;
+            const int bytes = fixed_bytes + G * slot_bytes;
+            if (bytes > kGlowLdsBytes - 1024) break;
+            int wgs = imin(kGlowLdsBytes / bytes, 2048 / block);
+            const int wps = wgs * nw / 4;                         // waves per SIMD
+            const int NS = G * (kGlowMaxRows / G);
+            for (int i1 = 0; i1 < 3; ++i1)
+                for (int i2 = 0; i2 < 3; ++i2) {
+                    const int cg1 = cgs[i1], cg2 = cgs[i2];
+                    if ((want_cg1 && cg1 != want_cg1) || (want_cg2 && cg2 != want_cg2)) continue;
+                    // wave-instructions per round of each stage (fma + patch loads), rounds per G samples
+                    const double c1 = 4 * (36.0 * cg1 + 10), c2 = 8 * (36.0 * cg2 + 10), c3 = 8 * (36.0 + 10);
+                    const double spent = (NS / G) * (stage_rounds(g.p1h * g.p1w, G, 8 / cg1, nw) * c1 +
+                                                     stage_rounds(g.p2h * g.p2w, G, 8 / cg2, nw) * c2 +
+                                                     stage_rounds(16, G, 4, nw) * c3) * nw
+                                         + 60.0 * g.n_tiles;       // Linear tiles + transform, per 16 samples
+                    const double useful = NS * (g.p1h * g.p1w * 4 * 288.0 + g.p2h * g.p2w * 8 * 288.0 + 16 * 8 * 144.0) / 64.0;
+                    double eff = useful / spent;
+                    eff *= wps >= 4 ? 1.0 : wps == 3 ? 0.97 : wps == 2 ? 0.9 : 0.55;
+                    if (eff > best) best = eff, bs = G, bb = block, b1 = cg1, b2 = cg2;
+                }
+        }
+    }
+    g.slots = bs, g.cg1 = b1, g.cg2 = b2;
+    g.tile_rows = bs * (kGlowMaxRows / bs);
+    *block_out = bb;
+    return best > 0.0;
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+namespace {
+
+int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, const char *fn)
+{
+    if (!L) return fail(TFK_EINVAL, "%s: null layer", fn);
+    if (L->kind != 0 && L->kind != 1) return fail(TFK_EINVAL, "%s: kind %d (0 affine, 1 invertible 1x1 convolution)", fn, L->kind);
+    if (L->c_in < 1 || L->hi < 1 || L->wi < 1 || L->oy < 0 || L->ox < 0 || L->oy + L->hi > kGlowFrame ||
+        L->ox + L->wi > kGlowFrame)
+        return fail(TFK_EINVAL, "%s: source image (%d, %d, %d) at (%d, %d) does not fit the %dx%d frame", fn, L->c_in,
+                    L->hi, L->wi, L->oy, L->ox, kGlowFrame, kGlowFrame);
+    if (L->T < 1 || L->n_params < 1 || D < 1) return fail(TFK_EINVAL, "%s: T = %d, n_params = %d, D = %d", fn, L->T, L->n_params, D);
+    if (L->kind == 0 && L->n_params != 2 * L->T)
+        return fail(TFK_EINVAL, "%s: an affine coupling of %d targets takes %d parameters, got %d", fn, L->T, 2 * L->T, L->n_params);
+    if (L->kind == 1 && (L->n_ch < 1 || L->n_ch > kGlowMaxCh || L->hw < 1 || L->n_ch * L->hw != L->T ||
+                         L->n_params != L->n_ch + L->n_ch * (L->n_ch - 1)))
+        return fail(TFK_EINVAL, "%s: 1x1 convolution with %d channels x %d pixels (T = %d, n_params = %d): need "
+                    "1 <= channels <= %d, T = channels * pixels, n_params = n + n (n - 1)", fn, L->n_ch, L->hw, L->T,
+                    L->n_params, kGlowMaxCh);
+    g = GlowGeom{};
+    g.c_in = L->c_in, g.hi = L->hi, g.wi = L->wi, g.oy = L->oy, g.ox = L->ox;
+    g.T = L->T, g.n_params = L->n_params, g.n_tiles = (L->n_params + 15) / 16, g.D = D;
+    g.kind = L->kind, g.n_ch = L->n_ch, g.hw = L->hw;
+    g.h_stride = g.n_tiles * 16 + 1;
+    g.fixed_floats = 512 + (L->kind == 1 ? ((kGlowMaxRows * g.h_stride + 3) & ~3) : 0);
+    glow_windows(g);
+    if (!glow_plan(g, L->slots, L->block, L->cg1, L->cg2, block))
+        return fail(TFK_EINVAL, "%s: no launch shape fits (slots %d, block %d, channel groups %d / %d; %d B per slot)",
+                    fn, L->slots, L->block, L->cg1, L->cg2, 4 * g.slot_floats);
+    return TFK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfk_glow_plan(const tfk_glow_layer *layer, int32_t D, int32_t *slots, int32_t *block, int32_t *cg1, int32_t *cg2,
+                  int32_t *lds_bytes, int32_t *tile_rows)
+{
+    GlowGeom g;
+    int blk = 0;
+    const int rc = glow_geometry(layer, D, g, &blk, "tfk_glow_plan");
+    if (rc != TFK_OK) return rc;
+    if (slots) *slots = g.slots;
+    if (block) *block = blk;
+    if (cg1) *cg1 = g.cg1;
+    if (cg2) *cg2 = g.cg2;
+    if (lds_bytes) *lds_bytes = 4 * (g.fixed_floats + g.slots * g.slot_floats);
+    if (tile_rows) *tile_rows = g.tile_rows;
+    return TFK_OK;
+}
+
+int64_t tfk_glow_weight_floats(int32_t c_in) { return c_in < 1 ? 0 : gw_total(c_in); }
+
+int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tfk_glow_layer *layer, int32_t inverse,
+                      void *stream)
+{
+    const char *fn = "tfk_glow_coupling";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    GlowGeom g;
+    int block = 0;
+    const int rc = glow_geometry(layer, D, g, &block, fn);
+    if (rc != TFK_OK) return rc;
+    if (N == 0) return TFK_OK;
+    if (!rows || !logdet || !layer->src_idx || !layer->src_st || !layer->tgt_idx || !layer->tgt_st || !layer->weights ||
+        !layer->bg1 || !layer->bg2 || !layer->w_eff || !layer->b_eff)
+        return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(layer->w_eff) || !aligned16(layer->b_eff) || (reinterpret_cast<uintptr_t>(layer->src_st) & 7u) ||
+        (reinterpret_cast<uintptr_t>(layer->tgt_st) & 7u))
+        return fail(TFK_EINVAL, "%s: w_eff / b_eff need 16-byte, src_st / tgt_st 8-byte alignment", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = 4 * (size_t)(g.fixed_floats + g.slots * g.slot_floats);
+    const int wgs_per_cu = imax(1, imin((int)(kGlowLdsBytes / lds), 2048 / block));
+    const int64_t tiles = (N + g.tile_rows - 1) / g.tile_rows;
+    int64_t grid = layer->grid > 0 ? layer->grid : (int64_t)cu_count() * wgs_per_cu;
+    if (grid > tiles) grid = tiles;
+    static bool attr_done[4] = {false, false, false, false};
+#define TFK_GLOW(K, I)                                                                                               \
+    do {                                                                                                             \
+        auto kern = k_glow_coupling<K, I>;                                                                           \
+        if (!attr_done[2 * K + I]) {                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    kGlowLdsBytes) != hipSuccess)                                                    \
+                return fail(TFK_ELAUNCH, "%s: cannot raise the dynamic LDS limit: %s", fn,                           \
+                            hipGetErrorString(hipGetLastError()));                                                   \
+            attr_done[2 * K + I] = true;                                                                             \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, s, rows, logdet, (long long)N, g,           \
+                           layer->src_idx, reinterpret_cast<const float2 *>(layer->src_st), layer->tgt_idx,          \
+                           reinterpret_cast<const float2 *>(layer->tgt_st), layer->weights, layer->bg1, layer->bg2,  \
+                           reinterpret_cast<const float4 *>(layer->w_eff),                                           \
+                           reinterpret_cast<const float4 *>(layer->b_eff));                                          \
+    } while (0)
+    if (layer->kind == 0 && !inverse) TFK_GLOW(0, false);
+    else if (layer->kind == 0) TFK_GLOW(0, true);
+    else if (!inverse) TFK_GLOW(1, false);
+    else TFK_GLOW(1, true);
+#undef TFK_GLOW
+    return check_launch(fn);
+}
+
+int tfk_rows_fma(float *rows, const float *st, int64_t N, int32_t D, void *stream)
+{
+    const char *fn = "tfk_rows_fma";
+    if (N < 0 || D < 1) return fail(TFK_EINVAL, "%s: N = %lld, D = %d", fn, (long long)N, D);
+    if (N == 0) return TFK_OK;
+    if (!rows || !st) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((D % 4) == 0 && aligned16(rows) && aligned16(st))
+        hipLaunchKernelGGL(k_rows_fma, dim3(grid_for(N * (D / 4), kBlock)), dim3(kBlock), 0, s, rows,
+                           reinterpret_cast<const float2 *>(st), (long long)N, D / 4);
+    else
+        hipLaunchKernelGGL(k_rows_fma1, dim3(grid_for(N * (int64_t)D, kBlock)), dim3(kBlock), 0, s, rows,
+                           reinterpret_cast<const float2 *>(st), (long long)N, D);
+    return check_launch(fn);
+}
+
+}  // extern "C"

@@ -140,7 +140,7 @@ static int lrs_coupling(const float *x, const float *h, float *z, float *logdet,
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    const int64_t grid = n_tiles < (int64_t)kCUs * per_cu ? n_tiles : (int64_t)kCUs * per_cu;
+    const int64_t grid = n_tiles < (int64_t)cu_count() * per_cu ? n_tiles : (int64_t)cu_count() * per_cu;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (K == 8)
         hipLaunchKernelGGL((k_lrs_coupling<8, INVERSE>), dim3((unsigned)grid), dim3(kBlock), lds, s, x, h, z, logdet,
@@ -451,7 +451,7 @@ int tfk_lrs_coupling_bwd(const float *x, const float *h, float *g, const float *
     C.scale = (float)(1.0 - 1e-2 * (double)K);
     C.c = (float)log(exp(1.0 - 1e-5) - 1.0);
     const int64_t n_tiles = (N * (int64_t)T + kBlock - 1) / kBlock;
-    const int grid = (int)(n_tiles < (int64_t)kCUs * 4 ? n_tiles : (int64_t)kCUs * 4);
+    const int grid = (int)(n_tiles < (int64_t)cu_count() * 4 ? n_tiles : (int64_t)cu_count() * 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define TFK_LB(KT_, INV_)                                                                                     \
     hipLaunchKernelGGL((k_lrs_coupling_bwd<KT_, INV_>), dim3(grid), dim3(kBlock), 0, s, x, h, g, gld, gh,     \

@@ -109,7 +109,7 @@ static int launch_made(const float *z, float *x, float *logdet, int64_t N, int D
         return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
     }
     int64_t grid = (N + block - 1) / block;
-    if (grid > kMaxGrid) grid = kMaxGrid;
+    if (grid > max_grid()) grid = max_grid();
     if (divide)
         hipLaunchKernelGGL((k_made_affine_sequential<HMAX, true>), dim3((int)grid), dim3(block), lds, s, z, x, logdet,
                            (long long)N, D, W1t, b1, W2, b2, accumulate);
@@ -230,7 +230,7 @@ static int launch_made_rqs(const float *z, float *x, float *logdet, int64_t N, i
         return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
     }
     int64_t grid = (N + block - 1) / block;
-    if (grid > kMaxGrid) grid = kMaxGrid;
+    if (grid > max_grid()) grid = max_grid();
     hipLaunchKernelGGL((k_made_rqs_sequential<HMAX, KT, LRS, CT>), dim3((int)grid), dim3(block), lds, s, z, x, logdet,
                        (long long)N, D, W1t, b1, W2, b2, C, accumulate);
     return check_launch(fn);

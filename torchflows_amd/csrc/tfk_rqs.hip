@@ -286,7 +286,7 @@ static int rqs_coupling(const float *x, const float *h, float *z, float *logdet,
     const int max_blocks = 2048 / tile > 28 ? 28 : 2048 / tile;     // 32 waves per CU, ~7 per SIMD by VGPRs
     if (per_cu < 1) per_cu = 1;
     if (per_cu > max_blocks) per_cu = max_blocks;
-    int64_t grid = n_tiles < (int64_t)kCUs * per_cu ? n_tiles : (int64_t)kCUs * per_cu;
+    int64_t grid = n_tiles < (int64_t)cu_count() * per_cu ? n_tiles : (int64_t)cu_count() * per_cu;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int h_vec_ok = aligned16(h) ? 1 : 0;
 
@@ -298,7 +298,7 @@ static int rqs_coupling(const float *x, const float *h, float *z, float *logdet,
             const int64_t tiles = (N + Rr - 1) / Rr;
             int pc = (int)((160 * 1024) / lds2);
             if (pc > 8) pc = 8;
-            const int64_t g = tiles < (int64_t)kCUs * pc ? tiles : (int64_t)kCUs * pc;
+            const int64_t g = tiles < (int64_t)cu_count() * pc ? tiles : (int64_t)cu_count() * pc;
             if (K == 8)
                 hipLaunchKernelGGL((k_rqs_coupling_dma<8, INVERSE>), dim3((unsigned)g), dim3(kBlock), lds2, s,
                                    x, h, z, logdet, (long long)N, D, tgt_idx, T, T_shift, C, accumulate, inplace ? 1 : 0);

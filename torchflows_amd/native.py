@@ -45,9 +45,10 @@ SYMBOLS = (
     "tfk_made_affine_sequential", "tfk_made_rqs_sequential_lds_bytes", "tfk_made_rqs_sequential",
     "tfk_made_lrs_sequential_lds_bytes", "tfk_made_lrs_sequential",
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
+    "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
 )
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class NativeError(RuntimeError):
@@ -57,6 +58,18 @@ class NativeError(RuntimeError):
 _vp = C.c_void_p
 _i32 = C.c_int32
 _i64 = C.c_int64
+
+
+
+class GlowLayer(C.Structure):
+    """``tfk_glow_layer`` of include/tfk.h: one convolutional coupling of an image flow, everything that does not
+    depend on the sample prepared by the caller (torchflows_amd/image_program.py)."""
+    _fields_ = [("kind", _i32), ("c_in", _i32), ("hi", _i32), ("wi", _i32), ("oy", _i32), ("ox", _i32),
+                ("T", _i32), ("n_params", _i32), ("n_ch", _i32), ("hw", _i32),
+                ("slots", _i32), ("block", _i32), ("cg1", _i32), ("cg2", _i32), ("grid", _i32),
+                ("src_idx", _vp), ("src_st", _vp), ("tgt_idx", _vp), ("tgt_st", _vp),
+                ("weights", _vp), ("bg1", _vp), ("bg2", _vp), ("w_eff", _vp), ("b_eff", _vp)]
+
 
 _lib: Optional[C.CDLL] = None
 calls = 0   # number of kernel entry points invoked (tests assert the HIP path really ran)
@@ -137,6 +150,12 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
     L.tfk_bounded_sigmoid.argtypes = [_vp, _vp, _i64, C.c_float, C.c_float, _vp]
     L.tfk_conv1x1_frame.argtypes = [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
+    L.tfk_glow_weight_floats.argtypes = [_i32]
+    L.tfk_glow_weight_floats.restype = _i64
+    pi = C.POINTER(_i32)
+    L.tfk_glow_plan.argtypes = [C.POINTER(GlowLayer), _i32, pi, pi, pi, pi, pi, pi]
+    L.tfk_glow_coupling.argtypes = [_vp, _vp, _i64, _i32, C.POINTER(GlowLayer), _i32, _vp]
+    L.tfk_rows_fma.argtypes = [_vp, _vp, _i64, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -752,6 +771,39 @@ def flow_run_mfma(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params
         rc = lib().tfk_flow_run_mfma(*args, _stream(x))
     calls += 1
     _check(rc, name)
+
+
+def glow_plan(layer: GlowLayer, D: int) -> dict:
+    """The launch shape libtfk picks for this layer (or the overrides, validated)."""
+    vals = [_i32(0) for _ in range(6)]
+    rc = lib().tfk_glow_plan(C.byref(layer), D, *[C.byref(v) for v in vals])
+    _check(rc, "tfk_glow_plan")
+    return dict(zip(("slots", "block", "cg1", "cg2", "lds_bytes", "tile_rows"), (int(v.value) for v in vals)))
+
+
+def glow_coupling(rows: torch.Tensor, logdet: torch.Tensor, layer: GlowLayer, inverse: bool = False) -> None:
+    """One convolutional coupling in place on the rows (conditioner, bounded output, transform, log-det added)."""
+    global calls
+    N, D = _rows(rows, "tfk_glow_coupling")
+    if logdet.numel() != N:
+        raise NativeError(f"tfk_glow_coupling: logdet has {logdet.numel()} elements, expected {N}")
+    with _device_guard(rows):
+        rc = lib().tfk_glow_coupling(_f32(rows, "tfk_glow_coupling"), _f32(logdet, "tfk_glow_coupling"), N, D,
+                                     C.byref(layer), 1 if inverse else 0, _stream(rows))
+    calls += 1
+    _check(rc, "tfk_glow_coupling")
+
+
+def rows_fma(rows: torch.Tensor, st: torch.Tensor) -> None:
+    """rows[n, d] = st[d, 0] * rows[n, d] + st[d, 1] in place."""
+    global calls
+    N, D = _rows(rows, "tfk_rows_fma")
+    if st.numel() != 2 * D:
+        raise NativeError(f"tfk_rows_fma: st has {st.numel()} elements, expected 2 * {D}")
+    with _device_guard(rows):
+        rc = lib().tfk_rows_fma(_f32(rows, "tfk_rows_fma"), _f32(st, "tfk_rows_fma"), N, D, _stream(rows))
+    calls += 1
+    _check(rc, "tfk_rows_fma")
 
 
 def sum_f32(values: torch.Tensor) -> torch.Tensor:
