@@ -426,16 +426,21 @@ int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float h
  * (s, t) interleaved: the value the layer sees is s * rows[n, idx] + t (the deferred ActNorm layers in front of it;
  * (1, 0) = none); targets are stored in final form.
  * The caller evaluates everything that does not depend on the sample (see torchflows_amd/image_program.py):
- *   weights  tfk_glow_weight_floats(c_in) floats: first ConvModifier W (4, c_in), b (4) | conv1 W as [ci=4][co=8][3][3],
- *            b1 (8), BatchNorm-1 scale (8), shift (8) | conv2 W as [ci=8][co=8][3][3], b2, scale, shift (8 each) |
- *            conv3 W as [ci=8][co=4][3][3], b3 (4) | second ConvModifier's 4 weights times BatchNorm-3's scales, then its
+ *   weights  tfk_glow_weight_floats(c_in) floats: first ConvModifier W (4, c_in), b (4) | conv1 W as [ci=4][3][3][co=8],
+ *            b1 (8), BatchNorm-1 scale (8), shift (8) | conv2 W as [ci=8][3][3][co=8], b2, scale, shift (8 each) |
+ *            conv3 W as [ci=8][3][3][co=4], b3 (4) | second ConvModifier's 4 weights times BatchNorm-3's scales, then its
  *            bias + sum_c weight_c shift_c   (BatchNorm in inference form: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
  *   bg1, bg2 (8, 16, 16) and (8, 8, 8): the outputs of conv blocks 1 and 2 for the all-bias image (every pixel of the
  *            (4, 32, 32) frame = the first ConvModifier's bias), i.e. what the blocks produce wherever the source image's
  *            receptive field does not reach; only the window it does reach is computed per sample
- *   w_eff    ceil(n_params / 16) tiles of [64 lanes][4] floats: tile t, lane l, k-step ks = W_eff[16 t + (l & 15)][4 ks + (l >> 4)]
- *            where W_eff (n_params, 16) are the Linear layer's columns of the 4x4 interior of the (1, 10, 10) image
- *   b_eff    16 * tiles floats: Linear bias + its 84 frame columns times the second ConvModifier's bias (zero padded)
+ *   w_eff    tiles of [64 lanes][4] floats: tile t, lane l, k-step ks = W[16 t + (l & 15)][4 ks + (l >> 4)], where the rows
+ *            of W are rows of W_eff (n_params, 16) -- the Linear layer's columns of the 4x4 interior of the (1, 10, 10)
+ *            image -- in KERNEL ORDER.  1x1 convolution: ceil(n_params / 16) tiles, rows in the order of h.  Affine:
+ *            2 * ceil(T / 16) tiles; for the target listed at position 16 m + j of tgt_idx, row 32 m + j is its scale
+ *            logit (h[n, t, 0]) and row 32 m + 16 + j its shift (h[n, t, 1]); rows of padding are zero
+ *   b_eff    16 * tiles floats in the same row order: Linear bias + its 84 frame columns times the second ConvModifier's bias
+ * tgt_idx (affine) may list the targets in any order -- ascending physical position makes the 16 targets of a tile pair
+ * neighbours in the row -- padded, like tgt_st, to a multiple of 16 entries.
  * Supported: first ConvModifier with a 1x1 kernel (hi, wi <= 32 with 32 - hi, 32 - wi even: it sits at (oy, ox) =
  * ((32 - hi) / 2, (32 - wi) / 2)), ConvNet kernels (8, 8, 4), 1x1 convolutions of <= 16 channels.
  * slots / block / cg1 / cg2 / grid = 0 let the library choose the launch shape (tfk_glow_plan reports it). */
@@ -449,8 +454,8 @@ typedef struct tfk_glow_layer {
     int32_t slots, block, cg1, cg2, grid;   /* launch shape overrides, 0 = default */
     const int32_t *src_idx;    /* device int32[c_in * hi * wi] */
     const float *src_st;       /* device float[2 * c_in * hi * wi] */
-    const int32_t *tgt_idx;    /* device int32[T] */
-    const float *tgt_st;       /* device float[2 * T] */
+    const int32_t *tgt_idx;    /* device int32[T]; affine: padded to 16 * ceil(T / 16) entries */
+    const float *tgt_st;       /* device float[2 * T], padded likewise (any values), 8-byte aligned */
     const float *weights, *bg1, *bg2, *w_eff, *b_eff;
 } tfk_glow_layer;
 int64_t tfk_glow_weight_floats(int32_t c_in);

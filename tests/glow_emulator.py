@@ -32,11 +32,11 @@ def _unpack_weights(w, c_in):
         o += n
         return v
     out = dict(Wm=take(4 * c_in).view(4, c_in), bm=take(4))
-    out["W1"] = take(288).view(4, 8, 3, 3).permute(1, 0, 2, 3)     # packed [ci][co][3][3]
+    out["W1"] = take(288).view(4, 3, 3, 8).permute(3, 0, 1, 2)     # packed [ci][ky][kx][co]
     out["b1"], out["sc1"], out["sh1"] = take(8), take(8), take(8)
-    out["W2"] = take(576).view(8, 8, 3, 3).permute(1, 0, 2, 3)
+    out["W2"] = take(576).view(8, 3, 3, 8).permute(3, 0, 1, 2)
     out["b2"], out["sc2"], out["sh2"] = take(8), take(8), take(8)
-    out["W3"] = take(288).view(8, 4, 3, 3).permute(1, 0, 2, 3)
+    out["W3"] = take(288).view(8, 3, 3, 4).permute(3, 0, 1, 2)
     out["b3"] = take(4)
     out["m2"], out["bm2"] = take(4), take(1)
     assert o == w.numel()
@@ -76,17 +76,18 @@ def run_step(rows, logdet, step, check_windows=True):
         assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
     p3 = _block(p2, w["W3"], w["b3"])                                   # (N, 4, 4, 4), BatchNorm 3 folded below
     V = torch.einsum("c,nchw->nhw", w["m2"], p3).reshape(N, 16) + w["bm2"]
-    n_tiles = (L.n_params + 15) // 16
-    A = dd(w_eff).view(n_tiles, 4, 16, 4)            # [t][q][i][ks] = W_eff[16 t + i][4 ks + q]
-    W_eff = A.permute(0, 2, 3, 1).reshape(n_tiles * 16, 16)
-    h = V @ W_eff.t() + dd(b_eff)
-    h = h[:, :L.n_params]
+    n_tiles = w_eff.numel() // 256
+    A = dd(w_eff).view(n_tiles, 4, 16, 4)            # [t][q][i][ks] = W[16 t + i][4 ks + q]
+    W_k = A.permute(0, 2, 3, 1).reshape(n_tiles * 16, 16)
+    h = V @ W_k.t() + dd(b_eff)
     h = 4.0 / (1.0 + torch.exp(-h)) - 2.0
-    tst = dd(tgt_st).view(-1, 2)
-    tgt = tgt_idx.long()
+    tst = dd(tgt_st).view(-1, 2)[:L.T]             # (affine tables are padded to whole groups of 16 targets)
+    tgt = tgt_idx.long()[:L.T]
     xb = rows[:, tgt] * tst[:, 0] + tst[:, 1]
     if L.kind == 0:
-        u, beta = h[:, 0::2], h[:, 1::2]
+        rank = torch.arange(L.T)                   # target of rank 16 m + j: logit in row 32 m + j, shift in 32 m + 16 + j
+        row_u = 32 * (rank // 16) + rank % 16
+        u, beta = h[:, row_u], h[:, row_u + 16]
         wl = u * 0.5 + C0
         alpha = torch.exp(wl) + 1e-10
         if not step.inverse:
@@ -97,6 +98,7 @@ def run_step(rows, logdet, step, check_windows=True):
             logdet -= torch.log(alpha).sum(1)
     else:
         n, HW = L.n_ch, L.hw
+        h = h[:, :L.n_params]
         n_off = n * (n - 1) // 2
         ud = torch.exp(h[:, :n]) / 10 + 1
         U = torch.zeros(N, n, n, dtype=torch.float64)

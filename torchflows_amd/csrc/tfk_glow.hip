@@ -32,11 +32,14 @@
 // a wave works on the same channels).  The 16 numbers per sample that feed the Linear layer are collected for the
 // whole tile; then the Linear layer runs as v_mfma_f32_16x16x4_f32 tiles (16 parameters x 16 samples, K = 16), each
 // lane receiving the 4 parameters = 2 affine targets of one sample, transforms them and accumulates the log-det.
+#include <cstdlib>
+
 #include "tfk_common.h"
 
 namespace tfk {
 
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGlowMaxRows = 16;        // samples per tile = MFMA N
 constexpr int kGlowMaxCh = 16;          // 1x1 convolution: target channels kept in registers
@@ -55,6 +58,7 @@ struct GlowGeom {
     int kind, n_ch, hw;                 // 1x1 convolution: channels, pixels
     int cg1, cg2;                       // output channels per lane task in conv block 1 / 2
     int h_stride;                       // kind 1: floats per sample in the parameter buffer
+    int skip;                           // timing ablations only (TFK_GLOW_SKIP): 1 no S0, 2 no conv blocks, 4 no Linear / transform
 };
 
 // offsets into the packed fp32 weights of a layer (see tfk.h: tfk_glow_layer.weights)
@@ -70,18 +74,22 @@ __host__ __device__ inline int gw_total(int c_in) { return gw_m2(c_in) + 5; }
 
 // conv3x3(pad 1) -> ReLU -> MaxPool2d(2) -> per-channel scale / shift for one window of pooled pixels, all resident
 // slots at once.  Lane task = one pooled pixel x CG output channels; a wave's 64 tasks share the channel group, so its
-// weights are wave-uniform (scalar loads).  Input buffer: origin = (first conv row - 1, first conv column - 1), so the
-// 4x4 patch of pooled pixel (ly, lx) of the window starts at buffer (2 ly, 2 lx); even row width: aligned float2 reads.
+// weights are wave-uniform: scalar loads, packed [ci][ky][kx][co] so that two neighbouring output channels are one SGPR
+// pair and one v_pk_fma_f32 updates both (the patch value is broadcast by op_sel): 18 CG packed fmas per input channel
+// (measured on MI355X, tools/micro/rates.hip: v_pk_fma_f32 55 TMAC/s against 31 for v_fmac_f32).  Input buffer: origin =
+// (first conv row - 1, first conv column - 1), so the 4x4 patch of pooled pixel (ly, lx) of the window starts at buffer
+// (2 ly, 2 lx); even row width: aligned float2 reads.
 template <int CI, int CO, int CG, bool AFFINE>
 __device__ __forceinline__ void conv_stage(float *slot0, int slot_floats, int in_off, int ih, int iw, int out_off,
                                            int oh, int ow, int oy0, int ox0, int ph, int pw, int G,
                                            const float *__restrict__ w, const float *__restrict__ bias,
                                            const float *__restrict__ sc, const float *__restrict__ sh)
 {
+    static_assert(CG % 2 == 0 && CO % CG == 0, "channel groups are whole SGPR pairs");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int per_slot = ph * pw, n = G * per_slot;
     const int chunks = (n + 63) >> 6;
-    constexpr int NG = CO / CG;
+    constexpr int NG = CO / CG, CP = CG / 2;
     const int plane_in = ih * iw, plane_out = oh * ow;
     for (int c = wave; c < chunks * NG; c += nw) {
         const int cgi = __builtin_amdgcn_readfirstlane(c / chunks);
@@ -91,10 +99,10 @@ __device__ __forceinline__ void conv_stage(float *slot0, int slot_floats, int in
         const int slot = tt / per_slot, rem = tt - slot * per_slot;
         const int ly = rem / pw, lx = rem - ly * pw;
         const float *ip = slot0 + slot * slot_floats + in_off + (2 * ly) * iw + 2 * lx;
-        float acc[CG][4];
+        gf32x2 acc[CP][4];
 #pragma unroll
-        for (int co = 0; co < CG; ++co) acc[co][0] = acc[co][1] = acc[co][2] = acc[co][3] = 0.0f;
-        const float *wg = w + cgi * (CG * 9);
+        for (int cp = 0; cp < CP; ++cp) acc[cp][0] = acc[cp][1] = acc[cp][2] = acc[cp][3] = gf32x2{0.0f, 0.0f};
+        const float *wg = w + cgi * CG;
 #pragma unroll 1
         for (int ci = 0; ci < CI; ++ci) {
             float p[4][4];
@@ -104,18 +112,18 @@ __device__ __forceinline__ void conv_stage(float *slot0, int slot_floats, int in
                 const float2 b = *reinterpret_cast<const float2 *>(ip + r * iw + 2);
                 p[r][0] = a.x, p[r][1] = a.y, p[r][2] = b.x, p[r][3] = b.y;
             }
-            const float *wc = wg + ci * (CO * 9);
+            const float *wc = wg + ci * (9 * CO);
 #pragma unroll
-            for (int co = 0; co < CG; ++co)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float wv = wc[co * 9 + ky * 3 + kx];
-                        acc[co][0] = fmaf(wv, p[ky][kx], acc[co][0]);
-                        acc[co][1] = fmaf(wv, p[ky][kx + 1], acc[co][1]);
-                        acc[co][2] = fmaf(wv, p[ky + 1][kx], acc[co][2]);
-                        acc[co][3] = fmaf(wv, p[ky + 1][kx + 1], acc[co][3]);
+                    for (int cp = 0; cp < CP; ++cp) {
+                        const gf32x2 wv = *reinterpret_cast<const gf32x2 *>(wc + (ky * 3 + kx) * CO + 2 * cp);
+                        acc[cp][0] = __builtin_elementwise_fma(wv, gf32x2{p[ky][kx], p[ky][kx]}, acc[cp][0]);
+                        acc[cp][1] = __builtin_elementwise_fma(wv, gf32x2{p[ky][kx + 1], p[ky][kx + 1]}, acc[cp][1]);
+                        acc[cp][2] = __builtin_elementwise_fma(wv, gf32x2{p[ky + 1][kx], p[ky + 1][kx]}, acc[cp][2]);
+                        acc[cp][3] = __builtin_elementwise_fma(wv, gf32x2{p[ky + 1][kx + 1], p[ky + 1][kx + 1]}, acc[cp][3]);
                     }
             ip += plane_in;
         }
@@ -123,8 +131,8 @@ __device__ __forceinline__ void conv_stage(float *slot0, int slot_floats, int in
             float *op = slot0 + slot * slot_floats + out_off + (cgi * CG) * plane_out + (oy0 + ly) * ow + ox0 + lx;
 #pragma unroll
             for (int co = 0; co < CG; ++co) {
-                const int ch = cgi * CG + co;
-                float m = fmaxf(fmaxf(acc[co][0], acc[co][1]), fmaxf(acc[co][2], acc[co][3])) + bias[ch];
+                const int ch = cgi * CG + co, cp = co >> 1, e = co & 1;
+                float m = fmaxf(fmaxf(acc[cp][0][e], acc[cp][1][e]), fmaxf(acc[cp][2][e], acc[cp][3][e])) + bias[ch];
                 m = fmaxf(m, 0.0f);                       // max of ReLUs = ReLU of the max (bias shared by the window)
                 if (AFFINE) m = fmaf(sc[ch], m, sh[ch]);
                 op[co * plane_out] = m;
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
 
         for (int s0 = 0; s0 < g.tile_rows; s0 += G) {
             // ---- S0: pending map + ConvModifier (1x1 convolution c_in -> 4) into the image's rectangle ----
+            if (!(g.skip & 1))
             for (int t = tid; t < G * npix; t += nthr) {
                 const int slot = t / npix, pix = t - slot * npix;
                 const int iy = pix / g.wi, ix = pix - iy * g.wi;
@@ -215,14 +224,30 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                 if (row > N - 1) row = N - 1;
                 const float *xr = rows + row * D;
                 float o0 = bm[0], o1 = bm[1], o2 = bm[2], o3 = bm[3];
-                for (int c = 0; c < g.c_in; ++c) {
-                    const int e = c * npix + pix;
-                    const float2 st = src_st[e];
-                    const float v = fmaf(st.x, xr[src_idx[e]], st.y);
-                    o0 = fmaf(wts[c], v, o0);
-                    o1 = fmaf(wts[g.c_in + c], v, o1);
-                    o2 = fmaf(wts[2 * g.c_in + c], v, o2);
-                    o3 = fmaf(wts[3 * g.c_in + c], v, o3);
+                for (int c0 = 0; c0 < g.c_in; c0 += 4) {             // four channels' loads in flight together
+                    int idx[4];
+                    float2 st[4];
+                    float raw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u < g.c_in ? c0 + u : g.c_in - 1;
+                        const int e = c * npix + pix;
+                        idx[u] = src_idx[e];
+                        st[u] = src_st[e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) raw[u] = xr[idx[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u;
+                        const bool on = c < g.c_in;
+                        const int cc = on ? c : 0;
+                        const float v = on ? fmaf(st[u].x, raw[u], st[u].y) : 0.0f;
+                        o0 = fmaf(wts[cc], v, o0);
+                        o1 = fmaf(wts[g.c_in + cc], v, o1);
+                        o2 = fmaf(wts[2 * g.c_in + cc], v, o2);
+                        o3 = fmaf(wts[3 * g.c_in + cc], v, o3);
+                    }
                 }
                 float *a = slot0 + slot * g.slot_floats + (g.oy + iy - g.a0y0) * g.a0w + (g.ox + ix - g.a0x0);
                 const int plane = g.a0h * g.a0w;
@@ -231,6 +256,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
             __syncthreads();
             // ---- S1 .. S3: the three conv blocks on their windows ----
             const int ci = g.c_in;
+            if (!(g.skip & 2)) {
             conv_stage_cg<4, 8, true>(g.cg1, slot0, g.slot_floats, 0, g.a0h, g.a0w, g.off_p1, g.b1h, g.b1w,
                                       g.p1y0 - g.b1y0, g.p1x0 - g.b1x0, g.p1h, g.p1w, G, wts + gw_w1(ci),
                                       wts + gw_b1(ci), wts + gw_b1(ci) + 8, wts + gw_b1(ci) + 16);
@@ -239,9 +265,10 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                                       g.p2y0 + 1, g.p2x0 + 1, g.p2h, g.p2w, G, wts + gw_w2(ci), wts + gw_b2(ci),
                                       wts + gw_b2(ci) + 8, wts + gw_b2(ci) + 16);
             __syncthreads();
-            conv_stage<8, 4, 1, false>(slot0, g.slot_floats, g.off_p2, 10, 10, g.off_p3, 4, 4, 0, 0, 4, 4, G,
+            conv_stage<8, 4, 2, false>(slot0, g.slot_floats, g.off_p2, 10, 10, g.off_p3, 4, 4, 0, 0, 4, 4, G,
                                        wts + gw_w3(ci), wts + gw_b3(ci), nullptr, nullptr);
             __syncthreads();
+            }
             // ---- S4: BatchNorm 3 + second ConvModifier (4 -> 1 channel), folded on the host ----
             for (int t = tid; t < G * 16; t += nthr) {
                 const int slot = t >> 4, p = t & 15;
@@ -260,46 +287,74 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
 
         // ---- Linear layer on the matrix cores + bounded output + transform ----
         const int j = lane & 15, q = lane >> 4;
-        const bool row_ok = j < nrows;
-        const long long row = row_base + (row_ok ? j : 0);
         float bq[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bq[ks] = V[j * 16 + 4 * ks + q];
-        float ld = 0.0f;
-        if (KIND == 0) {
-            float *xr = rows + row * D;
-            for (int tl = wave; tl < g.n_tiles; tl += nw) {
-                const float4 a = w_eff[tl * 64 + lane];
-                const float4 b = b_eff[tl * 4 + q];
-                gf32x4 acc = {b.x, b.y, b.z, b.w};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[3], acc, 0, 0, 0);
-                const int t0 = 8 * tl + 2 * q;
+        if (g.skip & 4) {
+        } else if (KIND == 0) {
+            // Samples on the MFMA's M axis, parameters on N: tile 2 m holds the scale logits of targets 16 m .. 16 m + 15
+            // (sorted by physical position by the host), tile 2 m + 1 their shifts, so lane (q, jj) receives u and beta
+            // of target 16 m + jj for the four samples 4 q + r -- every row access of a wave instruction is four rows x
+            // 16 neighbouring targets (whole 128-byte lines), not 16 rows x 8 bytes.  Two target groups per step: their
+            // operands, tables and row elements are requested together (the loop is bound by memory latency otherwise).
+            const int n_pairs = g.n_tiles >> 1;
+            const float *b_eff1 = reinterpret_cast<const float *>(b_eff);
+            float ldr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float *xr0 = rows + (row_base + 4 * q) * D;
+            bool ok[4];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int t = t0 + k;
-                    if (t < g.T && row_ok) {
-                        const float u = bounded4(k ? acc[2] : acc[0]), beta = bounded4(k ? acc[3] : acc[1]);
-                        const int phys = tgt_idx[t];
-                        const float2 st = tgt_st[t];
-                        const float v = fmaf(st.x, xr[phys], st.y);
-                        const float wl = fmaf(u, 0.5f, kAffC0);           // affine.py:33-34, log(alpha) up to 1e-10
+            for (int r = 0; r < 4; ++r) ok[r] = 4 * q + r < nrows;
+            for (int pb = 2 * wave; pb < n_pairs; pb += 2 * nw) {
+                float4 au[2], ab[2];
+                float bu[2], bb[2], x[2][4];
+                float2 pst[2];
+                int ph[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = pb + u < n_pairs ? pb + u : n_pairs - 1;
+                    au[u] = w_eff[(2 * m) * 64 + lane];
+                    ab[u] = w_eff[(2 * m + 1) * 64 + lane];
+                    bu[u] = b_eff1[32 * m + j];
+                    bb[u] = b_eff1[32 * m + 16 + j];
+                    ph[u] = tgt_idx[16 * m + j];                 // (tables padded to whole groups of 16)
+                    pst[u] = tgt_st[16 * m + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][r] = ok[r] ? xr0[(long long)r * D + ph[u]] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    gf32x4 hu = {bu[u], bu[u], bu[u], bu[u]}, hb = {bb[u], bb[u], bb[u], bb[u]};
+                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], au[u].x, hu, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], ab[u].x, hb, 0, 0, 0);
+                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[1], au[u].y, hu, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[1], ab[u].y, hb, 0, 0, 0);
+                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2], au[u].z, hu, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2], ab[u].z, hb, 0, 0, 0);
+                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[3], au[u].w, hu, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[3], ab[u].w, hb, 0, 0, 0);
+                    const bool tgt_ok = pb + u < n_pairs && 16 * (pb + u) + j < g.T;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u_ = bounded4(hu[r]), beta = bounded4(hb[r]);
+                        const float v = fmaf(pst[u].x, x[u][r], pst[u].y);
+                        const float wl = fmaf(u_, 0.5f, kAffC0);          // affine.py:33-34, log(alpha) up to 1e-10
                         const float alpha = exp_lean(wl) + kAffMinScale;
-                        if (!INV) {
-                            xr[phys] = alpha * v + beta;
-                            ld += wl;
-                        } else {
-                            xr[phys] = (v - beta) * __builtin_amdgcn_rcpf(alpha);
-                            ld -= wl;
+                        const float out = INV ? (v - beta) * __builtin_amdgcn_rcpf(alpha) : alpha * v + beta;
+                        if (tgt_ok && ok[r]) {
+                            xr0[(long long)r * D + ph[u]] = out;
+                            ldr[r] += INV ? -wl : wl;
                         }
                     }
                 }
             }
-            ld += __shfl_xor(ld, 16, kWave);
-            ld += __shfl_xor(ld, 32, kWave);
-            if (q == 0) ldpart[wave * 16 + j] = ld;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) ldr[r] += __shfl_xor(ldr[r], o, kWave);
+                if (j == 0) ldpart[wave * 16 + 4 * q + r] = ldr[r];
+            }
             __syncthreads();
             if (tid < nrows) {
                 float s = 0.0f;
@@ -451,53 +506,30 @@ static void glow_windows(GlowGeom &g)
 
 constexpr int kGlowLdsBytes = 160 * 1024;
 
-static int stage_rounds(int tasks_per_slot, int G, int groups, int nw)
-{
-    const int chunks = ((G * tasks_per_slot + 63) / 64) * groups;
-    return (chunks + nw - 1) / nw;
-}
-
-// Pick slots / block / channel groups: the largest modelled throughput (lane work that is useful / lane slots spent,
-// times how well the resident waves can cover each other's issue gaps), unless the caller fixed them.
+// Launch shape.  Measured on MI355X over every coupling geometry of AffineGlow((3, 32, 32)) at 65 536 rows
+// (tools/glow_tune.py, gpurun_out/glow_tune2.log): 256-thread workgroups, three to a CU, each with as many resident
+// samples as 1/3 of the LDS holds (a power of two, so that tiles of 16 samples divide evenly), 4 output channels per
+// lane task -- within 3 % of the best shape of the sweep for every geometry; larger workgroups lose to the barrier
+// between the conv stages, 2 channels per task to the LDS reads of the patch, 8 to lane tasks that do not fill the waves.
+// Any field the caller sets (> 0) is kept.
 static bool glow_plan(GlowGeom &g, int want_slots, int want_block, int want_cg1, int want_cg2, int *block_out)
 {
     const int fixed_bytes = 4 * g.fixed_floats, slot_bytes = 4 * g.slot_floats;
-    double best = -1.0;
-    int bs = 1, bb = 256, b1 = 8, b2 = 8;
-    const int blocks[3] = {1024, 512, 256};
-    const int cgs[3] = {8, 4, 2};
-    for (int bi = 0; bi < 3; ++bi) {
-        const int block = blocks[bi];
-        if (want_block && block != want_block) continue;
-        const int nw = block / 64;
-        for (int G = 1; G <= kGlowMaxRows; ++G) {
-            if (want_slots && G != want_slots) continue;
-            const int bytes = fixed_bytes + G * slot_bytes;
-            if (bytes > kGlowLdsBytes - 1024) break;
-            int wgs = imin(kGlowLdsBytes / bytes, 2048 / block);
-            const int wps = wgs * nw / 4;                         // waves per SIMD
-            const int NS = G * (kGlowMaxRows / G);
-            for (int i1 = 0; i1 < 3; ++i1)
-                for (int i2 = 0; i2 < 3; ++i2) {
-                    const int cg1 = cgs[i1], cg2 = cgs[i2];
-                    if ((want_cg1 && cg1 != want_cg1) || (want_cg2 && cg2 != want_cg2)) continue;
-                    // wave-instructions per round of each stage (fma + patch loads), rounds per G samples
-                    const double c1 = 4 * (36.0 * cg1 + 10), c2 = 8 * (36.0 * cg2 + 10), c3 = 8 * (36.0 + 10);
-                    const double spent = (NS / G) * (stage_rounds(g.p1h * g.p1w, G, 8 / cg1, nw) * c1 +
-                                                     stage_rounds(g.p2h * g.p2w, G, 8 / cg2, nw) * c2 +
-                                                     stage_rounds(16, G, 4, nw) * c3) * nw
-                                         + 60.0 * g.n_tiles;       // Linear tiles + transform, per 16 samples
-                    const double useful = NS * (g.p1h * g.p1w * 4 * 288.0 + g.p2h * g.p2w * 8 * 288.0 + 16 * 8 * 144.0) / 64.0;
-                    double eff = useful / spent;
-                    eff *= wps >= 4 ? 1.0 : wps == 3 ? 0.97 : wps == 2 ? 0.9 : 0.55;
-                    if (eff > best) best = eff, bs = G, bb = block, b1 = cg1, b2 = cg2;
-                }
-        }
+    const int block = want_block ? want_block : 256;
+    if (block != 256 && block != 512 && block != 1024) return false;
+    const int budget = want_slots ? kGlowLdsBytes - 1024 : (block == 256 ? kGlowLdsBytes / 3 : block == 512 ? kGlowLdsBytes / 2 : kGlowLdsBytes) - 1024;
+    int slots = want_slots;
+    if (!slots) {
+        slots = 1;
+        while (2 * slots <= kGlowMaxRows && fixed_bytes + 2 * slots * slot_bytes <= budget) slots *= 2;
     }
-    g.slots = bs, g.cg1 = b1, g.cg2 = b2;
-    g.tile_rows = bs * (kGlowMaxRows / bs);
-    *block_out = bb;
-    return best > 0.0;
+    if (slots < 1 || slots > kGlowMaxRows || fixed_bytes + slots * slot_bytes > kGlowLdsBytes - 1024) return false;
+    const int cg1 = want_cg1 ? want_cg1 : 4, cg2 = want_cg2 ? want_cg2 : 4;
+    if ((cg1 != 8 && cg1 != 4 && cg1 != 2) || (cg2 != 8 && cg2 != 4 && cg2 != 2)) return false;
+    g.slots = slots, g.cg1 = cg1, g.cg2 = cg2;
+    g.tile_rows = slots * (kGlowMaxRows / slots);
+    *block_out = block;
+    return true;
 }
 
 }  // namespace tfk
@@ -524,11 +556,16 @@ int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, c
                     L->n_params, kGlowMaxCh);
     g = GlowGeom{};
     g.c_in = L->c_in, g.hi = L->hi, g.wi = L->wi, g.oy = L->oy, g.ox = L->ox;
-    g.T = L->T, g.n_params = L->n_params, g.n_tiles = (L->n_params + 15) / 16, g.D = D;
+    g.T = L->T, g.n_params = L->n_params, g.D = D;
+    g.n_tiles = L->kind == 0 ? 2 * ((L->T + 15) / 16) : (L->n_params + 15) / 16;
     g.kind = L->kind, g.n_ch = L->n_ch, g.hw = L->hw;
     g.h_stride = g.n_tiles * 16 + 1;
     g.fixed_floats = 512 + (L->kind == 1 ? ((kGlowMaxRows * g.h_stride + 3) & ~3) : 0);
     glow_windows(g);
+    {
+        const char *e = getenv("TFK_GLOW_SKIP");
+        g.skip = e ? atoi(e) : 0;
+    }
     if (!glow_plan(g, L->slots, L->block, L->cg1, L->cg2, block))
         return fail(TFK_EINVAL, "%s: no launch shape fits (slots %d, block %d, channel groups %d / %d; %d B per slot)",
                     fn, L->slots, L->block, L->cg1, L->cg2, 4 * g.slot_floats);
@@ -570,8 +607,8 @@ int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tf
     if (!rows || !logdet || !layer->src_idx || !layer->src_st || !layer->tgt_idx || !layer->tgt_st || !layer->weights ||
         !layer->bg1 || !layer->bg2 || !layer->w_eff || !layer->b_eff)
         return fail(TFK_EINVAL, "%s: null pointer", fn);
-    if (!aligned16(layer->w_eff) || !aligned16(layer->b_eff) || (reinterpret_cast<uintptr_t>(layer->src_st) & 7u) ||
-        (reinterpret_cast<uintptr_t>(layer->tgt_st) & 7u))
+    if (!aligned16(layer->w_eff) || !aligned16(layer->b_eff) || (reinterpret_cast<uintptr_t>(layer->tgt_st) & 7u) ||
+        (reinterpret_cast<uintptr_t>(layer->src_st) & 7u))
         return fail(TFK_EINVAL, "%s: w_eff / b_eff need 16-byte, src_st / tgt_st 8-byte alignment", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = 4 * (size_t)(g.fixed_floats + g.slots * g.slot_floats);

@@ -114,8 +114,8 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
         sc, sh = _bn_affine(blk.bn)
         affs.append((sc, sh))
     for i, blk in enumerate((b1, b2)):
-        parts += [dd(blk.conv.weight).permute(1, 0, 2, 3).reshape(-1), dd(blk.conv.bias), affs[i][0], affs[i][1]]
-    parts += [dd(b3.conv.weight).permute(1, 0, 2, 3).reshape(-1), dd(b3.conv.bias)]
+        parts += [dd(blk.conv.weight).permute(1, 2, 3, 0).reshape(-1), dd(blk.conv.bias), affs[i][0], affs[i][1]]
+    parts += [dd(b3.conv.weight).permute(1, 2, 3, 0).reshape(-1), dd(b3.conv.bias)]       # [ci][ky][kx][co]
     wm2, bm2 = dd(c2.weight).reshape(4), dd(c2.bias).reshape(())
     sc3, sh3 = affs[2]
     parts += [wm2 * sc3, (bm2 + (wm2 * sh3).sum()).reshape(1)]
@@ -133,15 +133,21 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
     frame_mask[interior] = False
     W_eff = W[:, interior]
     b_eff = b + W[:, frame_mask].sum(1) * bm2
-    n_tiles = (n_params + 15) // 16
-    Wp = torch.zeros(n_tiles * 16, 16, dtype=torch.float64)
-    Wp[:n_params] = W_eff
-    bp = torch.zeros(n_tiles * 16, dtype=torch.float64)
-    bp[:n_params] = b_eff
-    # tile t, lane l = 16 q + i, k-step ks  <-  W_eff[16 t + i][4 ks + q]
-    w_tiles = Wp.view(n_tiles, 16, 4, 4).permute(0, 3, 1, 2).reshape(-1)
     return dict(oy=oy, ox=ox, n_params=n_params, weights=weights, bg1=bg1.float().contiguous(),
-                bg2=bg2.float().contiguous(), w_eff=w_tiles.float().contiguous(), b_eff=bp.float())
+                bg2=bg2.float().contiguous(), W_eff=W_eff, b_eff=b_eff)
+
+
+def _tile_pack(W_rows: torch.Tensor, b_rows: torch.Tensor):
+    """(rows, 16) / (rows,) in kernel row order -> MFMA operand tiles [t][64 lanes][4 k-steps] and the padded bias:
+    tile t, lane l = 16 q + i, k-step ks  <-  W[16 t + i][4 ks + q]."""
+    n = W_rows.shape[0]
+    n_tiles = (n + 15) // 16
+    Wp = torch.zeros(n_tiles * 16, 16, dtype=torch.float64)
+    Wp[:n] = W_rows
+    bp = torch.zeros(n_tiles * 16, dtype=torch.float64)
+    bp[:n] = b_rows
+    w_tiles = Wp.view(n_tiles, 16, 4, 4).permute(0, 3, 1, 2).reshape(-1)
+    return w_tiles.float().contiguous(), bp.float().contiguous()
 
 
 class _Builder:
@@ -199,9 +205,28 @@ class _Builder:
         if int(src.numel()) != c_in * hi * wi:
             raise _Decline("source mask does not fill the conditioner image")
         dev = self.device
-        st = lambda idx: torch.stack([self.s[idx], self.t[idx]], dim=1).float().contiguous().to(dev)
-        keep = (src.to(torch.int32).to(dev), st(src), tgt.to(torch.int32).to(dev), st(tgt),
-                pk["weights"].to(dev), pk["bg1"].to(dev), pk["bg2"].to(dev), pk["w_eff"].to(dev), pk["b_eff"].to(dev))
+        st = lambda idx: torch.stack([self.s[idx], self.t[idx]], dim=1).float().contiguous()
+        if kind == "affine":
+            # the kernel takes the targets in any order: ascending physical position, so that the 16 targets of a tile
+            # pair are neighbours in the row; tile 2 m = their scale logits (h[..., t, 0]), tile 2 m + 1 their shifts
+            order = torch.argsort(tgt, stable=True)
+            tgt_k = tgt[order]
+            n_groups = (T + 15) // 16
+            rank = torch.arange(T)
+            row_u = 32 * (rank // 16) + rank % 16
+            Wk = torch.zeros(32 * n_groups, 16, dtype=torch.float64)
+            bk = torch.zeros(32 * n_groups, dtype=torch.float64)
+            Wk[row_u], bk[row_u] = pk["W_eff"][2 * order], pk["b_eff"][2 * order]
+            Wk[row_u + 16], bk[row_u + 16] = pk["W_eff"][2 * order + 1], pk["b_eff"][2 * order + 1]
+            w_tiles, b_tiles = _tile_pack(Wk, bk)
+            pad = 16 * n_groups - T                        # the kernel reads the tables in whole groups of 16 targets
+            tgt_i = torch.cat([tgt_k.to(torch.int32), torch.zeros(pad, dtype=torch.int32)])
+            tgt_m = torch.cat([st(tgt_k), torch.zeros(pad, 2)])
+        else:
+            w_tiles, b_tiles = _tile_pack(pk["W_eff"], pk["b_eff"])
+            tgt_i, tgt_m = tgt.to(torch.int32), st(tgt)
+        keep = (src.to(torch.int32).to(dev), st(src).to(dev), tgt_i.to(dev), tgt_m.to(dev),
+                pk["weights"].to(dev), pk["bg1"].to(dev), pk["bg2"].to(dev), w_tiles.to(dev), b_tiles.to(dev))
         env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_" + k, "0") or 0)
         L = native.GlowLayer(kind=1 if kind == "conv1x1" else 0, c_in=c_in, hi=hi, wi=wi, oy=pk["oy"], ox=pk["ox"],
                              T=T, n_params=pk["n_params"], n_ch=n_ch, hw=hw, slots=env("SLOTS"), block=env("BLOCK"),
