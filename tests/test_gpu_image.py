@@ -125,7 +125,8 @@ def test_affine_glow_config5_golden_on_hip(native):
         lp = flow.log_prob(x)
         z, ld = flow.bijection.forward(x)
         xr, ldr = flow.bijection.inverse(z_in)
-    assert native.calls - before > 100
+    # one launch per coupling (19) + the flush of the deferred ActNorm maps (+ the base density for log_prob)
+    assert native.calls - before == 21 + 20 + 20
     e = dict(log_prob=rel(lp.cpu().numpy(), fx["log_prob"]), z=rel(z.cpu().numpy(), fx["z"]),
              log_det=rel(ld.cpu().numpy(), fx["log_det"]), x_inv=rel(xr.cpu().numpy(), fx["x_inv"]),
              log_det_inv=rel(ldr.cpu().numpy(), fx["log_det_inv"]))
@@ -163,6 +164,88 @@ def test_affine_glow_config5_full_size_properties(native):
         xr, ldr = flow.bijection.inverse(z)
         assert float((xr - x[sel]).abs().max()) < 1e-3            # the reference's own round-trip bar
         assert rel((-ldr).cpu().numpy(), ld.cpu().numpy()) < 2e-5
+
+
+def _clone_layer(native, layer, **kw):
+    import ctypes as C
+    new = native.GlowLayer()
+    C.memmove(C.byref(new), C.byref(layer), C.sizeof(layer))
+    for k, v in kw.items():
+        setattr(new, k, v)
+    return new
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+def test_glow_coupling_kernel_vs_emulator(native, direction):
+    """tfk_glow_coupling, launch by launch, against the float64 emulator of its documented semantics
+    (tests/glow_emulator.py) on config 5's 19 couplings: 37 rows (a ragged last tile), both directions, the default
+    launch shape and -- for each distinct geometry -- other slots / block / channel-group choices (every template
+    path of the conv stages).  Targets within 1e-5, untouched elements bit-identical, log-det within 1e-5."""
+    import glow_emulator as ge
+    from golden_util import load_glow32
+    from torchflows_amd import image_program
+    flow, fx = load_glow32()
+    flow = flow.cuda()
+    prog = image_program.get_program(flow.bijection, direction, torch.device("cuda", 0))
+    assert prog is not None and len(prog.steps) == 19
+    torch.manual_seed(11)
+    N = 37
+    rows = torch.randn(N, prog.D) * 1.5
+    shapes = [dict(), dict(slots=1, block=256, cg1=8, cg2=8), dict(slots=3, block=512, cg1=2, cg2=2),
+              dict(slots=4, block=1024, cg1=4, cg2=8)]
+    seen = set()
+    for step in prog.steps:
+        key = (step.info["kind"], step.info["image"])
+        variants = shapes if key not in seen else shapes[:1]
+        seen.add(key)
+        ref = rows.double().clone()
+        ld_ref = torch.zeros(N, dtype=torch.float64)
+        ge.run_step(ref, ld_ref, step)
+        tgt = step.keep[2][: step.layer.T].long().cpu()
+        untouched = torch.ones(prog.D, dtype=torch.bool)
+        untouched[tgt] = False
+        for kw in variants:
+            layer = _clone_layer(native, step.layer, **kw) if kw else step.layer
+            try:
+                native.glow_plan(layer, prog.D)
+            except native.NativeError:
+                continue                                 # this shape does not fit the LDS for this geometry
+            out = rows.cuda()
+            ld = torch.full((N,), 0.25, device="cuda")
+            native.glow_coupling(out, ld, layer, step.inverse)
+            out, ld = out.cpu(), ld.cpu()
+            assert torch.equal(out[:, untouched], rows[:, untouched]), (key, kw)
+            assert rel(out[:, tgt].numpy(), ref[:, tgt].numpy()) < 1e-5, (key, kw)
+            assert rel(ld.numpy() - 0.25, ld_ref.numpy()) < 1e-5, (key, kw)
+        rows = ref.float()                               # feed the next layer what this one produced
+
+
+def test_glow_program_rows_and_batch_shapes(native):
+    """Ragged row counts around the 16-row tiles, a batch shape of rank 2, inputs left untouched, and the program
+    against the package's own layer-by-layer HIP route (TORCHFLOWS_AMD_IMAGE_PROGRAM=0 semantics via the ATen host path)."""
+    import glow_emulator as ge
+    from golden_util import load_glow32
+    from torchflows_amd import image_program
+    flow, fx = load_glow32()
+    flow = flow.cuda()
+    prog = image_program.get_program(flow.bijection, 0, torch.device("cuda", 0))
+    torch.manual_seed(5)
+    for n in (1, 15, 16, 17, 250):
+        x = torch.randn(n, 3, 32, 32)
+        xd = x.cuda()
+        keep = xd.clone()
+        with torch.no_grad():
+            z, ld = flow.bijection.forward(xd)
+        assert torch.equal(xd, keep)
+        z_ref, ld_ref = ge.run_program(prog, x, check_windows=False)
+        assert rel(z.cpu().numpy(), z_ref.numpy()) < 1e-5 and rel(ld.cpu().numpy(), ld_ref.numpy()) < 1e-5, n
+    x = torch.randn(3, 5, 3, 32, 32).cuda()
+    with torch.no_grad():
+        z, ld = flow.bijection.forward(x)
+        z2, ld2 = flow.bijection.forward(x.reshape(15, 3, 32, 32))
+        lp = flow.log_prob(x)
+    assert z.shape == x.shape and ld.shape == (3, 5) and lp.shape == (3, 5)
+    assert torch.equal(z.reshape(15, 3, 32, 32), z2) and torch.equal(ld.reshape(15), ld2)
 
 
 @pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])

@@ -1,0 +1,110 @@
+"""The host-side compiler of the image flows (torchflows_amd/image_program.py: squeeze / chunk folded into index
+tables, deferred ActNorm layers, folded conditioner constants, MFMA tile order) checked WITHOUT a GPU: the compiled
+program is decoded by the float64 emulator of the kernel's documented semantics (tests/glow_emulator.py) and compared
+with the reference's own outputs (tests/golden/flow_glow_3x32x32.npz, flow_glow_3x8x8.npz) and with this package's
+ATen composite path.  The kernel itself is compared with the same emulator and fixtures in tests/test_gpu_image.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import glow_emulator as ge
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def libtfk():
+    from torchflows_amd import native
+    if not native.available():
+        pytest.skip("libtfk.so not built")
+    return native
+
+
+def test_glow32_program_matches_reference_fp64(libtfk):
+    """Config 5's model: 19 launches + one flush; against the REFERENCE evaluated in float64 the decoded program is
+    exact up to the fp32 rounding of the folded constants (measured 3.5e-7 on z, 1.6e-9 on the log-det)."""
+    from golden_util import load_glow32
+    from torchflows_amd import image_program
+    flow, fx = load_glow32()
+    prog = image_program.compile_program(flow.bijection, 0, torch.device("cpu"))
+    assert prog is not None and len(prog.steps) == 19 and prog.flush is not None
+    kinds = [s.info["kind"] for s in prog.steps]
+    assert kinds.count("conv1x1") == 3 and kinds[3:9:2] == ["conv1x1"] * 3       # only the top block's
+    z, ld = ge.run_program(prog, torch.from_numpy(fx["x"]))
+    assert rel(z.numpy(), fx["z64"]) < 2e-6 and rel(ld.numpy(), fx["log_det64"]) < 1e-7
+    inv = image_program.compile_program(flow.bijection, 1, torch.device("cpu"))
+    assert [s.inverse for s in inv.steps] == [True] * 19
+    x, ldi = ge.run_program(inv, torch.from_numpy(fx["z_in"]))
+    assert rel(x.numpy(), fx["x_inv"]) < 5e-6 and rel(ldi.numpy(), fx["log_det_inv"]) < 1e-6
+    # the index tables of a step partition the positions the layer touches; targets are listed in ascending order
+    for s in prog.steps:
+        src, tgt = s.keep[0][: s.layer.c_in * s.layer.hi * s.layer.wi], s.keep[2][: s.layer.T]
+        assert not set(src.tolist()) & set(tgt.tolist())
+        if s.layer.kind == 0:
+            assert bool((tgt[1:] > tgt[:-1]).all())
+
+
+def test_small_glow_program_matches_fixture_and_host(libtfk):
+    import torchflows_amd as tfa
+    from torchflows_amd import image_program
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    fx = load_golden("flow_glow_3x8x8.npz")
+    flow = tfa.Flow(AffineGlow((3, 8, 8), n_layers=2))
+    flow.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")})
+    flow.eval()
+    prog = image_program.compile_program(flow.bijection, 0, torch.device("cpu"))
+    assert prog is not None
+    z, ld = ge.run_program(prog, torch.from_numpy(fx["x"]))
+    assert rel(z.numpy(), fx["z"]) < 2e-5 and rel(ld.numpy(), fx["log_det"]) < 2e-5
+    with torch.no_grad():                               # the package's own ATen path in float64: same weights
+        z64, ld64 = flow.double().bijection.forward(torch.from_numpy(fx["x"]).double())
+    assert rel(z.numpy(), z64.numpy()) < 2e-6 and rel(ld.numpy(), ld64.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("event_shape,n_layers", [((3, 16, 16), None), ((2, 32, 32), 2), ((4, 8, 16), 1)])
+def test_program_vs_host_other_shapes(libtfk, event_shape, n_layers):
+    import torchflows_amd as tfa
+    from torchflows_amd import image_program
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow, MultiscaleRealNVP
+    torch.manual_seed(3)
+    cls = AffineGlow if event_shape[0] > 2 else MultiscaleRealNVP
+    flow = tfa.Flow(cls(event_shape, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(32, *event_shape))                 # ActNorm init, BatchNorm statistics
+    flow.eval()
+    x = torch.randn(5, *event_shape)
+    for d in (0, 1):
+        prog = image_program.compile_program(flow.bijection, d, torch.device("cpu"))
+        assert prog is not None
+        out, ld = ge.run_program(prog, x)
+        with torch.no_grad():
+            f64 = flow.double()
+            ref, ld_ref = (f64.bijection.forward if d == 0 else f64.bijection.inverse)(x.double())
+            flow.float()
+        assert rel(out.numpy(), ref.numpy()) < 5e-6 and rel(ld.numpy(), ld_ref.numpy()) < 1e-6, (d, event_shape)
+
+
+def test_program_declines_what_it_does_not_cover(libtfk):
+    import torchflows_amd as tfa
+    from torchflows_amd import image_program
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow, MultiscaleNICE
+    cpu = torch.device("cpu")
+    torch.manual_seed(0)
+    # odd padding somewhere down the recursion: a ConvModifier with a 2-wide kernel (classic.py:26-27)
+    assert image_program.compile_program(AffineGlow((1, 28, 28)).eval(), 0, cpu) is None
+    # images beyond the 32x32 frame: the modifier is a real convolution
+    assert image_program.compile_program(AffineGlow((3, 64, 64)).eval(), 0, cpu) is None
+    # a transformer without a fused kernel
+    assert image_program.compile_program(MultiscaleNICE((3, 16, 16)).eval(), 0, cpu) is None
+    # ActNorm before its first batch, BatchNorm in training mode
+    fresh = AffineGlow((3, 16, 16))
+    assert fresh.training and image_program.compile_program(fresh, 0, cpu) is None
+    ok = AffineGlow((3, 16, 16)).eval()
+    assert image_program.compile_program(ok, 0, cpu) is not None
+    ok.checkerboard_layers[0].invert()
+    assert image_program.compile_program(ok, 0, cpu) is None
