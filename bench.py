@@ -42,7 +42,7 @@ WORKLOADS = {
     "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
     "nsf64": ("CouplingRQNSF", 64, 8, 1 << 20, 1 << 18),     # configs[2]
     "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
-    "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 13),  # configs[4] (3 blocks, 3.2 M params)
+    "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 16),  # configs[4] (3 blocks, 3.2 M params); chunks of 2^16 rows
     "lrs64": ("CouplingLRS", 64, 8, 1 << 20, 1 << 18),       # sibling preset (linear rational splines), not a BASELINE config
     "realnvp128": ("RealNVP", 128, 8, 1 << 20, None),        # between configs 2 and 4 (tuning the 128-wide kernel)
 }
@@ -85,7 +85,10 @@ class KernelTimer:
                             ("conv3x3_relu_pool_affine",
                              lambda a, k: 4 * (a[0].numel() + a[0].shape[0] * a[1].shape[0] * (a[0].shape[2] // 2) * (a[0].shape[3] // 2))),
                             ("conv1x1_frame", lambda a, k: 4 * (a[0].numel() + a[0].shape[0] * a[1].shape[0] * a[3] * a[4])),
-                            ("bounded_sigmoid", lambda a, k: 8 * a[0].numel())):
+                            ("bounded_sigmoid", lambda a, k: 8 * a[0].numel()),
+                            # image flows, one launch per coupling (csrc/tfk_glow.hip): args (rows, logdet, layer, inverse)
+                            ("glow_coupling", self._glow_bytes),
+                            ("rows_fma", lambda a, k: 8 * a[0].numel())):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -126,6 +129,11 @@ class KernelTimer:
         return N * ((8 * T if inplace else 8 * D) + 4 * (h.numel() // N) + 8)
 
     @staticmethod
+    def _glow_bytes(a, k):
+        from torchflows_amd import image_program
+        return a[0].shape[0] * image_program.layer_cost(a[2])["bytes"]
+
+    @staticmethod
     def _elementwise_bytes(a, k):
         x = a[0]
         N, D = x.shape
@@ -143,13 +151,18 @@ class KernelTimer:
             r = inner(*a, **k)
             e.record()
             variant = name
-            if name.endswith("_coupling") and name != "conv1x1_coupling":
+            if name.endswith("_coupling") and name not in ("conv1x1_coupling", "glow_coupling"):
                 variant += "[inplace]" if a[2].data_ptr() == a[0].data_ptr() else "[out-of-place]"
             flops = self._flow_flops(a, name == "flow_run_mfma") if name.startswith("flow_run") else 0
             if name == "conv3x3_relu_pool_affine":      # 2 * 9 * c_in * c_out per output position of the convolution
                 n_, ci_, hh_, ww_ = a[0].shape
                 variant += f"[{ci_}->{a[1].shape[0]}@{hh_}x{ww_}]"
                 flops = 18 * ci_ * a[1].shape[0] * hh_ * ww_ * n_
+            if name == "glow_coupling":
+                from torchflows_amd import image_program
+                L = a[2]
+                variant += f"[{'conv1x1' if L.kind else 'affine'} {L.c_in}x{L.hi}x{L.wi}]"
+                flops = a[0].shape[0] * image_program.layer_cost(L)["flops"]
             if name == "affine_coupling_train_bwd":
                 # conditioner re-evaluation + MLP backward + weight gradients: 3 x the forward's
                 # 2*(S*H + H*T*P) per row, true (unpadded) hidden width
@@ -237,6 +250,7 @@ class KernelTimer:
             d["bytes"] += nbytes
             d["flops"] += flops
         for d in agg.values():
+            d["flops_per_launch"] = d["flops"] // d["launches"]
             d["avg_us"] = 1e3 * d["ms"] / d["launches"]
             d["bytes_per_launch"] = d["bytes"] // d["launches"]
             d["GBps"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
@@ -368,6 +382,107 @@ def spawn_ranks(n, argv):
     sys.exit(rc)
 
 
+def config_leg(workload, dev, timer, steps=12, warmup=3, layerwise=False):
+    """One further BASELINE.json configuration on this GPU, bounded to a few seconds: `steps` Flow.log_prob + fp64-sum
+    passes over the configuration's device-resident batch, each bracketed by HIP events on the launch stream (median
+    reported); the dominant libtfk kernel with the numbers its roofline fraction is computed from (algorithmic FLOPs
+    or bytes per launch, mean launch time); parity of the timed output against the CPU oracle (vector flows: 512 rows)
+    or the reference's own fixture (config 5)."""
+    from torchflows_amd import native
+    from torchflows_amd.distributed import sharded_log_likelihood
+    arch, D, n_layers, rows, chunk = WORKLOADS[workload]
+    flow_host = make_flow(arch, D, n_layers)
+    for layer in flow_host.bijection.modules():
+        seq = getattr(getattr(layer, "conditioner_transform", None), "sequential", None)
+        if seq is not None and not isinstance(D, tuple):
+            KernelTimer.true_hidden[D] = seq[0].out_features
+    flow = make_flow(arch, D, n_layers).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    shape = D if isinstance(D, tuple) else (D,)
+    x = torch.randn(rows, *shape, device=dev, generator=gen)
+    step_rows = chunk if isinstance(D, tuple) else rows
+    timer.records = []
+    with torch.no_grad():
+        for _ in range(warmup):
+            lp, total = sharded_log_likelihood(flow, x, chunk_rows=step_rows)
+        torch.cuda.synchronize()
+        before = native.calls
+        timer.active = True
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
+        for i in range(steps):
+            lp, total = sharded_log_likelihood(flow, x, chunk_rows=step_rows)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        timer.active = False
+        launches = (native.calls - before) / steps
+    ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    med = ms[len(ms) // 2]
+    kernels = timer.summary()
+    dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
+    dom = kernels[dom_name]
+    out = {"workload": f"{arch}(D={D}, n_layers={n_layers}), {rows} rows" + (f" in chunks of {step_rows}" if step_rows != rows else ""),
+           "rows": rows, "steps": steps, "ms_per_step": med, "min_ms": ms[0], "max_ms": ms[-1],
+           "evals_per_s": rows / (med * 1e-3), "libtfk_launches_per_step": launches,
+           "log_likelihood_sum": float(total.item())}
+    if dom["flops"]:
+        out["roofline"] = {"bound": "mfma" if dom_name.startswith("flow_run") else "valu", "kernel": dom_name,
+                           "flops_per_launch": dom["flops_per_launch"], "bytes_per_launch": dom["bytes_per_launch"],
+                           "avg_us": dom["avg_us"], "launches": dom["launches"], "achieved": dom["TFLOPs"],
+                           "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS,
+                           "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None}
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
+                           "avg_us": dom["avg_us"], "launches": dom["launches"], "achieved": dom["GBps"],
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None}
+    out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GBps": round(v["GBps"], 1),
+                          "TFLOPs": round(v["TFLOPs"], 2)} for k, v in kernels.items()}
+    if isinstance(D, tuple):
+        if D == (3, 32, 32):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from golden_util import load_glow32
+            gflow, fx = load_glow32()
+            gflow = gflow.to(dev)
+            with torch.no_grad():
+                glp = gflow.log_prob(torch.from_numpy(fx["x"]).to(dev)).cpu().numpy()
+            d = np.abs(glp - fx["log_prob"])
+            out["parity"] = {"log_prob_max_rel_vs_reference": float(np.max(d / np.maximum(1.0, np.abs(fx["log_prob"])))),
+                             "rows_checked": int(glp.shape[0])}
+    else:
+        from oracle import oracle as orc
+        sd = {k: v.detach().cpu().numpy() for k, v in flow_host.state_dict().items()}
+        ref = orc.preset_from_state_dict(arch, D, n_layers, sd)
+        orc.set_num_threads(host_cores())
+        idx = torch.arange(0, rows, max(rows // 512, 1), device=dev)[:512]
+        lp_ref = ref.log_prob(x[idx].cpu().numpy())
+        d = np.abs(lp[idx].cpu().numpy() - lp_ref)
+        out["parity"] = {"log_prob_max_rel_vs_oracle": float(np.max(d / np.maximum(1.0, np.abs(lp_ref)))),
+                         "rows_checked": int(idx.numel()),
+                         "pass_rate_1e-5": float(np.mean(d <= 1e-5 * np.maximum(1.0, np.abs(lp_ref))))}
+    if layerwise and not isinstance(D, tuple):
+        # the per-layer route of the same configuration (conditioner GEMMs on PyTorch-ROCm, h through HBM): the
+        # HBM-bound transform kernels north_star's 40 % target is about
+        os.environ["TORCHFLOWS_AMD_FUSED"] = "0"
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        timer.records = []
+        with torch.no_grad():
+            sharded_log_likelihood(flow, x, chunk_rows=chunk or rows)
+            torch.cuda.synchronize()
+            timer.active = True
+            sharded_log_likelihood(flow, x, chunk_rows=chunk or rows)
+            torch.cuda.synchronize()
+            timer.active = False
+        os.environ["TORCHFLOWS_AMD_FUSED"] = "1"
+        flow.bijection.__dict__.pop("_tfk_compiled", None)
+        out["layerwise_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                                        "bytes_per_launch": v["bytes_per_launch"], "GBps": round(v["GBps"], 1),
+                                        "hbm_frac": round(v["GBps"] / HBM_PEAK_GBS, 3)}
+                                    for k, v in timer.summary().items()}
+    del x, flow
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +502,8 @@ def main():
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
     ap.add_argument("--no-sample", action="store_true", help="skip the Flow.sample throughput leg")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd + bwd + AdamW) leg")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the bounded legs over the other BASELINE configurations (nsf64, realnvp256, glow32)")
     ap.add_argument("--no-mfma", action="store_true",
                     help="fused flow programs on the VALU interpreter (k_flow_run) instead of k_flow_run_mfma")
     args = ap.parse_args()
@@ -570,6 +687,19 @@ def main():
                     busy = 4.0 * (valu - n_mfma) + 32.0 * n_mfma
                     roofline["mfma_insts_per_launch"] = n_mfma
                     roofline["fp32_datapath_frac"] = busy / (dom["avg_us"] * 1e-6 * 256 * 4 * 2.4e9)
+        elif dom_name.startswith("glow_coupling"):
+            # a whole convolutional coupling in one launch: the conv blocks are direct convolutions on the vector ALUs
+            # (v_pk_fma_f32: c_out = 8 / 4 would waste half / three quarters of a 16-wide MFMA tile), so the launch is
+            # priced against the fp32 vector peak; FLOPs = what the kernel executes (conv blocks on the windows the
+            # source image reaches, Linear at K = 16), fewer than the reference's formulation of the same values
+            roofline = {"bound": "valu", "achieved": dom["TFLOPs"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": traffic,
+                        "flops_per_launch": dom["flops"] // dom["launches"],
+                        "note": "tfk_glow_coupling: ConvNet conditioner (LDS-resident) + Linear (MFMA) + bounded "
+                                "sigmoid + transform in one launch; achieved = executed multiply-adds x 2 / launch "
+                                "time against the fp32 vector peak (packed v_pk_fma_f32; tools/micro/rates.hip measures "
+                                "111 TFLOP/s for a pure stream of them)",
+                        "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS}
         elif dom_name.startswith("conv3x3_relu_pool_affine"):
             # direct convolution on the vector ALUs (c_out = 8 would waste half of a 16-wide MFMA tile and
             # the fp32 MFMA peak equals the vector peak): priced against the fp32 vector peak
@@ -650,7 +780,11 @@ def main():
                 "frac": lw[lw_name]["GBps"] / HBM_PEAK_GBS, "traffic": tr, "kernel": lw_name,
                 "bytes_per_launch": lw[lw_name]["bytes_per_launch"], "avg_us": lw[lw_name]["avg_us"],
                 "launches": lw[lw_name]["launches"], "evals_per_s": rows * 3 / lw_elapsed,
-                "note": "same workload with TORCHFLOWS_AMD_FUSED=0 (bench.py --no-fused), 3 steps"}
+                "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                                "bytes_per_launch": v["bytes_per_launch"], "GBps": round(v["GBps"], 1),
+                                "hbm_frac": round(v["GBps"] / HBM_PEAK_GBS, 3)} for k, v in lw.items()},
+                "note": "same workload with TORCHFLOWS_AMD_FUSED=0 (bench.py --no-fused), 3 steps; `kernels` lists every "
+                        "per-layer kernel's HBM fraction (affine_coupling[inplace] is the coupling transform pass)"}
         if world == 1 and not args.no_sample:
             # sample throughput next to log_prob (Flow.sample = base draw +
             # bijection.inverse with log-det, flows.py:117-146), same rows, not part of `value`
@@ -784,6 +918,16 @@ def main():
                                     "pass_rate_1e-5": float(np.mean(d <= 1e-5 * np.maximum(1.0, np.abs(fx["log_prob"])))),
                                     "note": "HIP path vs the reference's own log_prob of the config-5 model "
                                             "(seed-0 weights pinned by sha256, data-dependent state from the fixture)"}
+        if world == 1 and args.workload == "realnvp64" and not args.no_configs and not args.no_fused:
+            result["configs"] = {}
+            for name in ("nsf64", "realnvp256", "glow32"):
+                t_leg = time.perf_counter()
+                try:
+                    leg = config_leg(name, dev, timer, layerwise=(name == "nsf64"))
+                except Exception as exc:                      # a leg must not take the headline line with it
+                    leg = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                leg["leg_seconds"] = time.perf_counter() - t_leg
+                result["configs"][name] = leg
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -150,6 +150,26 @@ def _tile_pack(W_rows: torch.Tensor, b_rows: torch.Tensor):
     return w_tiles.float().contiguous(), bp.float().contiguous()
 
 
+def layer_cost(layer) -> dict:
+    """What one tfk_glow_coupling launch moves and computes PER ROW (for bench.py's roofline): algorithmic HBM bytes
+    (source elements read, targets read and written, the log-det read and written) and the multiply-adds the kernel
+    executes -- the conv blocks on the windows of csrc/tfk_glow.hip:glow_windows, the Linear layer at K = 16 -- next to
+    the multiply-adds of the reference's formulation (full 32x32 / 16x16 / 8x8 convolutions, Linear at K = 100)."""
+    def axis(o, n):
+        lo, hi_ = max(o - 1, 0), min(o + n + 1, 32)
+        c0, c1 = lo & ~1, (hi_ + 1) & ~1
+        q0, q1 = max(c0 // 2 - 1, 0), min(c1 // 2 + 1, 16)
+        return c1 - c0, ((q1 + 1) & ~1) - (q0 & ~1)
+    (c1h, c2h), (c1w, c2w) = axis(layer.oy, layer.hi), axis(layer.ox, layer.wi)
+    S = layer.c_in * layer.hi * layer.wi
+    macs = 4 * S + c1h * c1w * 8 * 36 + c2h * c2w * 8 * 72 + 64 * 4 * 72 + 64 + 16 * layer.n_params
+    ref = 4 * S + 1024 * 8 * 36 + 256 * 8 * 72 + 64 * 4 * 72 + 16 * 4 + 100 * layer.n_params
+    if layer.kind == 1:
+        macs += layer.hw * layer.n_ch * layer.n_ch
+        ref += layer.hw * layer.n_ch * layer.n_ch
+    return dict(bytes=4 * (S + 2 * layer.T) + 8, flops=2 * macs, flops_reference=2 * ref)
+
+
 class _Builder:
     def __init__(self, D: int, device: torch.device):
         self.D, self.device = D, device
