@@ -622,3 +622,43 @@ def test_lean_context_programs_against_fp64_emulator(arch, D, C, direction):
     got = rows[:, chain.pos]
     assert float((got - want).abs().max() / want.abs().max()) < 2e-5
     assert float((ld - ld_want).abs().max() / max(1.0, float(ld_want.abs().max()))) < 2e-5
+
+
+def test_compiled_programs_retire_on_replacement_move_and_context_width():
+    """(i) a replaced Parameter retires EVERY cached program of the composition (the other direction was
+    served stale when its version happened to match), (ii) moving a CHILD retires the parent's programs (a process-wide
+    epoch, bumped by every ``_apply``), (iii) a context of another width is rejected like the reference's Linear layer
+    does instead of being truncated / zero-padded to the kernel's k-steps, (iv) sharded_fit refuses an empty shard
+    up front (that rank would never join the ActNorm all-reduce) and keeps one loss per step."""
+    import torchflows_amd as tfa
+    from torchflows_amd import fused
+    from torchflows_amd.distributed import sharded_fit
+    cpu = torch.device("cpu")
+    torch.manual_seed(0)
+    flow = tfa.Flow(tfa.RealNVP(64, n_layers=2)).eval()
+    comp = flow.bijection
+    fwd0, inv0 = fused.get_compiled(comp, 0, cpu), fused.get_compiled(comp, 1, cpu)
+    assert fwd0 is not None and inv0 is not None
+    assert fused.get_compiled(comp, 0, cpu) is fwd0 and fused.get_compiled(comp, 1, cpu) is inv0
+    lin = [m for m in comp.modules() if isinstance(m, torch.nn.Linear)][0]
+    lin.weight = torch.nn.Parameter(lin.weight.detach() * 2.0)              # new tensor, version counter 0 like the old
+    fwd1 = fused.get_compiled(comp, 0, cpu)
+    inv1 = fused.get_compiled(comp, 1, cpu)
+    assert fwd1 is not fwd0 and inv1 is not inv0
+    assert not torch.equal(inv1.segments[0].params, inv0.segments[0].params)
+    # (ii) only a child is converted: the parent's entries must not survive
+    comp.layers[1].double()
+    comp.layers[1].float()
+    assert fused.get_compiled(comp, 0, cpu) is not fwd1 and fused.get_compiled(comp, 1, cpu) is not inv1
+    # (iii) context width
+    torch.manual_seed(1)
+    cflow = tfa.Flow(tfa.RealNVP(64, n_layers=2, context_shape=(3,))).eval()
+    chain = fused.get_compiled(cflow.bijection, 0, cpu, context=True)
+    if chain is not None:                                                      # (declined without the lean kernels: nothing to check)
+        assert chain.ctx_width == 3
+        with pytest.raises(ValueError):
+            fused.run_chain(chain, torch.zeros(4, 64), want_rows=True, context=torch.zeros(4, 4))
+    # (iv)
+    small = tfa.Flow(tfa.RealNVP(4, n_layers=1))
+    losses = sharded_fit(small, torch.randn(40, 4), n_epochs=3, batch_size=16, lr=1e-3)
+    assert len(losses) == 9 and all(np.isfinite(losses))

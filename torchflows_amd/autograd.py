@@ -886,7 +886,11 @@ def run(composition, plan, x: torch.Tensor, context=None) -> Tuple[torch.Tensor,
     from torchflows_amd.utils import as_rows
     rows, batch = as_rows(x, composition.event_shape)
     if context is not None:
-        plan.context = context.reshape(rows.shape[0], *composition.context_shape).contiguous()
+        # (a hand-built composition takes its context_shape from its FIRST layer, which may have none: the layers that
+        # do take a context reshape the flat rows themselves)
+        cs = composition.context_shape
+        plan.context = (context.reshape(rows.shape[0], *cs) if cs is not None
+                        else context.reshape(rows.shape[0], -1)).contiguous()
     params: List[torch.Tensor] = []
     for layer, _, kind in plan:
         params.extend(_layer_params(layer, kind))

@@ -166,11 +166,18 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
         sizes = [int(t.item()) for t in sizes_t]
     else:
         sizes = [n_local]
+    if distributed and min(sizes) == 0:
+        # such a rank would never enter flow.log_prob on the first step and so never join the per-ActNorm all-reduce of
+        # the data-dependent initialisation the other ranks issue from inside it: the job would hang
+        raise ValueError(f"sharded_fit: every rank needs at least one training row, got shard sizes {sizes}")
     steps_per_epoch = max(-(-n // local_bs) for n in sizes)
     opt = (optimizer or make_adamw)(flow.parameters(), lr)
     gen = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
     flow.train()
-    losses = []
+    # one slot per step, written on the device (no host sync per step, and no view that would keep each step's whole
+    # flat gradient buffer alive until the end of training)
+    losses = torch.empty(n_epochs * steps_per_epoch, dtype=params[0].dtype, device=dev)
+    n_steps = 0
     ctx = _GlobalActNormInit(flow, group) if distributed else None
     if ctx is not None:
         ctx.__enter__()
@@ -200,10 +207,11 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
                     n = p.numel()
                     p.grad = flat[lo_f:lo_f + n].view_as(p)
                     lo_f += n
-                losses.append(flat[-1])                                          # stays on the device: no host sync per step
+                losses[n_steps].copy_(flat[-1])
+                n_steps += 1
                 opt.step()
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
     flow.eval()
-    return [float(v) for v in torch.stack(losses).cpu()] if losses else []
+    return [float(v) for v in losses[:n_steps].cpu()]

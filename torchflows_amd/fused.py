@@ -97,6 +97,7 @@ class CompiledChain:
     version: int
     D_log: int = 0             # event size; < D when the two halves are padded to a supported width
     pos_in: Optional[torch.Tensor] = None     # padded chains: physical position of logical element l on entry
+    ctx_width: Optional[int] = None           # context programs: elements per context row the packed weights expect
 
 
 def _pad4(t: torch.Tensor) -> torch.Tensor:
@@ -135,6 +136,13 @@ def _tensor_slots(module: nn.Module):
     return slots
 
 
+# Bumped whenever ANY module of this package has its tensors moved or converted (``_apply``: .to() / .cuda() /
+# .double() ...) and whenever a tensor slot is found replaced: mixed into every version below, so that a cache entry built
+# before such an event -- under any key, on the moved module or on an ancestor whose program packs its weights -- can never
+# match again.  (A move keeps the tensor objects and their version counters; only the storage changes.)
+_EPOCH = [0]
+
+
 def _params_version(module: nn.Module) -> int:
     """Changes whenever a parameter / buffer below ``module`` is modified in place (version counter) or replaced by
     another tensor (slot identity).  Moves and conversions (``.to()``, ``.cuda()``, ``.double()``: the tensor object
@@ -144,15 +152,14 @@ def _params_version(module: nn.Module) -> int:
     slots = module.__dict__.get("_tfk_slots")
     if slots is None:
         slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
-    v = len(slots)
     for owner, k, t in slots:
-        if owner.get(k) is not t:                     # a tensor was replaced: re-walk the tree
+        if owner.get(k) is not t:                     # a tensor was replaced: re-walk the tree, retire every older entry
             slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
             module.__dict__.pop("_tfk_static_ok", None)
-            v = len(slots) + 7
-            for _, _, t2 in slots:
-                v = v * 1000003 + t2._version
-            return v & 0xFFFFFFFFFFFFFFF
+            _EPOCH[0] += 1
+            break
+    v = len(slots) + 1000003 * _EPOCH[0]
+    for _, _, t in slots:
         v = v * 1000003 + t._version
     return v & 0xFFFFFFFFFFFFFFF
 
@@ -170,8 +177,8 @@ def static_ok(module: nn.Module) -> bool:
     """Every floating-point parameter / buffer below ``module`` is fp32 on one HIP device (cached until a tensor moves:
     ``_apply`` drops the cache)."""
     hit = module.__dict__.get("_tfk_static_ok")
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0] == _EPOCH[0]:
+        return hit[1]
     slots = module.__dict__.get("_tfk_slots")
     if slots is None:
         slots = module.__dict__["_tfk_slots"] = _tensor_slots(module)
@@ -182,7 +189,7 @@ def static_ok(module: nn.Module) -> bool:
             devices.add(t.device)
             ok = ok and t.device.type == "cuda" and t.dtype == torch.float32
     ok = ok and len(devices) <= 1
-    module.__dict__["_tfk_static_ok"] = ok
+    module.__dict__["_tfk_static_ok"] = (_EPOCH[0], ok)
     return ok
 
 
@@ -190,6 +197,7 @@ def tensors_moved(module: nn.Module) -> None:
     """Called from ``_apply`` (``.to()`` / ``.cuda()`` / ``.float()`` ...): every cache that depends on where the
     tensors live or on their values is dropped, on this module and -- because a parent's program packs this module's
     weights -- this is also invoked for every ancestor that is itself being moved (Module._apply recurses)."""
+    _EPOCH[0] += 1                      # ancestors that are NOT being moved hold programs packed from these tensors too
     for m in module.modules():          # (submodules that are not bijections -- conditioner blocks -- keep caches too)
         d = m.__dict__
         for k in [k for k in d if k.startswith("_tfk_") and k != "_tfk_declined_warned"]:
@@ -1328,9 +1336,11 @@ def sample_ready(chain: Optional[CompiledChain]) -> bool:
 
 def invalidate(module: nn.Module, compiled_only: bool = False) -> None:
     """Drop EVERY cached packing below ``module``: compiled flow programs (``_tfk_compiled``), MADE weight packs,
-    elementwise blocks, BatchNorm scale / shift, training packs, the flat tensor lists.  The caches are keyed on the
-    tensors' autograd version counters, data pointers and slot identity -- which an in-place edit through ``.data``
-    (``p.data.mul_(0.5)``, manual weight averaging or clamping) or a replayed hipGraph does NOT move.  After such an
+    elementwise blocks, BatchNorm scale / shift, image programs, training packs, the flat tensor lists.  The caches are
+    keyed on the tensors' autograd version counters, on slot identity (a replaced Parameter) and on a process-wide epoch
+    that every ``.to()`` / ``.cuda()`` / dtype conversion of a module of this package bumps -- NOT on data pointers.  An
+    in-place edit through ``.data`` (``p.data.mul_(0.5)``, manual weight averaging or clamping), an assignment
+    ``p.data = other`` or a replayed hipGraph moves none of these.  After such an
     edit call this (``Bijection.invalidate_native_caches()`` / ``Flow.invalidate_native_caches()``); ``train()`` /
     ``eval()`` and ``load_state_dict`` call it themselves.
     ``compiled_only``: just the compiled flow programs -- what ``Flow.fit`` drops after an epoch of hipGraph replays
@@ -1384,6 +1394,9 @@ def get_compiled(composition, direction: int, device: torch.device, context: boo
                     "moving (an in-place edit through .data?): call invalidate_native_caches() after such edits")
         return hit[1]
     chain = compile_chain(composition, direction, device, context=context)
+    if chain is not None and context:
+        from torchflows_amd.utils import event_size
+        chain.ctx_width = event_size(composition.context_shape)
     cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
     if chain is None:
         warn_declined(composition, direction)
@@ -1483,6 +1496,11 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     ``sum_out`` (1-element float64, ``sum_ready`` chains with ``base``): receives the fp64 sum of the log-probabilities
     from the same launch."""
     assert sum_out is None or (sum_ready(chain) and base is not None and not base_of_input and context is None)
+    if context is not None and chain.ctx_width is not None and (context.dim() != 2 or context.shape[1] != chain.ctx_width):
+        # the kernels only count 4-wide k-steps: a context of another width would be truncated or zero-padded in
+        # silence where the reference's Linear layer raises a shape error (conditioning/context.py:46-60)
+        raise ValueError(f"context rows have {tuple(context.shape[1:])} elements, the flow was built for "
+                         f"context_shape with {chain.ctx_width}")
     if base_of_input:
         assert sample_ready(chain) and base is not None
         N, D = rows.shape
