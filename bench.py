@@ -549,8 +549,20 @@ def main():
         if seq is not None and not isinstance(D, tuple):
             KernelTimer.true_hidden[D] = seq[0].out_features
     flow = make_flow(arch, D, n_layers).to(dev)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(rows, *(D if isinstance(D, tuple) else (D,)), device=dev, generator=gen)
+    shape = D if isinstance(D, tuple) else (D,)
+    DATA_BLOCK = 4096
+    if args.total_rows and rows % DATA_BLOCK == 0:
+        # strong scaling: ONE global data set whatever the rank count -- block b of 4096 rows is drawn from seed
+        # 1234 + b, rank r holds the blocks of its row range -- so that the all-reduced log-likelihood of N ranks can be
+        # held against the 1-rank value (tests/test_gpu_bench_contract.py)
+        first = rank * rows // DATA_BLOCK
+        x = torch.empty(rows, *shape, device=dev)
+        for b in range(rows // DATA_BLOCK):
+            gen = torch.Generator(device=dev).manual_seed(1234 + first + b)
+            x[b * DATA_BLOCK:(b + 1) * DATA_BLOCK] = torch.randn(DATA_BLOCK, *shape, device=dev, generator=gen)
+    else:
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        x = torch.randn(rows, *shape, device=dev, generator=gen)
     # the layer-by-layer path materialises h (2.9 KB per row per RQS layer): evaluate in chunks;
     # the fused programs never hold h, so they take the whole batch at once
     step_rows = (chunk or rows) if (args.no_fused or isinstance(D, tuple)) else rows
@@ -605,7 +617,15 @@ def main():
             torch.cuda.synchronize()
             step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.stats_steps))
     rows_total = world * rows
+    rank_ms, rank_sums = [1e3 * elapsed / args.steps], None
     if world > 1:
+        # every rank's own step time (a straggler shows as max >> min) and its shard of the log-likelihood (the shards
+        # must add up to the all-reduced total): two small all-gathers AFTER the timed region
+        mine = torch.tensor([elapsed, float(native.sum_f32(lp).item())], dtype=torch.float64, device=dev)
+        both = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(both, mine)
+        rank_ms = [1e3 * float(b[0]) / args.steps for b in both]
+        rank_sums = [float(b[1]) for b in both]
         t = torch.tensor([elapsed, float(rows)], dtype=torch.float64, device=dev)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         r = t[1:].clone()
@@ -739,6 +759,8 @@ def main():
             "collective_backend": (backend if world > 1 else None),
             "rows_all_ranks": rows_total,
             "log_likelihood_sum": float(total.item()),
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+            "log_likelihood_shards": rank_sums,
             "step_stats": ({"steps": len(step_ms), "median_ms": step_ms[len(step_ms) // 2], "min_ms": step_ms[0],
                             "max_ms": step_ms[-1], "p10_ms": step_ms[len(step_ms) // 10],
                             "p90_ms": step_ms[(9 * len(step_ms)) // 10],

@@ -38,6 +38,19 @@ def test_bench_json_contract():
     assert s["steps"] == 100 and s["min_ms"] <= s["median_ms"] <= s["max_ms"]
     assert d["cpu_baseline_aten"]["value"] > 0 and d["rccl_ranks"] == 1
     assert d["parity"]["pass_rate_1e-5"] == 1.0
+    # every other BASELINE configuration rides in the same line (bounded legs): step time, recomputable roofline, parity
+    for name in ("nsf64", "realnvp256", "glow32"):
+        leg = d["configs"][name]
+        assert "error" not in leg, leg
+        assert leg["ms_per_step"] > 0 and abs(leg["evals_per_s"] - leg["rows"] / (leg["ms_per_step"] * 1e-3)) < 1e-6 * leg["evals_per_s"]
+        r = leg["roofline"]
+        per_launch = r["flops_per_launch"] / 1e12 if r["unit"] == "TFLOP/s" else r["bytes_per_launch"] / 1e9
+        assert abs(r["achieved"] - per_launch / (r["avg_us"] * 1e-6)) <= 0.02 * r["achieved"], (name, r)
+        assert 0 < r["frac"] <= 1.0
+        assert max(v for k, v in leg["parity"].items() if k.startswith("log_prob_max_rel")) < 1e-5, (name, leg["parity"])
+    assert d["configs"]["glow32"]["libtfk_launches_per_step"] <= 4 * 60
+    lw = d["roofline_layerwise"]["kernels"]
+    assert "affine_coupling[inplace]" in lw and 0 < lw["affine_coupling[inplace]"]["hbm_frac"] <= 1.0
 
 
 def test_bench_starts_its_own_ranks():
@@ -66,3 +79,35 @@ def test_bench_starts_its_own_ranks():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["scaling"] == "strong" and d["rows_all_ranks"] == 65536 and d["config"]["rows_per_gpu"] == 32768
+
+
+def _run_bench(args, env, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_four_ranks_rehearsal():
+    """The path the driver's 1 / 2 / 4 / 8-GPU scaling run takes, rehearsed with everything but RCCL: four ranks that
+    share this box's one card (the pool allows at most 6 GPU processes; the 8-rank launch is the driver's) over gloo,
+    started by `python bench.py --gpus 4` itself.  Config 2 weak scaling, then config 4's strong-scaling form, whose
+    all-reduced log-likelihood must equal the ONE-rank value of the same global data set to 1e-9 and be the sum of the
+    ranks' shards; every rank reports its own step time (a straggler would show as max >> min)."""
+    env = dict(os.environ, TORCHFLOWS_AMD_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--rows", "16384", "--stats-steps", "0"], env)
+    assert d["n_gpus"] == d["rccl_ranks"] == 4 and d["rows_all_ranks"] == 4 * 16384 and d["scaling"] == "weak"
+    assert len(d["rank_ms_per_step"]["per_rank"]) == 4 and 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"]
+    assert abs(sum(d["log_likelihood_shards"]) - d["log_likelihood_sum"]) <= 1e-9 * abs(d["log_likelihood_sum"])
+    strong = ["--workload", "realnvp256", "--total-rows", "131072", "--steps", "2", "--warmup", "1", "--stats-steps", "0",
+              "--no-sample", "--no-train", "--no-cpu-baseline"]
+    one = _run_bench(["--gpus", "1"] + strong, env)
+    four = _run_bench(["--gpus", "4"] + strong, env)
+    assert four["n_gpus"] == four["rccl_ranks"] == 4 and four["scaling"] == "strong"
+    assert four["rows_all_ranks"] == one["rows_all_ranks"] == 131072 and four["config"]["rows_per_gpu"] == 32768
+    assert abs(four["log_likelihood_sum"] - one["log_likelihood_sum"]) <= 1e-9 * abs(one["log_likelihood_sum"])
+    assert abs(sum(four["log_likelihood_shards"]) - four["log_likelihood_sum"]) <= 1e-9 * abs(four["log_likelihood_sum"])

@@ -176,7 +176,7 @@ def test_batch_and_event_shapes(pkg):
                     z, ld = flow.bijection.forward(x.cuda())
                     xr, ldr = flow.bijection.inverse(z)
                 assert lp_dev.shape == bs and z.shape == x.shape
-                assert rel(lp_dev.cpu().numpy(), lp_host.numpy()) < 4e-5
+                assert rel(lp_dev.cpu().numpy(), lp_host.numpy()) < (1e-5 if ctor is pkg.RealNVP else 4e-5)
                 assert torch.allclose(xr.cpu(), x, atol=1e-3)          # reference data_atol
                 assert torch.allclose(ld, -ldr, atol=1e-3)             # reference log_det_atol
 

@@ -315,13 +315,16 @@ def test_invert_and_composition_api():
 
 
 # ------------------------------------------------------------------ 2 ranks over gloo
-def test_sharded_log_likelihood_two_ranks_gloo():
-    """N > 1 path on CPU: each rank evaluates its shard, one all-reduce of the fp64 sum."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_log_likelihood_two_ranks_gloo(world):
+    """N > 1 path on CPU: each rank evaluates its shard, one all-reduce of the fp64 sum.  world = 8 is the rank count
+    of the driver's scaling run (1001 rows: shards of 126 / 125 rows): every rank must hold the 1-process total."""
     script = os.path.join(ROOT, "tests", "dist_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", OMP_NUM_THREADS="2")
+    port = str(29653 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1" if world > 2 else "2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29653",
-                          script], capture_output=True, text=True, env=env, timeout=300)
+                          f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", port,
+                          script], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_OK" in out.stdout
 
