@@ -118,6 +118,18 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     # fp32 value.
     e_lp64 = rel(lp.cpu().numpy(), g("log_prob64"))
     print(f"    log_prob vs the reference in fp64: {e_lp64:.2e}")
+    # Elementwise accuracy where fp32 itself is the limit (spline knots = 100 * cumsum(softmax) - 50: one ulp of a logit
+    # moves a knot by up to 1e-5): two independent fp32 evaluations differ from EACH OTHER by the sum of their distances
+    # from the exact value, so the kernels are held to the exact value instead -- their elementwise 1e-5 pass rate
+    # against the reference evaluated in fp64 must be within 0.05 of the reference's own fp32 pass rate against it
+    # (measured on flow_nsf64 init: z 0.80 vs 0.80, x 0.75 vs 0.76; against the reference's fp32 VALUE every fp32
+    # implementation sits lower -- 0.68 here, 0.66 for the bit-faithful per-layer kernels behind hipBLASLt GEMMs).
+    pr_z, pr_z_ref = pass_rate(z.cpu().numpy(), g("z64")), pass_rate(g("z"), g("z64"))
+    pr_x, pr_x_ref = pass_rate(xr.cpu().numpy(), g("x_inv64")), pass_rate(g("x_inv"), g("x_inv64"))
+    print(f"    elementwise 1e-5 pass rate vs the reference in fp64: z {pr_z:.4f} (reference's fp32 {pr_z_ref:.4f}), "
+          f"x_inv {pr_x:.4f} (reference's fp32 {pr_x_ref:.4f})")
+    slack = 0.05 + 1.5 / np.sqrt(z.numel())           # (+ sampling noise of the small fixtures: 120 elements in flow_ma*5)
+    assert pr_z >= pr_z_ref - slack and pr_x >= pr_x_ref - slack, (pr_z, pr_z_ref, pr_x, pr_x_ref)
     if variant == "init" and name in ("flow_realnvp3.npz", "flow_realnvp64.npz", "flow_nsf64.npz", "flow_realnvp256.npz"):
         assert e_lp < 1e-5, e_lp
     assert e_lp < 1e-5 or e_lp64 < max(1e-5, 2 * floor_lp), (e_lp, e_lp64, floor_lp)

@@ -72,6 +72,21 @@ typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef int ci32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v); }
+// v_rcp_f32 + one Newton step: the reciprocal to ~0.5 ulp instead of 1 ulp.  For the three reciprocals whose error is
+// multiplied by a knot position / bin size of up to 100 (the normaliser of each softmax, the bin width, the denominator of
+// the rational function) -- 8 fmas per spline element; -DTFK_RQS_NEWTON=0 restores the 1-ulp forms.
+#ifndef TFK_RQS_NEWTON
+#define TFK_RQS_NEWTON 1
+#endif
+__device__ __forceinline__ float rcp_n(float v)
+{
+    const float r = __builtin_amdgcn_rcpf(v);
+#if TFK_RQS_NEWTON
+    return fmaf(fmaf(-v, r, 1.0f), r, r);
+#else
+    return r;
+#endif
+}
 __device__ __forceinline__ float exp2_f(float v) { return __builtin_amdgcn_exp2f(v); }
 __device__ __forceinline__ float log2_f(float v) { return __builtin_amdgcn_logf(v); }
 
@@ -107,7 +122,7 @@ __device__ __forceinline__ void spline_knots(const float *u, const RqsLean &C, f
 #pragma unroll
         for (int j = 1; j < 8; ++j) pre[j] = pre[j - 1] + exp2_f(u[j] - m);
     }
-    const float g = C.g * rcp_f(pre[7]);
+    const float g = C.g * rcp_n(pre[7]);
     K[0] = C.minimum;
     K[8] = C.maximum;
 #pragma unroll
@@ -160,7 +175,7 @@ __device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, con
     const float LN2 = __int_as_float(0x3f317218);
     const float dk = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t0, 126.0f))), kRqsMinDelta);
     const float dk1 = fmaf(LN2, log2_f(1.0f + exp2_f(fminf(t1, 126.0f))), kRqsMinDelta);
-    const float rw = rcp_f(wk);
+    const float rw = rcp_n(wk);
     const float s = hk * rw;                                  // :94 / :159
     const float term1 = fmaf(-2.0f, s, dk1 + dk);            // :97 / :162
     float xi;
@@ -183,7 +198,7 @@ __device__ __forceinline__ void rqs_eval_lean(const float (&p)[24], float v, con
     const float q = xi * omx;                                 // :101 / :175
     const float xi2 = xi * xi;
     const float den = fmaf(term1, q, s);                      // :105
-    const float rden = rcp_f(den);
+    const float rden = rcp_n(den);
     if constexpr (!INVERSE) {
         const float num = hk * fmaf(dk, q, s * xi2);          // :104
         out = fmaf(num, rden, byk);                           // :106
