@@ -43,6 +43,10 @@ typedef float gf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGlowMaxRows = 16;        // samples per tile = MFMA N
 constexpr int kGlowMaxCh = 16;          // 1x1 convolution: target channels kept in registers
+#ifndef TFK_GLOW_PB
+#define TFK_GLOW_PB 2
+#endif
+constexpr int kGlowPB = TFK_GLOW_PB;     // target groups (of 16) per wave and step of the Linear / transform loop
 constexpr int kGlowFrame = 32;          // ConvModifier's target height / width (classic.py:13-16)
 
 struct GlowGeom {
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
             // Samples on the MFMA's M axis, parameters on N: tile 2 m holds the scale logits of targets 16 m .. 16 m + 15
             // (sorted by physical position by the host), tile 2 m + 1 their shifts, so lane (q, jj) receives u and beta
             // of target 16 m + jj for the four samples 4 q + r -- every row access of a wave instruction is four rows x
-            // 16 neighbouring targets (whole 128-byte lines), not 16 rows x 8 bytes.  Two target groups per step: their
+            // 16 neighbouring targets (whole 128-byte lines), not 16 rows x 8 bytes.  kGlowPB target groups per step: their
             // operands, tables and row elements are requested together (the loop is bound by memory latency otherwise).
             const int n_pairs = g.n_tiles >> 1;
             const float *b_eff1 = reinterpret_cast<const float *>(b_eff);
@@ -304,13 +308,13 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
             bool ok[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) ok[r] = 4 * q + r < nrows;
-            for (int pb = 2 * wave; pb < n_pairs; pb += 2 * nw) {
-                float4 au[2], ab[2];
-                float bu[2], bb[2], x[2][4];
-                float2 pst[2];
-                int ph[2];
+            for (int pb = kGlowPB * wave; pb < n_pairs; pb += kGlowPB * nw) {
+                float4 au[kGlowPB], ab[kGlowPB];
+                float bu[kGlowPB], bb[kGlowPB], x[kGlowPB][4];
+                float2 pst[kGlowPB];
+                int ph[kGlowPB];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < kGlowPB; ++u) {
                     const int m = pb + u < n_pairs ? pb + u : n_pairs - 1;
                     au[u] = w_eff[(2 * m) * 64 + lane];
                     ab[u] = w_eff[(2 * m + 1) * 64 + lane];
@@ -320,11 +324,11 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                     pst[u] = tgt_st[16 * m + j];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < kGlowPB; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[u][r] = ok[r] ? xr0[(long long)r * D + ph[u]] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < kGlowPB; ++u) {
                     gf32x4 hu = {bu[u], bu[u], bu[u], bu[u]}, hb = {bb[u], bb[u], bb[u], bb[u]};
                     hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], au[u].x, hu, 0, 0, 0);
                     hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], ab[u].x, hb, 0, 0, 0);
