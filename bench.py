@@ -421,6 +421,13 @@ def config_leg(workload, dev, timer, steps=12, warmup=3, layerwise=False):
     kernels = timer.summary()
     dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
     dom = kernels[dom_name]
+    traffic = None                 # PMC HBM bytes per launch of the dominant kernel, if taken from THESE kernel sources
+    try:
+        db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if db.get("csrc_sha256") == csrc_sha256():
+            traffic = db.get(workload, {}).get(dom_name)
+    except (OSError, ValueError):
+        pass
     out = {"workload": f"{arch}(D={D}, n_layers={n_layers}), {rows} rows" + (f" in chunks of {step_rows}" if step_rows != rows else ""),
            "rows": rows, "steps": steps, "ms_per_step": med, "min_ms": ms[0], "max_ms": ms[-1],
            "evals_per_s": rows / (med * 1e-3), "libtfk_launches_per_step": launches,
@@ -430,11 +437,11 @@ def config_leg(workload, dev, timer, steps=12, warmup=3, layerwise=False):
                            "flops_per_launch": dom["flops_per_launch"], "bytes_per_launch": dom["bytes_per_launch"],
                            "avg_us": dom["avg_us"], "launches": dom["launches"], "achieved": dom["TFLOPs"],
                            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / FP32_PEAK_TFLOPS,
-                           "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None}
+                           "hbm_GBps": dom["GBps"], "hbm_frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
     else:
         out["roofline"] = {"bound": "hbm", "kernel": dom_name, "bytes_per_launch": dom["bytes_per_launch"],
                            "avg_us": dom["avg_us"], "launches": dom["launches"], "achieved": dom["GBps"],
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None}
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
     out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GBps": round(v["GBps"], 1),
                           "TFLOPs": round(v["TFLOPs"], 2)} for k, v in kernels.items()}
     if isinstance(D, tuple):
