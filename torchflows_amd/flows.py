@@ -521,10 +521,12 @@ class Flow(BaseFlow):
 
 
 class FlowMixture(BaseFlow):
-    """Mixture of flows with categorical weights (reference flows.py:716-829).  ``log_prob`` is a
-    log-sum-exp over the components' ``Flow.log_prob`` -- each of them a flow program on an
-    MI355X; ``sample`` draws from every component and keeps one per row (the reference's scheme,
-    including its ``return_log_prob`` convention: the mixture of the components' sample log-probs)."""
+    """Mixture of flows with categorical weights (reference flows.py:716-829).  OUTSIDE the hot-path scope of this
+    build (SURVEY.md 2 lists it out of scope, 8(f) does not name it): plain host code over the components'
+    ``Flow.log_prob`` / ``Flow.sample`` kept so that code written against the reference's ``torchflows.flows`` imports;
+    it has no kernel, no entry point and no bench line of its own.  ``log_prob`` is a log-sum-exp over the components'
+    ``Flow.log_prob``; ``sample`` draws from every component and keeps one per row (the reference's scheme, including
+    its ``return_log_prob`` convention: the mixture of the components' sample log-probs)."""
 
     def __init__(self, flows, weights=None, trainable_weights: bool = False, constrain_weights: bool = False):
         super().__init__(event_shape=flows[0].event_shape)
