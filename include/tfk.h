@@ -434,11 +434,12 @@ int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float h
  *            (4, 32, 32) frame = the first ConvModifier's bias), i.e. what the blocks produce wherever the source image's
  *            receptive field does not reach; only the window it does reach is computed per sample
  *   w_eff    tiles of [64 lanes][4] floats: tile t, lane l, k-step ks = W[16 t + (l & 15)][4 ks + (l >> 4)], where the rows
- *            of W are rows of W_eff (n_params, 16) -- the Linear layer's columns of the 4x4 interior of the (1, 10, 10)
+ *            of W are log2(e) times the rows of W_eff (n_params, 16) -- the Linear layer's columns of the 4x4 interior of the (1, 10, 10)
  *            image -- in KERNEL ORDER.  1x1 convolution: ceil(n_params / 16) tiles, rows in the order of h.  Affine:
  *            2 * ceil(T / 16) tiles; for the target listed at position 16 m + j of tgt_idx, row 32 m + j is its scale
  *            logit (h[n, t, 0]) and row 32 m + 16 + j its shift (h[n, t, 1]); rows of padding are zero
- *   b_eff    16 * tiles floats in the same row order: Linear bias + its 84 frame columns times the second ConvModifier's bias
+ *   b_eff    16 * tiles floats in the same row order: log2(e) times (Linear bias + its 84 frame columns times the second
+ *            ConvModifier's bias) -- the kernel's sigmoid is 1 / (1 + exp2(-h log2 e))
  * tgt_idx (affine) may list the targets in any order -- ascending physical position makes the 16 targets of a tile pair
  * neighbours in the row -- padded, like tgt_st, to a multiple of 16 entries.
  * Supported: first ConvModifier with a 1x1 kernel (hi, wi <= 32 with 32 - hi, 32 - wi even: it sits at (oy, ox) =

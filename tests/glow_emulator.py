@@ -79,7 +79,7 @@ def run_step(rows, logdet, step, check_windows=True):
     n_tiles = w_eff.numel() // 256
     A = dd(w_eff).view(n_tiles, 4, 16, 4)            # [t][q][i][ks] = W[16 t + i][4 ks + q]
     W_k = A.permute(0, 2, 3, 1).reshape(n_tiles * 16, 16)
-    h = V @ W_k.t() + dd(b_eff)
+    h = (V @ W_k.t() + dd(b_eff)) / 1.4426950408889634        # the packed rows carry a factor log2(e)
     h = 4.0 / (1.0 + torch.exp(-h)) - 2.0
     tst = dd(tgt_st).view(-1, 2)[:L.T]             # (affine tables are padded to whole groups of 16 targets)
     tgt = tgt_idx.long()[:L.T]

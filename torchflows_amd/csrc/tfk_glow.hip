@@ -156,11 +156,11 @@ __device__ __forceinline__ void conv_stage_cg(int cg, float *slot0, int slot_flo
     else conv_stage<CI, CO, 2, AFFINE>(slot0, slot_floats, in_off, ih, iw, out_off, oh, ow, oy0, ox0, ph, pw, G, w, bias, sc, sh);
 }
 
-// lo + (hi - lo) * sigmoid(h) with (lo, hi) = (-2, 2): s * 4 is exact, so the reference's multiply-then-add is one fma
-__device__ __forceinline__ float bounded4(float h)
+// lo + (hi - lo) * sigmoid(h) with (lo, hi) = (-2, 2); the caller hands in h * log2(e) (the rows of W_eff / b_eff arrive
+// pre-multiplied), so the exponential is one v_exp_f32; s * 4 is exact, so the reference's multiply-then-add is one fma
+__device__ __forceinline__ float bounded4(float h_log2e)
 {
-    const float e = exp_lean(-h);
-    return fmaf(__builtin_amdgcn_rcpf(1.0f + e), 4.0f, -2.0f);
+    return fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-h_log2e)), 4.0f, -2.0f);
 }
 
 template <int KIND, bool INV>
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                         const float u_ = bounded4(hu[r]), beta = bounded4(hb[r]);
                         const float v = fmaf(pst[u].x, x[u][r], pst[u].y);
                         const float wl = fmaf(u_, 0.5f, kAffC0);          // affine.py:33-34, log(alpha) up to 1e-10
-                        const float alpha = exp_lean(wl) + kAffMinScale;
+                        const float alpha = __builtin_amdgcn_exp2f(wl * __int_as_float(0x3fb8aa3b)) + kAffMinScale;   // (|wl| <= 1: 1 ulp)
                         const float out = INV ? (v - beta) * __builtin_amdgcn_rcpf(alpha) : alpha * v + beta;
                         if (tgt_ok && ok[r]) {
                             xr0[(long long)r * D + ph[u]] = out;
@@ -391,12 +391,24 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                 float *xr = rows + (row_base + s) * D;
                 const float *hr = Hs + s * g.h_stride;
                 float v[kGlowMaxCh];
+                int pos[kGlowMaxCh];
+                // four channels at a time, indices clamped into the tables: the table reads and then the row reads of a group
+                // leave together (a branch per channel serialises them: table -> row element, n times over)
 #pragma unroll
-                for (int c = 0; c < kGlowMaxCh; ++c)
-                    if (c < n) {
-                        const int e = c * HW + p;
-                        const float2 st = tgt_st[e];
-                        v[c] = fmaf(st.x, xr[tgt_idx[e]], st.y);
+                for (int c0 = 0; c0 < kGlowMaxCh; c0 += 4)
+                    if (c0 < n) {
+                        float2 st[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = c0 + u < n ? c0 + u : n - 1;
+                            pos[c0 + u] = tgt_idx[c * HW + p];
+                            st[u] = tgt_st[c * HW + p];
+                        }
+                        float raw[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) raw[u] = xr[pos[c0 + u]];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[c0 + u] = fmaf(st[u].x, raw[u], st[u].y);
                     }
                 // U entry (r, c), r < c: hr[n + r n - r (r + 1) / 2 + (c - r - 1)];  L entry (r, c), c < r:
                 // hr[n + n_off + r (r - 1) / 2 + c]   (triu_indices / tril_indices order, matrix.py:40-48)
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
                 }
 #pragma unroll
                 for (int c = 0; c < kGlowMaxCh; ++c)
-                    if (c < n) xr[tgt_idx[c * HW + p]] = v[c];
+                    if (c < n) xr[pos[c]] = v[c];
                 if (p == 0) {                                   // sum_r log U_rr, ONCE per sample
                     float s_ld = 0.0f;
                     for (int r = 0; r < n; ++r) s_ld += logf(hr[r]);

@@ -138,14 +138,16 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
 
 
 def _tile_pack(W_rows: torch.Tensor, b_rows: torch.Tensor):
-    """(rows, 16) / (rows,) in kernel row order -> MFMA operand tiles [t][64 lanes][4 k-steps] and the padded bias:
+    """(rows, 16) / (rows,) in kernel row order -> MFMA operand tiles [t][64 lanes][4 k-steps] and the padded bias, both
+    multiplied by log2(e):
     tile t, lane l = 16 q + i, k-step ks  <-  W[16 t + i][4 ks + q]."""
     n = W_rows.shape[0]
     n_tiles = (n + 15) // 16
+    log2e = 1.4426950408889634          # the kernel's sigmoid is 1 / (1 + exp2(-h')): h' = h log2(e)
     Wp = torch.zeros(n_tiles * 16, 16, dtype=torch.float64)
-    Wp[:n] = W_rows
+    Wp[:n] = W_rows * log2e
     bp = torch.zeros(n_tiles * 16, dtype=torch.float64)
-    bp[:n] = b_rows
+    bp[:n] = b_rows * log2e
     w_tiles = Wp.view(n_tiles, 16, 4, 4).permute(0, 3, 1, 2).reshape(-1)
     return w_tiles.float().contiguous(), bp.float().contiguous()
 
