@@ -42,7 +42,7 @@ WORKLOADS = {
     "realnvp64": ("RealNVP", 64, 8, 1 << 20, None),          # configs[1] -- the metric's config
     "nsf64": ("CouplingRQNSF", 64, 8, 1 << 20, 1 << 18),     # configs[2]
     "realnvp256": ("RealNVP", 256, 8, 1 << 19, None),        # configs[3], one rank's shard
-    "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 16),  # configs[4] (3 blocks, 3.2 M params); chunks of 2^16 rows
+    "glow32": ("AffineGlow", (3, 32, 32), 3, 1 << 18, 1 << 17),  # configs[4] (3 blocks, 3.2 M params); chunks of 2^17 rows
     "lrs64": ("CouplingLRS", 64, 8, 1 << 20, 1 << 18),       # sibling preset (linear rational splines), not a BASELINE config
     "realnvp128": ("RealNVP", 128, 8, 1 << 20, None),        # between configs 2 and 4 (tuning the 128-wide kernel)
 }
@@ -509,6 +509,8 @@ def main():
                     help="layer-by-layer kernels + PyTorch-ROCm conditioner GEMMs (the split path)")
     ap.add_argument("--no-sample", action="store_true", help="skip the Flow.sample throughput leg")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd + bwd + AdamW) leg")
+    ap.add_argument("--chunk-rows", type=int, default=None,
+                    help="rows per Flow.log_prob call of a step (default: the configuration's; 0 = the whole batch)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the bounded legs over the other BASELINE configurations (nsf64, realnvp256, glow32)")
     ap.add_argument("--no-mfma", action="store_true",
@@ -547,6 +549,8 @@ def main():
     timer = KernelTimer(native)
 
     arch, D, n_layers, rows, chunk = WORKLOADS[args.workload]
+    if args.chunk_rows is not None:
+        chunk = args.chunk_rows or None
     rows = args.rows or rows
     if args.total_rows:
         rows = args.total_rows // world

@@ -13,6 +13,6 @@ python tools/summarize_profile.py gpurun_out/prof_r03_sample > /dev/null; rm -rf
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03_train/trace -o trace -- python tools/train_probe.py > gpurun_out/prof_r03_train/probe.txt 2> gpurun_out/prof_r03_train/err.txt
 python tools/summarize_profile.py gpurun_out/prof_r03_train > /dev/null; rm -rf gpurun_out/prof_r03_train/trace
 # one coupling launch of config 5 (the first checkerboard layer) under the SQ / TCC counters
-bash tools/glow_pmc.sh r03_step0 0 65536 > gpurun_out/prof_r03_glow32/step0_pmc.txt 2>&1
-bash tools/glow_pmc.sh r03_step3 3 65536 > gpurun_out/prof_r03_glow32/step3_pmc.txt 2>&1
+bash tools/glow_pmc.sh r03_step0 0 131072 > gpurun_out/prof_r03_glow32/step0_pmc.txt 2>&1
+bash tools/glow_pmc.sh r03_step3 3 131072 > gpurun_out/prof_r03_glow32/step3_pmc.txt 2>&1
 echo PROFILE_DONE
