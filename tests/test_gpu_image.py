@@ -248,6 +248,38 @@ def test_glow_program_rows_and_batch_shapes(native):
     assert torch.equal(z.reshape(15, 3, 32, 32), z2) and torch.equal(ld.reshape(15), ld2)
 
 
+@pytest.mark.parametrize("cls_name,event_shape,n_layers", [("MultiscaleRealNVP", (2, 32, 32), 2), ("AffineGlow", (4, 8, 16), 1),
+                                                          ("MultiscaleRealNVP", (1, 16, 16), None), ("AffineGlow", (6, 16, 8), 2)])
+def test_image_programs_other_presets_vs_host(native, cls_name, event_shape, n_layers):
+    """The image-program route beyond config 5: the multiscale RealNVP preset (normalised couplings, no 1x1 convolutions),
+    non-square images, one-block models, single-channel images -- forward, inverse and log_prob on the HIP path (one launch
+    per coupling, asserted) against this package's ATen path on the host."""
+    import torchflows_amd as tfa
+    from torchflows_amd import image_program
+    from torchflows_amd.bijections.finite import multiscale
+    torch.manual_seed(7)
+    flow = tfa.Flow(getattr(multiscale, cls_name)(event_shape, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(48, *event_shape))
+    flow.eval()
+    x = torch.randn(21, *event_shape)
+    with torch.no_grad():
+        z_h, ld_h = flow.bijection.forward(x)
+        lp_h = flow.log_prob(x)
+        flow = flow.cuda()
+        prog = image_program.get_program(flow.bijection, 0, torch.device("cuda", 0))
+        assert prog is not None, "the compiler declined a model it should cover"
+        before = native.calls
+        z, ld = flow.bijection.forward(x.cuda())
+        assert native.calls - before == len(prog.steps) + (1 if prog.flush is not None else 0)
+        lp = flow.log_prob(x.cuda())
+        xr, ldr = flow.bijection.inverse(z)
+    assert rel(z.cpu().numpy(), z_h.numpy()) < 1e-5 and rel(ld.cpu().numpy(), ld_h.numpy()) < 1e-5
+    assert rel(lp.cpu().numpy(), lp_h.numpy()) < 1e-5
+    assert rel(xr.cpu().numpy(), x.numpy()) < 1e-4 and rel((-ldr).cpu().numpy(), ld.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])
 def test_glow_hip_vs_host_config5(native, event_shape, n):
     """Config 5 model (AffineGlow on 32x32x3, 3.2 M parameters), HIP path vs this package's
