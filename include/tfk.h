@@ -437,20 +437,21 @@ int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float h
  *            of W are log2(e) times the rows of W_eff (n_params, 16) -- the Linear layer's columns of the 4x4 interior of the (1, 10, 10)
  *            image -- in KERNEL ORDER.  1x1 convolution: ceil(n_params / 16) tiles, rows in the order of h.  Affine:
  *            2 * ceil(T / 16) tiles; for the target listed at position 16 m + j of tgt_idx, row 32 m + j is its scale
- *            logit (h[n, t, 0]) and row 32 m + 16 + j its shift (h[n, t, 1]); rows of padding are zero
+ *            logit (h[n, t, 0]) and row 32 m + 16 + j its shift (h[n, t, 1]); rows of padding are zero.  Shift:
+ *            ceil(T / 16) tiles, row 16 m + j = the shift of the target at position 16 m + j of tgt_idx
  *   b_eff    16 * tiles floats in the same row order: log2(e) times (Linear bias + its 84 frame columns times the second
  *            ConvModifier's bias) -- the kernel's sigmoid is 1 / (1 + exp2(-h log2 e))
- * tgt_idx (affine) may list the targets in any order -- ascending physical position makes the 16 targets of a tile pair
+ * tgt_idx (affine, shift) may list the targets in any order -- ascending physical position makes the 16 targets of a tile pair
  * neighbours in the row -- padded, like tgt_st, to a multiple of 16 entries.
  * Supported: first ConvModifier with a 1x1 kernel (hi, wi <= 32 with 32 - hi, 32 - wi even: it sits at (oy, ox) =
  * ((32 - hi) / 2, (32 - wi) / 2)), ConvNet kernels (8, 8, 4), 1x1 convolutions of <= 16 channels.
  * slots / block / cg1 / cg2 / grid = 0 let the library choose the launch shape (tfk_glow_plan reports it). */
 typedef struct tfk_glow_layer {
-    int32_t kind;              /* 0 affine, 1 invertible 1x1 convolution */
+    int32_t kind;              /* 0 affine, 1 invertible 1x1 convolution, 2 shift (z = x +/- h, log-det 0; affine.py:137-159) */
     int32_t c_in, hi, wi;      /* conditioner input image */
     int32_t oy, ox;            /* its position in ConvModifier's 32x32 frame */
     int32_t T;                 /* target elements */
-    int32_t n_params;          /* 2 T (affine) or n + n (n - 1) (1x1 convolution of n channels) */
+    int32_t n_params;          /* 2 T (affine), T (shift) or n + n (n - 1) (1x1 convolution of n channels) */
     int32_t n_ch, hw;          /* 1x1 convolution: target channels, pixels per channel (T = n_ch * hw); else 0 */
     int32_t slots, block, cg1, cg2, grid;   /* launch shape overrides, 0 = default */
     const int32_t *src_idx;    /* device int32[c_in * hi * wi] */

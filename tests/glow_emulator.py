@@ -96,6 +96,9 @@ def run_step(rows, logdet, step, check_windows=True):
         else:
             rows[:, tgt] = (xb - beta) / alpha
             logdet -= torch.log(alpha).sum(1)
+    elif L.kind == 2:                                  # shift: row 16 m + j of the tiles = the listed target's shift
+        beta = h[:, :L.T]
+        rows[:, tgt] = xb - beta if step.inverse else xb + beta
     else:
         n, HW = L.n_ch, L.hw
         h = h[:, :L.n_params]

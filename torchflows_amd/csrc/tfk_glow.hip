@@ -295,13 +295,16 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bq[ks] = V[j * 16 + 4 * ks + q];
         if (g.skip & 4) {
-        } else if (KIND == 0) {
+        } else if (KIND == 0 || KIND == 2) {
+            // (KIND 2, Shift, affine.py:137-159: one tile per group -- the shifts --, z = x +/- h, log-det 0)
+            constexpr bool SHIFT = KIND == 2;
+            constexpr int TPG = SHIFT ? 1 : 2;               // MFMA tiles per group of 16 targets
             // Samples on the MFMA's M axis, parameters on N: tile 2 m holds the scale logits of targets 16 m .. 16 m + 15
             // (sorted by physical position by the host), tile 2 m + 1 their shifts, so lane (q, jj) receives u and beta
             // of target 16 m + jj for the four samples 4 q + r -- every row access of a wave instruction is four rows x
             // 16 neighbouring targets (whole 128-byte lines), not 16 rows x 8 bytes.  kGlowPB target groups per step: their
             // operands, tables and row elements are requested together (the loop is bound by memory latency otherwise).
-            const int n_pairs = g.n_tiles >> 1;
+            const int n_pairs = g.n_tiles / TPG;
             const float *b_eff1 = reinterpret_cast<const float *>(b_eff);
             float ldr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float *xr0 = rows + (row_base + 4 * q) * D;
@@ -316,10 +319,10 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
 #pragma unroll
                 for (int u = 0; u < kGlowPB; ++u) {
                     const int m = pb + u < n_pairs ? pb + u : n_pairs - 1;
-                    au[u] = w_eff[(2 * m) * 64 + lane];
-                    ab[u] = w_eff[(2 * m + 1) * 64 + lane];
-                    bu[u] = b_eff1[32 * m + j];
-                    bb[u] = b_eff1[32 * m + 16 + j];
+                    au[u] = w_eff[(TPG * m) * 64 + lane];
+                    ab[u] = w_eff[(TPG * m + TPG - 1) * 64 + lane];
+                    bu[u] = b_eff1[16 * TPG * m + j];
+                    bb[u] = b_eff1[16 * TPG * m + 16 * (TPG - 1) + j];
                     ph[u] = tgt_idx[16 * m + j];                 // (tables padded to whole groups of 16)
                     pst[u] = tgt_st[16 * m + j];
                 }
@@ -330,22 +333,28 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
 #pragma unroll
                 for (int u = 0; u < kGlowPB; ++u) {
                     gf32x4 hu = {bu[u], bu[u], bu[u], bu[u]}, hb = {bb[u], bb[u], bb[u], bb[u]};
-                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], au[u].x, hu, 0, 0, 0);
+                    if (!SHIFT) hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], au[u].x, hu, 0, 0, 0);
                     hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[0], ab[u].x, hb, 0, 0, 0);
-                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[1], au[u].y, hu, 0, 0, 0);
+                    if (!SHIFT) hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[1], au[u].y, hu, 0, 0, 0);
                     hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[1], ab[u].y, hb, 0, 0, 0);
-                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2], au[u].z, hu, 0, 0, 0);
+                    if (!SHIFT) hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2], au[u].z, hu, 0, 0, 0);
                     hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2], ab[u].z, hb, 0, 0, 0);
-                    hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[3], au[u].w, hu, 0, 0, 0);
+                    if (!SHIFT) hu = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[3], au[u].w, hu, 0, 0, 0);
                     hb = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[3], ab[u].w, hb, 0, 0, 0);
                     const bool tgt_ok = pb + u < n_pairs && 16 * (pb + u) + j < g.T;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float u_ = bounded4(hu[r]), beta = bounded4(hb[r]);
+                        const float beta = bounded4(hb[r]);
                         const float v = fmaf(pst[u].x, x[u][r], pst[u].y);
-                        const float wl = fmaf(u_, 0.5f, kAffC0);          // affine.py:33-34, log(alpha) up to 1e-10
-                        const float alpha = __builtin_amdgcn_exp2f(wl * __int_as_float(0x3fb8aa3b)) + kAffMinScale;   // (|wl| <= 1: 1 ulp)
-                        const float out = INV ? (v - beta) * __builtin_amdgcn_rcpf(alpha) : alpha * v + beta;
+                        float out, wl = 0.0f;
+                        if (SHIFT) {
+                            out = INV ? v - beta : v + beta;
+                        } else {
+                            const float u_ = bounded4(hu[r]);
+                            wl = fmaf(u_, 0.5f, kAffC0);                  // affine.py:33-34, log(alpha) up to 1e-10
+                            const float alpha = __builtin_amdgcn_exp2f(wl * __int_as_float(0x3fb8aa3b)) + kAffMinScale;   // (|wl| <= 1: 1 ulp)
+                            out = INV ? (v - beta) * __builtin_amdgcn_rcpf(alpha) : alpha * v + beta;
+                        }
                         if (tgt_ok && ok[r]) {
                             xr0[(long long)r * D + ph[u]] = out;
                             ldr[r] += INV ? -wl : wl;
@@ -557,12 +566,14 @@ namespace {
 int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, const char *fn)
 {
     if (!L) return fail(TFK_EINVAL, "%s: null layer", fn);
-    if (L->kind != 0 && L->kind != 1) return fail(TFK_EINVAL, "%s: kind %d (0 affine, 1 invertible 1x1 convolution)", fn, L->kind);
+    if (L->kind < 0 || L->kind > 2) return fail(TFK_EINVAL, "%s: kind %d (0 affine, 1 invertible 1x1 convolution, 2 shift)", fn, L->kind);
     if (L->c_in < 1 || L->hi < 1 || L->wi < 1 || L->oy < 0 || L->ox < 0 || L->oy + L->hi > kGlowFrame ||
         L->ox + L->wi > kGlowFrame)
         return fail(TFK_EINVAL, "%s: source image (%d, %d, %d) at (%d, %d) does not fit the %dx%d frame", fn, L->c_in,
                     L->hi, L->wi, L->oy, L->ox, kGlowFrame, kGlowFrame);
     if (L->T < 1 || L->n_params < 1 || D < 1) return fail(TFK_EINVAL, "%s: T = %d, n_params = %d, D = %d", fn, L->T, L->n_params, D);
+    if (L->kind == 2 && L->n_params != L->T)
+        return fail(TFK_EINVAL, "%s: a shift coupling of %d targets takes %d parameters, got %d", fn, L->T, L->T, L->n_params);
     if (L->kind == 0 && L->n_params != 2 * L->T)
         return fail(TFK_EINVAL, "%s: an affine coupling of %d targets takes %d parameters, got %d", fn, L->T, 2 * L->T, L->n_params);
     if (L->kind == 1 && (L->n_ch < 1 || L->n_ch > kGlowMaxCh || L->hw < 1 || L->n_ch * L->hw != L->T ||
@@ -573,7 +584,7 @@ int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, c
     g = GlowGeom{};
     g.c_in = L->c_in, g.hi = L->hi, g.wi = L->wi, g.oy = L->oy, g.ox = L->ox;
     g.T = L->T, g.n_params = L->n_params, g.D = D;
-    g.n_tiles = L->kind == 0 ? 2 * ((L->T + 15) / 16) : (L->n_params + 15) / 16;
+    g.n_tiles = L->kind == 0 ? 2 * ((L->T + 15) / 16) : (L->n_params + 15) / 16;        // (shift: one tile per 16 targets)
     g.kind = L->kind, g.n_ch = L->n_ch, g.hw = L->hw;
     g.h_stride = g.n_tiles * 16 + 1;
     g.fixed_floats = 512 + (L->kind == 1 ? ((kGlowMaxRows * g.h_stride + 3) & ~3) : 0);
@@ -632,7 +643,7 @@ int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tf
     const int64_t tiles = (N + g.tile_rows - 1) / g.tile_rows;
     int64_t grid = layer->grid > 0 ? layer->grid : (int64_t)cu_count() * wgs_per_cu;
     if (grid > tiles) grid = tiles;
-    static bool attr_done[4] = {false, false, false, false};
+    static bool attr_done[6] = {false, false, false, false, false, false};
 #define TFK_GLOW(K, I)                                                                                               \
     do {                                                                                                             \
         auto kern = k_glow_coupling<K, I>;                                                                           \
@@ -651,6 +662,8 @@ int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tf
     } while (0)
     if (layer->kind == 0 && !inverse) TFK_GLOW(0, false);
     else if (layer->kind == 0) TFK_GLOW(0, true);
+    else if (layer->kind == 2 && !inverse) TFK_GLOW(2, false);
+    else if (layer->kind == 2) TFK_GLOW(2, true);
     else if (!inverse) TFK_GLOW(1, false);
     else TFK_GLOW(1, true);
 #undef TFK_GLOW

@@ -19,7 +19,7 @@ recursion is *compiled* once per parameter version into a flat list of ``tfk_glo
   ``(n_params, 16)`` matrix in MFMA tile order.
 
 A model the compiler does not cover (another conditioner, a modifier whose kernel is not 1x1 -- images larger than 32
-pixels or odd paddings --, a transformer other than Affine / the 1x1 convolution, a context, ``invert()``-ed layers, an
+pixels or odd paddings --, a transformer other than Affine / Shift / the 1x1 convolution, a context, ``invert()``-ed layers, an
 ActNorm that still waits for its first batch) returns None and runs layer by layer as before.
 """
 from __future__ import annotations
@@ -204,7 +204,7 @@ class _Builder:
     # -- couplings: one launch each --------------------------------------------------------------------------------
     def coupling(self, layer, d: int, M: torch.Tensor) -> None:
         kind = layer.transformer.native_kind
-        if kind not in ("affine", "conv1x1") or layer.context_shape is not None:
+        if kind not in ("affine", "shift", "conv1x1") or layer.context_shape is not None:
             raise _Decline(f"no fused kernel for transformer kind {kind!r}")
         cs = tuple(layer.coupling.constant_shape)
         if len(cs) != 3:
@@ -222,13 +222,21 @@ class _Builder:
             hw = T // n_ch
             if pk["n_params"] != n_ch + n_ch * (n_ch - 1):
                 raise _Decline("unexpected LU parameter count")
-        elif pk["n_params"] != 2 * T:
-            raise _Decline("unexpected affine parameter count")
+        elif pk["n_params"] != (T if kind == "shift" else 2 * T):
+            raise _Decline("unexpected parameter count")
         if int(src.numel()) != c_in * hi * wi:
             raise _Decline("source mask does not fill the conditioner image")
         dev = self.device
         st = lambda idx: torch.stack([self.s[idx], self.t[idx]], dim=1).float().contiguous()
-        if kind == "affine":
+        if kind == "shift":                                # one tile per 16 targets (sorted by position): their shifts
+            order = torch.argsort(tgt, stable=True)
+            tgt_k = tgt[order]
+            n_groups = (T + 15) // 16
+            w_tiles, b_tiles = _tile_pack(pk["W_eff"][order], pk["b_eff"][order])
+            pad = 16 * n_groups - T
+            tgt_i = torch.cat([tgt_k.to(torch.int32), torch.zeros(pad, dtype=torch.int32)])
+            tgt_m = torch.cat([st(tgt_k), torch.zeros(pad, 2)])
+        elif kind == "affine":
             # the kernel takes the targets in any order: ascending physical position, so that the 16 targets of a tile
             # pair are neighbours in the row; tile 2 m = their scale logits (h[..., t, 0]), tile 2 m + 1 their shifts
             order = torch.argsort(tgt, stable=True)
@@ -250,7 +258,7 @@ class _Builder:
         keep = (src.to(torch.int32).to(dev), st(src).to(dev), tgt_i.to(dev), tgt_m.to(dev),
                 pk["weights"].to(dev), pk["bg1"].to(dev), pk["bg2"].to(dev), w_tiles.to(dev), b_tiles.to(dev))
         env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_" + k, "0") or 0)
-        L = native.GlowLayer(kind=1 if kind == "conv1x1" else 0, c_in=c_in, hi=hi, wi=wi, oy=pk["oy"], ox=pk["ox"],
+        L = native.GlowLayer(kind={"affine": 0, "conv1x1": 1, "shift": 2}[kind], c_in=c_in, hi=hi, wi=wi, oy=pk["oy"], ox=pk["ox"],
                              T=T, n_params=pk["n_params"], n_ch=n_ch, hw=hw, slots=env("SLOTS"), block=env("BLOCK"),
                              cg1=env("CG1"), cg2=env("CG2"), grid=env("GRID"),
                              src_idx=keep[0].data_ptr(), src_st=keep[1].data_ptr(), tgt_idx=keep[2].data_ptr(),
