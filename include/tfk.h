@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 24
+#define TFK_ABI_VERSION 25
 
 enum {
     TFK_OK = 0,
@@ -426,7 +426,7 @@ int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float h
  * (s, t) interleaved: the value the layer sees is s * rows[n, idx] + t (the deferred ActNorm layers in front of it;
  * (1, 0) = none); targets are stored in final form.
  * The caller evaluates everything that does not depend on the sample (see torchflows_amd/image_program.py):
- *   weights  tfk_glow_weight_floats(c_in) floats: first ConvModifier W (4, c_in), b (4) | conv1 W as [ci=4][3][3][co=8],
+ *   weights  tfk_glow_weight_floats(c_in * kh * kw) floats: first ConvModifier W (4, c_in, kh, kw), b (4) | conv1 W as [ci=4][3][3][co=8],
  *            b1 (8), BatchNorm-1 scale (8), shift (8) | conv2 W as [ci=8][3][3][co=8], b2, scale, shift (8 each) |
  *            conv3 W as [ci=8][3][3][co=4], b3 (4) | second ConvModifier's 4 weights times BatchNorm-3's scales, then its
  *            bias + sum_c weight_c shift_c   (BatchNorm in inference form: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
@@ -443,13 +443,15 @@ int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float h
  *            ConvModifier's bias) -- the kernel's sigmoid is 1 / (1 + exp2(-h log2 e))
  * tgt_idx (affine, shift) may list the targets in any order -- ascending physical position makes the 16 targets of a tile pair
  * neighbours in the row -- padded, like tgt_st, to a multiple of 16 entries.
- * Supported: first ConvModifier with a 1x1 kernel (hi, wi <= 32 with 32 - hi, 32 - wi even: it sits at (oy, ox) =
- * ((32 - hi) / 2, (32 - wi) / 2)), ConvNet kernels (8, 8, 4), 1x1 convolutions of <= 16 channels.
+ * Supported: first ConvModifier as the reference builds it for images up to 32 pixels (classic.py:21-33: kernel 1 and padding
+ * (32 - size) / 2 along an axis where 32 - size is even, kernel 2 and padding (33 - size) / 2 where it is odd -- e.g. the
+ * 7-row conditioner images of 28x28 inputs), ConvNet kernels (8, 8, 4), 1x1 convolutions of <= 16 channels.
  * slots / block / cg1 / cg2 / grid = 0 let the library choose the launch shape (tfk_glow_plan reports it). */
 typedef struct tfk_glow_layer {
     int32_t kind;              /* 0 affine, 1 invertible 1x1 convolution, 2 shift (z = x +/- h, log-det 0; affine.py:137-159) */
     int32_t c_in, hi, wi;      /* conditioner input image */
-    int32_t oy, ox;            /* its position in ConvModifier's 32x32 frame */
+    int32_t oy, ox;            /* where the modifier's non-constant rectangle starts in its 32x32 frame: padding - (kernel - 1) */
+    int32_t kh, kw;            /* first ConvModifier's kernel, 1 or 2 per axis (0 = 1); the rectangle is (hi + kh - 1, wi + kw - 1) */
     int32_t T;                 /* target elements */
     int32_t n_params;          /* 2 T (affine), T (shift) or n + n (n - 1) (1x1 convolution of n channels) */
     int32_t n_ch, hw;          /* 1x1 convolution: target channels, pixels per channel (T = n_ch * hw); else 0 */
@@ -460,7 +462,7 @@ typedef struct tfk_glow_layer {
     const float *tgt_st;       /* device float[2 * T], padded likewise (any values), 8-byte aligned */
     const float *weights, *bg1, *bg2, *w_eff, *b_eff;
 } tfk_glow_layer;
-int64_t tfk_glow_weight_floats(int32_t c_in);
+int64_t tfk_glow_weight_floats(int32_t c_in_times_taps);
 int tfk_glow_plan(const tfk_glow_layer *layer, int32_t D, int32_t *slots, int32_t *block, int32_t *cg1, int32_t *cg2,
                   int32_t *lds_bytes, int32_t *tile_rows);
 int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tfk_glow_layer *layer, int32_t inverse,

@@ -11,7 +11,7 @@ C0 = float(np.float32(np.log(1 - 1e-10)))
 F = torch.nn.functional
 
 
-def _windows(hi, wi, oy, ox):
+def _windows(hi, wi, oy, ox):   # (hi, wi: the rectangle of the frame that is not the modifier's bias)
     """The windows of csrc/tfk_glow.hip:glow_windows (pooled-1 rows / cols, pooled-2 rows / cols), half-open."""
     def axis(o, n):
         lo, hi_ = max(o - 1, 0), min(o + n + 1, 32)
@@ -31,7 +31,7 @@ def _unpack_weights(w, c_in):
         v = w[o:o + n]
         o += n
         return v
-    out = dict(Wm=take(4 * c_in).view(4, c_in), bm=take(4))
+    out = dict(Wm=take(4 * c_in), bm=take(4))           # (c_in here = channels x kernel taps of the first modifier)
     out["W1"] = take(288).view(4, 3, 3, 8).permute(3, 0, 1, 2)     # packed [ci][ky][kx][co]
     out["b1"], out["sc1"], out["sh1"] = take(8), take(8), take(8)
     out["W2"] = take(576).view(8, 3, 3, 8).permute(3, 0, 1, 2)
@@ -57,16 +57,18 @@ def run_step(rows, logdet, step, check_windows=True):
     dd = lambda t: t.double()
     N = rows.shape[0]
     c_in, hi, wi, oy, ox = L.c_in, L.hi, L.wi, L.oy, L.ox
-    w = _unpack_weights(dd(weights), c_in)
+    kh, kw = max(L.kh, 1), max(L.kw, 1)
+    w = _unpack_weights(dd(weights), c_in * kh * kw)
     st = dd(src_st).view(-1, 2)
     v = rows[:, src_idx.long()] * st[:, 0] + st[:, 1]
     img = v.view(N, c_in, hi, wi)
-    frame = w["bm"].view(1, 4, 1, 1).expand(N, 4, 32, 32).clone()
-    frame[:, :, oy:oy + hi, ox:ox + wi] = torch.einsum("oc,nchw->nohw", w["Wm"], img) + w["bm"].view(1, 4, 1, 1)
+    # the first ConvModifier as the reference runs it: ONE zero-padded convolution (classic.py:35-42)
+    frame = F.conv2d(img, w["Wm"].view(4, c_in, kh, kw), w["bm"], padding=(oy + kh - 1, ox + kw - 1))
+    assert frame.shape[-2:] == (32, 32)
     p1 = _block(frame, w["W1"], w["b1"], w["sc1"], w["sh1"])
     p2 = _block(p1, w["W2"], w["b2"], w["sc2"], w["sh2"])
     if check_windows:
-        (y1, x1), (y2, x2) = _windows(hi, wi, oy, ox)
+        (y1, x1), (y2, x2) = _windows(hi + kh - 1, wi + kw - 1, oy, ox)
         m1 = torch.ones(16, 16, dtype=torch.bool)
         m1[y1[0]:y1[1], x1[0]:x1[1]] = False
         m2 = torch.ones(8, 8, dtype=torch.bool)

@@ -250,10 +250,12 @@ def test_glow_program_rows_and_batch_shapes(native):
 
 @pytest.mark.parametrize("cls_name,event_shape,n_layers", [("MultiscaleRealNVP", (2, 32, 32), 2), ("AffineGlow", (4, 8, 16), 1),
                                                           ("MultiscaleRealNVP", (1, 16, 16), None), ("AffineGlow", (6, 16, 8), 2),
-                                                          ("ShiftGlow", (3, 16, 16), None), ("MultiscaleNICE", (2, 8, 8), 1)])
+                                                          ("ShiftGlow", (3, 16, 16), None), ("MultiscaleNICE", (2, 8, 8), 1),
+                                                          ("MultiscaleRealNVP", (1, 28, 28), None), ("AffineGlow", (3, 14, 30), 1)])
 def test_image_programs_other_presets_vs_host(native, cls_name, event_shape, n_layers):
     """The image-program route beyond config 5: the multiscale RealNVP preset (normalised couplings, no 1x1 convolutions),
-    non-square images, one-block models, single-channel images, the shift-coupling presets (NICE, ShiftGlow) -- forward, inverse and log_prob on the HIP path (one launch
+    non-square images, one-block models, single-channel images, the shift-coupling presets (NICE, ShiftGlow), MNIST-shaped images whose
+    conditioner images need a 2-wide ConvModifier kernel (odd padding, classic.py:26-33) -- forward, inverse and log_prob on the HIP path (one launch
     per coupling, asserted) against this package's ATen path on the host."""
     import torchflows_amd as tfa
     from torchflows_amd import image_program

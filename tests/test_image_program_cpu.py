@@ -66,13 +66,13 @@ def test_small_glow_program_matches_fixture_and_host(libtfk):
 
 
 @pytest.mark.parametrize("event_shape,n_layers", [((3, 16, 16), None), ((2, 32, 32), 2), ((4, 8, 16), 1), ((6, 16, 16), 2),
-                                                  ((5, 8, 8), 1)])
+                                                  ((5, 8, 8), 1), ((1, 28, 28), None), ((3, 14, 30), 1)])
 def test_program_vs_host_other_shapes(libtfk, event_shape, n_layers):
     import torchflows_amd as tfa
     from torchflows_amd import image_program
     from torchflows_amd.bijections.finite.multiscale import AffineGlow, MultiscaleNICE, MultiscaleRealNVP, ShiftGlow
     torch.manual_seed(3)
-    cls = {2: MultiscaleRealNVP, 6: ShiftGlow, 5: MultiscaleNICE}.get(event_shape[0], AffineGlow)
+    cls = {2: MultiscaleRealNVP, 6: ShiftGlow, 5: MultiscaleNICE, 1: MultiscaleRealNVP}.get(event_shape[0], AffineGlow)
     flow = tfa.Flow(cls(event_shape, n_layers=n_layers))
     flow.train()
     with torch.no_grad():
@@ -96,8 +96,8 @@ def test_program_declines_what_it_does_not_cover(libtfk):
     from torchflows_amd.bijections.finite.multiscale import AffineGlow
     cpu = torch.device("cpu")
     torch.manual_seed(0)
-    # odd padding somewhere down the recursion: a ConvModifier with a 2-wide kernel (classic.py:26-27)
-    assert image_program.compile_program(AffineGlow((1, 28, 28)).eval(), 0, cpu) is None
+    # (odd paddings -- a ConvModifier with a 2-wide kernel, classic.py:26-27, as in MNIST-shaped models -- ARE covered)
+    assert image_program.compile_program(AffineGlow((1, 28, 28)).eval(), 0, cpu) is not None
     # images beyond the 32x32 frame: the modifier is a real convolution
     assert image_program.compile_program(AffineGlow((3, 64, 64)).eval(), 0, cpu) is None
     # a transformer without a fused kernel

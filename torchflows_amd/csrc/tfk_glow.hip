@@ -50,7 +50,8 @@ constexpr int kGlowPB = TFK_GLOW_PB;     // target groups (of 16) per wave and s
 constexpr int kGlowFrame = 32;          // ConvModifier's target height / width (classic.py:13-16)
 
 struct GlowGeom {
-    int c_in, hi, wi, oy, ox;           // source image and where it sits in the 32x32 frame
+    int c_in, hi, wi, oy, ox;           // source image; where the modifier's non-constant rectangle starts in the 32x32 frame
+    int kh, kw, rh, rw, cm;             // modifier kernel (1 or 2 per axis); the rectangle's size (hi + kh - 1, wi + kw - 1); c_in kh kw
     int a0h, a0w, a0y0, a0x0;           // modifier output buffer (4 channels): dims, frame coordinates of its origin
     int p1h, p1w, p1y0, p1x0;           // pooled-1 window computed per sample (16x16 frame)
     int b1h, b1w, b1y0, b1x0;           // pooled-1 buffer (8 channels)
@@ -163,6 +164,65 @@ __device__ __forceinline__ float bounded4(float h_log2e)
     return fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-h_log2e)), 4.0f, -2.0f);
 }
 
+// S0 of k_glow_coupling: the source elements of G resident samples (gathered through the layer's table, pending maps applied)
+// through the first ConvModifier into the modifier buffer's rectangle.  ONE: the 1x1 kernel (every BASELINE shape), taps and
+// bounds tests compiled out (the general form costs the 1x1 case 5 %, same-box A/B).
+template <bool ONE>
+__device__ __forceinline__ void s0_modifier(const GlowGeom &g, const float *rows, long long N, long long row_first, int G,
+                                            float *slot0, const int *__restrict__ src_idx,
+                                            const float2 *__restrict__ src_st, const float *__restrict__ wts)
+{
+    const int npix = g.hi * g.wi, rpix = g.rh * g.rw;
+    const float *bm = wts + gw_bm(g.cm);
+    const int taps = ONE ? 1 : g.kh * g.kw;
+    for (int t = threadIdx.x; t < G * rpix; t += blockDim.x) {
+        const int slot = t / rpix, pix = t - slot * rpix;
+        const int iy = pix / g.rw, ix = pix - iy * g.rw;
+        long long row = row_first + slot;
+        if (row > N - 1) row = N - 1;
+        const float *xr = rows + row * g.D;
+        float o0 = bm[0], o1 = bm[1], o2 = bm[2], o3 = bm[3];
+        for (int tap = 0; tap < taps; ++tap) {
+            bool inside = true;
+            int spix = pix;
+            if (!ONE) {
+                const int ky = tap / g.kw, kx = tap - ky * g.kw;
+                const int sy = iy - (g.kh - 1) + ky, sx = ix - (g.kw - 1) + kx;      // out[Y] = sum_k W[k] x[Y + k - pad]
+                inside = sy >= 0 && sy < g.hi && sx >= 0 && sx < g.wi;
+                spix = inside ? sy * g.wi + sx : 0;
+            }
+            for (int c0 = 0; c0 < g.c_in; c0 += 4) {             // four channels' loads in flight together
+                int idx[4];
+                float2 st[4];
+                float raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u < g.c_in ? c0 + u : g.c_in - 1;
+                    const int e = c * npix + spix;
+                    idx[u] = src_idx[e];
+                    st[u] = src_st[e];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = xr[idx[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u;
+                    const bool on = c < g.c_in;
+                    const int w = (on ? c : 0) * taps + tap;
+                    const float v = (on && inside) ? fmaf(st[u].x, raw[u], st[u].y) : 0.0f;
+                    o0 = fmaf(wts[w], v, o0);
+                    o1 = fmaf(wts[g.cm + w], v, o1);
+                    o2 = fmaf(wts[2 * g.cm + w], v, o2);
+                    o3 = fmaf(wts[3 * g.cm + w], v, o3);
+                }
+            }
+        }
+        float *a = slot0 + slot * g.slot_floats + (g.oy + iy - g.a0y0) * g.a0w + (g.ox + ix - g.a0x0);
+        const int plane = g.a0h * g.a0w;
+        a[0] = o0, a[plane] = o1, a[2 * plane] = o2, a[3 * plane] = o3;
+    }
+}
+
 template <int KIND, bool INV>
 __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logdet, long long N, GlowGeom g,
                                                         const int *__restrict__ src_idx,
@@ -183,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int G = g.slots;
     const int D = g.D;
-    const float *bm = wts + gw_bm(g.c_in);
+    const float *bm = wts + gw_bm(g.cm);
 
     // ---- once per workgroup: everything of the buffers that no sample changes ----
     {
@@ -213,53 +273,20 @@ __global__ __launch_bounds__(1024) void k_glow_coupling(float *rows, float *logd
     __syncthreads();
 
     const long long n_tiles_rows = (N + g.tile_rows - 1) / g.tile_rows;
-    const int npix = g.hi * g.wi;
     for (long long tile = blockIdx.x; tile < n_tiles_rows; tile += gridDim.x) {
         const long long row_base = tile * g.tile_rows;
         const int nrows = (int)((N - row_base) < (long long)g.tile_rows ? (N - row_base) : (long long)g.tile_rows);
 
         for (int s0 = 0; s0 < g.tile_rows; s0 += G) {
-            // ---- S0: pending map + ConvModifier (1x1 convolution c_in -> 4) into the image's rectangle ----
-            if (!(g.skip & 1))
-            for (int t = tid; t < G * npix; t += nthr) {
-                const int slot = t / npix, pix = t - slot * npix;
-                const int iy = pix / g.wi, ix = pix - iy * g.wi;
-                long long row = row_base + s0 + slot;
-                if (row > N - 1) row = N - 1;
-                const float *xr = rows + row * D;
-                float o0 = bm[0], o1 = bm[1], o2 = bm[2], o3 = bm[3];
-                for (int c0 = 0; c0 < g.c_in; c0 += 4) {             // four channels' loads in flight together
-                    int idx[4];
-                    float2 st[4];
-                    float raw[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = c0 + u < g.c_in ? c0 + u : g.c_in - 1;
-                        const int e = c * npix + pix;
-                        idx[u] = src_idx[e];
-                        st[u] = src_st[e];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) raw[u] = xr[idx[u]];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = c0 + u;
-                        const bool on = c < g.c_in;
-                        const int cc = on ? c : 0;
-                        const float v = on ? fmaf(st[u].x, raw[u], st[u].y) : 0.0f;
-                        o0 = fmaf(wts[cc], v, o0);
-                        o1 = fmaf(wts[g.c_in + cc], v, o1);
-                        o2 = fmaf(wts[2 * g.c_in + cc], v, o2);
-                        o3 = fmaf(wts[3 * g.c_in + cc], v, o3);
-                    }
-                }
-                float *a = slot0 + slot * g.slot_floats + (g.oy + iy - g.a0y0) * g.a0w + (g.ox + ix - g.a0x0);
-                const int plane = g.a0h * g.a0w;
-                a[0] = o0, a[plane] = o1, a[2 * plane] = o2, a[3 * plane] = o3;
+            // ---- S0: pending map + ConvModifier (c_in -> 4 channels; kernel 1x1, or 2 wide along an axis whose padding is
+            //      odd, classic.py:26-33) into the rectangle of the frame that is not the bias ----
+            if (!(g.skip & 1)) {
+                if (g.kh * g.kw == 1) s0_modifier<true>(g, rows, N, row_base + s0, G, slot0, src_idx, src_st, wts);
+                else s0_modifier<false>(g, rows, N, row_base + s0, G, slot0, src_idx, src_st, wts);
             }
             __syncthreads();
             // ---- S1 .. S3: the three conv blocks on their windows ----
-            const int ci = g.c_in;
+            const int ci = g.cm;
             if (!(g.skip & 2)) {
             conv_stage_cg<4, 8, true>(g.cg1, slot0, g.slot_floats, 0, g.a0h, g.a0w, g.off_p1, g.b1h, g.b1w,
                                       g.p1y0 - g.b1y0, g.p1x0 - g.b1x0, g.p1h, g.p1w, G, wts + gw_w1(ci),
@@ -513,8 +540,8 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 // windows and buffers from the image's rectangle (rows [oy, oy + hi), columns [ox, ox + wi) of the 32x32 frame)
 static void glow_windows(GlowGeom &g)
 {
-    const int y0 = imax(g.oy - 1, 0), y1 = imin(g.oy + g.hi + 1, kGlowFrame);
-    const int x0 = imax(g.ox - 1, 0), x1 = imin(g.ox + g.wi + 1, kGlowFrame);
+    const int y0 = imax(g.oy - 1, 0), y1 = imin(g.oy + g.rh + 1, kGlowFrame);
+    const int x0 = imax(g.ox - 1, 0), x1 = imin(g.ox + g.rw + 1, kGlowFrame);
     const int c1y0 = floor2(y0), c1y1 = ceil2(y1), c1x0 = floor2(x0), c1x1 = ceil2(x1);
     g.a0y0 = c1y0 - 1, g.a0x0 = c1x0 - 1, g.a0h = c1y1 - c1y0 + 2, g.a0w = c1x1 - c1x0 + 2;
     g.p1y0 = c1y0 / 2, g.p1x0 = c1x0 / 2, g.p1h = (c1y1 - c1y0) / 2, g.p1w = (c1x1 - c1x0) / 2;
@@ -567,10 +594,12 @@ int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, c
 {
     if (!L) return fail(TFK_EINVAL, "%s: null layer", fn);
     if (L->kind < 0 || L->kind > 2) return fail(TFK_EINVAL, "%s: kind %d (0 affine, 1 invertible 1x1 convolution, 2 shift)", fn, L->kind);
-    if (L->c_in < 1 || L->hi < 1 || L->wi < 1 || L->oy < 0 || L->ox < 0 || L->oy + L->hi > kGlowFrame ||
-        L->ox + L->wi > kGlowFrame)
-        return fail(TFK_EINVAL, "%s: source image (%d, %d, %d) at (%d, %d) does not fit the %dx%d frame", fn, L->c_in,
-                    L->hi, L->wi, L->oy, L->ox, kGlowFrame, kGlowFrame);
+    const int kh = L->kh > 0 ? L->kh : 1, kw = L->kw > 0 ? L->kw : 1;
+    if (kh > 2 || kw > 2) return fail(TFK_EINVAL, "%s: modifier kernel %dx%d (1 or 2 per axis)", fn, kh, kw);
+    if (L->c_in < 1 || L->hi < 1 || L->wi < 1 || L->oy < 0 || L->ox < 0 || L->oy + L->hi + kh - 1 > kGlowFrame ||
+        L->ox + L->wi + kw - 1 > kGlowFrame)
+        return fail(TFK_EINVAL, "%s: source image (%d, %d, %d), kernel %dx%d, at (%d, %d) does not fit the %dx%d frame", fn,
+                    L->c_in, L->hi, L->wi, kh, kw, L->oy, L->ox, kGlowFrame, kGlowFrame);
     if (L->T < 1 || L->n_params < 1 || D < 1) return fail(TFK_EINVAL, "%s: T = %d, n_params = %d, D = %d", fn, L->T, L->n_params, D);
     if (L->kind == 2 && L->n_params != L->T)
         return fail(TFK_EINVAL, "%s: a shift coupling of %d targets takes %d parameters, got %d", fn, L->T, L->T, L->n_params);
@@ -583,6 +612,7 @@ int glow_geometry(const tfk_glow_layer *L, int32_t D, GlowGeom &g, int *block, c
                     L->n_params, kGlowMaxCh);
     g = GlowGeom{};
     g.c_in = L->c_in, g.hi = L->hi, g.wi = L->wi, g.oy = L->oy, g.ox = L->ox;
+    g.kh = kh, g.kw = kw, g.rh = L->hi + kh - 1, g.rw = L->wi + kw - 1, g.cm = L->c_in * kh * kw;
     g.T = L->T, g.n_params = L->n_params, g.D = D;
     g.n_tiles = L->kind == 0 ? 2 * ((L->T + 15) / 16) : (L->n_params + 15) / 16;        // (shift: one tile per 16 targets)
     g.kind = L->kind, g.n_ch = L->n_ch, g.hw = L->hw;
@@ -619,7 +649,7 @@ int tfk_glow_plan(const tfk_glow_layer *layer, int32_t D, int32_t *slots, int32_
     return TFK_OK;
 }
 
-int64_t tfk_glow_weight_floats(int32_t c_in) { return c_in < 1 ? 0 : gw_total(c_in); }
+int64_t tfk_glow_weight_floats(int32_t c_in_taps) { return c_in_taps < 1 ? 0 : gw_total(c_in_taps); }
 
 int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tfk_glow_layer *layer, int32_t inverse,
                       void *stream)

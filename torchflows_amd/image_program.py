@@ -18,8 +18,8 @@ recursion is *compiled* once per parameter version into a flat list of ``tfk_glo
   (``bg1`` / ``bg2``), the second ConvModifier + BatchNorm 3 + the 84 constant inputs of the Linear layer folded into a
   ``(n_params, 16)`` matrix in MFMA tile order.
 
-A model the compiler does not cover (another conditioner, a modifier whose kernel is not 1x1 -- images larger than 32
-pixels or odd paddings --, a transformer other than Affine / Shift / the 1x1 convolution, a context, ``invert()``-ed layers, an
+A model the compiler does not cover (another conditioner, a modifier that is a real convolution -- images larger than 32
+pixels --, a transformer other than Affine / Shift / the 1x1 convolution, a context, ``invert()``-ed layers, an
 ActNorm that still waits for its first batch) returns None and runs layer by layer as before.
 """
 from __future__ import annotations
@@ -92,11 +92,14 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
     if not (isinstance(mod1, ConvModifier) and isinstance(mod2, ConvModifier)):
         raise _Decline("unexpected ConvNet layout")
     c1, c2 = mod1.conv, mod2.conv
-    if tuple(c1.kernel_size) != (1, 1) or tuple(c1.weight.shape) != (4, c_in, 1, 1) or hi > 32 or wi > 32:
-        raise _Decline("first ConvModifier is not a 1x1 convolution onto (4, 32, 32)")
-    oy, ox = (int(p) for p in c1.padding)
-    if hi + 2 * oy != 32 or wi + 2 * ox != 32 or tuple(c1.stride) != (1, 1) or c1.bias is None:
+    kh, kw = (int(k) for k in c1.kernel_size)
+    if kh > 2 or kw > 2 or tuple(c1.weight.shape) != (4, c_in, kh, kw) or hi > 32 or wi > 32:
+        raise _Decline("first ConvModifier is not a padding convolution onto (4, 32, 32)")
+    py, px = (int(p) for p in c1.padding)
+    if (hi + 2 * py - kh + 1 != 32 or wi + 2 * px - kw + 1 != 32 or py < kh - 1 or px < kw - 1
+            or tuple(c1.stride) != (1, 1) or tuple(c1.dilation) != (1, 1) or c1.bias is None):
         raise _Decline("first ConvModifier does not produce a 32x32 frame")
+    oy, ox = py - (kh - 1), px - (kw - 1)                   # first output row / column that sees the image
     shapes = [(8, 4, 3, 3), (8, 8, 3, 3), (4, 8, 3, 3)]
     for blk, shp in zip((b1, b2, b3), shapes):
         cv = blk.conv
@@ -107,7 +110,7 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
             or net.linear.in_features != 100):
         raise _Decline("second ConvModifier is not (4, 4, 4) -> (1, 10, 10)")
     dd = lambda t: t.detach().double().cpu()
-    Wm, bm = dd(c1.weight).reshape(4, c_in), dd(c1.bias)
+    Wm, bm = dd(c1.weight).reshape(4, c_in * kh * kw), dd(c1.bias)
     parts = [Wm.reshape(-1), bm]
     affs = []
     for blk in (b1, b2, b3):
@@ -120,7 +123,7 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
     sc3, sh3 = affs[2]
     parts += [wm2 * sc3, (bm2 + (wm2 * sh3).sum()).reshape(1)]
     weights = torch.cat(parts).float()
-    assert weights.numel() == int(native.lib().tfk_glow_weight_floats(c_in))
+    assert weights.numel() == int(native.lib().tfk_glow_weight_floats(c_in * kh * kw))
     # the blocks' response to the all-bias frame
     frame = bm.view(4, 1, 1).expand(4, 32, 32).contiguous()
     bg1 = _block(frame, dd(b1.conv.weight), dd(b1.conv.bias), *affs[0])
@@ -133,7 +136,7 @@ def _pack_conditioner(cond, c_in: int, hi: int, wi: int):
     frame_mask[interior] = False
     W_eff = W[:, interior]
     b_eff = b + W[:, frame_mask].sum(1) * bm2
-    return dict(oy=oy, ox=ox, n_params=n_params, weights=weights, bg1=bg1.float().contiguous(),
+    return dict(oy=oy, ox=ox, kh=kh, kw=kw, n_params=n_params, weights=weights, bg1=bg1.float().contiguous(),
                 bg2=bg2.float().contiguous(), W_eff=W_eff, b_eff=b_eff)
 
 
@@ -162,10 +165,11 @@ def layer_cost(layer) -> dict:
         c0, c1 = lo & ~1, (hi_ + 1) & ~1
         q0, q1 = max(c0 // 2 - 1, 0), min(c1 // 2 + 1, 16)
         return c1 - c0, ((q1 + 1) & ~1) - (q0 & ~1)
-    (c1h, c2h), (c1w, c2w) = axis(layer.oy, layer.hi), axis(layer.ox, layer.wi)
+    kh, kw = max(layer.kh, 1), max(layer.kw, 1)
+    (c1h, c2h), (c1w, c2w) = axis(layer.oy, layer.hi + kh - 1), axis(layer.ox, layer.wi + kw - 1)
     S = layer.c_in * layer.hi * layer.wi
-    macs = 4 * S + c1h * c1w * 8 * 36 + c2h * c2w * 8 * 72 + 64 * 4 * 72 + 64 + 16 * layer.n_params
-    ref = 4 * S + 1024 * 8 * 36 + 256 * 8 * 72 + 64 * 4 * 72 + 16 * 4 + 100 * layer.n_params
+    macs = 4 * S * kh * kw + c1h * c1w * 8 * 36 + c2h * c2w * 8 * 72 + 64 * 4 * 72 + 64 + 16 * layer.n_params
+    ref = 4 * 1024 * layer.c_in * kh * kw + 1024 * 8 * 36 + 256 * 8 * 72 + 64 * 4 * 72 + 16 * 4 + 100 * layer.n_params
     if layer.kind == 1:
         macs += layer.hw * layer.n_ch * layer.n_ch
         ref += layer.hw * layer.n_ch * layer.n_ch
@@ -259,7 +263,7 @@ class _Builder:
                 pk["weights"].to(dev), pk["bg1"].to(dev), pk["bg2"].to(dev), w_tiles.to(dev), b_tiles.to(dev))
         env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_" + k, "0") or 0)
         L = native.GlowLayer(kind={"affine": 0, "conv1x1": 1, "shift": 2}[kind], c_in=c_in, hi=hi, wi=wi, oy=pk["oy"], ox=pk["ox"],
-                             T=T, n_params=pk["n_params"], n_ch=n_ch, hw=hw, slots=env("SLOTS"), block=env("BLOCK"),
+                             kh=pk["kh"], kw=pk["kw"], T=T, n_params=pk["n_params"], n_ch=n_ch, hw=hw, slots=env("SLOTS"), block=env("BLOCK"),
                              cg1=env("CG1"), cg2=env("CG2"), grid=env("GRID"),
                              src_idx=keep[0].data_ptr(), src_st=keep[1].data_ptr(), tgt_idx=keep[2].data_ptr(),
                              tgt_st=keep[3].data_ptr(), weights=keep[4].data_ptr(), bg1=keep[5].data_ptr(),

@@ -48,7 +48,7 @@ SYMBOLS = (
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
 )
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class NativeError(RuntimeError):
@@ -65,7 +65,7 @@ class GlowLayer(C.Structure):
     """``tfk_glow_layer`` of include/tfk.h: one convolutional coupling of an image flow, everything that does not
     depend on the sample prepared by the caller (torchflows_amd/image_program.py)."""
     _fields_ = [("kind", _i32), ("c_in", _i32), ("hi", _i32), ("wi", _i32), ("oy", _i32), ("ox", _i32),
-                ("T", _i32), ("n_params", _i32), ("n_ch", _i32), ("hw", _i32),
+                ("kh", _i32), ("kw", _i32), ("T", _i32), ("n_params", _i32), ("n_ch", _i32), ("hw", _i32),
                 ("slots", _i32), ("block", _i32), ("cg1", _i32), ("cg2", _i32), ("grid", _i32),
                 ("src_idx", _vp), ("src_st", _vp), ("tgt_idx", _vp), ("tgt_st", _vp),
                 ("weights", _vp), ("bg1", _vp), ("bg2", _vp), ("w_eff", _vp), ("b_eff", _vp)]
