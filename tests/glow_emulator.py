@@ -3,7 +3,16 @@ packed buffers of a compiled image program (torchflows_amd/image_program.py) exa
 index tables, pending maps, packed conv weights, background images, MFMA tile order of the folded Linear layer -- and
 checks the one structural assumption the kernel relies on: outside the windows that csrc/tfk_glow.hip computes per
 sample, the conv blocks' outputs equal the background images.  Test infrastructure: lets the host-side compiler be
-verified without a GPU (tests/test_image_program_cpu.py) and gives the GPU tests a second, independent expected value."""
+verified without a GPU (tests/test_image_program_cpu.py) and gives the GPU tests a second, independent expected value.
+
+What it restates, in the reference's terms (paths relative to torchflows/): the coupling skeleton
+bijections/finite/autoregressive/layers_base.py:145-163; the conditioner bijections/finite/multiscale/conditioning/classic.py
+(ConvModifier :8-42 as ONE zero-padded convolution, ConvNetBlock.forward :60-61 = conv3x3 -> ReLU -> MaxPool2d(2) ->
+BatchNorm2d in inference form, the second modifier + Linear :105-122) and the (-2, 2) bound of
+conditioning/transforms.py:107-113; Affine.forward / inverse transformers/linear/affine.py:33-59, Shift :137-159,
+LUTransformer transformers/linear/matrix.py:22-99 under Invertible1x1ConvolutionTransformer linear/convolution.py:33-64
+(log-det once per sample).  Pinned to the reference through tests/golden/flow_glow_3x32x32.npz and
+flow_glow_3x8x8.npz (tests/test_image_program_cpu.py)."""
 import numpy as np
 import torch
 
