@@ -844,17 +844,21 @@ def main():
             from torchflows_amd.utils import make_adamw
             opt = make_adamw(flow.parameters(), 1e-4)
 
-            def train_step():
+            wt = torch.ones(trows, device=xt.device)
+
+            def train_step():                    # the step Flow.fit runs (flows.py: _base_batch_loss, reference :199-224)
                 opt.zero_grad(set_to_none=True)
-                loss = -flow.log_prob(xt).mean() / flow.event_size + flow.regularization()
+                loss = flow._base_batch_loss((xt, wt), reduction=torch.mean, use_regularization=True)
                 loss.backward()
                 opt.step()
                 return loss
 
-            train_step()
+            for _ in range(3):                   # lazy state: optimiser moments, index maps, allocator blocks
+                train_step()
             torch.cuda.synchronize()
+            n_train_steps = 20
             t3 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(n_train_steps):
                 loss = train_step()
             torch.cuda.synchronize()
             t_elapsed = time.perf_counter() - t3
@@ -869,17 +873,19 @@ def main():
             bwd = {k: v for k, v in tk.items() if k.endswith("_bwd") and not k.endswith("_train_bwd")}
             top = max(bwd, key=lambda k: bwd[k]["ms"]) if bwd else None
             result["train"] = {
-                "value": trows * 5 / t_elapsed, "unit": "samples/s", "rows": trows, "steps": 5,
-                "ms_per_step": 1e3 * t_elapsed / 5, "loss": float(loss.detach()),
+                "value": trows * n_train_steps / t_elapsed, "unit": "samples/s", "rows": trows, "steps": n_train_steps,
+                "ms_per_step": 1e3 * t_elapsed / n_train_steps, "loss": float(loss.detach()),
+                "optimizer": type(opt).__name__,
                 "libtfk_ms_per_step": sum(v["ms"] for v in tk.values()) / 2,
                 "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                                 "GBps": round(v["GBps"], 1)} for k, v in tk.items()},
-                "note": "Flow.log_prob with autograd + backward + AdamW: libtfk layer kernels, single-op MFMA "
-                        "flow programs for the coupling forward, fused coupling backward (conditioner, "
-                        "transform, MLP and weight-gradient sums in one launch) where supported, else "
-                        "reverse-mode kernels + PyTorch-ROCm GEMMs; libtfk_ms_per_step is the share spent in "
-                        "libtfk kernels (HIP events over two extra steps); the eager step is bound by "
-                        "launch / Python overhead"}
+                "note": "the step Flow.fit runs, eager (no hipGraph): _base_batch_loss with autograd + backward + "
+                        "AdamW.  libtfk layer kernels, single-op MFMA flow programs for the coupling forward, fused "
+                        "coupling backward (conditioner, transform, MLP and weight-gradient sums in one launch) where "
+                        "supported, else reverse-mode kernels + PyTorch-ROCm GEMMs; the parameters live in one buffer "
+                        "(flat_optim.py): operands by one gather, the L2 penalty inside the chain's autograd node, "
+                        "gradients as slices of one buffer, AdamW as torch's own _foreach calls on that buffer; "
+                        "libtfk_ms_per_step is the share spent in libtfk kernels (HIP events over two extra steps)"}
             if args.workload == "realnvp64":
                 # the same step captured once into a hipGraph and replayed (TORCHFLOWS_AMD_GRAPH=1 in
                 # Flow.fit).  Measured in a child process: an invalidated capture crashes the process

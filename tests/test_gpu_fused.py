@@ -279,10 +279,12 @@ def test_flow_run_argument_checks(pkg):
 
 
 @pytest.mark.parametrize("arch", ["RealNVP", "NICE"])
-@pytest.mark.parametrize("D,n_hidden", [(64, 17), (64, 24), (64, 32), (64, 40), (64, 64), (128, 48), (256, 33)])
+@pytest.mark.parametrize("D,n_hidden", [(64, 17), (64, 24), (64, 32), (64, 40), (64, 64), (128, 48), (256, 33),
+                                        (64, 65), (64, 100), (64, 128), (128, 96), (30, 72)])
 def test_fused_wide_hidden_layers(pkg, oracle, monkeypatch, arch, D, n_hidden):
-    """Hidden widths 17..64 run on the matrix-core flow program too (2 or 4 tiles of 16 units in
-    GEMM 1, up to 16 k-steps in GEMM 2); parity with the oracle and the layer-by-layer route."""
+    """Hidden widths 17..128 run on the matrix-core flow program too (2, 4 or 8 tiles of 16 units in
+    GEMM 1, up to 32 k-steps in GEMM 2; above 64 units one coupling's operands fill a launch's LDS, so the chain is one
+    launch per coupling -- still a quarter of the layer-by-layer route's); parity with the oracle and that route."""
     from torchflows_amd import fused as fz
     torch.manual_seed(D + n_hidden)
     ctor = getattr(pkg, arch)
@@ -296,6 +298,10 @@ def test_fused_wide_hidden_layers(pkg, oracle, monkeypatch, arch, D, n_hidden):
     x[:40] *= 3
     fused, fused_valu, layer = run_both(flow, x.cuda(), monkeypatch)
     assert fused["launches"] < layer["launches"]
+    if n_hidden > 64:
+        # (four passes: forward_with_log_prob, log_prob, forward, inverse -- one launch per coupling each, and one for a
+        # leading elementwise layer that does not fit beside the first)
+        assert len(chain.segments) <= 5 and fused["launches"] <= 4 * (len(chain.segments) + 1), (len(chain.segments), fused["launches"])
     z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
     xr_ref, ldi_ref = ref.inverse(x.numpy())
     for name, got in (("fused", fused), ("layerwise", layer)):

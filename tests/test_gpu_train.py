@@ -376,3 +376,75 @@ def test_context_conditioned_flows_train_on_the_hip_path(native, arch, D, C):
     for (k, _), got, want in zip([("x", None)] + named, grads, truth):
         e = float((got.detach().cpu().double() - want).abs().max() / max(1.0, float(want.abs().max())))
         assert e < tol, (k, e)
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("NICE", 64), ("RealNVP", 128)])
+def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeypatch, arch, D):
+    """make_adamw on the device homes the parameters in ONE buffer (flat_optim.py); the chain's autograd node then packs
+    its operands by one gather, evaluates the L2 penalty itself and returns every gradient as a slice of one buffer,
+    which FlatAdamW updates with torch's own _foreach calls.  Against the per-tensor route (TORCHFLOWS_AMD_FLAT=0 and
+    torch.optim.AdamW): identical gradients (the same kernels filled the same accumulators; the penalty's term is added
+    in the same precision), a bit-identical trajectory over 6 steps, every update on the fast path, and an eval-mode
+    log_prob afterwards that sees the trained weights (the version counters moved with the buffer)."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    from torchflows_amd.utils import make_adamw
+    from torchflows_amd.flat_optim import FlatAdamW
+    torch.manual_seed(D)
+    flat_route = arch == "RealNVP"
+    x = torch.randn(3000, D, device="cuda") * 0.7 + 0.2
+    w = torch.rand(3000, device="cuda") + 0.5
+    flow = Flow(getattr(A, arch)(D, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x.cpu())
+    a, b = copy.deepcopy(flow).cuda(), copy.deepcopy(flow).cuda()
+    with torch.no_grad():
+        lp0 = a.log_prob(x).clone()               # (eval-mode programs compiled on the initial weights)
+    oa = make_adamw(a.parameters(), 0.01)
+    assert isinstance(oa, FlatAdamW) and oa.flat.intact()
+    ob = torch.optim.AdamW(b.parameters(), 0.01)
+    for step in range(6):
+        monkeypatch.setenv("TORCHFLOWS_AMD_FLAT", "1")
+        oa.zero_grad()
+        la = a._base_batch_loss((x, w))
+        la.backward()
+        monkeypatch.setenv("TORCHFLOWS_AMD_FLAT", "0")
+        ob.zero_grad()
+        lb = b._base_batch_loss((x, w))
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))          # (the penalty is summed in another order)
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            if pb.grad is None:
+                assert pa.grad is None or not pa.requires_grad, n
+                continue
+            assert torch.equal(pa.grad, pb.grad), (step, n, float((pa.grad - pb.grad).abs().max()))
+        assert (oa.flat.grads_are_flat() is not None) == flat_route
+        oa.step()
+        ob.step()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.equal(pa, pb), (step, n)
+    # (NICE: shift couplings have no fused training launch -- the per-tensor route, and the update over views)
+    assert (oa.fast_steps, oa.general_steps) == ((6, 0) if flat_route else (0, 6)) and oa.flat.intact()
+    a.eval()
+    b.eval()
+    with torch.no_grad():
+        lpa, lpb = a.log_prob(x), b.log_prob(x)
+    assert torch.equal(lpa, lpb) and not torch.equal(lpa, lp0)
+    # a gradient that arrives any other way (here: only the likelihood term, through autograd.grad's per-tensor results)
+    # takes the same update over views
+    a.train()
+    oa.zero_grad()
+    grads = torch.autograd.grad(-a.log_prob(x).mean(), [p for p in a.parameters() if p.requires_grad], allow_unused=True)
+    for p, g in zip([p for p in a.parameters() if p.requires_grad], grads):
+        p.grad = None if g is None else g.clone()
+    oa.step()
+    assert oa.general_steps == (1 if flat_route else 7) and oa.flat.intact()
+    # moving the module re-homes the parameters at the next step
+    a = a.cpu().cuda()
+    assert not oa.flat.intact()
+    oa.zero_grad()
+    a._base_batch_loss((x, w)).backward()
+    oa.step()
+    assert oa.flat.intact()

@@ -11,6 +11,7 @@ import bench  # noqa: E402
 
 flow = bench.make_flow("RealNVP", 64, 8).cuda()
 x = torch.randn(1 << 18, 64, device="cuda")
+w = torch.ones(1 << 18, device="cuda")
 flow.train()
 from torchflows_amd.utils import make_adamw
 opt = make_adamw(flow.parameters(), 1e-4)
@@ -18,7 +19,7 @@ opt = make_adamw(flow.parameters(), 1e-4)
 
 def step():
     opt.zero_grad(set_to_none=True)
-    loss = -flow.log_prob(x).mean() / flow.event_size + flow.regularization()
+    loss = flow._base_batch_loss((x, w), reduction=torch.mean, use_regularization=True)
     loss.backward()
     opt.step()
 

@@ -79,22 +79,36 @@ def _step_kind(layer) -> Optional[str]:
 
 def training_plan(composition, direction: int):
     """[(layer, direction, kind)] if every layer has forward and reverse-mode kernels, else None."""
+    # the steps depend on the layer objects and their configuration only: kept on the composition per direction, keyed
+    # by the identity of its layers (dropped with every other ``_tfk_`` cache on train() / eval() / load_state_dict /
+    # a move); 27 layers x isinstance chains cost 60 us of a 1.5 ms step
+    from torchflows_amd import fused
+    key = (fused._EPOCH[0], tuple(map(id, composition.layers)))
+    cache = composition.__dict__.setdefault("_tfk_train_plan", {})
+    hit = cache.get(direction)
+    if hit is not None and hit[0] == key:
+        return None if hit[1] is None else Plan(hit[1])
     order = composition.layers if direction == FORWARD else list(composition.layers)[::-1]
     flat = _flatten(order, "forward" if direction == FORWARD else "inverse")
-    if flat is None:
-        return None
-    plan = Plan()
-    for layer, d in flat:
-        kind = _step_kind(layer)
-        if kind is None or (kind == "made" and d == layer._sequential_when):
-            return None         # (the element-by-element map is not differentiated on the HIP path)
-        plan.append((layer, d, kind))
-    return plan
+    steps = None
+    if flat is not None:
+        steps = []
+        for layer, d in flat:
+            kind = _step_kind(layer)
+            if kind is None or (kind == "made" and d == layer._sequential_when):
+                steps = None    # (the element-by-element map is not differentiated on the HIP path)
+                break
+            steps.append((layer, d, kind))
+    cache[direction] = (key, steps)
+    return None if steps is None else Plan(steps)
 
 
 class Plan(list):
-    """[(layer, direction, kind)] + the context rows (N, *context_shape) of this call, or None."""
+    """[(layer, direction, kind)] + the context rows (N, *context_shape) of this call, or None; ``l2``: the
+    {coefficient: [parameters]} of the L2 penalty the caller wants evaluated in the same autograd node
+    (``Flow._base_batch_loss``), or None."""
     context = None
+    l2 = None
 
 
 def applicable(composition, x: torch.Tensor, context) -> bool:
@@ -325,6 +339,12 @@ def _fused_rqs_layer(layer, D: int):
     return mlp
 
 
+def flat_enabled() -> bool:
+    """Operands gathered from / gradients returned as slices of ONE buffer when the parameters live in one
+    (torchflows_amd/flat_optim.py; TORCHFLOWS_AMD_FLAT=0: always the per-tensor route)."""
+    return os.environ.get("TORCHFLOWS_AMD_FLAT", "1") != "0"
+
+
 def fused_train_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_TRAIN_FUSED", "1") != "0"
 
@@ -433,6 +453,103 @@ class _PlanPacks:
             self.n_out_total = off_out
             self.zero = self.layers[0][3].zero
 
+    # ---- parameters that live in ONE buffer (torchflows_amd/flat_optim.py) --------------------------------------
+    def flat_capable(self) -> bool:
+        """Every step is a permutation, a global elementwise layer or a coupling with the fused training launches:
+        all gradients of the plan then come out of libtfk accumulators and can leave as slices of one buffer."""
+        if not self.layers:
+            return False
+        for i, (layer, d, kind) in enumerate(self.plan):
+            if kind in ("perm", "elementwise") or (kind == "coupling" and i in self.slot):
+                continue
+            return False
+        return True
+
+    def flat_maps(self, fb):
+        """Index maps between a FlatParams buffer and this plan, built once per buffer:
+        ``src_index``: position in torch.cat([fb.P, aux]) of every element of the packed operand blocks (aux = the blocks
+        of the folded fixed elementwise layers); ``grad_src``: for every element of fb.P the position of its gradient in
+        the backward pass's output buffer [coupling accumulators | trainable elementwise gradients | one zero];
+        ``ret``: per plan parameter (in ChainFunction's argument order) the piece of fb.split_sizes and its shape."""
+        hit = self.__dict__.get("_flat_maps")
+        if hit is not None and hit[0]() is fb:
+            return hit[1]
+        import weakref
+        dev = fb.P.device
+        D = self.D
+        slot_of = fb.slot_of
+        cat_to_src, aux_layers, aux_off = [], [], fb.n
+        for (i, lin1, lin2, pack), (ew_step, _) in zip(self.layers, self.fold):
+            for t in (lin1.weight, lin1.bias, lin2.weight, lin2.bias):
+                k = slot_of.get(id(t))
+                if k is None:
+                    return None                  # (a frozen conditioner weight: the general route)
+                cat_to_src.append(torch.arange(fb.numel[k]) + fb.offset[k])
+            cat_to_src.append(torch.tensor([fb.zero_slot]))
+            if ew_step is not None:
+                ew_layer, ew_d, _ = self.plan[ew_step]
+                n_ew = (3 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else (2 * D + 4)
+                cat_to_src.append(torch.arange(n_ew) + aux_off)
+                aux_layers.append((ew_layer, ew_d))
+                aux_off += n_ew
+        cat_to_src = torch.cat(cat_to_src).to(dev)
+        src_index = cat_to_src[self.param_index]
+        # gradients: accumulator layout of all layers | trainable elementwise (D, 2) blocks | zero
+        grad_src = torch.full((fb.n,), -1, dtype=torch.long)
+        lo = 0
+        gi = self.grad_index.cpu()
+        for i, lin1, lin2, pack in self.layers:
+            for t, n in zip((lin1.weight, lin1.bias, lin2.weight, lin2.bias), pack.sizes):
+                k = slot_of[id(t)]
+                grad_src[fb.offset[k]:fb.offset[k] + n] = gi[lo:lo + n]
+                lo += n
+        ext = self.n_out_total
+        ew_out = {}
+        for i, (layer, d, kind) in enumerate(self.plan):
+            if kind == "elementwise" and i not in self.folded_steps and layer.value.requires_grad:
+                k = slot_of.get(id(layer.value))
+                if k is None:
+                    return None
+                ew_out[i] = ext
+                grad_src[fb.offset[k]:fb.offset[k] + 2 * D] = torch.arange(2 * D) + ext
+                ext += 2 * D
+        grad_src[grad_src < 0] = ext                 # padding, parameters outside the plan: the zero
+        ret = []
+        for layer, _, kind in self.plan:
+            for t in _layer_params(layer, kind):
+                k = slot_of.get(id(t)) if t.requires_grad else None
+                ret.append(None if k is None else (fb.piece_of_slot[k], tuple(t.shape)))
+        maps = dict(src_index=src_index, aux_layers=aux_layers, grad_src=grad_src.to(dev), ew_out=ew_out,
+                    n_ext=ext + 1, ret=ret, l2={})
+        self.__dict__["_flat_maps"] = (weakref.ref(fb), maps)
+        return maps
+
+    def pack_flat(self, fb, maps):
+        """``pack()`` as ONE gather out of the parameter buffer (+ the cached blocks of the folded fixed layers)."""
+        src = fb.P
+        if maps["aux_layers"]:
+            src = torch.cat([fb.P] + [_ew_block(l, d, self.D) for l, d in maps["aux_layers"]])
+        return list(src.index_select(0, maps["src_index"]).split(self.block_sizes))
+
+    @staticmethod
+    def l2_vector(fb, maps, l2):
+        """coef at the positions of the L2-regularised parameters of ``l2`` = {coef: [parameters]}, 0 elsewhere
+        (cached per parameter set); None when one of them is not in the buffer."""
+        key = tuple((c, tuple(id(t) for t in ps)) for c, ps in sorted(l2.items()))
+        vec = maps["l2"].get(key)
+        if vec is None:
+            v = torch.zeros(fb.n, dtype=torch.float32)
+            for c, ps in l2.items():
+                for t in ps:
+                    k = fb.slot_of.get(id(t))
+                    if k is None or fb.params[k] is not t:
+                        return None
+                    v[fb.offset[k]:fb.offset[k] + fb.numel[k]] = c
+            if len(maps["l2"]) > 4:
+                maps["l2"].clear()
+            vec = maps["l2"][key] = v.to(fb.P.device)
+        return vec
+
     def pack(self):
         """[packed block of layer k: operands (+ the folded elementwise parameters)] for the
         current weights."""
@@ -538,7 +655,20 @@ class ChainFunction(torch.autograd.Function):
         needs_init = any(kind == "elementwise" and isinstance(layer, ActNorm) and d == FORWARD
                          and layer.training and layer.first_training_batch_pass for layer, d, kind in plan)
         packs = _plan_packs(plan, D, rows.device, fold=not needs_init)
-        packed = packs.pack() if packs.layers else []
+        # parameters homed in one buffer (FlatAdamW): operands by one gather, gradients as slices of one buffer
+        fb = maps = l2vec = None
+        if flat_enabled() and packs.flat_capable():
+            from torchflows_amd import flat_optim
+            fb = flat_optim.lookup(params)
+            maps = packs.flat_maps(fb) if fb is not None else None
+            if maps is None:
+                fb = None
+        if fb is not None:
+            packed = packs.pack_flat(fb, maps)
+            if plan.l2:
+                l2vec = packs.l2_vector(fb, maps, plan.l2)
+        else:
+            packed = packs.pack() if packs.layers else []
         rqs_blocks = {}
         for step, (layer, d, kind) in enumerate(plan):
             if step in packs.folded_steps:
@@ -658,16 +788,25 @@ class ChainFunction(torch.autograd.Function):
         ctx.n_params = len(params)
         ctx.packs, ctx.packed = packs, packed
         ctx.rqs_blocks = rqs_blocks
+        ctx.flat, ctx.flat_maps, ctx.l2vec = fb, maps, l2vec
+        if l2vec is not None:
+            # sum_coef coef * sum_p ||p||^2 (layers_base.py:38-48) over the buffer: the gradient joins the flat one
+            ctx.flat_version = fb.P._version
+            reg = torch.dot(fb.P * l2vec, fb.P)
+            return cur, logdet, reg
         return cur, logdet
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rows: Optional[torch.Tensor], g_logdet: Optional[torch.Tensor]):
+    def backward(ctx, g_rows: Optional[torch.Tensor], g_logdet: Optional[torch.Tensor],
+                 g_reg: Optional[torch.Tensor] = None):
         plan, saved = ctx.plan, ctx.saved_rows
+        fb, maps = ctx.flat, ctx.flat_maps
         first = next(s for s in saved if s is not None) if any(s is not None for s in saved) else None
         ref = g_rows if g_rows is not None else (g_logdet if g_logdet is not None else first)
         device = ref.device
-        N = g_logdet.shape[0] if g_logdet is not None else g_rows.shape[0]
+        N = (g_logdet.shape[0] if g_logdet is not None else
+             (g_rows.shape[0] if g_rows is not None else first.shape[0]))     # (only the L2 output was differentiated)
         D = plan[0][0].n_dim
         g = (torch.zeros(N, D, dtype=torch.float32, device=device) if g_rows is None
              else g_rows.contiguous().clone())
@@ -675,8 +814,12 @@ class ChainFunction(torch.autograd.Function):
                else g_logdet.contiguous())
         grads_per_step: List[List[Optional[torch.Tensor]]] = [[] for _ in plan]
         packs = ctx.packs
-        out_all = (torch.empty(packs.n_out_total, dtype=torch.float32, device=device)
-                   if packs.layers else None)
+        if fb is not None:
+            out_all = torch.empty(maps["n_ext"], dtype=torch.float32, device=device)
+            out_all[-1:].zero_()
+        else:
+            out_all = (torch.empty(packs.n_out_total, dtype=torch.float32, device=device)
+                       if packs.layers else None)
         for i in range(len(plan) - 1, -1, -1):
             layer, d, kind = plan[i]
             x_in = saved[i]
@@ -690,8 +833,10 @@ class ChainFunction(torch.autograd.Function):
                 g = out
             elif kind == "elementwise":
                 want = layer.value.requires_grad
+                lo = maps["ew_out"].get(i) if fb is not None else None
                 gv = native.elementwise_affine_bwd(x_in, layer.value.detach().reshape(D, 2).contiguous(), g,
-                                                   gld, want, inverse=_affine_form_is_inverse(layer, d))
+                                                   gld, want, inverse=_affine_form_is_inverse(layer, d),
+                                                   out=None if lo is None else out_all[lo:lo + 2 * D])
                 grads_per_step[i] = [gv.view_as(layer.value) if want else None]
             elif kind == "elementwise_ctx":
                 cparams = _module_params(layer.conditioner_transform)
@@ -838,6 +983,19 @@ class ChainFunction(torch.autograd.Function):
                     g[:, :S].add_(g_xa)
                 else:
                     g.index_add_(1, layer._source_index, g_xa)
+        if fb is not None:
+            # ONE gather: accumulator layout of every layer -> the layout of the parameter buffer; the gradients leave
+            # as slices of it (what FlatAdamW.step looks for)
+            G = out_all.index_select(0, maps["grad_src"])
+            if ctx.l2vec is not None and g_reg is not None:
+                if fb.P._version != ctx.flat_version:
+                    raise RuntimeError("the parameter buffer was modified between the forward and the backward pass")
+                G.addcmul_(fb.P, ctx.l2vec * g_reg, value=2.0)
+            fb.last_grad = G
+            pieces = G.split_with_sizes(fb.split_sizes)
+            flat = [None if r is None else pieces[r[0]].view(r[1]) for r in maps["ret"]]
+            assert len(flat) == ctx.n_params
+            return (None, g if ctx.needs_input_grad[1] else None, *flat)
         if packs.layers:                    # accumulator layout -> parameter layout, all layers at once
             pieces = out_all[packs.grad_index]
             lo = 0
@@ -894,5 +1052,8 @@ def run(composition, plan, x: torch.Tensor, context=None) -> Tuple[torch.Tensor,
     params: List[torch.Tensor] = []
     for layer, _, kind in plan:
         params.extend(_layer_params(layer, kind))
-    out, ld = ChainFunction.apply(plan, rows, *params)
+    outs = ChainFunction.apply(plan, rows, *params)
+    out, ld = outs[0], outs[1]
+    if plan.l2:                      # the caller asked for the L2 penalty in the same node: hand it over (or None)
+        composition.__dict__["_tfk_l2_out"] = outs[2] if len(outs) == 3 else None
     return out.view(x.shape), ld.view(batch)

@@ -116,6 +116,8 @@ class Bijection(nn.Module):
     def invert(self):
         """Swap the two maps on this instance (reference :155-156)."""
         self.forward, self.inverse = self.inverse, self.forward
+        from torchflows_amd import fused
+        fused._EPOCH[0] += 1             # plans and programs that walked through this layer's old direction retire
 
 
 def invert(bijection: Bijection) -> Bijection:
@@ -216,7 +218,37 @@ class BijectiveComposition(Bijection):
         plan = hip_autograd.training_plan(self, d)
         if plan is None:
             return None
+        plan.l2 = self.__dict__.pop("_tfk_l2_request", None)
         return hip_autograd.run(self, plan, x, context)
+
+    def _request_l2(self) -> bool:
+        """Ask the next differentiable pass through this composition to evaluate ``regularization()`` inside its own
+        autograd node (Flow._base_batch_loss: the penalty's gradient then joins the chain's in one buffer instead of
+        meeting it in 32 small additions).  Only when the penalty is the plain L2 rule on every layer; the result --
+        or None when the pass could not fold it -- is left in ``_tfk_l2_out``."""
+        self.__dict__.pop("_tfk_l2_out", None)
+        by_coef = {}
+        for layer in self.layers:
+            terms = getattr(layer, "_l2_terms", None)
+            got = terms() if terms is not None else None
+            if got is None:
+                if type(layer).regularization is Bijection.regularization:
+                    continue                     # (the base class's constant zero)
+                from torchflows_amd.bijections.finite.matrix.base import InvertibleMatrix
+                if isinstance(layer, InvertibleMatrix) and type(layer).regularization is InvertibleMatrix.regularization:
+                    # permutations, triangular / orthogonal factors: sum_p ||p||^2 when switched on (matrix/base.py:44-49)
+                    ps = [p for p in layer.parameters() if p.requires_grad] if layer.l2_regularization else []
+                    if ps:
+                        by_coef.setdefault(1.0, []).extend(ps)
+                    continue
+                return False
+            coef, params = got
+            if params:
+                by_coef.setdefault(coef, []).extend(params)
+        if not by_coef:
+            return False
+        self.__dict__["_tfk_l2_request"] = by_coef
+        return True
 
     @forward_method
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):

@@ -344,7 +344,7 @@ __device__ __forceinline__ void ewc_m(const MOp op, const float *prm, int lane, 
 
 // Parameter block of a coupling op (floats), EPL source steps, T2 tiles of GEMM 2:
 //   A1[EPL][HT][64] | b1[HT][4][4] | A2[T2][steps2][64] | b2[T2][4][4],  HT = ceil(steps2 / 4) rounded
-//   up to 1, 2 or 4 (hidden width <= 64)
+//   up to 1, 2, 4 or 8 (hidden width <= 128)
 // Elementwise ops use the layout of tfk_flow.hip: alpha[D] | beta[D] | ldc, pad[3] | 1/alpha[D].
 template <int EPL, int KIND, int HTMAX, bool CTX = false>
 __device__ __forceinline__ void couple_any(const MOp op, const float *prm, int lane, int q,
@@ -356,7 +356,8 @@ __device__ __forceinline__ void couple_any(const MOp op, const float *prm, int l
     } else {
         if (op.steps2 <= 4) couple_m<EPL, KIND, 1>(op, prm, lane, q, src, tgt, ld);
         else if (op.steps2 <= 8) couple_m<EPL, KIND, 2>(op, prm, lane, q, src, tgt, ld);
-        else couple_m<EPL, KIND, 4>(op, prm, lane, q, src, tgt, ld);
+        else if (HTMAX == 4 || op.steps2 <= 16) couple_m<EPL, KIND, 4>(op, prm, lane, q, src, tgt, ld);
+        else if constexpr (HTMAX == 8) couple_m<EPL, KIND, 8>(op, prm, lane, q, src, tgt, ld);
     }
 }
 
@@ -445,7 +446,8 @@ __device__ __forceinline__ void apply_op_m(const MOp op, const float *prm, int l
         } else {
             if (op.steps2 <= 4) { if (div) made_m<EPL, true, 1>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 1>(op, prm, lane, q, a, b, ld); }
             else if (op.steps2 <= 8) { if (div) made_m<EPL, true, 2>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 2>(op, prm, lane, q, a, b, ld); }
-            else { if (div) made_m<EPL, true, 4>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 4>(op, prm, lane, q, a, b, ld); }
+            else if (HTMAX == 4 || op.steps2 <= 16) { if (div) made_m<EPL, true, 4>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 4>(op, prm, lane, q, a, b, ld); }
+            else if constexpr (HTMAX == 8) { if (div) made_m<EPL, true, 8>(op, prm, lane, q, a, b, ld); else made_m<EPL, false, 8>(op, prm, lane, q, a, b, ld); }
         }
         return;
     }
@@ -640,16 +642,22 @@ static int launch_m(const float *x, float *z, float *logdet, const float *loc, c
                      : launch_mb<EPL, kBlock, 1, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params,
                                                              prog, accumulate, s, fn, context, C);
     }
-    bool wide = false;                     // a coupling with hidden width > 16 in the program?
+    bool wide = false, wider = false;      // a coupling with hidden width > 16 (> 64) in the program?
     for (int i = 0; i < prog.n_ops; ++i)
-        wide = wide || (((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||
-                         (prog.op[i].kind == TFK_OP_MADE_FWD || prog.op[i].kind == TFK_OP_MADE_INV)) && prog.op[i].steps2 > 4);
+        if ((prog.op[i].kind >= TFK_OP_AFFINE_FWD && prog.op[i].kind <= TFK_OP_SHIFT_INV) ||
+            (prog.op[i].kind == TFK_OP_MADE_FWD || prog.op[i].kind == TFK_OP_MADE_INV)) {
+            wide = wide || prog.op[i].steps2 > 4;
+            wider = wider || prog.op[i].steps2 > 16;
+        }
     const bool big = N >= (int64_t)cu_count() * 3 * 128;
     bool made = false;
     for (int i = 0; i < prog.n_ops; ++i)      // (TFK_OP_PLANE_SWAP = 11 lies above the MADE kinds: not a MADE op)
         made = made || (prog.op[i].kind >= TFK_OP_MADE_FWD && prog.op[i].kind <= TFK_OP_MADE_RQS);
 #define TFK_MB(BLOCK_, HT_, MADE_) \
     launch_mb<EPL, BLOCK_, HT_, MADE_>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, accumulate, s, fn)
+    // hidden width 65..128: 8 hidden tiles = 32 accumulators + 32 activations beside the row; one instantiation
+    // (256 threads: such a coupling's operands are 48 KB at D = 64 and the LDS holds one per launch anyway)
+    if (wider) return made ? TFK_MB(kBlock, 8, true) : TFK_MB(kBlock, 8, false);
     if (made) {
         if (wide) return big ? TFK_MB(512, 4, true) : TFK_MB(kBlock, 4, true);
         return big ? TFK_MB(512, 1, true) : TFK_MB(kBlock, 1, true);

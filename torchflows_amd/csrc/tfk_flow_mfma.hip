@@ -349,10 +349,10 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         else if (o.kind == TFK_OP_EW_MULADD) need = 2 * (int64_t)D + 4;
         else if (o.kind == TFK_OP_EW_SUBDIV) need = 3 * (int64_t)D + 4;
         else if (o.kind >= TFK_OP_AFFINE_FWD && o.kind <= TFK_OP_SHIFT_INV) {
-            if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
+            if (o.steps2 < 1 || o.steps2 > 32) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 32] (hidden width <= 128)", fn, i, o.steps2);
             if ((o.src_plane & ~0xf1) != 0) return fail(TFK_EINVAL, "%s: op %d: src_plane %d", fn, i, o.src_plane);
             const int T2 = (o.kind <= TFK_OP_AFFINE_INV) ? EPL / 2 : EPL / 4;
-            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
+            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : (o.steps2 <= 16 ? 4 : 8));
             if (cs && HT != 1) return fail(TFK_EINVAL, "%s: op %d: context-conditioned couplings need hidden width <= 16", fn, i);
             need = (int64_t)EPL * HT * 64 + HT * 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16 + (int64_t)cs * HT * 64;
         } else if (o.kind == TFK_OP_RQS_FWD || o.kind == TFK_OP_RQS_INV) {
@@ -364,8 +364,8 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
             const int T2 = EPL * 6;
             need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * o.steps2 * 64 + (int64_t)T2 * 16 + (int64_t)cs * 64;
         } else if (o.kind == TFK_OP_MADE_FWD || o.kind == TFK_OP_MADE_INV) {
-            if (o.steps2 < 1 || o.steps2 > 16) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 16] (hidden width <= 64)", fn, i, o.steps2);
-            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : 4);
+            if (o.steps2 < 1 || o.steps2 > 32) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 32] (hidden width <= 128)", fn, i, o.steps2);
+            const int HT = o.steps2 <= 4 ? 1 : (o.steps2 <= 8 ? 2 : (o.steps2 <= 16 ? 4 : 8));
             need = (int64_t)2 * EPL * HT * 64 + HT * 16 + (int64_t)EPL * o.steps2 * 64 + (int64_t)EPL * 16;
         } else if (o.kind == TFK_OP_MADE_RQS) {
             if (o.steps2 < 1 || o.steps2 > 4) return fail(TFK_EINVAL, "%s: op %d: GEMM-2 steps %d not in [1, 4] (hidden width <= 16)", fn, i, o.steps2);

@@ -187,10 +187,19 @@ class Flow(BaseFlow):
         x, weights = batch[:2]
         context = batch[2] if len(batch) == 3 else None
         dev = self.get_device()
+        # on the HIP path the L2 penalty of the coupling layers is evaluated inside the chain's autograd node when the
+        # parameters live in one buffer (autograd.py, flat_optim.py); otherwise as the reference does, below
+        b = self.bijection
+        folded = (use_regularization and dev.type == "cuda" and torch.is_grad_enabled()
+                  and hasattr(b, "_request_l2") and b._request_l2())
         lp = self.log_prob(x.to(dev), context=context)
+        reg = None
+        if folded:
+            b.__dict__.pop("_tfk_l2_request", None)
+            reg = b.__dict__.pop("_tfk_l2_out", None)
         loss = -reduction(lp * weights.to(dev)) / self.event_size
         if use_regularization:
-            loss = loss + self.regularization()
+            loss = loss + (reg if reg is not None else self.regularization())
         return loss
 
     def _graph_safe(self) -> bool:

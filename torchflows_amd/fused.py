@@ -239,7 +239,7 @@ def _elementwise_op(layer, d: int, pos: torch.Tensor, D: int, Dp: Optional[int] 
 def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p):
     """Parameter block of one affine / shift coupling for tfk_flow_run_mfma
     (csrc/tfk_flow_mfma.hip): A1[EPL][HT][64] | b1[HT][4][4] | A2[T2][steps2][64] | b2[T2][4][4]
-    (HT = 1, 2 or 4 tiles of 16 hidden units; RQS: HT = 1).
+    (HT = 1, 2, 4 or 8 tiles of 16 hidden units; RQS: HT = 1).
     Lane l = (q = l >> 4, i = l & 15).  GEMM 1: D-row i <-> hidden unit 4*(i & 3) + (i >> 2),
     k-step s of lane-group q <-> physical source element EPL*q + s.  GEMM 2, tile t: D-row
     i = 4*q2 + r <-> parameter (r & 1) of target element EPL*q2 + 2t + (r >> 1) (affine) or
@@ -248,7 +248,7 @@ def _pack_mfma(kind: str, d: int, plane: int, H: int, D: int, W1t, b1, W2p, b2p)
     dev, dt = W1t.device, W1t.dtype
     P = W2p.shape[1]
     steps2 = (H + 3) // 4
-    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)       # 16-unit tiles of the hidden layer
+    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else (4 if steps2 <= 16 else 8))       # 16-unit tiles of the hidden layer
     W1pad = torch.zeros(16 * HT, half, dtype=dt, device=dev)
     W1pad[:H] = W1t
     b1pad = torch.zeros(16 * HT, dtype=dt, device=dev)
@@ -356,7 +356,7 @@ def _coupling_op(layer, d: int, pos: torch.Tensor, D: int, mfma: bool = False, D
     b2p = torch.zeros(hp, P, dtype=b2.dtype, device=b2.device)
     b2p[m_t] = b2.reshape(T, P)
     if mfma:
-        if H > (16 if kind == "rqs" else 64) or (kind == "rqs" and Dp > 128):
+        if H > (16 if kind == "rqs" else 128) or (kind == "rqs" and Dp > 128):
             return None
         head, block = _pack_mfma(kind, d, plane, H, Dp, W1t, b1, W2p, b2p)
         if C:                                 # further GEMM-1 k-steps: A1c[cs][64], lane (q, i) <-> context element 4 s + q
@@ -486,14 +486,14 @@ def _made_op(layer, d: int, pos: torch.Tensor, D: int, Dp: Optional[int] = None)
         return None
     H = mods[0].out_features
     Dp = D if Dp is None else Dp              # padded row width: padding elements get zero weights (identity)
-    if mods[0].in_features != D or H > 64 or (Dp == 256 and H > 16):
+    if mods[0].in_features != D or H > 128 or (Dp == 256 and H > 16):
         return None
     if kind == "rqs":
         return _made_rqs_op(layer, mods, pos, D, H, Dp)
     half, EPL = Dp // 2, Dp // 8
     T2 = EPL // 2
     steps2 = (H + 3) // 4
-    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
+    HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else (4 if steps2 <= 16 else 8))
     W1 = (mods[0].weight * mods[0].mask).detach()                       # (H, D) logical columns
     W2 = (mods[2].weight * mods[2].mask).detach().view(D, 2, H)        # logical element, parameter, unit
     dev, dt = W1.device, W1.dtype
@@ -1452,7 +1452,7 @@ def _why_declined(composition, direction: int) -> str:
             hidden = getattr(seq[0], "out_features", None) if seq is not None and len(seq) else None
             kind = layer.transformer.native_kind
             plain = type(ct).__name__ in ("FeedForward", "MADE") and hidden is not None
-            if plain and kind in ("affine", "inverse_affine", "shift") and hidden <= 64:
+            if plain and kind in ("affine", "inverse_affine", "shift") and hidden <= 128:
                 continue
             if plain and kind == "rqs" and hidden <= 16 and getattr(layer.transformer, "n_bins", 8) == 8 and D <= 128:
                 continue

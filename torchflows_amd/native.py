@@ -466,8 +466,9 @@ def lrs_coupling_bwd(x, h, g, gld, gh, tgt_idx, T, n_bins, boundary, inverse=Fal
     _check(rc, name)
 
 
-def elementwise_affine_bwd(x, value, g, gld, want_param, inverse=False):
-    """In place on g (all D columns).  Returns dL/dvalue (D, 2) when ``want_param``."""
+def elementwise_affine_bwd(x, value, g, gld, want_param, inverse=False, out=None):
+    """In place on g (all D columns).  Returns dL/dvalue (D, 2) when ``want_param`` (written into ``out``, 2 D
+    contiguous floats, when given)."""
     global calls
     name = "tfk_elementwise_affine_bwd"
     N, D = _rows(g, name)
@@ -477,7 +478,9 @@ def elementwise_affine_bwd(x, value, g, gld, want_param, inverse=False):
     if want_param:
         if x is None or x.shape != g.shape or gld is None or gld.numel() != N:
             raise NativeError(f"{name}: the parameter gradient needs x (N, D) and gld (N,)")
-        gvalue = torch.empty(D, 2, dtype=torch.float32, device=g.device)
+        if out is not None and (out.numel() != 2 * D or not out.is_contiguous() or out.dtype != torch.float32):
+            raise NativeError(f"{name}: out must hold 2*D = {2 * D} contiguous floats")
+        gvalue = torch.empty(D, 2, dtype=torch.float32, device=g.device) if out is None else out.view(D, 2)
         nbytes = int(lib().tfk_elementwise_affine_bwd_workspace_bytes(N, D))
         ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g.device)
     args = (_f32(x if want_param else None, name), _f32(value, name), _f32(g, name),
@@ -645,6 +648,21 @@ def _pack_ops(ops):
     packed (``fused.Segment.packed_ops``) passes through."""
     if isinstance(ops, C.Array):
         return ops
+    key = tuple(ops)                      # (the training step packs the same few one- and two-op programs every step)
+    hit = _OPS_CACHE.get(key)
+    if hit is not None:
+        return hit
+    arr = _pack_ops_uncached(ops)
+    if len(_OPS_CACHE) > 256:
+        _OPS_CACHE.clear()
+    _OPS_CACHE[key] = arr
+    return arr
+
+
+_OPS_CACHE = {}
+
+
+def _pack_ops_uncached(ops):
     flat = []
     for op in ops:
         kind, plane, H, off = (int(v) for v in op[:4])

@@ -54,6 +54,15 @@ def make_adamw(params, lr: float, capturable: bool = False):
     import os
     import torch
     params = list(params)
+    # every parameter fp32 on one GPU: the same update over ONE buffer (flat_optim.py: torch's own _foreach calls on
+    # one-element lists, bit-identical trajectories, a tenth of the host time).  TORCHFLOWS_AMD_FLAT_ADAMW=0 turns it
+    # off, =1 forces it on the host as well (tests).
+    flat = os.environ.get("TORCHFLOWS_AMD_FLAT_ADAMW", "")
+    trainable = [p for p in params if p.requires_grad]
+    if (not capturable and flat != "0" and trainable and len({p.device for p in trainable}) == 1
+            and all(p.dtype == torch.float32 for p in trainable) and (trainable[0].is_cuda or flat == "1")):
+        from torchflows_amd.flat_optim import FlatAdamW
+        return FlatAdamW(params, lr=lr)
     fused = (os.environ.get("TORCHFLOWS_AMD_FUSED_ADAMW", "0") == "1" and len(params) > 0
              and all(p.is_cuda and torch.is_floating_point(p) for p in params))
     if fused:
