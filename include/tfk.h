@@ -301,9 +301,11 @@ int tfk_flow_run(const float *x, float *z, float *logdet, const float *gauss_loc
  * accumulator layout of one GEMM the B-operand of the next (csrc/tfk_flow_mfma.hip;
  * packed by torchflows_amd/fused.py:_pack_mfma). */
 int tfk_flow_mfma_supported(int32_t D);
-/* Row widths the LEAN programs (TFK_OP_*_LEAN) run at: tfk_flow_mfma_supported's and 32 -- event sizes <= 32 are
+/* Row widths the LEAN programs (TFK_OP_*_LEAN) run at: tfk_flow_mfma_supported's, 32 and 16 -- event sizes <= 32 are
  * padded to 32 instead of 64 (the straight-line kernels are instantiated for D / 8 = 4 as well; spline chains at
- * D = 32 in the bf16 x 3 operand format only). */
+ * D = 32 in the bf16 x 3 operand format only), and chains of affine / shift couplings on event sizes <= 16 to 16
+ * (D / 8 = 2 row elements per lane and plane: A1 is [64][2], a shift coupling's single GEMM-2 tile uses rows r < 2 of
+ * every group of four; fp32 operands, no context, no MADE / spline ops). */
 int tfk_flow_lean_supported(int32_t D);
 int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gauss_loc,
                       const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,

@@ -584,7 +584,8 @@ def test_context_conditioned_flows_run_as_flow_programs(name, arch, n_layers, ct
 
 
 @pytest.mark.parametrize("arch,D", [("RealNVP", 22), ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("CouplingRQNSF", 22),
-                                    ("CouplingRQNSF", 6)])
+                                    ("CouplingRQNSF", 6), ("RealNVP", 16), ("RealNVP", 8), ("RealNVP", 4), ("NICE", 16),
+                                    ("NICE", 6)])
 def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
     """Event sizes that are not 64 / 128 / 256: lean programs read the caller's (N, D) rows themselves
     (tfk_flow_run_mfma_in) instead of a host-side padding pass; same values as with the padding pass, and as the
@@ -613,6 +614,28 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
     assert rel(lp1.cpu().numpy(), lp_h.numpy()) < tol
     assert torch.equal(lp1, lp0) and torch.equal(z1, z0)
     assert torch.allclose(xr1.cpu(), x, atol=1e-3)
+    if D <= 16 and "RQ" not in arch:
+        # affine / shift chains on event sizes <= 16 run at row width 16 (two row elements per lane and plane); the same
+        # values as at width 32 up to the order of the (zero) padding terms, and Flow.sample's inverse launch as well
+        from torchflows_amd import fused as fz
+        monkeypatch.delenv("TORCHFLOWS_AMD_NARROW_IN")
+        chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
+        assert chain is not None and chain.D == 16 and len(chain.segments) == 1
+        with torch.no_grad():
+            before = native.calls
+            torch.manual_seed(11)
+            xs, lps = flow.sample((500,), return_log_prob=True)
+            assert native.calls - before <= 2
+            monkeypatch.setenv("TORCHFLOWS_AMD_ROWS16", "0")
+            flow.invalidate_native_caches()
+            z32, lp32 = flow.forward_with_log_prob(xd)
+            xr32, _ = flow.bijection.inverse(z1)
+            assert fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0)).D == 32
+            torch.manual_seed(11)                              # the same noise through the 32-wide program
+            xs32, lps32 = flow.sample((500,), return_log_prob=True)
+        assert rel(lp1.cpu().numpy(), lp32.cpu().numpy()) < 2e-6 and normwise(z1.cpu().numpy(), z32.cpu().numpy()) < 2e-6
+        assert normwise(xr1.cpu().numpy(), xr32.cpu().numpy()) < 2e-6
+        assert normwise(xs.cpu().numpy(), xs32.cpu().numpy()) < 2e-6 and rel(lps.cpu().numpy(), lps32.cpu().numpy()) < 2e-6
 
 
 def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):

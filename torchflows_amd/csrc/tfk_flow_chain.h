@@ -51,6 +51,17 @@ struct ChainProg {
 };
 
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+
+// EPL = 2 (16-wide rows, event sizes <= 16): a lane's two contiguous row elements / parameters are ONE 8-byte access where
+// the wider kernels take EPL / 4 16-byte ones.  The wider kernels keep their own code (register allocation at their
+// VGPR caps is not to be disturbed); every place that differs is an `if constexpr (EPL >= 4) ... else ...`.
+__device__ __forceinline__ void load2(const float *p, float &v0, float &v1)
+{
+    const cf32x2 w = *reinterpret_cast<const cf32x2 *>(p);
+    v0 = w[0];
+    v1 = w[1];
+}
 
 // log2 of the two scales of one GEMM-2 tile, alpha = exp2(u) + 1e-10 (affine.py:33-42):
 //   log2 alpha = u + log2(1 + 1e-10 * 2^-u),
@@ -83,7 +94,7 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
 {
     constexpr bool affine = KIND < 2;
     constexpr int HALF = 4 * EPL;
-    constexpr int T2 = affine ? EPL / 2 : EPL / 4;
+    constexpr int T2 = affine ? EPL / 2 : (EPL + 3) / 4;     // (EPL = 2, shift: one tile, rows r >= 2 of every group unused)
     constexpr int NA2 = (T2 * STEPS2 + 3) & ~3;
     const cf32x4 *A1 = reinterpret_cast<const cf32x4 *>(prm);
     const float *b1 = prm + EPL * 64;
@@ -93,12 +104,19 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
 
     // GEMM 1 (weights pre-scaled by 2 log2 e): exp2(acc) = exp(2 * pre-activation)
     cf32x4 acc = *reinterpret_cast<const cf32x4 *>(b1 + 4 * q);
+    if constexpr (EPL >= 4) {
 #pragma unroll
     for (int g = 0; g < EPL / 4; ++g) {
         const cf32x4 w = A1[g * 64 + lane];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], src[4 * g + k], acc, 0, 0, 0);
+    }
+    } else {                                                 // A1[64][2]
+        float w0, w1;
+        load2(prm + 2 * lane, w0, w1);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, src[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, src[1], acc, 0, 0, 0);
     }
     if constexpr (CTX) {                                     // [x_A | context] (conditioning/context.py:38-64)
         const cf32x4 w = *reinterpret_cast<const cf32x4 *>(pre + 2 * HALF + 4 * lane);
@@ -107,12 +125,20 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
             if (k < cs) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], cx[k], acc, 0, 0, 0);
     }
     // the elements about to be transformed take their pending elementwise layers now (one fma)
+    if constexpr (EPL >= 4) {
 #pragma unroll
     for (int i = 0; i < EPL / 4; ++i) {
         const cf32x4 s = *reinterpret_cast<const cf32x4 *>(pre + EPL * q + 4 * i);
         const cf32x4 t = *reinterpret_cast<const cf32x4 *>(pre + HALF + EPL * q + 4 * i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) tgt[4 * i + k] = fmaf(s[k], tgt[4 * i + k], t[k]);
+    }
+    } else {
+        float s0, s1, t0, t1;
+        load2(pre + EPL * q, s0, s1);
+        load2(pre + HALF + EPL * q, t0, t1);
+        tgt[0] = fmaf(s0, tgt[0], t0);
+        tgt[1] = fmaf(s1, tgt[1], t1);
     }
     float hid[4];
 #pragma unroll
@@ -158,7 +184,7 @@ __device__ __forceinline__ void couple_lean(const float *prm, int lane, int q, c
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < (EPL < 4 ? EPL : 4); ++i) {
                 const int e = 4 * t + i;
                 if constexpr (KIND == 2) tgt[e] = tgt[e] + o[i];                     // affine.py:150
                 else tgt[e] = tgt[e] - o[i];                                         // affine.py:158
@@ -394,6 +420,7 @@ template <int EPL>
 __device__ __forceinline__ void ew_fma_apply(const float *ew, int q, float (&a)[EPL], float (&b)[EPL], float &ld)
 {
     constexpr int D = 8 * EPL, HALF = 4 * EPL;
+    if constexpr (EPL >= 4) {
 #pragma unroll
     for (int i = 0; i < EPL / 4; ++i) {
         const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
@@ -404,6 +431,18 @@ __device__ __forceinline__ void ew_fma_apply(const float *ew, int q, float (&a)[
         for (int k = 0; k < 4; ++k) {
             a[4 * i + k] = fmaf(sa[k], a[4 * i + k], ta[k]);
             b[4 * i + k] = fmaf(sb[k], b[4 * i + k], tb[k]);
+        }
+    }
+    } else {
+        float sa[2], sb[2], ta[2], tb[2];
+        load2(ew + EPL * q, sa[0], sa[1]);
+        load2(ew + HALF + EPL * q, sb[0], sb[1]);
+        load2(ew + D + EPL * q, ta[0], ta[1]);
+        load2(ew + D + HALF + EPL * q, tb[0], tb[1]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a[k] = fmaf(sa[k], a[k], ta[k]);
+            b[k] = fmaf(sb[k], b[k], tb[k]);
         }
     }
     if (q == 0) ld = ld + ew[2 * D];
@@ -454,7 +493,7 @@ __device__ __forceinline__ void side_op(int kind, const float *prm, int cs, int 
 template <int EPL, int STEPS2, int KIND>
 constexpr int chain_block_floats()
 {
-    constexpr int T2 = KIND < 2 ? EPL / 2 : EPL / 4;
+    constexpr int T2 = KIND < 2 ? EPL / 2 : (EPL + 3) / 4;
     constexpr int NA2 = (T2 * (STEPS2 == 0 ? 1 : STEPS2) + 3) & ~3;
     return EPL * 64 + 16 + NA2 * 64 + T2 * 16 + 8 * EPL;
 }
@@ -591,6 +630,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
         float a[EPL], b[EPL];
         auto load_rows = [&]() {
         if (xw == D) {
+            if constexpr (EPL >= 4) {
             const float4 *pa = reinterpret_cast<const float4 *>(x + rr * D + EPL * q);
             const float4 *pb = reinterpret_cast<const float4 *>(x + rr * D + HALF + EPL * q);
 #pragma unroll
@@ -598,6 +638,10 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
                 const float4 va = pa[i], vb = pb[i];
                 a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
                 b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+            }
+            } else {
+                load2(x + rr * D + EPL * q, a[0], a[1]);
+                load2(x + rr * D + HALF + EPL * q, b[0], b[1]);
             }
         } else {
             // rows narrower than the kernel's planes (event sizes that are not 32 / 64 / 128 / 256): the caller's rows
@@ -618,6 +662,20 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
         float ld = (q == 0 && logdet && accumulate) ? logdet[rr] : 0.0f;
         float sq = 0.0f;                                              // sum of squared standardised elements
         auto base_terms = [&]() {                                     // gaussian.py:46-54
+            if constexpr (EPL < 4) {
+                float la[2], lb[2], ia[2], ib[2];
+                load2(base_s + EPL * q, la[0], la[1]);
+                load2(base_s + HALF + EPL * q, lb[0], lb[1]);
+                load2(base_s + D + EPL * q, ia[0], ia[1]);
+                load2(base_s + D + HALF + EPL * q, ib[0], ib[1]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float ta = (a[k] - la[k]) * ia[k];
+                    const float tb = (b[k] - lb[k]) * ib[k];
+                    sq = fmaf(ta, ta, sq);
+                    sq = fmaf(tb, tb, sq);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < EPL / 4; ++i) {
                 const cf32x4 la = *reinterpret_cast<const cf32x4 *>(base_s + EPL * q + 4 * i);
@@ -693,6 +751,10 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
 
         if (!CTX && prog.ew_offset >= 0) {                            // what is still pending, one fma per element
             const float *ew = ew_s;
+            if constexpr (EPL < 4) {
+                float ld_const = 0.0f;                                // (the constant log-det is added below)
+                ew_fma_apply<EPL>(ew, q, a, b, ld_const);
+            }
 #pragma unroll
             for (int i = 0; i < EPL / 4; ++i) {
                 const cf32x4 sa = *reinterpret_cast<const cf32x4 *>(ew + EPL * q + 4 * i);
@@ -716,6 +778,17 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
             sq += __shfl_xor(sq, 32, kWave);
         }
         if (row < N) {
+            if constexpr (EPL < 4) {
+                if (z) {                                              // (reversed: element e of plane A lands in column D - 1 - e)
+                    float *pa = reverse_out ? z + row * D + D - EPL * (q + 1) : z + row * D + EPL * q;
+                    float *pb = reverse_out ? z + row * D + HALF - EPL * (q + 1) : z + row * D + HALF + EPL * q;
+                    cf32x2 va, vb;
+                    va[0] = reverse_out ? a[1] : a[0]; va[1] = reverse_out ? a[0] : a[1];
+                    vb[0] = reverse_out ? b[1] : b[0]; vb[1] = reverse_out ? b[0] : b[1];
+                    *reinterpret_cast<cf32x2 *>(pa) = va;
+                    *reinterpret_cast<cf32x2 *>(pb) = vb;
+                }
+            } else
             if (z && !reverse_out) {
                 float4 *qa = reinterpret_cast<float4 *>(z + row * D + EPL * q);
                 float4 *qb = reinterpret_cast<float4 *>(z + row * D + HALF + EPL * q);
@@ -857,6 +930,16 @@ static int launch_chain(const float *x, float *z, float *logdet, const float *lo
                         float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
                         int kind, int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
+    if constexpr (EPL < 4) {            // 16-wide rows: affine / shift couplings only (fp32 operands, resident, no context)
+        if (kind >= 4 || steps2 == 0 || prog.context)
+            return fail(TFK_EINVAL, "%s: 16-wide lean programs hold affine / shift couplings with fp32 operands and no context", fn);
+        switch (kind) {
+        case 0: return launch_chain_k<EPL, 0>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+        case 1: return launch_chain_k<EPL, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+        case 2: return launch_chain_k<EPL, 2>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+        default: return launch_chain_k<EPL, 3>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
+        }
+    } else
     switch (kind) {
     case 0: return launch_chain_k<EPL, 0>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);
     case 1: return launch_chain_k<EPL, 1>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, steps2, flags, xw, s, fn);

@@ -5,6 +5,8 @@
 #include "tfk_flow_rqs_chain.h"
 
 namespace tfk {
+int flow_chain_launch_2(const float *, float *, float *, const float *, const float *, float *, int64_t,
+                        const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_4(const float *, float *, float *, const float *, const float *, float *, int64_t,
                         const float *, int, const ChainProg &, int, int, int, int, hipStream_t, const char *);
 int flow_chain_launch_8(const float *, float *, float *, const float *, const float *, float *, int64_t,
@@ -231,7 +233,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
                 if (src != ((prog.first_src + prog.n_c) & 1))
                     return fail(TFK_EINVAL, "%s: op %d: the source plane of lean couplings must alternate", fn, i);
             }
-            const int T2 = (kind < 2) ? EPL / 2 : EPL / 4;
+            const int T2 = (kind < 2) ? EPL / 2 : (EPL + 3) / 4;
             const int nA2 = (T2 * st + 3) & ~3;
             const bool f3 = rec[4] == 256;               // K field: 256 = bf16 x 3 operands (no b2, A23[T2][2][64][4])
             if (prog.n_c == 0) fmt3 = f3;
@@ -249,6 +251,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     }
     if (kind < 0) kind = 2;
     if (fmt3) steps2 = 0;
+    if (EPL == 2) return flow_chain_launch_2(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 4) return flow_chain_launch_4(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 8) return flow_chain_launch_8(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
     if (EPL == 32) return flow_chain_launch_32(x, z, logdet, loc, log_scale, logprob, N, params, (int)n_params, prog, kind, steps2, flags, xw, s, fn);
@@ -269,7 +272,8 @@ extern "C" {
 
 int tfk_flow_mfma_supported(int32_t D) { return (D == 64 || D == 128 || D == 256) ? 1 : 0; }
 
-int tfk_flow_lean_supported(int32_t D) { return (D == 32 || tfk_flow_mfma_supported(D)) ? 1 : 0; }
+// (D = 16: chains of affine / shift couplings only -- fp32 operands, no context, no MADE / spline ops)
+int tfk_flow_lean_supported(int32_t D) { return (D == 16 || D == 32 || tfk_flow_mfma_supported(D)) ? 1 : 0; }
 
 static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *logdet, const float *gauss_loc,
                               const float *gauss_log_scale, float *logprob, int64_t N, int32_t D,
@@ -297,7 +301,9 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
                                           first_kind != TFK_OP_EW_FMA) ||
                                          (first_kind >= TFK_OP_MADE_FWD_LEAN && first_kind <= TFK_OP_MADE_LRS_INV_LEAN)));
     if (!(lean ? tfk_flow_lean_supported(D) : tfk_flow_mfma_supported(D)))
-        return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256 (lean programs: 32 as well)", fn, D);
+        return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256 (lean programs: 32 as well, affine / shift chains: 16)", fn, D);
+    if (D == 16 && (context || (first_kind >= 0 && !(first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN))))
+        return fail(TFK_EINVAL, "%s: D = 16: chains of affine / shift couplings without a context only", fn);
     if (n_ops < 0 || n_ops > kMaxOpsM) return fail(TFK_EINVAL, "%s: n_ops = %d must be in [0, %d]", fn, n_ops, kMaxOpsM);
     if (n_params < 0 || (n_params & 3)) return fail(TFK_EINVAL, "%s: n_params must be a non-negative multiple of 4", fn);
     if (N == 0) return TFK_OK;

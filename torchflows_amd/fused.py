@@ -99,6 +99,18 @@ class CompiledChain:
     pos_in: Optional[torch.Tensor] = None     # padded chains: physical position of logical element l on entry
     ctx_width: Optional[int] = None           # context programs: elements per context row the packed weights expect
 
+    def reversed_out(self) -> bool:
+        """The rows come out exactly reversed (an odd number of ReversePermutationMatrix layers behind the last fold) and
+        the last launch is a matrix-core one: its store writes column c to D - 1 - c (flag bit 1 of tfk_flow_run_mfma)
+        instead of a tfk_permute pass over the rows afterwards."""
+        hit = self.__dict__.get("_reversed_out")
+        if hit is None:
+            hit = (not self.identity_out and self.pos_in is None and bool(self.segments) and self.segments[-1].mfma
+                   and self.pos.numel() == self.D
+                   and bool(torch.equal(self.pos, torch.arange(self.D - 1, -1, -1, device=self.pos.device))))
+            self.__dict__["_reversed_out"] = hit
+        return hit
+
 
 def _pad4(t: torch.Tensor) -> torch.Tensor:
     r = (-t.numel()) % 4
@@ -680,22 +692,27 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3
     ql, il = lane >> 4, lane & 15
     unit1 = 4 * (il & 3) + (il >> 2)
     A1 = torch.stack([W1pad[unit1, EPL * ql + s] for s in range(EPL)])                 # (EPL, 64)
-    A1 = A1.reshape(EPL // 4, 4, 64).permute(0, 2, 1)                                  # lane-major groups of 4 k-steps
+    VW = min(EPL, 4)                                                                   # (16-wide rows: A1[64][2])
+    A1 = A1.reshape(EPL // VW, VW, 64).permute(0, 2, 1)                                # lane-major groups of 4 k-steps
     qq, rr = torch.meshgrid(torch.arange(4, device=dev), torch.arange(4, device=dev), indexing="ij")
     b1m = b1pad[4 * rr + qq]                                                           # [q][r]
     q2, r2 = il >> 2, il & 3
-    T2 = EPL // 2 if P == 2 else EPL // 4
+    T2 = EPL // 2 if P == 2 else (EPL + 3) // 4
     A2, b2m = [], []
     for t in range(T2):
+        ok_l = ok_b = None
         if P == 2:
             m_l, p_l = EPL * q2 + 2 * t + (r2 >> 1), r2 & 1
             m_b, p_b = EPL * qq + 2 * t + (rr >> 1), rr & 1
         else:
             m_l, p_l = EPL * q2 + 4 * t + r2, torch.zeros_like(r2)
             m_b, p_b = EPL * qq + 4 * t + rr, torch.zeros_like(rr)
+            if EPL < 4:                              # 16-wide rows: rows r >= EPL of every group belong to no element
+                ok_l, ok_b = (r2 < EPL).to(torch.float64), (rr < EPL).to(torch.float64)
+                m_l, m_b = m_l.clamp(max=hp - 1), m_b.clamp(max=hp - 1)
         for r1 in range(steps2):
-            A2.append(W2pad[m_l, p_l, 4 * r1 + ql])
-        b2m.append(b2q[m_b, p_b])
+            A2.append(W2pad[m_l, p_l, 4 * r1 + ql] if ok_l is None else W2pad[m_l, p_l, 4 * r1 + ql] * ok_l)
+        b2m.append(b2q[m_b, p_b] if ok_b is None else b2q[m_b, p_b] * ok_b)
     if bf16x3:
         # GEMM 2 in the bf16 x 3 operand format (csrc/tfk_flow_chain.h: couple_lean3): per tile and lane
         # [W_hi | W_mid] and [W_lo | W_hi], 4 bf16 each (slot i <-> hidden unit 4 i + q); b2 = the weight of unit 15
@@ -1035,7 +1052,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     t[pos] = alpha * t[pos] + beta
                     ld_const = ld_const + torch.log(alpha).sum()
             elif isinstance(layer, MaskedAutoregressiveBijection):
-                if context:
+                if context or Dp < 32:
                     return None
                 got = _lean_made(layer, d, pos, D, Dp)       # MAF density / IAF sampling: the parallel map
                 if got is None:
@@ -1093,6 +1110,8 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 if kind0 is not None and kind0 in (6, 7, 10, 12):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
+                if Dp < 32 and lk >= 4:
+                    return None                               # (16-wide rows: affine / shift chains only)
                 if lk >= 8 and not rqs_bf16x3_enabled():
                     return None                               # (linear rational splines: bf16 x 3 operands only)
                 if lk >= 4 and rqs_bf16x3_enabled():
@@ -1246,7 +1265,9 @@ def compile_chain(composition, direction: int, device: torch.device,
     if mfma and not slots and lean_enabled():
         # event sizes <= 32: the straight-line kernels exist at row width 32 as well (half the work of a 64-wide row)
         # (conditional flows: the elementwise layers around the chain are interpreter launches -- 64 columns at least)
-        widths = ([32] if (D % 2 == 0 and 4 <= D <= 32 and narrow_rows_enabled() and not context) else []) + [Dp]
+        narrow = D % 2 == 0 and narrow_rows_enabled() and not context
+        widths = (([16] if (narrow and 4 <= D <= 16 and rows16_enabled()) else [])
+                  + ([32] if (narrow and 4 <= D <= 32) else []) + [Dp])
         for w in widths:
             if w != D and not padded_enabled(D, w):
                 continue
@@ -1317,6 +1338,11 @@ def stream_chain_enabled() -> bool:
     """One launch with streamed operands for affine / shift chains that do not fit the LDS (TORCHFLOWS_AMD_STREAM_CHAIN=0:
     one launch per LDS-full of couplings, as before)."""
     return os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") != "0"
+
+
+def rows16_enabled() -> bool:
+    """Row width 16 for affine / shift chains on event sizes <= 16 (TORCHFLOWS_AMD_ROWS16=0: width 32 as before)."""
+    return os.environ.get("TORCHFLOWS_AMD_ROWS16", "1") != "0"
 
 
 def narrow_rows_enabled() -> bool:
@@ -1508,8 +1534,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
         out = torch.empty_like(rows)
         seg = chain.segments[0]
         native.flow_run_mfma(rows, out, None, base[0], base[1], logprob, seg.packed_ops(), seg.params,
-                             base_of_input=True)
-        if not chain.identity_out:
+                             base_of_input=True, reverse_out=chain.reversed_out())
+        if not chain.identity_out and not chain.reversed_out():
             cur, out = out, torch.empty_like(out)
             native.permute(cur, chain.pos.to(torch.int32), out)
         return out, None, logprob
@@ -1569,6 +1595,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
             kw["context"] = context
         if sum_out is not None:
             kw["sum_out"] = sum_out
+        if last and need_rows and chain.reversed_out():
+            kw["reverse_out"] = True              # (the reversal behind the program, folded into its store)
         run(cur, out, None if (last and base is not None and n_seg == 1) else logdet,
             loc_p if last else None, ls_p if last else None,
             logprob if last else None, seg.packed_ops(), seg.params, accumulate=(i > 0), **kw)
@@ -1578,7 +1606,7 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     if want_rows and padded:
         out_rows = cur.index_select(1, chain.pos)            # logical order, padding dropped
     elif want_rows:
-        if chain.identity_out:
+        if chain.identity_out or chain.reversed_out():
             out_rows = cur
         else:                                     # logical l <- physical pos[l]
             out_rows = torch.empty_like(cur)
