@@ -15,18 +15,19 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 flow = bench.make_flow(arch, D, 8).cuda()
 x = torch.randn(1 << 18, D, device="cuda")
 flow.train()
-import os
-opt = torch.optim.AdamW(flow.parameters(), lr=1e-4, fused=bool(int(os.environ.get("FUSED_OPT", "0"))))
+from torchflows_amd.utils import make_adamw
+opt = make_adamw(flow.parameters(), 1e-4)          # what Flow.fit builds (on the device: flat_optim.FlatAdamW)
+w = torch.ones(x.shape[0], device="cuda")
 
 
-def step():
+def step():                                        # the step Flow.fit runs
     opt.zero_grad(set_to_none=True)
-    loss = -flow.log_prob(x).mean() / flow.event_size + flow.regularization()
+    loss = flow._base_batch_loss((x, w), reduction=torch.mean, use_regularization=True)
     loss.backward()
     opt.step()
 
 
-for _ in range(2):
+for _ in range(3):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
