@@ -258,7 +258,11 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     calls = native.calls
     dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     assert native.calls > calls
-    assert dev._fit_stats == {"eager_steps": 40, "graph_replays": 0, "graph_captures": 0}
+    # (RealNVP-64: every coupling runs as the fused launches -> 40 full-size steps are enough for TORCHFLOWS_AMD_GRAPH's
+    # default "auto" to capture the step after two eager ones; the others stay eager)
+    want = ({"eager_steps": 2, "graph_replays": 38, "graph_captures": 1} if (arch, D) == ("RealNVP", 64)
+            else {"eager_steps": 40, "graph_replays": 0, "graph_captures": 0})
+    assert dev._fit_stats == want
     with torch.no_grad():
         after_h = float(host.log_prob(x).mean())
         after_d = float(dev.log_prob(x.cuda()).mean())
@@ -448,3 +452,49 @@ def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeyp
     a._base_batch_loss((x, w)).backward()
     oa.step()
     assert oa.flat.intact()
+
+
+def test_fit_drops_the_captured_step_when_a_parameter_moves(native):
+    """Flow.fit captures the fully fused step by default (TORCHFLOWS_AMD_GRAPH unset = "auto") and checks before every
+    replay that parameters and buffers still live where the capture saw them: here the validation pass of the second
+    epoch re-homes one weight, the next step notices, the rest of the fit runs eagerly -- same likelihood as a fit that
+    never captured, no crash."""
+    import copy
+    import os
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive.architectures import RealNVP
+    assert os.environ.get("TORCHFLOWS_AMD_GRAPH", "auto") == "auto"
+    torch.manual_seed(0)
+    D = 64
+    mix = torch.randn(8192, D)
+    x = torch.cat([mix[:, :32] * 0.3 + 2.0, torch.tanh(mix[:, 32:]) + 0.1 * mix[:, :32]], dim=1).cuda()
+    flow = Flow(RealNVP(D, n_layers=2)).cuda()
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x)
+    ref = copy.deepcopy(flow)
+    inner = flow._base_batch_loss
+    calls = {"val": 0}
+
+    def spy(batch, reduction=torch.mean, use_regularization=True):
+        if not use_regularization:                       # the validation pass
+            calls["val"] += 1
+            if calls["val"] == 2:
+                w = flow.bijection.layers[2].conditioner_transform.sequential[0].weight
+                w.data = w.data.clone()                  # the weight now lives somewhere else
+        return inner(batch, reduction=reduction, use_regularization=use_regularization)
+    flow._base_batch_loss = spy
+    with pytest.warns(UserWarning, match="moved since the training step was captured"):
+        flow.fit(x, n_epochs=5, lr=0.01, x_val=x[:1024], shuffle=False)
+    stats = flow._fit_stats
+    assert stats["graph_captures"] == 1 and stats.get("graph_dropped") == 1
+    assert stats["graph_replays"] == 14 and stats["eager_steps"] == 2 + 24, stats      # epochs 1-2 replayed, 3-5 eager
+    os.environ["TORCHFLOWS_AMD_GRAPH"] = "0"
+    try:
+        ref.fit(x, n_epochs=5, lr=0.01, x_val=x[:1024], shuffle=False)
+    finally:
+        del os.environ["TORCHFLOWS_AMD_GRAPH"]
+    assert ref._fit_stats["graph_captures"] == 0 and ref._fit_stats["eager_steps"] == 40
+    with torch.no_grad():
+        a, b = float(flow.log_prob(x).mean()), float(ref.log_prob(x).mean())
+    assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (a, b)

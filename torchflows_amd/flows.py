@@ -28,6 +28,9 @@ from torchflows_amd.base_distributions.gaussian import DiagonalGaussian
 from torchflows_amd.bijections.base import Bijection
 from torchflows_amd.utils import make_adamw, event_size, flatten_event, get_batch_shape, unflatten_event
 
+# Flow.fit, TORCHFLOWS_AMD_GRAPH=auto: full-size steps a call must run before its step is captured into a hipGraph
+GRAPH_AUTO_MIN_STEPS = 32
+
 
 def _drop_native_caches(module, incompatible_keys=None) -> None:
     module.invalidate_native_caches()
@@ -286,21 +289,25 @@ class Flow(BaseFlow):
                 max_batch_size = max(1, min(max_batch_size, int(max_batch_size_mb / (self.event_size / 2 ** 20))))
             batch_size = max(32, min(1024, n_train // 100))
 
-        # On the device the step is launch-bound (~120 launches of 5-50 us): after two eager steps
-        # (lazy initialisation, ActNorm statistics) a full-size batch step is captured ONCE into a
-        # hipGraph -- forward, backward and the AdamW update -- and replayed on static buffers.
-        # Only the route that is known to be capture-safe qualifies: a composition whose couplings
-        # all run as the fused launches (libtfk kernels + elementwise ATen ops on fixed shapes, no
-        # GEMM-library calls, no host synchronisation) and a fixed diagonal Gaussian base.  Steps
-        # with hipBLASLt GEMMs invalidated the capture on this stack, and an invalidated capture
-        # does not raise here, it crashes the process -- so no speculative tries.
-        # Opt-in (TORCHFLOWS_AMD_GRAPH=1) for that reason.  The whole loop then runs on a side
-        # stream: autograd state created on the legacy default stream would invalidate the capture.
-        use_graph = (dev.type == "cuda" and os.environ.get("TORCHFLOWS_AMD_GRAPH", "0") == "1"
-                     and context_train is None and self._graph_safe())
+        # On the device a small-batch step is bound by the host (~1.4 ms of Python / launch work per step whatever the
+        # batch size): after two eager steps (lazy initialisation, ActNorm statistics) a full-size batch step is captured
+        # ONCE into a hipGraph -- forward, backward and the AdamW update -- and replayed on static buffers.
+        # Only the route that is known to be capture-safe qualifies (``_graph_safe``): a composition whose couplings all
+        # run as the fused launches (libtfk kernels + elementwise ATen ops on fixed shapes, no GEMM-library calls, no
+        # host synchronisation) and a fixed diagonal Gaussian base.  Steps with hipBLASLt GEMMs invalidated the capture
+        # on this stack, and an invalidated capture does not raise here, it crashes the process -- so no speculative
+        # tries: TORCHFLOWS_AMD_GRAPH=1 captures whenever that route applies, "auto" (the default) additionally asks for
+        # a fixed batch size and enough full-size steps to pay for the capture, 0 never captures.  Every replay first
+        # checks that the parameters still live where the capture saw them (a replay over freed or moved tensors is the
+        # other way to lose the process) and drops to eager steps otherwise.  The whole loop then runs on a side stream:
+        # autograd state created on the legacy default stream would invalidate the capture.
+        graph_mode = os.environ.get("TORCHFLOWS_AMD_GRAPH", "auto")
+        use_graph = (dev.type == "cuda" and graph_mode != "0" and context_train is None and self._graph_safe())
+        if use_graph and graph_mode != "1":
+            use_graph = (not adaptive) and n_epochs * (n_train // max(int(batch_size), 1)) >= GRAPH_AUTO_MIN_STEPS
         if self._optimizer is None or reset_optimizer:
             self._optimizer = make_adamw(self.parameters(), lr, capturable=use_graph)
-        graphed = None               # (batch size, graph, static x, static w, static loss)
+        graphed = None               # (batch size, graph, static x, static w, static loss, tensor addresses)
         stats = {"eager_steps": 0, "graph_replays": 0, "graph_captures": 0}
         self._fit_stats = stats
 
@@ -309,6 +316,9 @@ class Flow(BaseFlow):
             main_stream = torch.cuda.current_stream(dev)
             side = torch.cuda.Stream(dev)
             side.wait_stream(main_stream)
+
+        def where():                     # what a replay reads and writes besides its static inputs
+            return tuple(t.data_ptr() for t in list(self.parameters()) + list(self.buffers()))
 
         def capture(xb, wb):
             xs, ws = xb.clone(), wb.clone()
@@ -319,7 +329,7 @@ class Flow(BaseFlow):
                 static_loss.backward()
                 self._optimizer.step()
             stats["graph_captures"] += 1
-            return len(xb), graph, xs, ws, static_loss
+            return len(xb), graph, xs, ws, static_loss, where()
 
         def snapshot():
             return {k: v.detach().clone() for k, v in self.state_dict().items()}
@@ -353,6 +363,10 @@ class Flow(BaseFlow):
                             use_graph, replay, graphed = False, False, None
                             torch.cuda.synchronize()
                             self._optimizer.zero_grad(set_to_none=True)
+                    if replay and graphed[5] != where():
+                        warnings.warn("a parameter or buffer moved since the training step was captured; running eagerly")
+                        use_graph, replay, graphed = False, False, None
+                        stats["graph_dropped"] = stats.get("graph_dropped", 0) + 1
                     if replay:
                         # (a non-finite loss is noticed after the captured update has run; the
                         # roll-back below restores the kept weights either way)
