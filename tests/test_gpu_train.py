@@ -258,9 +258,9 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     calls = native.calls
     dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     assert native.calls > calls
-    # (RealNVP-64: every coupling runs as the fused launches -> 40 full-size steps are enough for TORCHFLOWS_AMD_GRAPH's
-    # default "auto" to capture the step after two eager ones; the others stay eager)
-    want = ({"eager_steps": 2, "graph_replays": 38, "graph_captures": 1} if (arch, D) == ("RealNVP", 64)
+    # (RealNVP: every coupling runs as the fused launches -- D = 8 on rows padded to 64 -- so 40 full-size steps are enough
+    # for TORCHFLOWS_AMD_GRAPH's default "auto" to capture the step after two eager ones; the spline flow stays eager)
+    want = ({"eager_steps": 2, "graph_replays": 38, "graph_captures": 1} if arch == "RealNVP"
             else {"eager_steps": 40, "graph_replays": 0, "graph_captures": 0})
     assert dev._fit_stats == want
     with torch.no_grad():
@@ -498,3 +498,66 @@ def test_fit_drops_the_captured_step_when_a_parameter_moves(native):
     with torch.no_grad():
         a, b = float(flow.log_prob(x).mean()), float(ref.log_prob(x).mean())
     assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (a, b)
+
+
+@pytest.mark.parametrize("arch,D", [("RealNVP", 4), ("RealNVP", 6), ("RealNVP", 10), ("RealNVP", 22), ("RealNVP", 32),
+                                    ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10)])
+def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch, D):
+    """Even event sizes that are not 64 / 128 train on rows padded to the next of the two in the padded training layout
+    (first half at the head of plane A, second half at the tail of plane B: a logical reversal is the physical one) --
+    one forward program and one tfk_affine_coupling_train_bwd per [coupling, ActNorm, reversal] block, graph-capturable --
+    instead of the layer-by-layer reverse mode with its GEMM-library calls.  Gradients against the host ATen graph in
+    float64, against the unpadded route, launch counts, both directions, and one fit."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    from torchflows_amd import autograd as ag
+    torch.manual_seed(D)
+    flow = Flow(getattr(A, arch)(D, n_layers=3))
+    flow.train()
+    x = torch.randn(700, D) * 0.8 + 0.1
+    with torch.no_grad():
+        flow.log_prob(x)                                   # data-dependent init
+    ref = copy.deepcopy(flow).double()
+    dev = copy.deepcopy(flow).cuda()
+    names = [n for n, p in flow.named_parameters() if p.requires_grad and p.numel()]
+
+    def grads(f, xx, inverse=False):
+        xx = xx.clone().requires_grad_(True)
+        if inverse:
+            z, ld = f.bijection.inverse(xx)
+            loss = (z.square().sum(-1) * 0.3 + ld).sum()
+        else:
+            loss = f.log_prob(xx).sum()
+        ps = [p for n, p in f.named_parameters() if n in names]
+        return torch.autograd.grad(loss, [xx] + ps)
+
+    fused = arch == "RealNVP"                              # (NICE: shift couplings have no fused training launch)
+    for inverse in (False, True):
+        want = grads(ref, x.double(), inverse)
+        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
+        before = native.calls
+        got = grads(dev, x.cuda(), inverse)
+        n_pad = native.calls - before
+        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "0")
+        before = native.calls
+        plain = grads(dev, x.cuda(), inverse)
+        n_plain = native.calls - before
+        for name, g, w, p in zip(["x"] + names, got, want, plain):
+            scale = max(1.0, float(w.abs().max()))
+            assert float((g.double().cpu() - w).abs().max()) < 2e-4 * scale, (inverse, name)
+            assert float((g - p).abs().max()) < 2e-4 * scale, (inverse, name)
+        if fused:
+            assert n_pad < n_plain, (n_pad, n_plain)
+            assert n_pad <= 2 * (3 + 6) + 4, n_pad        # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps
+    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
+    plan = ag.training_plan(dev.bijection, 0)
+    assert ag.fully_fused(plan, D) == fused and (ag.plan_width(plan, D) in (64, 128)) == fused
+    if fused:
+        data = torch.randn(4096, D, device="cuda") * 0.5 + 0.2
+        with torch.no_grad():
+            lp0 = float(dev.log_prob(data).mean())
+        dev.fit(data, n_epochs=10, lr=0.01, batch_size=512, shuffle=False)
+        assert dev._fit_stats == {"eager_steps": 2, "graph_replays": 78, "graph_captures": 1}
+        with torch.no_grad():
+            assert float(dev.log_prob(data).mean()) > lp0

@@ -192,29 +192,36 @@ class _TrainPack:
     _cache = {}
 
     @classmethod
-    def get(cls, D: int, H: int, device) -> "_TrainPack":
-        key = (D, H, str(device))
+    def get(cls, D: int, H: int, device, D_log: Optional[int] = None) -> "_TrainPack":
+        key = (D, H, str(device), D_log or D)
         if key not in cls._cache:
-            cls._cache[key] = cls(D, H, device)
+            cls._cache[key] = cls(D, H, device, D_log or D)
         return cls._cache[key]
 
-    def __init__(self, D: int, H: int, device):
+    def __init__(self, D: int, H: int, device, D_log: Optional[int] = None):
+        """``D``: the row width the kernels see; ``D_log`` <= D: the layer's event size when its rows are padded
+        (training_layout: the source half at the head of plane A, the target half at the TAIL of plane B, zeros between) --
+        the weights of the padding are the appended zero, its accumulators are not mapped back."""
+        D_log = D_log or D
         half, EPL = D // 2, D // 8
+        h = D_log // 2                                    # real elements per plane
+        pad = half - h                                    # plane B: padding first, then the h targets
         T2, T1 = EPL // 2, EPL // 4
         self.steps2 = (H + 3) // 4
-        TP = 2 * half
-        off_b1 = H * half
+        TP = 2 * h
+        off_b1 = H * h
         off_W2 = off_b1 + H
         off_b2 = off_W2 + TP * H
         Z = off_b2 + TP                                   # index of the appended zero
         ar = torch.arange
         W1idx = torch.full((16, half), Z, dtype=torch.long)
-        W1idx[:H] = (ar(H)[:, None] * half + ar(half)[None, :])
+        W1idx[:H, :h] = (ar(H)[:, None] * h + ar(h)[None, :])
         b1idx = torch.full((16,), Z, dtype=torch.long)
         b1idx[:H] = off_b1 + ar(H)
         W2idx = torch.full((half, 2, 16), Z, dtype=torch.long)
-        W2idx[:, :, :H] = off_W2 + ((ar(half)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
-        b2idx = off_b2 + (ar(half)[:, None] * 2 + ar(2)[None, :])
+        W2idx[pad:, :, :H] = off_W2 + ((ar(h)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
+        b2idx = torch.full((half, 2), Z, dtype=torch.long)
+        b2idx[pad:] = off_b2 + (ar(h)[:, None] * 2 + ar(2)[None, :])
         lane = ar(64)
         ql, il = lane >> 4, lane & 15
         unit = 4 * (il & 3) + (il >> 2)
@@ -238,19 +245,19 @@ class _TrainPack:
         self.n_flat = Z + 1
         # accumulator layout -> [dW1 (H, half) | db1 (H) | dW2 (TP, H) | db2 (TP)]
         u = ar(H)
-        e = ar(half)
+        e = ar(h)                                         # (physical = logical source element)
         off1 = T2 * 256
         dW1 = off1 + (((e // 16)[None, :] * 64 + 16 * ((e % 16) // 4)[None, :] + u[:, None]) * 4 + (e % 4)[None, :])
         db1 = off1 + T1 * 256 + 4 * (u % 4) + (u // 4)
-        m = ar(half)[:, None].expand(half, 2).reshape(-1)
-        pbit = ar(2)[None, :].expand(half, 2).reshape(-1)
+        m = (pad + ar(h))[:, None].expand(h, 2).reshape(-1)          # physical target element of logical target t
+        pbit = ar(2)[None, :].expand(h, 2).reshape(-1)
         q_m, rem = m // EPL, m % EPL
         T_m, r_m = rem // 2, 2 * (rem % 2) + pbit
         dW2 = ((T_m * 64 + 16 * q_m)[:, None] + u[None, :]) * 4 + r_m[:, None]
         db2 = (T_m * 64 + 16 * q_m + 15) * 4 + r_m
         self.grad_index = torch.cat([dW1.reshape(-1), db1, dW2.reshape(-1), db2]).to(device)
-        self.sizes = (H * half, H, TP * H, TP)
-        self.shapes = ((H, half), (H,), (TP, H), (TP,))
+        self.sizes = (H * h, H, TP * H, TP)
+        self.shapes = ((H, h), (H,), (TP, H), (TP,))
         self.zero = torch.zeros(1, dtype=torch.float32, device=device)
         n_out = int(native.lib().tfk_coupling_train_bwd_out_floats(D))
         self.n_out = n_out
@@ -349,9 +356,64 @@ def fused_train_enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_TRAIN_FUSED", "1") != "0"
 
 
+def padded_train_enabled() -> bool:
+    """Fused training launches for even event sizes below 128 that are not 64 / 128, on rows padded to the next of the
+    two (TORCHFLOWS_AMD_TRAIN_PAD=0: the layer-by-layer reverse mode, as before round 3)."""
+    return os.environ.get("TORCHFLOWS_AMD_TRAIN_PAD", "1") != "0"
+
+
+def train_width(D: int) -> Optional[int]:
+    """Row width the fused training launches run an event size of ``D`` at, or None."""
+    if native.lib().tfk_coupling_train_bwd_supported(D):
+        return D
+    if padded_train_enabled() and D % 2 == 0 and 4 <= D < 128:
+        return 64 if D < 64 else 128
+    return None
+
+
+def _padding_capable(plan) -> bool:
+    """Every step keeps the padded training layout (source half at the head of plane A, target half at the tail of
+    plane B): reversals -- a logical reversal IS the physical one there --, global elementwise layers, and couplings
+    with the fused launches."""
+    D = plan[0][0].n_dim if len(plan) else 0
+    for layer, d, kind in plan:
+        if kind == "perm" and layer._is_reversal:
+            continue
+        if kind == "elementwise":
+            continue
+        if kind == "coupling" and _fused_bwd_layer(layer, D) is not None:
+            continue
+        return False
+    return True
+
+
+def plan_width(plan, D: int) -> int:
+    """The width of the rows ChainFunction runs this plan on: ``D``, or the padded width when D itself has no fused
+    training launches and every step keeps the padded layout."""
+    W = train_width(D)
+    if W is None or W == D or not _padding_capable(plan):
+        return D
+    return W
+
+
+def training_layout(D: int, W: int, device) -> torch.Tensor:
+    """Physical column of logical element l on rows padded from D to W: l for the first half, W - D + l for the
+    second -- so that reversing the D logical columns is reversing the W physical ones."""
+    key = (D, W, str(device))
+    hit = _LAYOUTS.get(key)
+    if hit is None:
+        l = torch.arange(D, device=device)
+        hit = _LAYOUTS[key] = torch.where(l < D // 2, l, l + (W - D))
+    return hit
+
+
+_LAYOUTS = {}
+
+
 def _fused_bwd_layer(layer, D: int):
-    """(lin1, lin2) when the layer's whole backward can run as tfk_affine_coupling_train_bwd."""
-    if not fused_train_enabled() or not native.lib().tfk_coupling_train_bwd_supported(D):
+    """(lin1, lin2) when the layer's whole backward can run as tfk_affine_coupling_train_bwd (at the width
+    ``train_width(D)``: whether a plan may be padded is ``plan_width``'s call)."""
+    if not fused_train_enabled() or train_width(D) is None:
         return None
     if layer.transformer.native_kind not in ("affine", "inverse_affine"):
         return None
@@ -367,20 +429,27 @@ def _fused_bwd_layer(layer, D: int):
     return mlp
 
 
-def _ew_block(layer, d: int, D: int) -> torch.Tensor:
+def _ew_block(layer, d: int, D: int, W: Optional[int] = None) -> torch.Tensor:
     """Parameter block of a fixed ElementwiseAffine / ActNorm op as tfk_flow_run reads it
-    (alpha[D] | beta[D] | sum log alpha, pad[3] | 1/alpha[D] for the dividing form), cached on the
-    layer until its value changes (ActNorm: once, at its data-dependent initialisation)."""
-    key = (layer.value._version, layer.value.data_ptr(), d)
+    (alpha[W] | beta[W] | sum log alpha, pad[3] | 1/alpha[W] for the dividing form), cached on the
+    layer until its value changes (ActNorm: once, at its data-dependent initialisation).  ``W`` > D: rows in the padded
+    training layout -- the padding columns get alpha = 1, beta = 0."""
+    W = W or D
+    key = (layer.value._version, layer.value.data_ptr(), d, W)
     hit = layer.__dict__.get("_tfk_ew_block")
     if hit is not None and hit[0] == key:
         return hit[1]
     v = layer.value.detach().reshape(D, 2)
     alpha = layer.transformer.constrain_scale(v[:, 0])                     # affine.py:33-34
+    beta = v[:, 1].contiguous()
     ldc = torch.log(alpha).sum().reshape(1)
+    if W != D:
+        phys = training_layout(D, W, v.device)
+        alpha = torch.ones(W, dtype=alpha.dtype, device=v.device).index_copy_(0, phys, alpha)
+        beta = torch.zeros(W, dtype=beta.dtype, device=v.device).index_copy_(0, phys, beta)
     inverse_form = _affine_form_is_inverse(layer, d)
     pad = torch.zeros(3, dtype=torch.float32, device=v.device)
-    parts = [alpha, v[:, 1].contiguous(), -ldc if inverse_form else ldc, pad]
+    parts = [alpha, beta, -ldc if inverse_form else ldc, pad]
     if inverse_form:
         parts.append(1.0 / alpha)
     block = torch.cat(parts).float().contiguous()
@@ -402,14 +471,19 @@ class _PlanPacks:
         self.fold = []                        # per fusable layer: (ew step or None, reversal step or None)
         self.folded_steps = set()
         self.D = D
+        # the rows' width: D, or -- event sizes without fused launches of their own, every step padding-capable -- the
+        # next width that has them, the rows in the padded training layout (training_layout)
+        self.W = W = plan_width(plan, D)
+        self.phys = training_layout(D, W, device) if W != D else None
+        fusable = bool(native.lib().tfk_coupling_train_bwd_supported(W))
         pidx, gidx, off_flat, off_out = [], [], 0, 0
         for i, (layer, d, kind) in enumerate(plan):
             if kind != "coupling":
                 continue
-            mlp = _fused_bwd_layer(layer, D)
+            mlp = _fused_bwd_layer(layer, D) if fusable else None
             if mlp is None:
                 continue
-            pack = _TrainPack.get(D, mlp[0].out_features, device)
+            pack = _TrainPack.get(W, mlp[0].out_features, device, D)
             ew_step = rev_step = None
             j = i + 1
             if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
@@ -424,7 +498,7 @@ class _PlanPacks:
             idx = [pack.param_index + off_flat]
             n_ew = 0
             if ew_step is not None:           # the elementwise block follows the operand block
-                n_ew = (3 * D + 4) if _affine_form_is_inverse(plan[ew_step][0], plan[ew_step][1]) else (2 * D + 4)
+                n_ew = (3 * W + 4) if _affine_form_is_inverse(plan[ew_step][0], plan[ew_step][1]) else (2 * W + 4)
                 idx.append(torch.arange(n_ew, device=device) + (off_flat + pack.n_flat))
             pidx.append(torch.cat(idx))
             gidx.append(pack.grad_index + off_out)
@@ -476,7 +550,8 @@ class _PlanPacks:
             return hit[1]
         import weakref
         dev = fb.P.device
-        D = self.D
+        D, W = self.D, self.W
+        phys = (self.phys if self.phys is not None else torch.arange(D)).cpu()
         slot_of = fb.slot_of
         cat_to_src, aux_layers, aux_off = [], [], fb.n
         for (i, lin1, lin2, pack), (ew_step, _) in zip(self.layers, self.fold):
@@ -488,7 +563,7 @@ class _PlanPacks:
             cat_to_src.append(torch.tensor([fb.zero_slot]))
             if ew_step is not None:
                 ew_layer, ew_d, _ = self.plan[ew_step]
-                n_ew = (3 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else (2 * D + 4)
+                n_ew = (3 * W + 4) if _affine_form_is_inverse(ew_layer, ew_d) else (2 * W + 4)
                 cat_to_src.append(torch.arange(n_ew) + aux_off)
                 aux_layers.append((ew_layer, ew_d))
                 aux_off += n_ew
@@ -510,9 +585,9 @@ class _PlanPacks:
                 k = slot_of.get(id(layer.value))
                 if k is None:
                     return None
-                ew_out[i] = ext
-                grad_src[fb.offset[k]:fb.offset[k] + 2 * D] = torch.arange(2 * D) + ext
-                ext += 2 * D
+                ew_out[i] = ext              # the kernel writes dL/dvalue as (W, 2): logical row l is physical row phys[l]
+                grad_src[fb.offset[k]:fb.offset[k] + 2 * D] = (ext + 2 * phys[:, None] + torch.arange(2)[None, :]).reshape(-1)
+                ext += 2 * W
         grad_src[grad_src < 0] = ext                 # padding, parameters outside the plan: the zero
         ret = []
         for layer, _, kind in self.plan:
@@ -528,7 +603,7 @@ class _PlanPacks:
         """``pack()`` as ONE gather out of the parameter buffer (+ the cached blocks of the folded fixed layers)."""
         src = fb.P
         if maps["aux_layers"]:
-            src = torch.cat([fb.P] + [_ew_block(l, d, self.D) for l, d in maps["aux_layers"]])
+            src = torch.cat([fb.P] + [_ew_block(l, d, self.D, self.W) for l, d in maps["aux_layers"]])
         return list(src.index_select(0, maps["src_index"]).split(self.block_sizes))
 
     @staticmethod
@@ -550,6 +625,26 @@ class _PlanPacks:
             vec = maps["l2"][key] = v.to(fb.P.device)
         return vec
 
+    # ---- rows in the padded training layout (self.W > self.D) -----------------------------------------------------
+    def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """(N, D) -> (N, W): first half at the head of plane A, second half at the tail of plane B, zeros between."""
+        h = self.D // 2
+        wide = rows.new_zeros(rows.shape[0], self.W)
+        wide[:, :h] = rows[:, :h]
+        wide[:, self.W - h:] = rows[:, h:]
+        return wide
+
+    def unpad_rows(self, wide: torch.Tensor) -> torch.Tensor:
+        h = self.D // 2
+        return torch.cat([wide[:, :h], wide[:, self.W - h:]], dim=1)
+
+    def ew_value(self, layer) -> torch.Tensor:
+        """``layer.value`` as the (W, 2) block the elementwise kernels read (padding rows: zeros = the identity)."""
+        v = layer.value.detach().reshape(self.D, 2)
+        if self.phys is None:
+            return v.contiguous()
+        return v.new_zeros(self.W, 2).index_copy_(0, self.phys, v)
+
     def pack(self):
         """[packed block of layer k: operands (+ the folded elementwise parameters)] for the
         current weights."""
@@ -558,7 +653,7 @@ class _PlanPacks:
             pieces += [lin1.weight.detach().reshape(-1), lin1.bias.detach(),
                        lin2.weight.detach().reshape(-1), lin2.bias.detach(), self.zero]
             if ew_step is not None:
-                pieces.append(_ew_block(self.plan[ew_step][0], self.plan[ew_step][1], self.D))
+                pieces.append(_ew_block(self.plan[ew_step][0], self.plan[ew_step][1], self.D, self.W))
         packed = torch.cat(pieces)[self.param_index]
         return list(packed.split(self.block_sizes))
 
@@ -566,7 +661,7 @@ class _PlanPacks:
 def _plan_packs(plan, D: int, device, fold: bool) -> _PlanPacks:
     owner = plan[0][0]
     key = (tuple(id(l) for l, _, _ in plan), tuple(d for _, d, _ in plan), str(device),
-           fused_train_enabled(), fold)
+           fused_train_enabled(), fold, padded_train_enabled())
     cache = owner.__dict__.setdefault("_tfk_plan_packs", {})
     if key not in cache:
         if len(cache) > 4:
@@ -580,6 +675,8 @@ def fully_fused(plan, D: int) -> bool:
     backward): the step then consists of libtfk kernels and elementwise ATen ops only -- no GEMM
     library calls -- which is the configuration verified to survive hipGraph capture."""
     couplings = [layer for layer, _, kind in plan if kind == "coupling"]
+    if not native.lib().tfk_coupling_train_bwd_supported(plan_width(plan, D)):
+        return False                          # (an event size that would need padding in a plan that cannot keep it)
     return bool(couplings) and all(_fused_bwd_layer(layer, D) is not None for layer in couplings)
 
 
@@ -669,6 +766,9 @@ class ChainFunction(torch.autograd.Function):
                 l2vec = packs.l2_vector(fb, maps, plan.l2)
         else:
             packed = packs.pack() if packs.layers else []
+        W = packs.W
+        if W != D:                   # padded training layout: every kernel below sees (N, W) rows
+            cur, cur_is_saved = packs.pad_rows(rows), False
         rqs_blocks = {}
         for step, (layer, d, kind) in enumerate(plan):
             if step in packs.folded_steps:
@@ -682,10 +782,10 @@ class ChainFunction(torch.autograd.Function):
                 cur, cur_is_saved = out, False
             elif kind == "elementwise":
                 if isinstance(layer, ActNorm) and d == FORWARD and layer.training and layer.first_training_batch_pass:
-                    layer._data_dependent_init(cur.view(N, *layer.event_shape))
+                    layer._data_dependent_init((cur if W == D else packs.unpad_rows(cur)).view(N, *layer.event_shape))
                 keep_input = layer.value.requires_grad
                 out = cur if (not cur_is_saved and not keep_input) else torch.empty_like(cur)
-                native.elementwise_affine(cur, layer.value.detach().reshape(D, 2).contiguous(), out, logdet,
+                native.elementwise_affine(cur, packs.ew_value(layer), out, logdet,
                                           layer.transformer.native_kind == "inverse_affine",
                                           accumulate=started, inverse=(d == INVERSE))
                 started = True
@@ -783,6 +883,8 @@ class ChainFunction(torch.autograd.Function):
             logdet.zero_()
         if cur is rows:
             cur = rows.clone()
+        if W != D:
+            cur = packs.unpad_rows(cur)
         ctx.plan = plan
         ctx.saved_rows = saved
         ctx.n_params = len(params)
@@ -808,8 +910,13 @@ class ChainFunction(torch.autograd.Function):
         N = (g_logdet.shape[0] if g_logdet is not None else
              (g_rows.shape[0] if g_rows is not None else first.shape[0]))     # (only the L2 output was differentiated)
         D = plan[0][0].n_dim
-        g = (torch.zeros(N, D, dtype=torch.float32, device=device) if g_rows is None
-             else g_rows.contiguous().clone())
+        W = ctx.packs.W                # (rows in the padded training layout when W > D)
+        if W != D:
+            g = (torch.zeros(N, W, dtype=torch.float32, device=device) if g_rows is None
+                 else ctx.packs.pad_rows(g_rows))
+        else:
+            g = (torch.zeros(N, D, dtype=torch.float32, device=device) if g_rows is None
+                 else g_rows.contiguous().clone())
         gld = (torch.zeros(N, dtype=torch.float32, device=device) if g_logdet is None
                else g_logdet.contiguous())
         grads_per_step: List[List[Optional[torch.Tensor]]] = [[] for _ in plan]
@@ -834,10 +941,12 @@ class ChainFunction(torch.autograd.Function):
             elif kind == "elementwise":
                 want = layer.value.requires_grad
                 lo = maps["ew_out"].get(i) if fb is not None else None
-                gv = native.elementwise_affine_bwd(x_in, layer.value.detach().reshape(D, 2).contiguous(), g,
+                gv = native.elementwise_affine_bwd(x_in, packs.ew_value(layer), g,
                                                    gld, want, inverse=_affine_form_is_inverse(layer, d),
-                                                   out=None if lo is None else out_all[lo:lo + 2 * D])
-                grads_per_step[i] = [gv.view_as(layer.value) if want else None]
+                                                   out=None if lo is None else out_all[lo:lo + 2 * W])
+                if want and W != D and fb is None:
+                    gv = gv.index_select(0, packs.phys)          # (W, 2) -> the D logical rows
+                grads_per_step[i] = [gv.view_as(layer.value) if (want and fb is None) else None]
             elif kind == "elementwise_ctx":
                 cparams = _module_params(layer.conditioner_transform)
                 with torch.enable_grad():
@@ -904,8 +1013,8 @@ class ChainFunction(torch.autograd.Function):
                     gscale = None
                     if ew_step is not None:     # d(alpha x + beta)/dx = alpha, d((x - beta)/alpha)/dx = 1/alpha
                         ew_layer, ew_d, _ = plan[ew_step]
-                        lo = n_train + ((2 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0)
-                        gscale = ctx.packed[k][lo:lo + D]
+                        lo = n_train + ((2 * W + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0)
+                        gscale = ctx.packed[k][lo:lo + W]
                     native.affine_coupling_train_bwd(x_in, g, gld, ctx.packed[k][:n_train], pack.steps2,
                                                      out_all[k * pack.n_out:(k + 1) * pack.n_out], pack.workspace,
                                                      inverse_form=_affine_form_is_inverse(layer, d),
@@ -995,7 +1104,8 @@ class ChainFunction(torch.autograd.Function):
             pieces = G.split_with_sizes(fb.split_sizes)
             flat = [None if r is None else pieces[r[0]].view(r[1]) for r in maps["ret"]]
             assert len(flat) == ctx.n_params
-            return (None, g if ctx.needs_input_grad[1] else None, *flat)
+            g_in = None if not ctx.needs_input_grad[1] else (g if W == D else packs.unpad_rows(g))
+            return (None, g_in, *flat)
         if packs.layers:                    # accumulator layout -> parameter layout, all layers at once
             pieces = out_all[packs.grad_index]
             lo = 0
@@ -1012,7 +1122,7 @@ class ChainFunction(torch.autograd.Function):
         for gs in grads_per_step:
             flat.extend(gs)
         assert len(flat) == ctx.n_params
-        g_in = g if ctx.needs_input_grad[1] else None
+        g_in = None if not ctx.needs_input_grad[1] else (g if W == D else packs.unpad_rows(g))
         return (None, g_in, *flat)
 
 
