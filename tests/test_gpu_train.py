@@ -396,7 +396,7 @@ def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeyp
     from torchflows_amd.utils import make_adamw
     from torchflows_amd.flat_optim import FlatAdamW
     torch.manual_seed(D)
-    flat_route = arch == "RealNVP"
+    flat_route = True                      # (NICE too: a shift coupling runs as the affine launches with a zero scale logit)
     x = torch.randn(3000, D, device="cuda") * 0.7 + 0.2
     w = torch.rand(3000, device="cuda") + 0.5
     flow = Flow(getattr(A, arch)(D, n_layers=4))
@@ -429,7 +429,6 @@ def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeyp
         ob.step()
         for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
             assert torch.equal(pa, pb), (step, n)
-    # (NICE: shift couplings have no fused training launch -- the per-tensor route, and the update over views)
     assert (oa.fast_steps, oa.general_steps) == ((6, 0) if flat_route else (0, 6)) and oa.flat.intact()
     a.eval()
     b.eval()
@@ -501,7 +500,7 @@ def test_fit_drops_the_captured_step_when_a_parameter_moves(native):
 
 
 @pytest.mark.parametrize("arch,D", [("RealNVP", 4), ("RealNVP", 6), ("RealNVP", 10), ("RealNVP", 22), ("RealNVP", 32),
-                                    ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10)])
+                                    ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("NICE", 64)])
 def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch, D):
     """Even event sizes that are not 64 / 128 train on rows padded to the next of the two in the padded training layout
     (first half at the head of plane A, second half at the tail of plane B: a logical reversal is the physical one) --
@@ -532,7 +531,7 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
         ps = [p for n, p in f.named_parameters() if n in names]
         return torch.autograd.grad(loss, [xx] + ps)
 
-    fused = arch == "RealNVP"                              # (NICE: shift couplings have no fused training launch)
+    fused = True                                           # (NICE: shift couplings = the affine launches with a zero scale logit)
     for inverse in (False, True):
         want = grads(ref, x.double(), inverse)
         monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
@@ -548,11 +547,11 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
             assert float((g.double().cpu() - w).abs().max()) < 2e-4 * scale, (inverse, name)
             assert float((g - p).abs().max()) < 2e-4 * scale, (inverse, name)
         if fused:
-            assert n_pad < n_plain, (n_pad, n_plain)
+            assert n_pad < n_plain or D in (64, 128), (n_pad, n_plain)   # (64 / 128: no padding either way)
             assert n_pad <= 2 * (3 + 6) + 4, n_pad        # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps
     monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
     plan = ag.training_plan(dev.bijection, 0)
-    assert ag.fully_fused(plan, D) == fused and (ag.plan_width(plan, D) in (64, 128)) == fused
+    assert ag.fully_fused(plan, D) and ag.plan_width(plan, D) in (64, 128)
     if fused:
         data = torch.randn(4096, D, device="cuda") * 0.5 + 0.2
         with torch.no_grad():

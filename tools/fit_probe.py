@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of Flow.fit at the reference's default batch size (1024) on the device: eager steps against the captured step
-(TORCHFLOWS_AMD_GRAPH=0 / auto).  RealNVP(D = argv[1] or 64, 8 layers), 65 536 training rows, 3 epochs = 192 steps."""
+(TORCHFLOWS_AMD_GRAPH=0 / auto).  argv[2] or RealNVP (D = argv[1] or 64, 8 layers), 65 536 training rows, 3 epochs = 192 steps."""
 import copy
 import os
 import sys
@@ -13,7 +13,8 @@ import bench  # noqa: E402
 
 torch.manual_seed(0)
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-base = bench.make_flow("RealNVP", D, 8).cuda()
+ARCH = sys.argv[2] if len(sys.argv) > 2 else "RealNVP"
+base = bench.make_flow(ARCH, D, 8).cuda()
 x = torch.randn(1 << 16, D, device="cuda") * 0.5 + 0.3
 for mode in ("0", "auto", "0", "auto"):
     os.environ["TORCHFLOWS_AMD_GRAPH"] = mode
@@ -25,5 +26,5 @@ for mode in ("0", "auto", "0", "auto"):
     dt = time.perf_counter() - t0
     with torch.no_grad():
         lp = float(flow.log_prob(x).mean())
-    print(f"RealNVP({D}) TORCHFLOWS_AMD_GRAPH={mode:5s} fit: {dt:.3f} s for 192 steps = {1e3 * dt / 192:.3f} ms per step, stats {flow._fit_stats}, "
+    print(f"{ARCH}({D}) TORCHFLOWS_AMD_GRAPH={mode:5s} fit: {dt:.3f} s for 192 steps = {1e3 * dt / 192:.3f} ms per step, stats {flow._fit_stats}, "
           f"mean log-likelihood {lp:.4f}", flush=True)

@@ -192,23 +192,26 @@ class _TrainPack:
     _cache = {}
 
     @classmethod
-    def get(cls, D: int, H: int, device, D_log: Optional[int] = None) -> "_TrainPack":
-        key = (D, H, str(device), D_log or D)
+    def get(cls, D: int, H: int, device, D_log: Optional[int] = None, shift: bool = False) -> "_TrainPack":
+        key = (D, H, str(device), D_log or D, shift)
         if key not in cls._cache:
-            cls._cache[key] = cls(D, H, device, D_log or D)
+            cls._cache[key] = cls(D, H, device, D_log or D, shift)
         return cls._cache[key]
 
-    def __init__(self, D: int, H: int, device, D_log: Optional[int] = None):
+    def __init__(self, D: int, H: int, device, D_log: Optional[int] = None, shift: bool = False):
         """``D``: the row width the kernels see; ``D_log`` <= D: the layer's event size when its rows are padded
         (training_layout: the source half at the head of plane A, the target half at the TAIL of plane B, zeros between) --
-        the weights of the padding are the appended zero, its accumulators are not mapped back."""
+        the weights of the padding are the appended zero, its accumulators are not mapped back.
+        ``shift``: a Shift coupling (NICE, affine.py:137-159) run as the affine coupling it is with a scale logit of
+        zero -- alpha = exp(0 / 2 + c0) + 1e-10 = 1 exactly, log alpha = 0: the conditioner's one output per element is the
+        shift row of GEMM 2, the logit rows are the appended zero, and their accumulators are not mapped back."""
         D_log = D_log or D
         half, EPL = D // 2, D // 8
         h = D_log // 2                                    # real elements per plane
         pad = half - h                                    # plane B: padding first, then the h targets
         T2, T1 = EPL // 2, EPL // 4
         self.steps2 = (H + 3) // 4
-        TP = 2 * h
+        TP = h if shift else 2 * h                        # rows of the real W2 / b2
         off_b1 = H * h
         off_W2 = off_b1 + H
         off_b2 = off_W2 + TP * H
@@ -219,9 +222,13 @@ class _TrainPack:
         b1idx = torch.full((16,), Z, dtype=torch.long)
         b1idx[:H] = off_b1 + ar(H)
         W2idx = torch.full((half, 2, 16), Z, dtype=torch.long)
-        W2idx[pad:, :, :H] = off_W2 + ((ar(h)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
         b2idx = torch.full((half, 2), Z, dtype=torch.long)
-        b2idx[pad:] = off_b2 + (ar(h)[:, None] * 2 + ar(2)[None, :])
+        if shift:
+            W2idx[pad:, 1, :H] = off_W2 + (ar(h)[:, None] * H + ar(H)[None, :])
+            b2idx[pad:, 1] = off_b2 + ar(h)
+        else:
+            W2idx[pad:, :, :H] = off_W2 + ((ar(h)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
+            b2idx[pad:] = off_b2 + (ar(h)[:, None] * 2 + ar(2)[None, :])
         lane = ar(64)
         ql, il = lane >> 4, lane & 15
         unit = 4 * (il & 3) + (il >> 2)
@@ -249,8 +256,11 @@ class _TrainPack:
         off1 = T2 * 256
         dW1 = off1 + (((e // 16)[None, :] * 64 + 16 * ((e % 16) // 4)[None, :] + u[:, None]) * 4 + (e % 4)[None, :])
         db1 = off1 + T1 * 256 + 4 * (u % 4) + (u // 4)
-        m = (pad + ar(h))[:, None].expand(h, 2).reshape(-1)          # physical target element of logical target t
-        pbit = ar(2)[None, :].expand(h, 2).reshape(-1)
+        if shift:
+            m, pbit = pad + ar(h), torch.ones(h, dtype=torch.long)   # (the shift rows only)
+        else:
+            m = (pad + ar(h))[:, None].expand(h, 2).reshape(-1)      # physical target element of logical target t
+            pbit = ar(2)[None, :].expand(h, 2).reshape(-1)
         q_m, rem = m // EPL, m % EPL
         T_m, r_m = rem // 2, 2 * (rem % 2) + pbit
         dW2 = ((T_m * 64 + 16 * q_m)[:, None] + u[None, :]) * 4 + r_m[:, None]
@@ -415,8 +425,8 @@ def _fused_bwd_layer(layer, D: int):
     ``train_width(D)``: whether a plan may be padded is ``plan_width``'s call)."""
     if not fused_train_enabled() or train_width(D) is None:
         return None
-    if layer.transformer.native_kind not in ("affine", "inverse_affine"):
-        return None
+    if layer.transformer.native_kind not in ("affine", "inverse_affine", "shift"):
+        return None                           # (shift: the affine launches with a scale logit of zero, _TrainPack)
     c = layer.coupling
     if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
             and c.target_event_size == D // 2):
@@ -483,7 +493,7 @@ class _PlanPacks:
             mlp = _fused_bwd_layer(layer, D) if fusable else None
             if mlp is None:
                 continue
-            pack = _TrainPack.get(W, mlp[0].out_features, device, D)
+            pack = _TrainPack.get(W, mlp[0].out_features, device, D, shift=layer.transformer.native_kind == "shift")
             ew_step = rev_step = None
             j = i + 1
             if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
