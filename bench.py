@@ -906,6 +906,26 @@ def main():
                                                                 + proc.stderr.strip()[-200:]}
                 except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
                     result["train"]["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                # Flow.fit itself at the reference's default batch size (1024 rows: pure host work per step), eager against
+                # the default ("auto": the fully fused step captured after two eager ones) -- also in a child process
+                try:
+                    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fit_probe.py"), "64"],
+                                          capture_output=True, text=True, timeout=240)
+                    got = {}
+                    for ln in proc.stdout.splitlines():
+                        if "TORCHFLOWS_AMD_GRAPH=" in ln and " ms per step" in ln:
+                            mode = ln.split("TORCHFLOWS_AMD_GRAPH=")[1].split()[0]
+                            got[mode] = float(ln.split(" = ")[1].split()[0])          # (the later, warm run of each mode)
+                    if proc.returncode == 0 and "0" in got and "auto" in got:
+                        result["train"]["fit_batch_1024"] = {
+                            "eager_ms_per_step": got["0"], "default_ms_per_step": got["auto"], "steps": 192,
+                            "note": "tools/fit_probe.py: Flow.fit(x[65536, 64], n_epochs=3) wall time / 192 steps, "
+                                    "TORCHFLOWS_AMD_GRAPH=0 against the default"}
+                    else:
+                        result["train"]["fit_batch_1024"] = {"error": f"exit code {proc.returncode}: "
+                                                                      + proc.stderr.strip()[-200:]}
+                except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as exc:
+                    result["train"]["fit_batch_1024"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
             rb = tk.get("rqs_coupling_train_bwd")
             if rb is not None:
                 result["train"]["roofline_fused_bwd"] = {
