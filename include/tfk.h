@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 25
+#define TFK_ABI_VERSION 26
 
 enum {
     TFK_OK = 0,
@@ -543,6 +543,26 @@ int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const
                                int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
                                int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
                                const float *gscale, int32_t g_reversed, void *stream);
+/* The same launch, also writing the hidden activations it re-evaluates:
+ *   hid_perm (N, 16): column 4 q + r = tanh(pre-activation of hidden unit 4 r + q), column 15 == 1 (hidden width <= 15:
+ *   the bias column of the weight-gradient products below). */
+int tfk_rqs_coupling_train_bwd_hid(const float *x, float *g, const float *gld, const float *params,
+                                   int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
+                                   float *hid_perm, int64_t N, int32_t D, int32_t n_bins, float boundary,
+                                   int32_t inverse, const float *gscale, int32_t g_reversed, void *stream);
+
+/* out[m][k] = sum_n A[n][m] * B[n][k], m < M, k < 16: the products of a training step that contract over the batch
+ * ROWS (dW2 = dL/dh^T hidden with A = gh_perm, M = 768; dW1^T = x_A^T dL/dpre with A = x, lda = D, M = 32; db1 with
+ * A = gpre_perm, M = 16, column 15 of B == 1) on v_mfma_f32_16x16x4_f32, deterministic (per-workgroup partial blocks
+ * added in a fixed order), with no GEMM-library call -- what makes the spline training step capturable into a hipGraph.
+ * A (N, lda) row-major, only its first M columns are read; M = 16, 32 or a multiple of 256 (<= 1024); B (N, 16).
+ * out holds M * 16 floats in ACCUMULATOR order: tile t (16 columns of A), lane (q, j), register r ->
+ *   out[(t * 64 + 16 q + j) * 4 + r] = sum_n A[n][col(t, 4 q + r)] * B[n][j],
+ *   col(t, i) = 64 (t >> 2) + 4 i + (t & 3) for M >= 256, 16 t + i for M = 16 / 32.
+ * workspace: tfk_rows_outer_workspace_bytes(M) bytes. */
+int64_t tfk_rows_outer_workspace_bytes(int32_t M);
+int tfk_rows_outer(const float *A, int32_t lda, int32_t M, const float *B, float *out, float *workspace,
+                   int64_t N, void *stream);
 
 #ifdef __cplusplus
 }

@@ -560,3 +560,64 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
         assert dev._fit_stats == {"eager_steps": 2, "graph_replays": 78, "graph_captures": 1}
         with torch.no_grad():
             assert float(dev.log_prob(data).mean()) > lp0
+
+
+@pytest.mark.parametrize("M,lda", [(16, 16), (32, 64), (256, 256), (768, 768), (1024, 1040)])
+@pytest.mark.parametrize("N", [1, 3, 4, 5, 1000, 4099])
+def test_rows_outer_vs_float64(native, M, lda, N):
+    """tfk_rows_outer: out = A[:, :M]^T B over the batch rows (the weight-gradient products of the spline training step),
+    against the float64 product; the accumulator order of include/tfk.h; bit-identical when repeated (fixed-order sums);
+    ragged row counts (the kernel contracts 4 rows per MFMA)."""
+    torch.manual_seed(M + N)
+    A = torch.randn(N, lda, device="cuda")
+    B = torch.randn(N, 16, device="cuda")
+    out = torch.empty(M * 16, device="cuda")
+    native.rows_outer(A, M, B, out)
+    out2 = torch.full((M * 16,), float("nan"), device="cuda")
+    native.rows_outer(A, M, B, out2)
+    assert torch.equal(out, out2)
+    full = (A[:, :M].double().t() @ B.double()).cpu()                      # (M, 16)
+    t, q, j, r = torch.meshgrid(torch.arange(M // 16), torch.arange(4), torch.arange(16), torch.arange(4), indexing="ij")
+    i = 4 * q + r
+    col = 64 * (t >> 2) + 4 * i + (t & 3) if M >= 256 else 16 * t + i
+    want = full[col, j].reshape(-1)
+    err = float((out.double().cpu() - want).abs().max())
+    assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+    with pytest.raises(native.NativeError):
+        native.rows_outer(A, 48, B, torch.empty(48 * 16, device="cuda"))
+
+
+def test_spline_training_step_without_gemm_library_calls(native, monkeypatch):
+    """CouplingRQNSF(64): the fused spline backward also writes the hidden activations it re-evaluates, and the three
+    products that contract over the batch rows run on tfk_rows_outer -- same gradients as the split-K GEMM route
+    (TORCHFLOWS_AMD_ROWS_OUTER=0) and as the host graph in float64, fewer launches."""
+    import copy
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive import architectures as A
+    torch.manual_seed(5)
+    flow = Flow(A.CouplingRQNSF(64, n_layers=3))
+    flow.train()
+    x = torch.randn(1500, 64) * 1.3
+    with torch.no_grad():
+        flow.log_prob(x)
+    ref = copy.deepcopy(flow).double()
+    dev = copy.deepcopy(flow).cuda()
+    names = [n for n, p in flow.named_parameters() if p.requires_grad and p.numel()]
+
+    def grads(f, xx):
+        xx = xx.clone().requires_grad_(True)
+        return torch.autograd.grad(f.log_prob(xx).sum(), [xx] + [p for n, p in f.named_parameters() if n in names])
+    want = grads(ref, x.double())
+    monkeypatch.setenv("TORCHFLOWS_AMD_ROWS_OUTER", "1")
+    before = native.calls
+    got = grads(dev, x.cuda())
+    n_new = native.calls - before
+    monkeypatch.setenv("TORCHFLOWS_AMD_ROWS_OUTER", "0")
+    before = native.calls
+    old = grads(dev, x.cuda())
+    n_old = native.calls - before
+    assert n_new == n_old + 3 * 3                          # three more libtfk launches per spline layer, no GEMMs
+    for name, g, w, o in zip(["x"] + names, got, want, old):
+        scale = max(1.0, float(w.abs().max()))
+        assert float((g.double().cpu() - w).abs().max()) < 5e-3 * scale, name
+        assert float((g - o).abs().max()) < 2e-4 * scale, name

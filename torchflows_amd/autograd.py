@@ -333,6 +333,26 @@ class _RqsTrainPack:
         u = ar(H)
         self.gpre_col = (4 * (u % 4) + u // 4).to(device)                                   # (H,)
         self.zero = torch.zeros(1, dtype=torch.float32, device=device)
+        # tfk_rows_outer route (hidden width <= 15): three products in accumulator order, one buffer
+        #   [gh_perm^T hid_perm (768 x 16) | x_A^T gpre_perm (32 x 16) | gpre_perm^T hid_perm (16 x 16)]
+        # and ONE gather to [dW1 (H, 32) | db1 (H) | dW2 (736, H) | db2 (736)]
+        self.n_acc = 768 * 16 + 32 * 16 + 16 * 16
+        if H <= 15:
+            slot = 4 * (u % 4) + u // 4                                   # column of hid_perm / gpre_perm that holds unit u
+            c = ((6 * e_ + pp // 4) * 16 + 4 * q_ + pp % 4).reshape(-1)  # gh_perm column of (target m, parameter p)
+            t1 = 4 * (c // 64) + (c % 64) % 4                             # its tile and M-index (include/tfk.h)
+            i1 = (c % 64) // 4
+            idx1 = lambda j: ((t1 * 64 + 16 * (i1 // 4))[:, None] + j[None, :]) * 4 + (i1 % 4)[:, None]
+            dW2 = idx1(slot)                                              # (736, H)
+            db2 = idx1(torch.tensor([15]))[:, 0]
+            e = ar(half)
+            base2 = 768 * 16
+            dW1 = base2 + (((e // 16) * 64 + 16 * ((e % 16) // 4))[None, :] + slot[:, None]) * 4 + ((e % 16) % 4)[None, :]
+            base3 = base2 + 32 * 16
+            db1 = base3 + (16 * (slot // 4) + 15) * 4 + slot % 4
+            self.acc_index = torch.cat([dW1.reshape(-1), db1, dW2.reshape(-1), db2]).to(device)
+            self.acc_sizes = (H * half, H, half * P * H, half * P)
+            self.acc_shapes = ((H, half), (H,), (half * P, H), (half * P,))
 
     def pack(self, lin1, lin2) -> torch.Tensor:
         flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
@@ -360,6 +380,12 @@ def flat_enabled() -> bool:
     """Operands gathered from / gradients returned as slices of ONE buffer when the parameters live in one
     (torchflows_amd/flat_optim.py; TORCHFLOWS_AMD_FLAT=0: always the per-tensor route)."""
     return os.environ.get("TORCHFLOWS_AMD_FLAT", "1") != "0"
+
+
+def rows_outer_enabled() -> bool:
+    """The weight-gradient products of the fused spline training step on tfk_rows_outer (TORCHFLOWS_AMD_ROWS_OUTER=0:
+    split-K batched GEMMs on the GEMM library, as before round 3)."""
+    return os.environ.get("TORCHFLOWS_AMD_ROWS_OUTER", "1") != "0"
 
 
 def fused_train_enabled() -> bool:
@@ -1035,6 +1061,8 @@ class ChainFunction(torch.autograd.Function):
                     rp = _RqsTrainPack.get(lin1.out_features, g.device)
                     gh_perm = torch.empty(N, 768, dtype=torch.float32, device=g.device)
                     gpre_perm = torch.empty(N, 16, dtype=torch.float32, device=g.device)
+                    outer = rows_outer_enabled() and lin1.out_features <= 15
+                    hid_perm = torch.empty(N, 16, dtype=torch.float32, device=g.device) if outer else None
                     ew_step, rev_step = packs.rqs_fold.get(i, (None, None))
                     gscale = None
                     if ew_step is not None:
@@ -1045,7 +1073,21 @@ class ChainFunction(torch.autograd.Function):
                     native.rqs_coupling_train_bwd(x_in, g, gld, ctx.rqs_blocks[i], rp.steps2, gh_perm, gpre_perm,
                                                   layer.transformer.n_bins, layer.transformer.boundary,
                                                   inverse=(d == INVERSE), gscale=gscale,
-                                                  g_reversed=rev_step is not None)
+                                                  g_reversed=rev_step is not None, hid_perm=hid_perm)
+                    if outer:
+                        # the three products that contract over the batch rows, on the matrix cores without a GEMM-library
+                        # call (tfk_rows_outer: deterministic, capturable), un-permuted by ONE gather
+                        acc = torch.empty(rp.n_acc, dtype=torch.float32, device=g.device)
+                        native.rows_outer(gh_perm, 768, hid_perm, acc[:768 * 16])
+                        native.rows_outer(x_in, 32, gpre_perm, acc[768 * 16:768 * 16 + 32 * 16])
+                        native.rows_outer(gpre_perm, 16, hid_perm, acc[768 * 16 + 32 * 16:])
+                        dW1, db1, dW2, db2 = (t.view(shp) for t, shp in
+                                              zip(acc.index_select(0, rp.acc_index).split(rp.acc_sizes), rp.acc_shapes))
+                        by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
+                        grads_per_step[i] = [
+                            (by_param[id(p)] if id(p) in by_param else torch.zeros_like(p)) if p.requires_grad else None
+                            for p in cparams]
+                        continue
                     x_a = x_in[:, :S]
                     a1 = torch.tanh(torch.addmm(lin1.bias, x_a, lin1.weight.t()))
                     ones = torch.ones(N, 1, dtype=torch.float32, device=g.device)

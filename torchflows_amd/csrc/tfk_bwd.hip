@@ -1015,7 +1015,7 @@ template <bool INVERSE>
 __global__ __launch_bounds__(512) void k_rqs_coupling_train_bwd(
     const float *__restrict__ x, float *g, const float *__restrict__ gld, const float *__restrict__ params,
     int n_params, int steps2, float *__restrict__ gh_perm, float *__restrict__ gpre_perm, long long N,
-    RqsConst C, const float *__restrict__ gscale, int g_reversed)
+    RqsConst C, const float *__restrict__ gscale, int g_reversed, float *__restrict__ hid_perm)
 {
     constexpr int EPL = 8, D = 64, HALF = 32, T2 = 48, T1 = 2, BLOCK = 512;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1151,6 +1151,10 @@ __global__ __launch_bounds__(512) void k_rqs_coupling_train_bwd(
         for (int r = 0; r < 4; ++r) gpre[r] = gha[r] * (1.0f - hid[r] * hid[r]);
         if (valid)
             *reinterpret_cast<float4 *>(gpre_perm + row * 16 + 4 * q) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
+        // the hidden activations in the same order, slot 15 (unit 15: hidden width <= 15) == 1 for the bias column of the
+        // weight-gradient products that contract over the rows (tfk_rows_outer)
+        if (valid && hid_perm)
+            *reinterpret_cast<float4 *>(hid_perm + row * 16 + 4 * q) = make_float4(hid[0], hid[1], hid[2], q == 3 ? 1.0f : hid[3]);
 
         // 4. dL/dx_A
 #pragma unroll
@@ -1178,12 +1182,11 @@ extern "C" {
 
 int tfk_rqs_coupling_train_bwd_supported(int32_t D, int32_t n_bins) { return (D == 64 && n_bins == 8) ? 1 : 0; }
 
-int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
-                               int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
-                               int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
-                               const float *gscale, int32_t g_reversed, void *stream)
+static int rqs_train_bwd_impl(const float *x, float *g, const float *gld, const float *params,
+                              int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm, float *hid_perm,
+                              int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
+                              const float *gscale, int32_t g_reversed, void *stream, const char *fn)
 {
-    const char *fn = "tfk_rqs_coupling_train_bwd";
     if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
     if (!tfk_rqs_coupling_train_bwd_supported(D, n_bins))
         return fail(TFK_EINVAL, "%s: D = %d, n_bins = %d (the kernel exists for D = 64, 8 bins)", fn, D, n_bins);
@@ -1218,10 +1221,135 @@ int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (inverse)
         hipLaunchKernelGGL((k_rqs_coupling_train_bwd<true>), dim3((int)grid), dim3(512), lds, s, x, g, gld, params,
-                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0);
+                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0, hid_perm);
     else
         hipLaunchKernelGGL((k_rqs_coupling_train_bwd<false>), dim3((int)grid), dim3(512), lds, s, x, g, gld, params,
-                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0);
+                           (int)n_params, gemm2_steps, gh_perm, gpre_perm, (long long)N, C, gscale, g_reversed ? 1 : 0, hid_perm);
+    return check_launch(fn);
+}
+
+int tfk_rqs_coupling_train_bwd(const float *x, float *g, const float *gld, const float *params,
+                               int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
+                               int64_t N, int32_t D, int32_t n_bins, float boundary, int32_t inverse,
+                               const float *gscale, int32_t g_reversed, void *stream)
+{
+    return rqs_train_bwd_impl(x, g, gld, params, n_params, gemm2_steps, gh_perm, gpre_perm, nullptr, N, D, n_bins,
+                              boundary, inverse, gscale, g_reversed, stream, "tfk_rqs_coupling_train_bwd");
+}
+
+int tfk_rqs_coupling_train_bwd_hid(const float *x, float *g, const float *gld, const float *params,
+                                   int64_t n_params, int32_t gemm2_steps, float *gh_perm, float *gpre_perm,
+                                   float *hid_perm, int64_t N, int32_t D, int32_t n_bins, float boundary,
+                                   int32_t inverse, const float *gscale, int32_t g_reversed, void *stream)
+{
+    const char *fn = "tfk_rqs_coupling_train_bwd_hid";
+    if (!hid_perm || !aligned16(hid_perm)) return fail(TFK_EINVAL, "%s: hid_perm must be a 16-byte aligned (N, 16) buffer", fn);
+    return rqs_train_bwd_impl(x, g, gld, params, n_params, gemm2_steps, gh_perm, gpre_perm, hid_perm, N, D, n_bins,
+                              boundary, inverse, gscale, g_reversed, stream, fn);
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// out[m][k] = sum_n A[n][m] * B[n][k]  (m < M, k < 16): the weight-gradient products of a training step that contract
+// over the batch ROWS -- dW2 = dL/dh^T hidden (M = 768), dW1^T = x_A^T dL/dpre (M = 32), db1 (M = 16) -- without a
+// GEMM-library call (those invalidate a hipGraph capture on this stack, and run a 768 x 17 output as ONE tile).
+// v_mfma_f32_16x16x4_f32 contracts over k = 4 consecutive rows: lane (q, i) supplies A[row 4 s + q][column of tile t,
+// M-index i] and B[row 4 s + q][i] -- both straight out of the row-major buffers, no transposes.  A lane reads its four
+// A-values of four tiles as ONE float4 (columns 64 T + 4 i + (t & 3) of tile t = 4 T + (t & 3)), so a quarter-wave reads
+// 256 contiguous bytes of a row.  Rows are strided over the waves of the grid; a workgroup adds its four waves' tiles in
+// the LDS and writes ONE partial block; k_colsum2d adds the blocks in a fixed order (deterministic).
+//   blockIdx.y = chunk of 256 columns (MT = 16 tiles) of A, or the single chunk of MT = 1 / 2 tiles (M = 16 / 32).
+//   Output order (floats): tile t, lane (q, j), register r  ->  [(t * 64 + 16 q + j) * 4 + r] = out[col(t, 4 q + r)][j],
+//   col(t, i) = 64 (t >> 2) + 4 i + (t & 3) for MT >= 4, 16 t + i otherwise.
+// =============================================================================================
+template <int MT>
+__global__ __launch_bounds__(256) void k_rows_outer(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                    float *__restrict__ part, long long N, int M_total)
+{
+    __shared__ __attribute__((aligned(16))) float red[3 * MT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    const int chunk = blockIdx.y;                      // 16 MT columns each
+    const float *Ac = A + chunk * 16 * MT;
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+    const long long n_steps = (N + 3) >> 2;
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long s = (long long)blockIdx.x * 4 + wave; s < n_steps; s += stride) {
+        const long long row = 4 * s + q;
+        const bool ok = row < N;
+        const long long rr = ok ? row : N - 1;
+        const float b = ok ? B[rr * 16 + i] : 0.0f;
+        if constexpr (MT >= 4) {
+#pragma unroll
+            for (int T = 0; T < MT / 4; ++T) {
+                const float4 a = *reinterpret_cast<const float4 *>(Ac + rr * lda + 64 * T + 4 * i);
+                acc[4 * T + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, acc[4 * T + 0], 0, 0, 0);
+                acc[4 * T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, acc[4 * T + 1], 0, 0, 0);
+                acc[4 * T + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, acc[4 * T + 2], 0, 0, 0);
+                acc[4 * T + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, acc[4 * T + 3], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[rr * lda + 16 * t + i], b, acc[t], 0, 0, 0);
+        }
+    }
+    // waves 1..3 -> LDS, wave 0 adds them in a fixed order and writes the workgroup's partial block
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            *reinterpret_cast<f32x4_t *>(red + (((wave - 1) * MT + t) * 64 + lane) * 4) = acc[t];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = part + ((long long)blockIdx.x * (M_total / 16) + chunk * MT) * 256;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f32x4_t v = acc[t];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4_t o = *reinterpret_cast<const f32x4_t *>(red + ((w * MT + t) * 64 + lane) * 4);
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            *reinterpret_cast<f32x4_t *>(dst + (t * 64 + lane) * 4) = v;
+        }
+    }
+}
+
+extern "C" {
+
+int64_t tfk_rows_outer_workspace_bytes(int32_t M)
+{
+    return (int64_t)cu_count() * 2 * (int64_t)M * 16 * (int64_t)sizeof(float);
+}
+
+int tfk_rows_outer(const float *A, int32_t lda, int32_t M, const float *B, float *out, float *workspace,
+                   int64_t N, void *stream)
+{
+    const char *fn = "tfk_rows_outer";
+    if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
+    if (!(M == 16 || M == 32 || (M >= 256 && M % 256 == 0)) || M > 1024)
+        return fail(TFK_EINVAL, "%s: M = %d must be 16, 32 or a multiple of 256 up to 1024", fn, M);
+    if (lda < M || (lda & 3)) return fail(TFK_EINVAL, "%s: lda = %d must be a multiple of 4 and >= M = %d", fn, lda, M);
+    if (!A || !B || !out || !workspace) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(A) || !aligned16(B) || !aligned16(out) || !aligned16(workspace))
+        return fail(TFK_EINVAL, "%s: buffers must be 16-byte aligned", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t steps = (N + 3) / 4;
+    int64_t grid = (steps + 3) / 4;
+    const int64_t cap = (int64_t)cu_count() * 2;              // (tfk_rows_outer_workspace_bytes)
+    if (grid > cap) grid = cap;
+    if (M == 16)
+        hipLaunchKernelGGL((k_rows_outer<1>), dim3((int)grid, 1), dim3(256), 0, s, A, lda, B, workspace, (long long)N, M);
+    else if (M == 32)
+        hipLaunchKernelGGL((k_rows_outer<2>), dim3((int)grid, 1), dim3(256), 0, s, A, lda, B, workspace, (long long)N, M);
+    else
+        hipLaunchKernelGGL((k_rows_outer<16>), dim3((int)grid, M / 256), dim3(256), 0, s, A, lda, B, workspace, (long long)N, M);
+    if (int rc = check_launch(fn)) return rc;
+    hipLaunchKernelGGL(k_colsum2d, dim3((M * 16 + 63) / 64), dim3(1024), 0, s, workspace, out, (int)grid, M * 16);
     return check_launch(fn);
 }
 

@@ -41,14 +41,15 @@ SYMBOLS = (
     "tfk_diag_gauss_logprob_bwd",
     "tfk_coupling_train_bwd_supported", "tfk_coupling_train_bwd_out_floats",
     "tfk_coupling_train_bwd_workspace_bytes", "tfk_affine_coupling_train_bwd",
-    "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd",
+    "tfk_rqs_coupling_train_bwd_supported", "tfk_rqs_coupling_train_bwd", "tfk_rqs_coupling_train_bwd_hid",
+    "tfk_rows_outer_workspace_bytes", "tfk_rows_outer",
     "tfk_made_affine_sequential", "tfk_made_rqs_sequential_lds_bytes", "tfk_made_rqs_sequential",
     "tfk_made_lrs_sequential_lds_bytes", "tfk_made_lrs_sequential",
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
 )
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 class NativeError(RuntimeError):
@@ -139,6 +140,11 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_rqs_coupling_train_bwd_supported.argtypes = [_i32, _i32]
     L.tfk_rqs_coupling_train_bwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                              C.c_float, _i32, _vp, _i32, _vp]
+    L.tfk_rqs_coupling_train_bwd_hid.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _i32,
+                                                 C.c_float, _i32, _vp, _i32, _vp]
+    L.tfk_rows_outer_workspace_bytes.argtypes = [_i32]
+    L.tfk_rows_outer_workspace_bytes.restype = _i64
+    L.tfk_rows_outer.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp]
     L.tfk_made_affine_sequential.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
     L.tfk_made_rqs_sequential_lds_bytes.argtypes = [_i32, _i32, _i32]
     L.tfk_made_rqs_sequential_lds_bytes.restype = _i64
@@ -531,21 +537,50 @@ def affine_coupling_train_bwd(x, g, gld, params, gemm2_steps, out, workspace, in
 
 
 def rqs_coupling_train_bwd(x, g, gld, params, gemm2_steps, gh_perm, gpre_perm, n_bins, boundary,
-                           inverse=False, gscale=None, g_reversed=False):
+                           inverse=False, gscale=None, g_reversed=False, hid_perm=None):
     """Conditioner re-evaluation + RQ-spline backward + dL/dhidden + dL/dx_A in one launch (in place on
-    g); gh_perm (N, 768) and gpre_perm (N, 16) in accumulator order."""
+    g); gh_perm (N, 768) and gpre_perm (N, 16) in accumulator order; ``hid_perm`` (N, 16): also the hidden activations,
+    column 15 == 1 (tfk_rqs_coupling_train_bwd_hid)."""
     global calls
-    name = "tfk_rqs_coupling_train_bwd"
+    name = "tfk_rqs_coupling_train_bwd" if hid_perm is None else "tfk_rqs_coupling_train_bwd_hid"
     N, D = _rows(g, name)
     if x.shape != g.shape or gld.numel() != N or gh_perm.shape != (N, 768) or gpre_perm.shape != (N, 16):
         raise NativeError(f"{name}: bad x / gld / gh_perm / gpre_perm shape")
+    if hid_perm is not None and hid_perm.shape != (N, 16):
+        raise NativeError(f"{name}: hid_perm must be (N, 16)")
     if gscale is not None and gscale.numel() != D:
         raise NativeError(f"{name}: gscale must hold D = {D} floats")
-    args = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
-            int(gemm2_steps), _f32(gh_perm, name), _f32(gpre_perm, name), N, D, int(n_bins),
-            C.c_float(float(boundary)), 1 if inverse else 0, _f32(gscale, name), 1 if g_reversed else 0)
+    head = (_f32(x, name), _f32(g, name), _f32(gld, name), _f32(params, name), params.numel(),
+            int(gemm2_steps), _f32(gh_perm, name), _f32(gpre_perm, name))
+    tail = (N, D, int(n_bins), C.c_float(float(boundary)), 1 if inverse else 0, _f32(gscale, name), 1 if g_reversed else 0)
     with _device_guard(g):
-        rc = lib().tfk_rqs_coupling_train_bwd(*args, _stream(g))
+        if hid_perm is None:
+            rc = lib().tfk_rqs_coupling_train_bwd(*head, *tail, _stream(g))
+        else:
+            rc = lib().tfk_rqs_coupling_train_bwd_hid(*head, _f32(hid_perm, name), *tail, _stream(g))
+    calls += 1
+    _check(rc, name)
+
+
+_rows_outer_ws = {}
+
+
+def rows_outer(A, M, B, out):
+    """out[M * 16] (accumulator order, include/tfk.h) = sum over the rows of A[n, :M]^T B[n, :16] (tfk_rows_outer):
+    the weight-gradient products that contract over the batch rows, deterministic, no GEMM-library call."""
+    global calls
+    name = "tfk_rows_outer"
+    N, lda = _rows(A, name)
+    if B.shape != (N, 16) or out.numel() != M * 16 or not out.is_contiguous():
+        raise NativeError(f"{name}: B must be (N, 16) and out hold M * 16 = {M * 16} contiguous floats")
+    key = (A.device.index, int(M), _stream(A))
+    ws = _rows_outer_ws.get(key)
+    if ws is None:
+        ws = _rows_outer_ws[key] = torch.empty(int(lib().tfk_rows_outer_workspace_bytes(int(M))) // 4,
+                                               dtype=torch.float32, device=A.device)
+    with _device_guard(A):
+        rc = lib().tfk_rows_outer(_f32(A, name), int(lda), int(M), _f32(B, name), _f32(out, name), _f32(ws, name), N,
+                                  _stream(A))
     calls += 1
     _check(rc, name)
 
