@@ -711,9 +711,16 @@ def fully_fused(plan, D: int) -> bool:
     backward): the step then consists of libtfk kernels and elementwise ATen ops only -- no GEMM
     library calls -- which is the configuration verified to survive hipGraph capture."""
     couplings = [layer for layer, _, kind in plan if kind == "coupling"]
-    if not native.lib().tfk_coupling_train_bwd_supported(plan_width(plan, D)):
-        return False                          # (an event size that would need padding in a plan that cannot keep it)
-    return bool(couplings) and all(_fused_bwd_layer(layer, D) is not None for layer in couplings)
+    if not couplings or any(kind not in ("coupling", "perm", "elementwise") for _, _, kind in plan):
+        return False
+    if all(_fused_bwd_layer(layer, D) is not None for layer in couplings):
+        # (an event size that would need padding in a plan that cannot keep it has no fused launches after all)
+        return bool(native.lib().tfk_coupling_train_bwd_supported(plan_width(plan, D)))
+    # RQ-spline couplings: the fused launch + the row-contracting products on tfk_rows_outer (hidden width <= 15)
+    def spline_ok(layer):
+        mlp = _fused_rqs_layer(layer, D)
+        return mlp is not None and rows_outer_enabled() and mlp[0].out_features <= 15
+    return all(spline_ok(layer) for layer in couplings)
 
 
 SPLIT_K_ROWS = 1024
