@@ -259,11 +259,10 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     calls = native.calls
     dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     assert native.calls > calls
-    # (RealNVP: every coupling runs as the fused launches -- D = 8 on rows padded to 64 -- so 40 full-size steps are enough
-    # for TORCHFLOWS_AMD_GRAPH's default "auto" to capture the step after two eager ones; so does the 64-wide spline flow
-    # -- fused spline backward + tfk_rows_outer, no GEMM-library call --; the 8-wide spline flow stays eager)
-    want = ({"eager_steps": 2, "graph_replays": 38, "graph_captures": 1} if (arch == "RealNVP" or D == 64)
-            else {"eager_steps": 40, "graph_replays": 0, "graph_captures": 0})
+    # (every coupling of these flows runs as the fused launches -- D = 8 on rows padded to 64, the splines with
+    # tfk_rows_outer instead of GEMM-library calls -- so 40 full-size steps are enough for TORCHFLOWS_AMD_GRAPH's default
+    # "auto" to capture the step after two eager ones)
+    want = {"eager_steps": 2, "graph_replays": 38, "graph_captures": 1}
     assert dev._fit_stats == want
     with torch.no_grad():
         after_h = float(host.log_prob(x).mean())
@@ -502,7 +501,8 @@ def test_fit_drops_the_captured_step_when_a_parameter_moves(native):
 
 
 @pytest.mark.parametrize("arch,D", [("RealNVP", 4), ("RealNVP", 6), ("RealNVP", 10), ("RealNVP", 22), ("RealNVP", 32),
-                                    ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("NICE", 64)])
+                                    ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("NICE", 64),
+                                    ("CouplingRQNSF", 6), ("CouplingRQNSF", 22), ("CouplingRQNSF", 62)])
 def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch, D):
     """Even event sizes that are not 64 / 128 train on rows padded to the next of the two in the padded training layout
     (first half at the head of plane A, second half at the tail of plane B: a logical reversal is the physical one) --
@@ -544,16 +544,19 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
         before = native.calls
         plain = grads(dev, x.cuda(), inverse)
         n_plain = native.calls - before
+        tol = 5e-3 if "RQ" in arch else 2e-4                   # (the spline's fp32 floor against float64, as in the 64-wide tests)
         for name, g, w, p in zip(["x"] + names, got, want, plain):
             scale = max(1.0, float(w.abs().max()))
-            assert float((g.double().cpu() - w).abs().max()) < 2e-4 * scale, (inverse, name)
-            assert float((g - p).abs().max()) < 2e-4 * scale, (inverse, name)
-        if fused:
+            assert float((g.double().cpu() - w).abs().max()) < tol * scale, (inverse, name)
+            assert float((g - p).abs().max()) < tol * scale, (inverse, name)
+        if fused and "RQ" not in arch:
             assert n_pad < n_plain or D in (64, 128), (n_pad, n_plain)   # (64 / 128: no padding either way)
             assert n_pad <= 2 * (3 + 6) + 4, n_pad        # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps
     monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
     plan = ag.training_plan(dev.bijection, 0)
     assert ag.fully_fused(plan, D) and ag.plan_width(plan, D) in (64, 128)
+    if "RQ" in arch:
+        assert ag.plan_width(plan, D) == 64
     if fused:
         data = torch.randn(4096, D, device="cuda") * 0.5 + 0.2
         with torch.no_grad():

@@ -282,29 +282,34 @@ class _RqsTrainPack:
     _cache = {}
 
     @classmethod
-    def get(cls, H: int, device) -> "_RqsTrainPack":
-        key = (H, str(device))
+    def get(cls, H: int, device, D_log: int = 64) -> "_RqsTrainPack":
+        key = (H, str(device), D_log)
         if key not in cls._cache:
-            cls._cache[key] = cls(H, device)
+            cls._cache[key] = cls(H, device, D_log)
         return cls._cache[key]
 
-    def __init__(self, H: int, device):
+    def __init__(self, H: int, device, D_log: int = 64):
+        """``D_log`` < 64: the layer's event size on rows in the padded training layout (its h = D_log / 2 sources at the
+        head of plane A, its h targets at the tail of plane B); a padding element's 23 spline parameters are the appended
+        zero -- equal bins, unit derivatives: the identity at its value 0 (a knot)."""
         half, EPL, P = 32, 8, 23
+        h = D_log // 2
+        pad = half - h
         self.H = H
         self.steps2 = (H + 3) // 4
-        off_b1 = H * half
+        off_b1 = H * h
         off_W2 = off_b1 + H
-        off_b2 = off_W2 + half * P * H
-        Z = off_b2 + half * P
+        off_b2 = off_W2 + h * P * H
+        Z = off_b2 + h * P
         ar = torch.arange
         W1idx = torch.full((16, half), Z, dtype=torch.long)
-        W1idx[:H] = ar(H)[:, None] * half + ar(half)[None, :]
+        W1idx[:H, :h] = ar(H)[:, None] * h + ar(h)[None, :]
         b1idx = torch.full((16,), Z, dtype=torch.long)
         b1idx[:H] = off_b1 + ar(H)
         W2idx = torch.full((half, 24, 16), Z, dtype=torch.long)
-        W2idx[:, :P, :H] = off_W2 + ((ar(half)[:, None, None] * P + ar(P)[None, :, None]) * H + ar(H)[None, None, :])
+        W2idx[pad:, :P, :H] = off_W2 + ((ar(h)[:, None, None] * P + ar(P)[None, :, None]) * H + ar(H)[None, None, :])
         b2idx = torch.full((half, 24), Z, dtype=torch.long)
-        b2idx[:, :P] = off_b2 + ar(half)[:, None] * P + ar(P)[None, :]
+        b2idx[pad:, :P] = off_b2 + ar(h)[:, None] * P + ar(P)[None, :]
         lane = ar(64)
         ql, il = lane >> 4, lane & 15
         unit = 4 * (il & 3) + (il >> 2)
@@ -325,8 +330,8 @@ class _RqsTrainPack:
                                       torch.stack(b2m).reshape(-1), torch.stack(A2T).reshape(-1),
                                       torch.stack(A1T).reshape(-1)]).to(device)
         self.n_fwd = EPL * 64 + 16 + 48 * self.steps2 * 64 + 48 * 16
-        # column of gh_perm that holds parameter p of target element m
-        m = ar(half)[:, None]
+        # column of gh_perm that holds parameter p of (physical) target element m = pad + logical target
+        m = (pad + ar(h))[:, None]
         pp = ar(P)[None, :]
         e_, q_ = m % EPL, m // EPL
         self.gh_col = ((6 * e_ + pp // 4) * 16 + 4 * q_ + pp % 4).reshape(-1).to(device)     # (736,)
@@ -345,14 +350,14 @@ class _RqsTrainPack:
             idx1 = lambda j: ((t1 * 64 + 16 * (i1 // 4))[:, None] + j[None, :]) * 4 + (i1 % 4)[:, None]
             dW2 = idx1(slot)                                              # (736, H)
             db2 = idx1(torch.tensor([15]))[:, 0]
-            e = ar(half)
+            e = ar(h)
             base2 = 768 * 16
             dW1 = base2 + (((e // 16) * 64 + 16 * ((e % 16) // 4))[None, :] + slot[:, None]) * 4 + ((e % 16) % 4)[None, :]
             base3 = base2 + 32 * 16
             db1 = base3 + (16 * (slot // 4) + 15) * 4 + slot % 4
             self.acc_index = torch.cat([dW1.reshape(-1), db1, dW2.reshape(-1), db2]).to(device)
-            self.acc_sizes = (H * half, H, half * P * H, half * P)
-            self.acc_shapes = ((H, half), (H,), (half * P, H), (half * P,))
+            self.acc_sizes = (H * h, H, h * P * H, h * P)
+            self.acc_shapes = ((H, h), (H,), (h * P, H), (h * P,))
 
     def pack(self, lin1, lin2) -> torch.Tensor:
         flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
@@ -364,8 +369,10 @@ def _fused_rqs_layer(layer, D: int):
     """(lin1, lin2) when the layer can use tfk_rqs_coupling_train_bwd (and the RQS flow-program op)."""
     if not fused_train_enabled() or layer.transformer.native_kind != "rqs":
         return None
-    if not native.lib().tfk_rqs_coupling_train_bwd_supported(D, int(layer.transformer.n_bins)):
-        return None
+    lib, K = native.lib(), int(layer.transformer.n_bins)
+    if not (lib.tfk_rqs_coupling_train_bwd_supported(D, K)
+            or (padded_train_enabled() and D % 2 == 0 and 4 <= D < 64 and lib.tfk_rqs_coupling_train_bwd_supported(64, K))):
+        return None                           # (D < 64: on rows padded to 64 -- whether the plan may be is plan_width's call)
     c = layer.coupling
     if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
             and c.target_event_size == D // 2):
@@ -419,6 +426,8 @@ def _padding_capable(plan) -> bool:
             continue
         if kind == "coupling" and _fused_bwd_layer(layer, D) is not None:
             continue
+        if kind == "coupling" and D < 64 and _fused_rqs_layer(layer, D) is not None:
+            continue                          # (the fused spline launches exist at 64 columns only)
         return False
     return True
 
@@ -543,7 +552,7 @@ class _PlanPacks:
         # RQ-spline couplings with the in-kernel conditioner: the same ride-along pattern
         self.rqs_fold = {}
         for i, (layer, d, kind) in enumerate(plan):
-            if kind != "coupling" or _fused_rqs_layer(layer, D) is None:
+            if kind != "coupling" or self.rqs_layer(layer) is None:
                 continue
             ew_step = rev_step = None
             j = i + 1
@@ -661,6 +670,12 @@ class _PlanPacks:
             vec = maps["l2"][key] = v.to(fb.P.device)
         return vec
 
+    def rqs_layer(self, layer):
+        """(lin1, lin2) when this coupling runs as the fused spline launches at this plan's row width."""
+        if not native.lib().tfk_rqs_coupling_train_bwd_supported(self.W, int(getattr(layer.transformer, "n_bins", 0) or 0)):
+            return None
+        return _fused_rqs_layer(layer, self.D)
+
     # ---- rows in the padded training layout (self.W > self.D) -----------------------------------------------------
     def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """(N, D) -> (N, W): first half at the head of plane A, second half at the tail of plane B, zeros between."""
@@ -720,7 +735,7 @@ def fully_fused(plan, D: int) -> bool:
     def spline_ok(layer):
         mlp = _fused_rqs_layer(layer, D)
         return mlp is not None and rows_outer_enabled() and mlp[0].out_features <= 15
-    return all(spline_ok(layer) for layer in couplings)
+    return plan_width(plan, D) == 64 and all(spline_ok(layer) for layer in couplings)
 
 
 SPLIT_K_ROWS = 1024
@@ -876,11 +891,11 @@ class ChainFunction(torch.autograd.Function):
                 started = True
                 saved.append(cur)
                 cur, cur_is_saved = out, False
-            elif kind == "coupling" and _fused_rqs_layer(layer, D) is not None:
+            elif kind == "coupling" and packs.rqs_layer(layer) is not None:
                 # conditioner + spline in one launch (single-op flow program); the operand block is
                 # kept for the backward kernel
-                lin1, lin2 = _fused_rqs_layer(layer, D)
-                rp = _RqsTrainPack.get(lin1.out_features, cur.device)
+                lin1, lin2 = packs.rqs_layer(layer)
+                rp = _RqsTrainPack.get(lin1.out_features, cur.device, D)
                 block = rp.pack(lin1, lin2)
                 tr = layer.transformer
                 import math
@@ -891,7 +906,7 @@ class ChainFunction(torch.autograd.Function):
                 if ew_step is not None:      # the fixed elementwise layer that follows rides along
                     ew_layer, ew_d, _ = plan[ew_step]
                     ops.append((1 if _affine_form_is_inverse(ew_layer, ew_d) else 0, 0, 0, rp.n_fwd))
-                    prm = torch.cat([prm, _ew_block(ew_layer, ew_d, D)])
+                    prm = torch.cat([prm, _ew_block(ew_layer, ew_d, D, W)])
                 out = torch.empty_like(cur)
                 native.flow_run_mfma(cur, out, logdet, None, None, None, ops, prm, accumulate=started,
                                      reverse_out=rev_step is not None)
@@ -1064,8 +1079,8 @@ class ChainFunction(torch.autograd.Function):
                                                      gscale=gscale, g_reversed=rev_step is not None)
                     continue
                 if i in ctx.rqs_blocks:     # conditioner re-evaluated in the kernel, dL/dh written once
-                    lin1, lin2 = _fused_rqs_layer(layer, D)
-                    rp = _RqsTrainPack.get(lin1.out_features, g.device)
+                    lin1, lin2 = packs.rqs_layer(layer)
+                    rp = _RqsTrainPack.get(lin1.out_features, g.device, D)
                     gh_perm = torch.empty(N, 768, dtype=torch.float32, device=g.device)
                     gpre_perm = torch.empty(N, 16, dtype=torch.float32, device=g.device)
                     outer = rows_outer_enabled() and lin1.out_features <= 15
@@ -1074,9 +1089,9 @@ class ChainFunction(torch.autograd.Function):
                     gscale = None
                     if ew_step is not None:
                         ew_layer, ew_d, _ = plan[ew_step]
-                        blk = _ew_block(ew_layer, ew_d, D)
-                        lo = (2 * D + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0
-                        gscale = blk[lo:lo + D]
+                        blk = _ew_block(ew_layer, ew_d, D, W)
+                        lo = (2 * W + 4) if _affine_form_is_inverse(ew_layer, ew_d) else 0
+                        gscale = blk[lo:lo + W]
                     native.rqs_coupling_train_bwd(x_in, g, gld, ctx.rqs_blocks[i], rp.steps2, gh_perm, gpre_perm,
                                                   layer.transformer.n_bins, layer.transformer.boundary,
                                                   inverse=(d == INVERSE), gscale=gscale,
