@@ -626,3 +626,22 @@ def test_spline_training_step_without_gemm_library_calls(native, monkeypatch):
         scale = max(1.0, float(w.abs().max()))
         assert float((g.double().cpu() - w).abs().max()) < 5e-3 * scale, name
         assert float((g - o).abs().max()) < 2e-4 * scale, name
+
+
+def test_sharded_fit_two_ranks_on_one_card(native):
+    """Data-parallel sharded_fit with FlatAdamW: the backward pass leaves the gradients as ONE buffer, which IS the
+    exchange buffer of the step's single all-reduce (loss in its tail padding) and the optimiser's input -- no
+    concatenation, no copy back.  Two replicas on this box's one card over gloo; bit-identical replicas, the one-process
+    trajectory."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_fit_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", script],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "DIST_FIT_GPU_OK" in out.stdout

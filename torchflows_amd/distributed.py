@@ -178,6 +178,7 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
     # flat gradient buffer alive until the end of training)
     losses = torch.empty(n_epochs * steps_per_epoch, dtype=params[0].dtype, device=dev)
     n_steps = 0
+    stats = flow._fit_stats = {"exchanged_in_place": 0, "exchanged_after_a_copy": 0}     # (steps, by how the buffer came about)
     ctx = _GlobalActNormInit(flow, group) if distributed else None
     if ctx is not None:
         ctx.__enter__()
@@ -190,24 +191,56 @@ def sharded_fit(flow, x_local: torch.Tensor, n_epochs: int = 500, lr: float = 0.
                 idx = slice(lo, lo + local_bs) if order is None else order[lo:lo + local_bs]
                 xb, wb = x_local[idx], w_local[idx]
                 opt.zero_grad(set_to_none=True)
-                loss = flow.regularization() / world
-                if xb.shape[0] > 0:
-                    lp = flow.log_prob(xb)
+                # (on the HIP path the L2 penalty is evaluated inside the chain's autograd node when the parameters live in
+                # one buffer -- Flow._base_batch_loss does the same --, so that the gradients leave as slices of ONE buffer)
+                b = flow.bijection
+                folded = (xb.shape[0] > 0 and dev.type == "cuda" and hasattr(b, "_request_l2") and b._request_l2())
+                lp = flow.log_prob(xb) if xb.shape[0] > 0 else None
+                reg = None
+                if folded:
+                    b.__dict__.pop("_tfk_l2_request", None)
+                    reg = b.__dict__.pop("_tfk_l2_out", None)
+                loss = (reg if reg is not None else flow.regularization()) / world
+                if lp is not None:
                     loss = loss - (lp * wb).sum() / (float(count) * flow.event_size)
                 if isinstance(loss, torch.Tensor) and loss.requires_grad:
                     loss.backward()
                 loss_t = loss.detach().reshape(1).to(dev) if isinstance(loss, torch.Tensor) \
                     else torch.tensor([float(loss)], device=dev)
-                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                  for p in params] + [loss_t.to(params[0].dtype)])
-                if distributed:
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)     # THE exchange step (the only one)
-                lo_f = 0
-                for p in params:
-                    n = p.numel()
-                    p.grad = flat[lo_f:lo_f + n].view_as(p)
-                    lo_f += n
-                losses[n_steps].copy_(flat[-1])
+                fb = getattr(opt, "flat", None)
+                if (fb is not None and fb.intact() and len(params) == len(fb.params)
+                        and all(p is q for p, q in zip(params, fb.params))):
+                    # FlatAdamW: the exchange buffer IS the optimiser's gradient buffer (flat_optim.py): filled by the
+                    # backward pass itself when the whole step ran on the fused launches (no copy at all), else from the
+                    # per-tensor gradients; the loss rides in its tail padding.  Every rank takes this branch together.
+                    G = fb.grads_are_flat()
+                    stats["exchanged_in_place" if G is not None else "exchanged_after_a_copy"] += 1
+                    if G is None:
+                        G = torch.zeros(fb.n, dtype=params[0].dtype, device=dev)
+                        for p, o, n in zip(fb.params, fb.offset, fb.numel):
+                            if p.grad is not None and n:
+                                G[o:o + n].copy_(p.grad.reshape(-1))
+                        for p, o, n in zip(fb.params, fb.offset, fb.numel):
+                            p.grad = G[o:o + n].view(p.shape)
+                        fb.last_grad = G
+                    slot = fb.zero_slot + 1
+                    G[slot:slot + 1].copy_(loss_t.to(G.dtype))
+                    if distributed:
+                        dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)    # THE exchange step (the only one)
+                    losses[n_steps].copy_(G[slot])
+                    G[slot:slot + 1].zero_()                  # (the buffer's tail stays zero: the optimiser updates all of it)
+                else:
+                    stats["exchanged_after_a_copy"] += 1
+                    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                      for p in params] + [loss_t.to(params[0].dtype)])
+                    if distributed:
+                        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)     # THE exchange step (the only one)
+                    lo_f = 0
+                    for p in params:
+                        n = p.numel()
+                        p.grad = flat[lo_f:lo_f + n].view_as(p)
+                        lo_f += n
+                    losses[n_steps].copy_(flat[-1])
                 n_steps += 1
                 opt.step()
     finally:
