@@ -80,7 +80,10 @@ class KernelTimer:
                             # fused training backward: x read, g read + written, gld
                             ("affine_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + 4 * a[1].shape[0]),
                             # RQS training backward: x read, g read + written, gld, dL/dh (768) and dL/dpre (16) written
-                            ("rqs_coupling_train_bwd", lambda a, k: a[1].numel() * 12 + a[1].shape[0] * (4 + 4 * 784)),
+                            ("rqs_coupling_train_bwd",
+                             lambda a, k: a[1].numel() * 12 + a[1].shape[0] * (4 + 4 * (784 + (16 if k.get("hid_perm") is not None else 0)))),
+                            # the products that contract over the batch rows: args (A, M, B, out): A's first M columns, B read
+                            ("rows_outer", lambda a, k: 4 * a[0].shape[0] * (a[1] + 16)),
                             # Glow ConvNet conditioner (csrc/tfk_convblock.hip): input read, output written
                             ("conv3x3_relu_pool_affine",
                              lambda a, k: 4 * (a[0].numel() + a[0].shape[0] * a[1].shape[0] * (a[0].shape[2] // 2) * (a[0].shape[3] // 2))),
@@ -158,6 +161,8 @@ class KernelTimer:
                 n_, ci_, hh_, ww_ = a[0].shape
                 variant += f"[{ci_}->{a[1].shape[0]}@{hh_}x{ww_}]"
                 flops = 18 * ci_ * a[1].shape[0] * hh_ * ww_ * n_
+            if name == "rows_outer":
+                variant += f"[{a[1]}x16]"
             if name == "glow_coupling":
                 from torchflows_amd import image_program
                 L = a[2]

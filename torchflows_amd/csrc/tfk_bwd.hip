@@ -1277,21 +1277,43 @@ __global__ __launch_bounds__(256) void k_rows_outer(const float *__restrict__ A,
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
     const long long n_steps = (N + 3) >> 2;
     const long long stride = (long long)gridDim.x * 4;
-    for (long long s = (long long)blockIdx.x * 4 + wave; s < n_steps; s += stride) {
-        const long long row = 4 * s + q;
-        const bool ok = row < N;
-        const long long rr = ok ? row : N - 1;
-        const float b = ok ? B[rr * 16 + i] : 0.0f;
-        if constexpr (MT >= 4) {
+    if constexpr (MT >= 4) {
+        // the next step's operands are in flight while this step's MFMAs issue (a wave's loads would otherwise wait
+        // behind 16 MFMAs of 32 cycles each: 3.7 -> 5.0 TB/s on 2^18 x 768, measured)
+        float4 a[MT / 4], an[MT / 4];
+        float b = 0.0f, bn = 0.0f;
+        auto fetch = [&](long long s, float4 (&dst)[MT / 4], float &bd) {
+            const long long row = 4 * s + q;
+            const bool ok = row < N;
+            const long long rr = ok ? row : N - 1;
+            bd = ok ? B[rr * 16 + i] : 0.0f;
+#pragma unroll
+            for (int T = 0; T < MT / 4; ++T) dst[T] = *reinterpret_cast<const float4 *>(Ac + rr * lda + 64 * T + 4 * i);
+        };
+        long long s = (long long)blockIdx.x * 4 + wave;
+        if (s < n_steps) fetch(s, a, b);
+        for (; s < n_steps; s += stride) {
+            const bool more = s + stride < n_steps;
+            if (more) fetch(s + stride, an, bn);
 #pragma unroll
             for (int T = 0; T < MT / 4; ++T) {
-                const float4 a = *reinterpret_cast<const float4 *>(Ac + rr * lda + 64 * T + 4 * i);
-                acc[4 * T + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, acc[4 * T + 0], 0, 0, 0);
-                acc[4 * T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, acc[4 * T + 1], 0, 0, 0);
-                acc[4 * T + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, acc[4 * T + 2], 0, 0, 0);
-                acc[4 * T + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, acc[4 * T + 3], 0, 0, 0);
+                acc[4 * T + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T].x, b, acc[4 * T + 0], 0, 0, 0);
+                acc[4 * T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T].y, b, acc[4 * T + 1], 0, 0, 0);
+                acc[4 * T + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T].z, b, acc[4 * T + 2], 0, 0, 0);
+                acc[4 * T + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T].w, b, acc[4 * T + 3], 0, 0, 0);
             }
-        } else {
+            if (more) {
+#pragma unroll
+                for (int T = 0; T < MT / 4; ++T) a[T] = an[T];
+                b = bn;
+            }
+        }
+    } else {
+        for (long long s = (long long)blockIdx.x * 4 + wave; s < n_steps; s += stride) {
+            const long long row = 4 * s + q;
+            const bool ok = row < N;
+            const long long rr = ok ? row : N - 1;
+            const float b = ok ? B[rr * 16 + i] : 0.0f;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[rr * lda + 16 * t + i], b, acc[t], 0, 0, 0);
