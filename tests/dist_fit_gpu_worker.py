@@ -32,10 +32,8 @@ def main():
         lo, hi = shard_bounds(x.shape[0], rank, world)
         losses = sharded_fit(flow, x[lo:hi].to(dev), n_epochs=3, lr=0.01, batch_size=256, shuffle=False)
         stats = dict(flow._fit_stats)
-        # affine chains: every step's gradients left the backward pass as ONE buffer and were exchanged in place; the
-        # spline chain's arrive per tensor and are copied into the optimiser's buffer first
-        want = ({"exchanged_in_place": 0, "exchanged_after_a_copy": 12} if "RQ" in arch
-                else {"exchanged_in_place": 12, "exchanged_after_a_copy": 0})
+        # every step's gradients left the backward pass as ONE buffer and were exchanged in place
+        want = {"exchanged_in_place": 12, "exchanged_after_a_copy": 0}
         assert stats == want, (arch, D, stats)
         flat = torch.cat([p.detach().reshape(-1) for p in flow.parameters()])
         other = [torch.zeros_like(flat) for _ in range(world)]

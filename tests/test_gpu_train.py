@@ -383,7 +383,8 @@ def test_context_conditioned_flows_train_on_the_hip_path(native, arch, D, C):
         assert e < tol, (k, e)
 
 
-@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("NICE", 64), ("RealNVP", 128)])
+@pytest.mark.parametrize("arch,D", [("RealNVP", 64), ("NICE", 64), ("RealNVP", 128), ("RealNVP", 10), ("CouplingRQNSF", 64),
+                                    ("CouplingRQNSF", 8)])
 def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeypatch, arch, D):
     """make_adamw on the device homes the parameters in ONE buffer (flat_optim.py); the chain's autograd node then packs
     its operands by one gather, evaluates the L2 penalty itself and returns every gradient as a slice of one buffer,

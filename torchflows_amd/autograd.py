@@ -551,6 +551,7 @@ class _PlanPacks:
             off_out += pack.n_out
         # RQ-spline couplings with the in-kernel conditioner: the same ride-along pattern
         self.rqs_fold = {}
+        self.rqs_layers = []                  # (plan index, lin1, lin2, _RqsTrainPack)
         for i, (layer, d, kind) in enumerate(plan):
             if kind != "coupling" or self.rqs_layer(layer) is None:
                 continue
@@ -563,7 +564,12 @@ class _PlanPacks:
                 rev_step = j
             self.rqs_fold[i] = (ew_step, rev_step)
             self.folded_steps.update(t for t in (ew_step, rev_step) if t is not None)
+            lin1, lin2 = self.rqs_layer(layer)
+            self.rqs_layers.append((i, lin1, lin2, _RqsTrainPack.get(lin1.out_features, device, D)))
+        self.rqs_slot = {i: k for k, (i, _, _, _) in enumerate(self.rqs_layers)}
         self.slot = {i: k for k, (i, _, _, _) in enumerate(self.layers)}
+        if not self.layers:
+            self.n_out_total = 0
         self.plan = list(plan)        # (a plain copy: the call's context must not be kept alive by the cache)
         if self.layers:
             self.block_sizes = [int(t.numel()) for t in pidx]
@@ -576,11 +582,14 @@ class _PlanPacks:
     def flat_capable(self) -> bool:
         """Every step is a permutation, a global elementwise layer or a coupling with the fused training launches:
         all gradients of the plan then come out of libtfk accumulators and can leave as slices of one buffer."""
-        if not self.layers:
+        if not self.layers and not self.rqs_layers:
             return False
+        outer = rows_outer_enabled()
         for i, (layer, d, kind) in enumerate(self.plan):
             if kind in ("perm", "elementwise") or (kind == "coupling" and i in self.slot):
                 continue
+            if kind == "coupling" and i in self.rqs_slot and outer and self.rqs_layers[self.rqs_slot[i]][1].out_features <= 15:
+                continue                      # (spline couplings: their row-contracting products on tfk_rows_outer)
             return False
         return True
 
@@ -612,18 +621,55 @@ class _PlanPacks:
                 cat_to_src.append(torch.arange(n_ew) + aux_off)
                 aux_layers.append((ew_layer, ew_d))
                 aux_off += n_ew
-        cat_to_src = torch.cat(cat_to_src).to(dev)
-        src_index = cat_to_src[self.param_index]
+        src_index = None
+        if self.layers:
+            cat_to_src = torch.cat(cat_to_src).to(dev)
+            src_index = cat_to_src[self.param_index]
+        # spline couplings: per layer the full operand block (what the backward kernel takes) and, when a fixed
+        # elementwise layer rides along, a second segment [forward operands | that layer's block] for the forward program
+        rqs_index, rqs_sizes, rqs_seg = [], [], []
+        for (i, lin1, lin2, rp) in self.rqs_layers:
+            pos = []
+            for t in (lin1.weight, lin1.bias, lin2.weight, lin2.bias):
+                k = slot_of.get(id(t))
+                if k is None:
+                    return None
+                pos.append(torch.arange(fb.numel[k]) + fb.offset[k])
+            pos = torch.cat(pos + [torch.tensor([fb.zero_slot])])
+            full = pos[rp.param_index.cpu()]
+            bwd_seg = len(rqs_sizes)
+            rqs_index.append(full)
+            rqs_sizes.append(int(full.numel()))
+            fwd_seg = None
+            ew_step = self.rqs_fold[i][0]
+            if ew_step is not None:
+                ew_layer, ew_d, _ = self.plan[ew_step]
+                n_ew = (3 * W + 4) if _affine_form_is_inverse(ew_layer, ew_d) else (2 * W + 4)
+                fwd_seg = len(rqs_sizes)
+                rqs_index.append(torch.cat([full[:rp.n_fwd], torch.arange(n_ew) + aux_off]))
+                rqs_sizes.append(rp.n_fwd + n_ew)
+                aux_layers.append((ew_layer, ew_d))
+                aux_off += n_ew
+            rqs_seg.append((bwd_seg, fwd_seg))
         # gradients: accumulator layout of all layers | trainable elementwise (D, 2) blocks | zero
         grad_src = torch.full((fb.n,), -1, dtype=torch.long)
         lo = 0
-        gi = self.grad_index.cpu()
+        gi = self.grad_index.cpu() if self.layers else None
         for i, lin1, lin2, pack in self.layers:
             for t, n in zip((lin1.weight, lin1.bias, lin2.weight, lin2.bias), pack.sizes):
                 k = slot_of[id(t)]
                 grad_src[fb.offset[k]:fb.offset[k] + n] = gi[lo:lo + n]
                 lo += n
         ext = self.n_out_total
+        rqs_out = {}
+        for (i, lin1, lin2, rp) in self.rqs_layers:       # the three tfk_rows_outer products of the layer, accumulator order
+            rqs_out[i] = ext
+            ai, lo_a = rp.acc_index.cpu(), 0
+            for t, n in zip((lin1.weight, lin1.bias, lin2.weight, lin2.bias), rp.acc_sizes):
+                k = slot_of[id(t)]
+                grad_src[fb.offset[k]:fb.offset[k] + n] = ext + ai[lo_a:lo_a + n]
+                lo_a += n
+            ext += rp.n_acc
         ew_out = {}
         for i, (layer, d, kind) in enumerate(self.plan):
             if kind == "elementwise" and i not in self.folded_steps and layer.value.requires_grad:
@@ -640,7 +686,8 @@ class _PlanPacks:
                 k = slot_of.get(id(t)) if t.requires_grad else None
                 ret.append(None if k is None else (fb.piece_of_slot[k], tuple(t.shape)))
         maps = dict(src_index=src_index, aux_layers=aux_layers, grad_src=grad_src.to(dev), ew_out=ew_out,
-                    n_ext=ext + 1, ret=ret, l2={})
+                    n_ext=ext + 1, ret=ret, l2={}, rqs_out=rqs_out, rqs_seg=rqs_seg, rqs_sizes=rqs_sizes,
+                    rqs_index=torch.cat(rqs_index).to(dev) if rqs_index else None)
         self.__dict__["_flat_maps"] = (weakref.ref(fb), maps)
         return maps
 
@@ -649,7 +696,10 @@ class _PlanPacks:
         src = fb.P
         if maps["aux_layers"]:
             src = torch.cat([fb.P] + [_ew_block(l, d, self.D, self.W) for l, d in maps["aux_layers"]])
-        return list(src.index_select(0, maps["src_index"]).split(self.block_sizes))
+        affine = list(src.index_select(0, maps["src_index"]).split(self.block_sizes)) if self.layers else []
+        rqs = (list(src.index_select(0, maps["rqs_index"]).split(maps["rqs_sizes"]))
+               if maps["rqs_index"] is not None else [])
+        return affine, rqs
 
     @staticmethod
     def l2_vector(fb, maps, l2):
@@ -712,7 +762,7 @@ class _PlanPacks:
 def _plan_packs(plan, D: int, device, fold: bool) -> _PlanPacks:
     owner = plan[0][0]
     key = (tuple(id(l) for l, _, _ in plan), tuple(d for _, d, _ in plan), str(device),
-           fused_train_enabled(), fold, padded_train_enabled())
+           fused_train_enabled(), fold, padded_train_enabled(), rows_outer_enabled())
     cache = owner.__dict__.setdefault("_tfk_plan_packs", {})
     if key not in cache:
         if len(cache) > 4:
@@ -818,8 +868,9 @@ class ChainFunction(torch.autograd.Function):
             maps = packs.flat_maps(fb) if fb is not None else None
             if maps is None:
                 fb = None
+        rqs_packed = None
         if fb is not None:
-            packed = packs.pack_flat(fb, maps)
+            packed, rqs_packed = packs.pack_flat(fb, maps)
             if plan.l2:
                 l2vec = packs.l2_vector(fb, maps, plan.l2)
         else:
@@ -896,7 +947,8 @@ class ChainFunction(torch.autograd.Function):
                 # kept for the backward kernel
                 lin1, lin2 = packs.rqs_layer(layer)
                 rp = _RqsTrainPack.get(lin1.out_features, cur.device, D)
-                block = rp.pack(lin1, lin2)
+                seg = maps["rqs_seg"][packs.rqs_slot[step]] if fb is not None else None
+                block = rqs_packed[seg[0]] if seg is not None else rp.pack(lin1, lin2)
                 tr = layer.transformer
                 import math
                 op = (7 if d == INVERSE else 6, 0, rp.steps2, 0, 8, float(tr.boundary),
@@ -906,7 +958,7 @@ class ChainFunction(torch.autograd.Function):
                 if ew_step is not None:      # the fixed elementwise layer that follows rides along
                     ew_layer, ew_d, _ = plan[ew_step]
                     ops.append((1 if _affine_form_is_inverse(ew_layer, ew_d) else 0, 0, 0, rp.n_fwd))
-                    prm = torch.cat([prm, _ew_block(ew_layer, ew_d, D, W)])
+                    prm = rqs_packed[seg[1]] if seg is not None else torch.cat([prm, _ew_block(ew_layer, ew_d, D, W)])
                 out = torch.empty_like(cur)
                 native.flow_run_mfma(cur, out, logdet, None, None, None, ops, prm, accumulate=started,
                                      reverse_out=rev_step is not None)
@@ -1098,11 +1150,16 @@ class ChainFunction(torch.autograd.Function):
                                                   g_reversed=rev_step is not None, hid_perm=hid_perm)
                     if outer:
                         # the three products that contract over the batch rows, on the matrix cores without a GEMM-library
-                        # call (tfk_rows_outer: deterministic, capturable), un-permuted by ONE gather
-                        acc = torch.empty(rp.n_acc, dtype=torch.float32, device=g.device)
+                        # call (tfk_rows_outer: deterministic, capturable), un-permuted by ONE gather -- per layer, or, with
+                        # the parameters in one buffer, by the gather that maps every accumulator of the plan at once
+                        lo_acc = maps["rqs_out"][i] if fb is not None else None
+                        acc = (out_all[lo_acc:lo_acc + rp.n_acc] if fb is not None
+                               else torch.empty(rp.n_acc, dtype=torch.float32, device=g.device))
                         native.rows_outer(gh_perm, 768, hid_perm, acc[:768 * 16])
                         native.rows_outer(x_in, 32, gpre_perm, acc[768 * 16:768 * 16 + 32 * 16])
                         native.rows_outer(gpre_perm, 16, hid_perm, acc[768 * 16 + 32 * 16:])
+                        if fb is not None:
+                            continue
                         dW1, db1, dW2, db2 = (t.view(shp) for t, shp in
                                               zip(acc.index_select(0, rp.acc_index).split(rp.acc_sizes), rp.acc_shapes))
                         by_param = {id(lin1.weight): dW1, id(lin1.bias): db1, id(lin2.weight): dW2, id(lin2.bias): db2}
