@@ -110,3 +110,32 @@ def test_fit_on_the_host_with_the_flat_optimiser_matches(monkeypatch):
     b.fit(x, n_epochs=4, lr=0.01, batch_size=128, shuffle=False, x_val=x[:64])
     for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert torch.equal(pa, pb), n
+
+
+def test_flows_and_their_optimiser_survive_deepcopy_and_pickle(monkeypatch):
+    """copy.deepcopy / pickle of a fitted flow: the caches of the HIP path (``_tfk_*``: device tensors, ctypes arrays, weak
+    references) stay behind, and the copied FlatAdamW re-homes the COPY's parameters at first use."""
+    import io
+    import pickle
+    import weakref
+    from torchflows_amd import Flow, RealNVP
+    torch.manual_seed(2)
+    x = torch.randn(256, 6)
+    flow = Flow(RealNVP(6, n_layers=2))
+    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "1")
+    flow.fit(x, n_epochs=2, lr=0.01, batch_size=128, shuffle=False)
+    assert isinstance(flow._optimizer, FlatAdamW)
+    anchor = torch.nn.Linear(1, 1)
+    flow.bijection.layers[0].__dict__["_tfk_probe"] = weakref.ref(anchor)       # what a device cache may hold
+    flow.__dict__["_tfk_probe"] = weakref.ref(anchor)
+    twin = copy.deepcopy(flow)
+    back = pickle.loads(pickle.dumps(flow))
+    buf = io.BytesIO()
+    torch.save(flow, buf)
+    for other in (twin, back):
+        assert "_tfk_probe" not in other.__dict__ and "_tfk_probe" not in other.bijection.layers[0].__dict__
+        for (n, a), b in zip(flow.named_parameters(), other.parameters()):
+            assert torch.equal(a, b) and (a.numel() == 0 or a.data_ptr() != b.data_ptr()), n
+        other.fit(x, n_epochs=1, lr=0.01, batch_size=128, shuffle=False, reset_optimizer=False)   # the copied optimiser works
+        assert other._optimizer.flat.intact() and other._optimizer.flat is not flow._optimizer.flat
+    assert flow._optimizer.flat.intact()                      # ... and the original was not disturbed

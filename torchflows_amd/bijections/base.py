@@ -72,6 +72,11 @@ class Bijection(nn.Module):
         self.invalidate_native_caches()
         return super().train(mode)
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the packed-weight caches (device tensors, ctypes arrays, weak references) stay behind;
+        # the copy rebuilds its own on first use
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_tfk_")}
+
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() ...: the tensors keep their identity and version counters but move -- the packed
         # copies (and the dtype / device check) are dropped here instead of comparing data pointers on every call

@@ -111,7 +111,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._flat = fb = FlatParams(self._trainable)
         M = torch.zeros_like(fb.P)
         V = torch.zeros_like(fb.P)
-        if old is not None:                  # the parameters were moved: the moments follow them
+        if old is not None and hasattr(self, "_M"):      # the parameters were moved: the moments follow them
             with torch.no_grad():
                 M.copy_(self._M.to(M.device))
                 V.copy_(self._V.to(V.device))
@@ -123,7 +123,19 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @property
     def flat(self) -> FlatParams:
+        if self._flat is None:
+            self._rehome()
         return self._flat
+
+    # copy.deepcopy / pickle go through torch.optim.Optimizer.__getstate__, which keeps defaults, state and param_groups
+    # only: the copy re-homes ITS parameters at first use and starts from zero moments (as documented above: the buffers
+    # are not part of the optimiser's portable state)
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._trainable = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        self._flat = None
+        self._steps = []
+        self.fast_steps = self.general_steps = 0
 
     def zero_grad(self, set_to_none: bool = True):
         if self._flat is not None:
@@ -137,7 +149,7 @@ class FlatAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         fb = self._flat
-        if not fb.intact():
+        if fb is None or not fb.intact():
             self._rehome()
             fb = self._flat
         group = self.param_groups[0]

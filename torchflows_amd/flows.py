@@ -55,6 +55,10 @@ class BaseFlow(nn.Module):
         self._optimizer = None
         self.register_load_state_dict_post_hook(_drop_native_caches)
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: caches of the HIP path stay behind (see Bijection.__getstate__)
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_tfk_")}
+
     def invalidate_native_caches(self) -> None:
         """Drop every packed copy of the parameters kept for the HIP kernels (see ``Bijection.invalidate_native_caches``):
         needed only after edits the version counters do not see (``p.data.mul_(...)``, manual weight averaging)."""
