@@ -646,3 +646,67 @@ def test_sharded_fit_two_ranks_on_one_card(native):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "DIST_FIT_GPU_OK" in out.stdout
+
+
+@pytest.mark.parametrize("lr", [0.5, 2.0, 4.0, 8.0, 15.0, 1e4])
+def test_fit_rolls_back_when_the_captured_step_diverges(native, lr):
+    """Replayed steps leave their losses on the device and Flow.fit reads them GRAPH_LOSS_LAG steps late: a step size that
+    blows the flow up is still noticed (eagerly or a few replays late, depending on where it happens), the kept weights come
+    back, and the flow stays usable."""
+    import warnings
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive.architectures import RealNVP
+    torch.manual_seed(3)
+    x = (torch.randn(8192, 64) * 2.0 + 1.0).cuda()
+    flow = Flow(RealNVP(64, n_layers=2)).cuda()
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x)
+    flow.eval()
+    with torch.no_grad():
+        before = float(flow.log_prob(x).mean())
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        flow.fit(x, n_epochs=6, lr=lr, shuffle=False)
+    diverged = any("diverged" in str(w.message) for w in caught)
+    with torch.no_grad():
+        after = flow.log_prob(x)
+    assert bool(torch.isfinite(after).all()), (lr, diverged)
+    assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
+    stats = flow._fit_stats
+    print(f"lr {lr}: diverged {diverged}, stats {stats}, mean log-likelihood {before:.3f} -> {float(after.mean()):.3f}")
+    if not diverged:
+        assert stats["graph_replays"] == 6 * 8 - 2
+
+
+def test_fit_notices_a_non_finite_loss_among_replayed_steps(native):
+    """The losses of replayed steps are read late and together: a NaN that enters the weights between two epochs (here:
+    written in place, so that the capture stays valid) shows up in the next drain, the fit stops and the last kept weights
+    come back."""
+    from torchflows_amd.flows import Flow
+    from torchflows_amd.bijections.finite.autoregressive.architectures import RealNVP
+    torch.manual_seed(0)
+    D = 64
+    x = (torch.randn(8192, D) * 0.7 + 0.3).cuda()
+    flow = Flow(RealNVP(D, n_layers=2)).cuda()
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x)
+    inner = flow._base_batch_loss
+    calls = {"val": 0}
+
+    def spy(batch, reduction=torch.mean, use_regularization=True):
+        if not use_regularization:                       # the validation pass (a NaN validation loss keeps no snapshot)
+            calls["val"] += 1
+            if calls["val"] == 2:
+                with torch.no_grad():
+                    flow.bijection.layers[2].conditioner_transform.sequential[0].bias.fill_(float("nan"))
+        return inner(batch, reduction=reduction, use_regularization=use_regularization)
+    flow._base_batch_loss = spy
+    with pytest.warns(UserWarning, match="diverged"):
+        flow.fit(x, n_epochs=6, lr=0.01, x_val=x[:1024], shuffle=False)
+    stats = flow._fit_stats
+    assert stats["graph_captures"] == 1 and 14 < stats["graph_replays"] <= 14 + 8, stats     # stopped in / after epoch 3
+    assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
+    with torch.no_grad():
+        assert bool(torch.isfinite(flow.log_prob(x)).all())

@@ -30,6 +30,8 @@ from torchflows_amd.utils import make_adamw, event_size, flatten_event, get_batc
 
 # Flow.fit, TORCHFLOWS_AMD_GRAPH=auto: full-size steps a call must run before its step is captured into a hipGraph
 GRAPH_AUTO_MIN_STEPS = 32
+# ... and how many replayed steps may run before their losses are read (one transfer for all of them)
+GRAPH_LOSS_LAG = 16
 
 
 def _drop_native_caches(module, incompatible_keys=None) -> None:
@@ -356,6 +358,24 @@ class Flow(BaseFlow):
                 if adaptive and epoch % 10 == 9 and batch_size < max_batch_size:
                     batch_size = min(2 * batch_size, max_batch_size)
                 total, count = 0.0, 0
+                # replayed steps leave their loss on the device; the values are read GRAPH_LOSS_LAG steps late, in one
+                # transfer (a read per step would idle the GPU while the host prepares the next replay).  A non-finite loss
+                # is therefore noticed a few updates late -- the roll-back restores the kept weights either way.
+                pending = []
+
+                def drain():
+                    nonlocal total, count
+                    if not pending:
+                        return True
+                    values = torch.stack(pending).tolist()
+                    pending.clear()
+                    for v in values:
+                        if v != v or v in (float("inf"), float("-inf")):
+                            return False
+                        total += v
+                        count += 1
+                    return True
+
                 for batch in batches(train, batch_size, shuffle):
                     replay = use_graph and stats["eager_steps"] >= 2 and len(batch[0]) == batch_size
                     if replay and (graphed is None or graphed[0] != batch_size):
@@ -377,12 +397,19 @@ class Flow(BaseFlow):
                         graphed[2].copy_(batch[0])
                         graphed[3].copy_(batch[1])
                         graphed[1].replay()
-                        value = float(graphed[4].detach())
                         stats["graph_replays"] += 1
+                        if pbar is None:
+                            pending.append(graphed[4].detach().clone())
+                            if len(pending) < GRAPH_LOSS_LAG or drain():
+                                continue
+                            value = float("nan")       # (a non-finite loss among the drained steps)
+                        else:
+                            value = float(graphed[4].detach())
                     else:
+                        ok = drain()
                         self._optimizer.zero_grad()
                         loss = self._base_batch_loss(batch, reduction=torch.mean, use_regularization=True)
-                        value = float(loss.detach())
+                        value = float(loss.detach()) if ok else float("nan")
                     if value != value or value in (float("inf"), float("-inf")):
                         self.load_state_dict(best_weights)     # the last kept (else the initial) weights
                         diverged = True
@@ -402,6 +429,10 @@ class Flow(BaseFlow):
                 if graphed is not None:       # replays move the weights, not their version counters
                     from torchflows_amd import fused
                     fused.invalidate(self, compiled_only=True)
+                if not diverged and not drain():
+                    self.load_state_dict(best_weights)
+                    diverged = True
+                    warnings.warn("Flow training diverged. Reverting to previous weights.")
                 if diverged:
                     break
                 average = total / count
