@@ -503,12 +503,16 @@ def test_fit_drops_the_captured_step_when_a_parameter_moves(native):
 
 @pytest.mark.parametrize("arch,D", [("RealNVP", 4), ("RealNVP", 6), ("RealNVP", 10), ("RealNVP", 22), ("RealNVP", 32),
                                     ("RealNVP", 62), ("RealNVP", 100), ("NICE", 10), ("NICE", 64),
-                                    ("CouplingRQNSF", 6), ("CouplingRQNSF", 22), ("CouplingRQNSF", 62)])
+                                    ("CouplingRQNSF", 6), ("CouplingRQNSF", 22), ("CouplingRQNSF", 62),
+                                    ("RealNVP", 3), ("RealNVP", 5), ("RealNVP", 21), ("RealNVP", 63), ("RealNVP", 99),
+                                    ("NICE", 9), ("CouplingRQNSF", 7), ("CouplingRQNSF", 21)])
 def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch, D):
-    """Even event sizes that are not 64 / 128 train on rows padded to the next of the two in the padded training layout
-    (first half at the head of plane A, second half at the tail of plane B: a logical reversal is the physical one) --
-    one forward program and one tfk_affine_coupling_train_bwd per [coupling, ActNorm, reversal] block, graph-capturable --
-    instead of the layer-by-layer reverse mode with its GEMM-library calls.  Gradients against the host ATen graph in
+    """Event sizes that are not 64 / 128 train on rows padded to the next of the two in the padded training layout
+    (the HalfSplit sources at the head of plane A, the targets at the tail of plane B: for even sizes a logical reversal is
+    the physical one; odd sizes -- one target more than sources, the middle element changes planes at every reversal --
+    run their reversals as a column gather) -- one forward program and one tfk_affine_coupling_train_bwd per
+    [coupling, ActNorm(, reversal)] block, graph-capturable -- instead of the layer-by-layer reverse mode with its
+    GEMM-library calls.  Gradients against the host ATen graph in
     float64, against the unpadded route, launch counts, both directions, and one fit."""
     import copy
     from torchflows_amd.flows import Flow
@@ -545,14 +549,16 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
         before = native.calls
         plain = grads(dev, x.cuda(), inverse)
         n_plain = native.calls - before
-        tol = 5e-3 if "RQ" in arch else 2e-4                   # (the spline's fp32 floor against float64, as in the 64-wide tests)
+        tol = 5e-3 if "RQ" in arch else 5e-4                   # (fp32 sums over 700 rows against float64; the spline's floor as in the 64-wide tests)
         for name, g, w, p in zip(["x"] + names, got, want, plain):
             scale = max(1.0, float(w.abs().max()))
             assert float((g.double().cpu() - w).abs().max()) < tol * scale, (inverse, name)
             assert float((g - p).abs().max()) < tol * scale, (inverse, name)
         if fused and "RQ" not in arch:
-            assert n_pad < n_plain or D in (64, 128), (n_pad, n_plain)   # (64 / 128: no padding either way)
-            assert n_pad <= 2 * (3 + 6) + 4, n_pad        # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps
+            # (64 / 128: no padding either way; odd sizes: libtfk launches replace ATen ones, the count need not drop)
+            assert n_pad < n_plain or D in (64, 128) or D % 2, (n_pad, n_plain)
+            # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps (odd sizes: 3 more reversals each way)
+            assert n_pad <= 2 * (3 + 6) + 4 + (6 if D % 2 else 0), n_pad
     monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
     plan = ag.training_plan(dev.bijection, 0)
     assert ag.fully_fused(plan, D) and ag.plan_width(plan, D) in (64, 128)

@@ -207,11 +207,12 @@ class _TrainPack:
         shift row of GEMM 2, the logit rows are the appended zero, and their accumulators are not mapped back."""
         D_log = D_log or D
         half, EPL = D // 2, D // 8
-        h = D_log // 2                                    # real elements per plane
-        pad = half - h                                    # plane B: padding first, then the h targets
+        h = D_log // 2                                    # sources (HalfSplit: the first D // 2 elements, coupling_masks)
+        ht = D_log - h                                    # targets: one more when the event size is odd
+        pad = half - ht                                   # plane B: padding first, then the targets
         T2, T1 = EPL // 2, EPL // 4
         self.steps2 = (H + 3) // 4
-        TP = h if shift else 2 * h                        # rows of the real W2 / b2
+        TP = ht if shift else 2 * ht                      # rows of the real W2 / b2
         off_b1 = H * h
         off_W2 = off_b1 + H
         off_b2 = off_W2 + TP * H
@@ -224,11 +225,11 @@ class _TrainPack:
         W2idx = torch.full((half, 2, 16), Z, dtype=torch.long)
         b2idx = torch.full((half, 2), Z, dtype=torch.long)
         if shift:
-            W2idx[pad:, 1, :H] = off_W2 + (ar(h)[:, None] * H + ar(H)[None, :])
-            b2idx[pad:, 1] = off_b2 + ar(h)
+            W2idx[pad:, 1, :H] = off_W2 + (ar(ht)[:, None] * H + ar(H)[None, :])
+            b2idx[pad:, 1] = off_b2 + ar(ht)
         else:
-            W2idx[pad:, :, :H] = off_W2 + ((ar(h)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
-            b2idx[pad:] = off_b2 + (ar(h)[:, None] * 2 + ar(2)[None, :])
+            W2idx[pad:, :, :H] = off_W2 + ((ar(ht)[:, None, None] * 2 + ar(2)[None, :, None]) * H + ar(H)[None, None, :])
+            b2idx[pad:] = off_b2 + (ar(ht)[:, None] * 2 + ar(2)[None, :])
         lane = ar(64)
         ql, il = lane >> 4, lane & 15
         unit = 4 * (il & 3) + (il >> 2)
@@ -257,10 +258,10 @@ class _TrainPack:
         dW1 = off1 + (((e // 16)[None, :] * 64 + 16 * ((e % 16) // 4)[None, :] + u[:, None]) * 4 + (e % 4)[None, :])
         db1 = off1 + T1 * 256 + 4 * (u % 4) + (u // 4)
         if shift:
-            m, pbit = pad + ar(h), torch.ones(h, dtype=torch.long)   # (the shift rows only)
+            m, pbit = pad + ar(ht), torch.ones(ht, dtype=torch.long)  # (the shift rows only)
         else:
-            m = (pad + ar(h))[:, None].expand(h, 2).reshape(-1)      # physical target element of logical target t
-            pbit = ar(2)[None, :].expand(h, 2).reshape(-1)
+            m = (pad + ar(ht))[:, None].expand(ht, 2).reshape(-1)    # physical target element of logical target t
+            pbit = ar(2)[None, :].expand(ht, 2).reshape(-1)
         q_m, rem = m // EPL, m % EPL
         T_m, r_m = rem // 2, 2 * (rem % 2) + pbit
         dW2 = ((T_m * 64 + 16 * q_m)[:, None] + u[None, :]) * 4 + r_m[:, None]
@@ -293,23 +294,24 @@ class _RqsTrainPack:
         head of plane A, its h targets at the tail of plane B); a padding element's 23 spline parameters are the appended
         zero -- equal bins, unit derivatives: the identity at its value 0 (a knot)."""
         half, EPL, P = 32, 8, 23
-        h = D_log // 2
-        pad = half - h
+        h = D_log // 2                                    # sources
+        ht = D_log - h                                    # targets (one more when the event size is odd)
+        pad = half - ht
         self.H = H
         self.steps2 = (H + 3) // 4
         off_b1 = H * h
         off_W2 = off_b1 + H
-        off_b2 = off_W2 + h * P * H
-        Z = off_b2 + h * P
+        off_b2 = off_W2 + ht * P * H
+        Z = off_b2 + ht * P
         ar = torch.arange
         W1idx = torch.full((16, half), Z, dtype=torch.long)
         W1idx[:H, :h] = ar(H)[:, None] * h + ar(h)[None, :]
         b1idx = torch.full((16,), Z, dtype=torch.long)
         b1idx[:H] = off_b1 + ar(H)
         W2idx = torch.full((half, 24, 16), Z, dtype=torch.long)
-        W2idx[pad:, :P, :H] = off_W2 + ((ar(h)[:, None, None] * P + ar(P)[None, :, None]) * H + ar(H)[None, None, :])
+        W2idx[pad:, :P, :H] = off_W2 + ((ar(ht)[:, None, None] * P + ar(P)[None, :, None]) * H + ar(H)[None, None, :])
         b2idx = torch.full((half, 24), Z, dtype=torch.long)
-        b2idx[pad:, :P] = off_b2 + ar(h)[:, None] * P + ar(P)[None, :]
+        b2idx[pad:, :P] = off_b2 + ar(ht)[:, None] * P + ar(P)[None, :]
         lane = ar(64)
         ql, il = lane >> 4, lane & 15
         unit = 4 * (il & 3) + (il >> 2)
@@ -331,7 +333,7 @@ class _RqsTrainPack:
                                       torch.stack(A1T).reshape(-1)]).to(device)
         self.n_fwd = EPL * 64 + 16 + 48 * self.steps2 * 64 + 48 * 16
         # column of gh_perm that holds parameter p of (physical) target element m = pad + logical target
-        m = (pad + ar(h))[:, None]
+        m = (pad + ar(ht))[:, None]
         pp = ar(P)[None, :]
         e_, q_ = m % EPL, m // EPL
         self.gh_col = ((6 * e_ + pp // 4) * 16 + 4 * q_ + pp % 4).reshape(-1).to(device)     # (736,)
@@ -356,8 +358,8 @@ class _RqsTrainPack:
             base3 = base2 + 32 * 16
             db1 = base3 + (16 * (slot // 4) + 15) * 4 + slot % 4
             self.acc_index = torch.cat([dW1.reshape(-1), db1, dW2.reshape(-1), db2]).to(device)
-            self.acc_sizes = (H * h, H, h * P * H, h * P)
-            self.acc_shapes = ((H, h), (H,), (h * P, H), (h * P,))
+            self.acc_sizes = (H * h, H, ht * P * H, ht * P)
+            self.acc_shapes = ((H, h), (H,), (ht * P, H), (ht * P,))
 
     def pack(self, lin1, lin2) -> torch.Tensor:
         flat = torch.cat([lin1.weight.detach().reshape(-1), lin1.bias.detach(),
@@ -371,11 +373,11 @@ def _fused_rqs_layer(layer, D: int):
         return None
     lib, K = native.lib(), int(layer.transformer.n_bins)
     if not (lib.tfk_rqs_coupling_train_bwd_supported(D, K)
-            or (padded_train_enabled() and D % 2 == 0 and 4 <= D < 64 and lib.tfk_rqs_coupling_train_bwd_supported(64, K))):
+            or (padded_train_enabled() and 3 <= D < 64 and lib.tfk_rqs_coupling_train_bwd_supported(64, K))):
         return None                           # (D < 64: on rows padded to 64 -- whether the plan may be is plan_width's call)
     c = layer.coupling
     if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
-            and c.target_event_size == D // 2):
+            and c.target_event_size == D - D // 2):
         return None
     mlp = _plain_mlp(layer)
     if mlp is None or mlp[0].out_features > 16:
@@ -409,7 +411,7 @@ def train_width(D: int) -> Optional[int]:
     """Row width the fused training launches run an event size of ``D`` at, or None."""
     if native.lib().tfk_coupling_train_bwd_supported(D):
         return D
-    if padded_train_enabled() and D % 2 == 0 and 4 <= D < 128:
+    if padded_train_enabled() and 3 <= D < 128:          # (odd sizes: D - D // 2 targets fit a plane of W / 2 as well)
         return 64 if D < 64 else 128
     return None
 
@@ -442,8 +444,10 @@ def plan_width(plan, D: int) -> int:
 
 
 def training_layout(D: int, W: int, device) -> torch.Tensor:
-    """Physical column of logical element l on rows padded from D to W: l for the first half, W - D + l for the
-    second -- so that reversing the D logical columns is reversing the W physical ones."""
+    """Physical column of logical element l on rows padded from D to W: l for the first D // 2 (the sources of a
+    HalfSplit coupling), W - D + l for the others (its targets) -- for even D reversing the D logical columns is then
+    reversing the W physical ones; for odd D it is not (the middle element is a target before AND after a reversal, so
+    it has to change planes): those plans run their reversals as the general column gather ``reversal_index``."""
     key = (D, W, str(device))
     hit = _LAYOUTS.get(key)
     if hit is None:
@@ -455,6 +459,19 @@ def training_layout(D: int, W: int, device) -> torch.Tensor:
 _LAYOUTS = {}
 
 
+def reversal_index(D: int, W: int, device) -> torch.Tensor:
+    """int32 (W,): out[:, c] = in[:, index[c]] reverses the D logical columns of rows in the padded training layout and
+    leaves the padding where it is (an involution: the backward pass uses the same index)."""
+    key = (D, W, str(device), "rev")
+    hit = _LAYOUTS.get(key)
+    if hit is None:
+        phys = training_layout(D, W, "cpu")
+        idx = torch.arange(W)
+        idx[phys] = phys.flip(0)                     # the column of logical j takes the column of logical D - 1 - j
+        hit = _LAYOUTS[key] = idx.to(torch.int32).to(device)
+    return hit
+
+
 def _fused_bwd_layer(layer, D: int):
     """(lin1, lin2) when the layer's whole backward can run as tfk_affine_coupling_train_bwd (at the width
     ``train_width(D)``: whether a plan may be padded is ``plan_width``'s call)."""
@@ -464,7 +481,7 @@ def _fused_bwd_layer(layer, D: int):
         return None                           # (shift: the affine launches with a scale logit of zero, _TrainPack)
     c = layer.coupling
     if not (layer._source_is_head and layer._target_is_tail and c.source_event_size == D // 2
-            and c.target_event_size == D // 2):
+            and c.target_event_size == D - D // 2):
         return None
     mlp = _plain_mlp(layer)
     if mlp is None or mlp[0].out_features > 15:
@@ -520,6 +537,10 @@ class _PlanPacks:
         # next width that has them, the rows in the padded training layout (training_layout)
         self.W = W = plan_width(plan, D)
         self.phys = training_layout(D, W, device) if W != D else None
+        # odd event sizes: a logical reversal is not the physical one -- no folding of reversals into the coupling
+        # launches, the permutation steps gather with reversal_index
+        self.rev_index = reversal_index(D, W, device) if (W != D and D % 2) else None
+        fold_rev = self.rev_index is None
         fusable = bool(native.lib().tfk_coupling_train_bwd_supported(W))
         pidx, gidx, off_flat, off_out = [], [], 0, 0
         for i, (layer, d, kind) in enumerate(plan):
@@ -534,7 +555,7 @@ class _PlanPacks:
             if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
                 ew_step = j
                 j += 1
-            if fold and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
+            if fold and fold_rev and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
                 rev_step = j
             self.layers.append((i, mlp[0], mlp[1], pack))
             self.fold.append((ew_step, rev_step))
@@ -560,7 +581,7 @@ class _PlanPacks:
             if fold and j < len(plan) and plan[j][2] == "elementwise" and not plan[j][0].value.requires_grad:
                 ew_step = j
                 j += 1
-            if fold and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
+            if fold and fold_rev and j < len(plan) and plan[j][2] == "perm" and plan[j][0]._is_reversal:
                 rev_step = j
             self.rqs_fold[i] = (ew_step, rev_step)
             self.folded_steps.update(t for t in (ew_step, rev_step) if t is not None)
@@ -729,15 +750,15 @@ class _PlanPacks:
     # ---- rows in the padded training layout (self.W > self.D) -----------------------------------------------------
     def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """(N, D) -> (N, W): first half at the head of plane A, second half at the tail of plane B, zeros between."""
-        h = self.D // 2
+        h = self.D // 2                               # (odd sizes: h sources at the head, D - h targets at the tail)
         wide = rows.new_zeros(rows.shape[0], self.W)
         wide[:, :h] = rows[:, :h]
-        wide[:, self.W - h:] = rows[:, h:]
+        wide[:, self.W - (self.D - h):] = rows[:, h:]
         return wide
 
     def unpad_rows(self, wide: torch.Tensor) -> torch.Tensor:
         h = self.D // 2
-        return torch.cat([wide[:, :h], wide[:, self.W - h:]], dim=1)
+        return torch.cat([wide[:, :h], wide[:, self.W - (self.D - h):]], dim=1)
 
     def ew_value(self, layer) -> torch.Tensor:
         """``layer.value`` as the (W, 2) block the elementwise kernels read (padding rows: zeros = the identity)."""
@@ -886,6 +907,8 @@ class ChainFunction(torch.autograd.Function):
             if kind == "perm":
                 out = torch.empty_like(cur)
                 perm = None if layer._is_reversal else (layer._fwd_index32 if d == FORWARD else layer._inv_index32)
+                if packs.rev_index is not None:      # (padded rows of an odd event size: reversals only, as a gather)
+                    perm = packs.rev_index
                 native.permute(cur, perm, out)
                 saved.append(None)
                 cur, cur_is_saved = out, False
@@ -1046,6 +1069,8 @@ class ChainFunction(torch.autograd.Function):
             if kind == "perm":
                 out = torch.empty_like(g)
                 perm = None if layer._is_reversal else (layer._inv_index32 if d == FORWARD else layer._fwd_index32)
+                if packs.rev_index is not None:      # (an involution: its own inverse)
+                    perm = packs.rev_index
                 native.permute(g, perm, out)
                 g = out
             elif kind == "elementwise":
