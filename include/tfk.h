@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 26
+#define TFK_ABI_VERSION 27
 
 enum {
     TFK_OK = 0,
@@ -215,7 +215,12 @@ enum {
      * tanh = 1 - 2 / (exp2(.) + 1), alpha = exp2(.) + 1e-10, log-det accumulated in base 2.
      * Op record field K = 256 (D = 64 only): GEMM 2 in the bf16 x 3 operand format described at TFK_OP_RQS_*_LEAN --
      * block A1 | b1 | A23[T2][2][64][4 dwords] | pre_s | pre_t, A23[t] = {[W_hi | W_mid], [W_lo | W_hi]}, b2 as the
-     * weight of hidden unit 15 (hidden width <= 15). */
+     * weight of hidden unit 15 (hidden width <= 15).
+     * Bit 2 of src_plane (ABI v27, odd event sizes): HalfSplit then has one target more than sources and -- with the
+     * reversals between the couplings -- the MIDDLE element is a target of EVERY coupling, so it has to sit in whichever
+     * plane is being transformed: both planes reserve their last column (D/2 - 1 of the plane) for it, and a coupling whose
+     * src_plane carries bit 2 first takes the element over from the other plane's last column and clears that one.
+     * Resident operands only (no streaming), no context. */
     TFK_OP_AFFINE_FWD_LEAN = 12,
     TFK_OP_AFFINE_INV_LEAN = 13,
     TFK_OP_SHIFT_FWD_LEAN = 14,

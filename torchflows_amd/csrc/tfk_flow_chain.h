@@ -48,6 +48,10 @@ struct ChainProg {
     // kind 0 none, 1 constant x -> s x + t (an EW_FMA block), 2 / 3 context-conditioned multiply-add / subtract-divide
     int pre_kind[kChainSideOps], pre_off[kChainSideOps];
     int post_kind[kChainSideOps], post_off[kChainSideOps];
+    // ODD event sizes (HalfSplit: one target more than sources; with reversals the MIDDLE element is a target of every
+    // coupling, i.e. it must sit in whichever plane is being transformed): both planes reserve their LAST slot for it, and
+    // bit o says that coupling o first takes it over from the other plane (one select + one clear, lanes q == 3 only)
+    unsigned long long move_mask;
 };
 
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
@@ -390,6 +394,14 @@ __device__ __forceinline__ void couple_fmt(const float *prm, int lane, int q, co
     else couple_lean<EPL, STEPS2, KIND, FAST, CTX>(prm, lane, q, src, tgt, ld2, umin, cx, cs);
 }
 
+// the middle element of an odd event size changes planes: slot EPL - 1 of lane group 3 (= column HALF - 1 of the plane)
+template <int EPL>
+__device__ __forceinline__ void move_middle(int q, float (&to)[EPL], float (&from)[EPL])
+{
+    to[EPL - 1] = (q == 3) ? from[EPL - 1] : to[EPL - 1];
+    from[EPL - 1] = (q == 3) ? 0.0f : from[EPL - 1];          // (a padding column again: it must read 0 from here on)
+}
+
 // the couplings (or MADE layers) of the program on the 16 rows a wave holds
 template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false>
 __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &prog, int lane, int q, float (&a)[EPL],
@@ -403,15 +415,22 @@ __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &
         for (; o < prog.n_c; ++o)
             made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
     } else {
+        const unsigned long long mv = prog.move_mask;          // (0 for even event sizes: the branches below are uniform)
         if (prog.first_src == 1 && prog.n_c > 0) {
+            if (mv & 1ull) move_middle<EPL>(q, a, b);
             couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[0], lane, q, b, a, ld2, umin, cx, cs);
             o = 1;
         }
         for (; o + 1 < prog.n_c; o += 2) {
+            if ((mv >> o) & 1ull) move_middle<EPL>(q, b, a);
             couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o], lane, q, a, b, ld2, umin, cx, cs);
+            if ((mv >> (o + 1)) & 1ull) move_middle<EPL>(q, a, b);
             couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o + 1], lane, q, b, a, ld2, umin, cx, cs);
         }
-        if (o < prog.n_c) couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o], lane, q, a, b, ld2, umin, cx, cs);
+        if (o < prog.n_c) {
+            if ((mv >> o) & 1ull) move_middle<EPL>(q, b, a);
+            couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[o], lane, q, a, b, ld2, umin, cx, cs);
+        }
     }
 }
 
@@ -865,6 +884,8 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
 {
     // operands that do not fit the LDS beside each other are streamed (chain_layers_stream): D >= 128, fp32 format
     if ((size_t)n_params + 16 * EPL + 4 > 160 * 1024 / sizeof(float) || ((flags & 8) && EPL >= 16 && KIND < 4 && steps2 != 0)) {
+        if (prog.move_mask)
+            return fail(TFK_EINVAL, "%s: programs of odd event sizes keep their operands resident (no streaming)", fn);
         if constexpr (EPL >= 16 && KIND < 4) {
 #ifndef TFK_STREAM_BLOCK
 #define TFK_STREAM_BLOCK 512

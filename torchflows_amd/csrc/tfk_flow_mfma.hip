@@ -172,6 +172,7 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
     prog.context = context;
     prog.ctx_n = Cn;
     prog.ctx_steps = cs_want;
+    prog.move_mask = 0;
     for (int i = 0; i < kChainSideOps; ++i) prog.pre_kind[i] = prog.post_kind[i] = prog.pre_off[i] = prog.post_off[i] = 0;
     int phase = 0;                                           // 0 before the couplings, 1 in them, 2 behind the closing EW_FMA
     int kind = -1, steps2 = 1;
@@ -185,6 +186,10 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
         if (k != TFK_OP_EW_FMA && (src >> 4) != (((k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN) || ewc) ? cs_want : 0))
             return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
         src &= 15;
+        const bool move_mid = (src & 4) != 0;                // odd event sizes: take the middle element over first
+        src &= 3;
+        if (move_mid && !(k >= TFK_OP_AFFINE_FWD_LEAN && k <= TFK_OP_SHIFT_INV_LEAN))
+            return fail(TFK_EINVAL, "%s: op %d: only affine / shift couplings move a middle element", fn, i);
         if (k == TFK_OP_EW_FMA || ewc) {
             // plain programs: one TFK_OP_EW_FMA, last.  Context programs: elementwise ops (constant or context-conditioned)
             // may also stand in front of the couplings and behind the closing TFK_OP_EW_FMA
@@ -241,6 +246,10 @@ static int run_chain(const float *x, float *z, float *logdet, const float *loc, 
             if (f3 && context) return fail(TFK_EINVAL, "%s: op %d: context-conditioned lean couplings use fp32 operands", fn, i);
             need = f3 ? (int64_t)EPL * 64 + 16 + (int64_t)T2 * 2 * 64 * 4 + 2 * HALF
                       : (int64_t)EPL * 64 + 16 + (int64_t)nA2 * 64 + (int64_t)T2 * 16 + 2 * HALF + (cs_want ? 256 : 0);
+            if (move_mid) {
+                if (context) return fail(TFK_EINVAL, "%s: op %d: context programs do not move a middle element", fn, i);
+                prog.move_mask |= 1ull << prog.n_c;
+            }
             prog.offset[prog.n_c++] = off;
         } else {
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean ops", fn, i, k);

@@ -617,8 +617,8 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int, allow_ctx:
     half = D // 2
     c = layer.coupling
     S, T = c.source_event_size, c.target_event_size
-    if not (c.source_is_head and c.target_is_tail and S == half and S + T == D and T == S):
-        return None
+    if not (c.source_is_head and c.target_is_tail and S == half and S + T == D and T - S in (0, 1)):
+        return None                                           # (T = S + 1: odd event sizes, _compile_lean(odd=True))
     ct = layer.conditioner_transform
     if type(ct) is not FeedForward or ct.n_global_parameters != 0:
         return None
@@ -936,7 +936,7 @@ def _pack_lean_made(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t) -> torch.
 
 
 def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor,
-                  context: bool = False):
+                  context: bool = False, odd: bool = False):
     """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
     folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
     alternates -- every RealNVP / NICE preset.  The elementwise layers are deferred: physical column c carries a
@@ -951,6 +951,15 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
         CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
     hp = Dp // 2
+    if odd:
+        # ODD event sizes (affine / shift chains): HalfSplit has one target more than sources, and with the reversals the
+        # MIDDLE element is a target of every coupling -- it has to sit in whichever plane is being transformed.  Both
+        # planes reserve their last column for it (the caller's layout puts it there); before a coupling that finds it in
+        # its SOURCE plane the kernel takes it over (bit 2 of the op's src_plane, csrc/tfk_flow_chain.h: move_middle), and
+        # its pending elementwise map moves with it here.
+        if context or (D + 1) // 2 > hp:
+            return None
+        pos = pos.clone()
     s = torch.ones(Dp, dtype=torch.float64, device=device)
     t = torch.zeros(Dp, dtype=torch.float64, device=device)
     ld_const = torch.zeros((), dtype=torch.float64, device=device)
@@ -1052,7 +1061,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     t[pos] = alpha * t[pos] + beta
                     ld_const = ld_const + torch.log(alpha).sum()
             elif isinstance(layer, MaskedAutoregressiveBijection):
-                if context or Dp < 32:
+                if context or Dp < 32 or odd:
                     return None
                 got = _lean_made(layer, d, pos, D, Dp)       # MAF density / IAF sampling: the parallel map
                 if got is None:
@@ -1093,6 +1102,22 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
             elif isinstance(layer, CouplingBijection):
                 if closed_flush is not None:
                     return None                               # (a coupling behind a context-conditioned elementwise layer)
+                moved = 0
+                if odd:
+                    S_ = layer.coupling.source_event_size
+                    src_plane = int(pos[0].item()) // hp
+                    wrong = ((pos[S_:] // hp) == src_plane).nonzero().flatten()
+                    if wrong.numel() > 1:
+                        return None
+                    if wrong.numel() == 1:                    # the middle element sits in the source plane: take it over
+                        l_mid = S_ + int(wrong[0].item())
+                        old, new = int(pos[l_mid].item()), (1 - src_plane) * hp + hp - 1
+                        if old != src_plane * hp + hp - 1:
+                            return None
+                        pos[l_mid] = new
+                        s[new], t[new] = s[old].clone(), t[old].clone()
+                        s[old], t[old] = 1.0, 0.0
+                        moved = 4
                 got = _lean_coupling(layer, d, pos, D, Dp, allow_ctx=context)
                 if got is None:
                     return None
@@ -1110,15 +1135,15 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 if kind0 is not None and kind0 in (6, 7, 10, 12):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
-                if Dp < 32 and lk >= 4:
-                    return None                               # (16-wide rows: affine / shift chains only)
+                if (Dp < 32 or odd) and lk >= 4:
+                    return None                               # (16-wide rows, odd event sizes: affine / shift chains only)
                 if lk >= 8 and not rqs_bf16x3_enabled():
                     return None                               # (linear rational splines: bf16 x 3 operands only)
                 if lk >= 4 and rqs_bf16x3_enabled():
                     steps2 = (H + 1 + 3) // 4                 # bf16 x 3 operands: counts the bias unit; > 4 = two hidden tiles
                 if kind0 is None:
                     kind0, steps0 = lk, steps2
-                elif (lk, steps2) != (kind0, steps0) or plane != 1 - items[-1][1]:
+                elif (lk, steps2) != (kind0, steps0) or plane != 1 - (items[-1][1] & 1):
                     return None
 
                 src = torch.arange(plane * hp, (plane + 1) * hp, device=device)
@@ -1152,7 +1177,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     if items and bool(items[-1][4]) != use3:
                         return None
                     block = _pack_lean(lk, H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(), bf16x3=use3, W1c=W1c)
-                    items.append((OP_AFFINE_FWD_LEAN + lk, plane, steps2, block, (256,) if use3 else ()))
+                    items.append((OP_AFFINE_FWD_LEAN + lk, plane | moved, steps2, block, (256,) if use3 else ()))
                 s[tgt] = 1.0
                 t[tgt] = 0.0
             else:
@@ -1182,7 +1207,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     # operands streamed block by block (csrc/tfk_flow_chain.h: chain_layers_stream) instead of one launch per LDS-full
     total = sum(block.numel() for _, _, _, block, _ in items) * 4
     if (not streamed and not context and kind0 in (0, 1, 2, 3) and Dp >= 128 and stream_chain_enabled() and len(items) <= 61
-            and total > 158 * 1024 and not any(extra for *_, extra in items)):
+            and total > 158 * 1024 and not any(extra for *_, extra in items) and not odd):
         streamed = True
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
@@ -1239,6 +1264,10 @@ def compile_chain(composition, direction: int, device: torch.device,
     slots = D % 2 == 1 and 3 <= D <= 64          # (the swap op is not built for 256-wide rows)
     if slots:
         Dp = 64 if D <= 32 else 128
+    # odd event sizes above 64: the straight-line kernels only (the middle element changes planes there, _compile_lean)
+    odd_wide = D % 2 == 1 and 64 < D < 256
+    if odd_wide:
+        Dp = 128 if D < 128 else 256
     if mfma is None:
         if mfma_enabled() and native.lib().tfk_flow_mfma_supported(Dp) and padded_enabled(D, Dp):
             chain = compile_chain(composition, direction, device, mfma=True, context=context)
@@ -1274,6 +1303,22 @@ def compile_chain(composition, direction: int, device: torch.device,
             chain = _compile_lean(composition, plan, device, D, w, planes(w), planes(w), context=context)
             if chain is not None:
                 return chain
+    if mfma and D % 2 == 1 and 3 <= D < 256 and lean_enabled() and odd_lean_enabled() and not context:
+        # odd event sizes on the straight-line kernels (affine / shift chains): sources at the head of plane A, the
+        # targets behind the middle element at the head of plane B, the middle element in plane B's last column
+        h_ = D // 2
+        for w in (16, 32, 64, 128, 256):
+            if (D + 1) // 2 > w // 2 or (w == 16 and not rows16_enabled()) or (w == 32 and not narrow_rows_enabled()) \
+                    or not padded_enabled(D, w):
+                continue
+            l_ = torch.arange(D, device=device)
+            lay = torch.where(l_ < h_, l_, torch.where(l_ == h_, torch.full_like(l_, w - 1), w // 2 + l_ - h_ - 1))
+            chain = _compile_lean(composition, plan, device, D, w, lay, lay.clone(), context=False, odd=True)
+            if chain is not None:
+                return chain
+            break                                # (a wider row would not make a chain lean that is not lean here)
+    if odd_wide:
+        return None                              # (no interpreter route at these sizes)
     pos = planes(Dp)
     pos_in = pos.clone()                         # (odd sizes: the whole row enters in plane 0, element l at index l)
     items = []                                   # [(op triple, block)]
@@ -1338,6 +1383,12 @@ def stream_chain_enabled() -> bool:
     """One launch with streamed operands for affine / shift chains that do not fit the LDS (TORCHFLOWS_AMD_STREAM_CHAIN=0:
     one launch per LDS-full of couplings, as before)."""
     return os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") != "0"
+
+
+def odd_lean_enabled() -> bool:
+    """Odd event sizes on the straight-line chain kernels (TORCHFLOWS_AMD_ODD_LEAN=0: the interpreter with a plane per
+    element, as before round 3)."""
+    return os.environ.get("TORCHFLOWS_AMD_ODD_LEAN", "1") != "0"
 
 
 def rows16_enabled() -> bool:
@@ -1553,8 +1604,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
             half, hp = chain.D_log // 2, chain.D // 2
             wide[:, :half] = rows[:, :half]
             wide[:, hp:hp + half] = rows[:, half:]
-        else:                                    # odd sizes: the row at the head of plane 0
-            wide[:, :chain.D_log] = rows
+        else:                                    # odd sizes: logical element l at column pos_in[l]
+            wide.index_copy_(1, chain.pos_in, rows)
         rows = wide
     logprob = torch.empty(N, dtype=torch.float32, device=dev) if base is not None else None
     logdet = torch.empty(N, dtype=torch.float32, device=dev) if (base is None or n_seg > 1) else None

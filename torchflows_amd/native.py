@@ -49,7 +49,7 @@ SYMBOLS = (
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
 )
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class NativeError(RuntimeError):
