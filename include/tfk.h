@@ -320,7 +320,10 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
  * (N, x_width), x_width even and <= D; its first half is read into the head of plane A, its second half into the head
  * of plane B, zeros behind them -- the layout the packer pads such flows to (zero weights make the padding an exact
  * identity), without a host-side padding pass over the rows.  Lean programs only; z / logdet / logprob as above
- * (z in the kernel's D-wide physical layout). */
+ * (z in the kernel's D-wide physical layout).
+ * An ODD x_width (ABI v27; affine / shift chains whose couplings carry the move bit, (x_width + 1) / 2 <= D / 2):
+ * x_width / 2 sources into the head of plane A, the middle element into plane B's LAST column, the remaining x_width / 2
+ * elements into the head of plane B. */
 /* tfk_flow_run_mfma_in for a LEAN program that ends in the base density, plus the fp64 sum of the launch's N
  * log-probabilities in sum_out[0] (device) -- the per-rank term of SURVEY.md 8(e)'s one all-reduce -- without further
  * launches: every workgroup leaves the fp64 sum of its rows in the workspace, the last one to finish adds them in index

@@ -666,15 +666,17 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
             // rows narrower than the kernel's planes (event sizes that are not 32 / 64 / 128 / 256): the caller's rows
             // are read as they are -- first half into the head of plane A, second half into the head of plane B, zeros
             // behind them (the padding is an exact identity by construction of the weights, fused.py)
-            const int hl = xw >> 1;
+            // (an ODD width: hl sources, then the middle element -- which goes to plane B's last column --, then hl targets)
+            const int hl = xw >> 1, odd = xw & 1;
             const float *xr = x + rr * xw;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int col = EPL * q + e;
                 const bool ok = col < hl;
                 a[e] = ok ? xr[col] : 0.0f;
-                b[e] = ok ? xr[hl + col] : 0.0f;
+                b[e] = ok ? xr[hl + odd + col] : 0.0f;
             }
+            if (odd && q == 3) b[EPL - 1] = xr[hl];
         }
         };
         load_rows();

@@ -328,8 +328,12 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
         return fail(TFK_EINVAL, "%s: of the lean programs only coupling chains take a context", fn);
     if (sum_ws && (!lean || !logprob || !sum_out))
         return fail(TFK_EINVAL, "%s: the in-kernel sum needs a lean program, logprob and sum_out", fn);
-    if (x_width != D && (!lean || x_width < 2 || x_width > D || (x_width & 1)))
-        return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d", fn, x_width, D);
+    // (an odd width: affine / shift chains whose couplings move the middle element -- it is read into plane B's last column)
+    const bool odd_ok = (x_width & 1) && x_width >= 3 && (x_width + 1) / 2 <= D / 2 && !lean_spline &&
+                        first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN;
+    if (x_width != D && (!lean || x_width < 2 || x_width > D || ((x_width & 1) && !odd_ok)))
+        return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d "
+                    "(odd: an affine / shift chain, (x_width + 1) / 2 <= D / 2)", fn, x_width, D);
     if (lean_spline)
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                              accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out, context, C);

@@ -1595,7 +1595,10 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     n_seg = len(chain.segments)
     padded = chain.pos_in is not None
     # lean programs read narrower rows themselves (tfk_flow_run_mfma_in): no padding pass over the rows
-    narrow_in = (padded and chain.D_log % 2 == 0 and n_seg > 0 and chain.segments[0].mfma and context is None
+    # (odd event sizes: the lean affine / shift chains read them in place too -- the interpreter's plane-per-element programs
+    # start with an op below OP_AFFINE_FWD_LEAN and take the padding pass)
+    narrow_in = (padded and n_seg > 0 and chain.segments[0].mfma and context is None
+                 and (chain.D_log % 2 == 0 or OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_SHIFT_INV_LEAN)
                  and (OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN
                       or chain.segments[0].ops[0][0] in (OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN)) and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
