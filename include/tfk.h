@@ -220,7 +220,8 @@ enum {
      * reversals between the couplings -- the MIDDLE element is a target of EVERY coupling, so it has to sit in whichever
      * plane is being transformed: both planes reserve their last column (D/2 - 1 of the plane) for it, and a coupling whose
      * src_plane carries bit 2 first takes the element over from the other plane's last column and clears that one.
-     * Resident operands only (no streaming), no context. */
+     * Resident operands only (no streaming), no context.  The lean spline couplings (TFK_OP_RQS_*_LEAN, TFK_OP_LRS_*_LEAN)
+     * take the same bit. */
     TFK_OP_AFFINE_FWD_LEAN = 12,
     TFK_OP_AFFINE_INV_LEAN = 13,
     TFK_OP_SHIFT_FWD_LEAN = 14,
@@ -321,7 +322,7 @@ int tfk_flow_run_mfma(const float *x, float *z, float *logdet, const float *gaus
  * of plane B, zeros behind them -- the layout the packer pads such flows to (zero weights make the padding an exact
  * identity), without a host-side padding pass over the rows.  Lean programs only; z / logdet / logprob as above
  * (z in the kernel's D-wide physical layout).
- * An ODD x_width (ABI v27; affine / shift chains whose couplings carry the move bit, (x_width + 1) / 2 <= D / 2):
+ * An ODD x_width (ABI v27; chains of affine / shift / spline couplings that carry the move bit, (x_width + 1) / 2 <= D / 2):
  * x_width / 2 sources into the head of plane A, the middle element into plane B's LAST column, the remaining x_width / 2
  * elements into the head of plane B. */
 /* tfk_flow_run_mfma_in for a LEAN program that ends in the base density, plus the fp64 sum of the launch's N

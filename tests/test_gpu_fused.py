@@ -435,7 +435,8 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
                                              ("RealNVP", 3, 2), ("RealNVP", 7, 3), ("NICE", 21, 4), ("RealNVP", 43, 8),
                                              ("RealNVP", 63, 5), ("RealNVP", 15, 4), ("RealNVP", 31, 3), ("NICE", 5, 3),
                                              ("RealNVP", 99, 3), ("RealNVP", 127, 2), ("NICE", 201, 3), ("CouplingRQNSF", 22, 3), ("CouplingRQNSF", 8, 2),
-                                             ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2),
+                                             ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2), ("CouplingRQNSF", 7, 2),
+                                             ("CouplingRQNSF", 63, 3), ("CouplingRQNSF", 99, 2),
                                              ("MAF", 6, 2), ("MAF", 21, 3), ("MAF", 43, 2), ("MAF", 100, 2),
                                              ("MaskedAutoregressiveRQNSF", 22, 2)])
 def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, arch, D, n_layers):
@@ -473,14 +474,14 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
              round_trip=normwise(xr.cpu().numpy(), x.numpy()), ld_sum=rel((ld + ldi).cpu().numpy(), 0.0))
     print(arch, D, n_layers, res["1"][5], res["0"][5], {k: f"{v:.1e}" for k, v in e.items()})
     assert z.shape == x.shape and xr.shape == x.shape
-    if D % 2 and arch in ("RealNVP", "NICE"):
+    if D % 2 and arch in ("RealNVP", "NICE", "CouplingRQNSF"):
         # odd event sizes of affine / shift chains: the straight-line kernel with the middle element changing planes
         # (round 3) -- ONE launch per pass at the narrowest row width that holds (D + 1) / 2 columns per plane; against the
         # interpreter's plane-per-element route (TORCHFLOWS_AMD_ODD_LEAN=0) to fp32 rounding
         from torchflows_amd import fused as fz
         flow.invalidate_native_caches()            # (the cache remembers that the chain was declined without padding)
         chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
-        want_w = next(w for w in (16, 32, 64, 128, 256) if (D + 1) // 2 <= w // 2)
+        want_w = next(w for w in ((32, 64, 128) if "RQ" in arch else (16, 32, 64, 128, 256)) if (D + 1) // 2 <= w // 2)
         assert chain is not None and chain.D == want_w and len(chain.segments) == 1, (chain.D, len(chain.segments))
         assert res["1"][5] == 3
         monkeypatch.setenv("TORCHFLOWS_AMD_ODD_LEAN", "0")
@@ -491,7 +492,8 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
             xs, lps = flow.sample((300,), return_log_prob=True)
         monkeypatch.delenv("TORCHFLOWS_AMD_ODD_LEAN")
         flow.invalidate_native_caches()
-        assert rel(lp.cpu().numpy(), lp_i.cpu().numpy()) < 1e-5 and normwise(z.cpu().numpy(), z_i.cpu().numpy()) < 1e-5
+        tol_i = 4e-5 if "RQ" in arch else 1e-5
+        assert rel(lp.cpu().numpy(), lp_i.cpu().numpy()) < tol_i and normwise(z.cpu().numpy(), z_i.cpu().numpy()) < tol_i
         with torch.no_grad():                      # the sampled rows evaluate to the density the other route returned
             x_back, ld_back = flow.bijection.inverse(flow.bijection.forward(xs)[0])
         assert normwise(x_back.cpu().numpy(), xs.cpu().numpy()) < 1e-4

@@ -100,6 +100,12 @@ static int run_rqs_chain(const float *x, float *z, float *logdet, const float *l
         if ((src >> 4) != cs_want)                           // src_plane bits 4..7: k-steps of context in GEMM 1
             return fail(TFK_EINVAL, "%s: op %d: %d context k-steps but the call carries a context of %d elements", fn, i, src >> 4, Cn);
         src &= 15;
+        if (src & 4) {                                       // odd event sizes: this layer first takes the middle element over
+            if (made || context || prog.n_layers >= 64)
+                return fail(TFK_EINVAL, "%s: op %d: only plain spline couplings (no MADE layers, no context) move a middle element", fn, i);
+            prog.move_mask |= 1ull << prog.n_layers;
+            src &= 3;
+        }
         if (k != TFK_OP_RQS_FWD_LEAN && k != TFK_OP_RQS_INV_LEAN && k != TFK_OP_LRS_FWD_LEAN && k != TFK_OP_LRS_INV_LEAN &&
             !(k >= TFK_OP_MADE_RQS_FWD_LEAN && k <= TFK_OP_MADE_LRS_INV_LEAN))
             return fail(TFK_EINVAL, "%s: op %d: kind %d cannot be mixed with lean spline ops", fn, i, k);
@@ -329,11 +335,13 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     if (sum_ws && (!lean || !logprob || !sum_out))
         return fail(TFK_EINVAL, "%s: the in-kernel sum needs a lean program, logprob and sum_out", fn);
     // (an odd width: affine / shift chains whose couplings move the middle element -- it is read into plane B's last column)
-    const bool odd_ok = (x_width & 1) && x_width >= 3 && (x_width + 1) / 2 <= D / 2 && !lean_spline &&
-                        first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN;
+    const bool odd_ok = (x_width & 1) && x_width >= 3 && (x_width + 1) / 2 <= D / 2 &&
+                        ((first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN) ||
+                         first_kind == TFK_OP_RQS_FWD_LEAN || first_kind == TFK_OP_RQS_INV_LEAN ||
+                         first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || ((x_width & 1) && !odd_ok)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d "
-                    "(odd: an affine / shift chain, (x_width + 1) / 2 <= D / 2)", fn, x_width, D);
+                    "(odd: a chain of couplings, (x_width + 1) / 2 <= D / 2)", fn, x_width, D);
     if (lean_spline)
         return run_rqs_chain(x, z, logdet, gauss_loc, gauss_log_scale, logprob, N, D, ops, n_ops, params, n_params,
                              accumulate, x_width, static_cast<hipStream_t>(stream), fn, sum_ws, sum_out, context, C);

@@ -60,6 +60,7 @@ struct RqsChainProg {
     RqsLean C;
     double *sum_ws;           // tfk_flow_run_mfma_sum (see ChainProg)
     double *sum_out;
+    unsigned long long move_mask;   // odd event sizes: layer l first takes the middle element over (ChainProg::move_mask)
 };
 
 constexpr int kRqsChunkFloats = 48 * 256 + 48 * 16;
@@ -804,15 +805,17 @@ void k_flow_rqs_chain(
             // rows narrower than the kernel's planes (event sizes that are not 64 / 128 / 256): the caller's rows are
             // read as they are -- first half into the head of plane A, second half into the head of plane B, zeros
             // behind them (the padding is an exact identity by construction of the weights, fused.py)
-            const int hl = xw >> 1;
+            // (an ODD width: hl sources, the middle element -- into plane B's last column --, hl targets; tfk_flow_chain.h)
+            const int hl = xw >> 1, odd = xw & 1;
             const float *xr = x + rr * xw;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int col = EPL * q + e;
                 const bool ok = col < hl;
                 a[e] = ok ? xr[col] : 0.0f;
-                b[e] = ok ? xr[hl + col] : 0.0f;
+                b[e] = ok ? xr[hl + odd + col] : 0.0f;
             }
+            if (odd && q == 3) b[EPL - 1] = xr[hl];
         }
         };
         load_rows();
@@ -850,15 +853,21 @@ void k_flow_rqs_chain(
                 if constexpr (MADE) {
                     rqs_made_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST>(gprm, stage, lane, q, C, a, b, ld2, amax);
                 } else if constexpr (F3) {
-                    if (((prog.first_src + l) & 1) == 0)
+                    if (((prog.first_src + l) & 1) == 0) {
+                        if ((prog.move_mask >> l) & 1ull) move_middle<EPL>(q, b, a);      // (odd event sizes)
                         rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST, CTX>(gprm, stage, lane, q, C, a, b, ld2, amax, cx, prog.ctx_steps);
-                    else
+                    } else {
+                        if ((prog.move_mask >> l) & 1ull) move_middle<EPL>(q, a, b);
                         rqs_layer3<EPL, BLOCK, HT3, INVERSE, LRS, FAST, CTX>(gprm, stage, lane, q, C, b, a, ld2, amax, cx, prog.ctx_steps);
+                    }
                 } else {
-                    if (((prog.first_src + l) & 1) == 0)
+                    if (((prog.first_src + l) & 1) == 0) {
+                        if ((prog.move_mask >> l) & 1ull) move_middle<EPL>(q, b, a);
                         rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, a, b, ld2);
-                    else
+                    } else {
+                        if ((prog.move_mask >> l) & 1ull) move_middle<EPL>(q, a, b);
                         rqs_layer<EPL, BLOCK, STEPS2, INVERSE>(gprm, stage, lane, q, C, b, a, ld2);
+                    }
                 }
             }
         };

@@ -1135,8 +1135,10 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                 if kind0 is not None and kind0 in (6, 7, 10, 12):
                     return None                               # (couplings and MADE layers do not share a program)
                 steps2 = (H + 3) // 4
-                if (Dp < 32 or odd) and lk >= 4:
-                    return None                               # (16-wide rows, odd event sizes: affine / shift chains only)
+                if Dp < 32 and lk >= 4:
+                    return None                               # (16-wide rows: affine / shift chains only)
+                if odd and lk >= 4 and not rqs_bf16x3_enabled():
+                    return None                               # (odd event sizes of spline chains: the bf16 x 3 format)
                 if lk >= 8 and not rqs_bf16x3_enabled():
                     return None                               # (linear rational splines: bf16 x 3 operands only)
                 if lk >= 4 and rqs_bf16x3_enabled():
@@ -1158,7 +1160,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                         return None
                     block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
                                            float(np.float32(tr.const)), bf16x3=True, lrs=True, W1c=W1c)
-                    items.append((OP_LRS_FWD_LEAN + lk - 8, plane, steps2, block, extra))
+                    items.append((OP_LRS_FWD_LEAN + lk - 8, plane | moved, steps2, block, extra))
                 elif lk >= 4:                                # RQ spline: one launch for the chain, operands streamed
                     tr = layer.transformer
                     fmt3 = rqs_bf16x3_enabled()                       # (the last hidden unit carries the bias: H <= 31)
@@ -1171,7 +1173,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                         return None
                     block = _pack_lean_rqs(H, Dp, W1f, b1f, W2p, b2p, s[tgt].clone(), t[tgt].clone(),
                                            float(np.float32(tr.boundary_u_delta)), bf16x3=fmt3, W1c=W1c)
-                    items.append((OP_RQS_FWD_LEAN + lk - 4, plane, steps2, block, extra))
+                    items.append((OP_RQS_FWD_LEAN + lk - 4, plane | moved, steps2, block, extra))
                 else:
                     use3 = aff3 and H <= 15 and not context
                     if items and bool(items[-1][4]) != use3:
@@ -1316,7 +1318,9 @@ def compile_chain(composition, direction: int, device: torch.device,
             chain = _compile_lean(composition, plan, device, D, w, lay, lay.clone(), context=False, odd=True)
             if chain is not None:
                 return chain
-            break                                # (a wider row would not make a chain lean that is not lean here)
+            if w >= 32:
+                break                            # (a wider row would not make a chain lean that is not lean here; 16-wide
+                                                 # rows are for affine / shift chains only: a spline chain gets 32)
     if odd_wide:
         return None                              # (no interpreter route at these sizes)
     pos = planes(Dp)
@@ -1598,7 +1602,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     # (odd event sizes: the lean affine / shift chains read them in place too -- the interpreter's plane-per-element programs
     # start with an op below OP_AFFINE_FWD_LEAN and take the padding pass)
     narrow_in = (padded and n_seg > 0 and chain.segments[0].mfma and context is None
-                 and (chain.D_log % 2 == 0 or OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_SHIFT_INV_LEAN)
+                 and (chain.D_log % 2 == 0 or OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_SHIFT_INV_LEAN
+                      or chain.segments[0].ops[0][0] in (OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN))
                  and (OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN
                       or chain.segments[0].ops[0][0] in (OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN)) and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
