@@ -665,3 +665,36 @@ def test_compiled_programs_retire_on_replacement_move_and_context_width():
     small = tfa.Flow(tfa.RealNVP(4, n_layers=1))
     losses = sharded_fit(small, torch.randn(40, 4), n_epochs=3, batch_size=16, lr=1e-3)
     assert len(losses) == 9 and all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("arch,D,want_w", [("RealNVP", 3, 16), ("RealNVP", 15, 16), ("NICE", 21, 32), ("RealNVP", 63, 64),
+                                           ("RealNVP", 99, 128), ("NICE", 201, 256), ("CouplingRQNSF", 7, 32),
+                                           ("CouplingRQNSF", 63, 64)])
+def test_odd_event_sizes_compile_to_lean_programs(arch, D, want_w):
+    """The packer's side of odd event sizes (no GPU needed: the programs are packed on the host): the narrowest row width
+    with (D + 1) / 2 columns per plane, ONE segment, the middle element reserved the last column of both planes -- it starts
+    in plane B's, every coupling that finds it in its source plane carries the move bit (bit 2 of src_plane) and the source
+    planes still alternate --, and the final layout a permutation of D distinct columns."""
+    import torchflows_amd as tfa
+    from torchflows_amd import fused as fz
+    torch.manual_seed(D)
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=4))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(128, D))
+    flow.eval()
+    for direction in (0, 1):
+        chain = fz.compile_chain(flow.bijection, direction, torch.device("cpu"))
+        assert chain is not None and chain.D == want_w and len(chain.segments) == 1 and chain.D_log == D
+        h, hp = D // 2, want_w // 2
+        assert chain.pos_in[:h].tolist() == list(range(h)) and int(chain.pos_in[h]) == want_w - 1
+        assert chain.pos_in[h + 1:].tolist() == [hp + i for i in range(h)]
+        assert len(set(chain.pos.tolist())) == D and int(chain.pos.max()) < want_w
+        couplings = [op for op in chain.segments[0].ops if op[0] != fz.OP_EW_FMA]
+        assert len(couplings) == 4
+        planes = [op[1] & 1 for op in couplings]
+        assert all(a != b for a, b in zip(planes, planes[1:]))                  # the source planes alternate
+        moves = [bool(op[1] & 4) for op in couplings]
+        # the middle element sits in plane B at first: a first coupling that reads plane B must take it over, and from then
+        # on every coupling does (its source plane is the previous one's target plane)
+        assert moves[0] == (planes[0] == 1) and all(moves[1:]), (planes, moves)

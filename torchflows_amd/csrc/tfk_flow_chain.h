@@ -403,7 +403,7 @@ __device__ __forceinline__ void move_middle(int q, float (&to)[EPL], float (&fro
 }
 
 // the couplings (or MADE layers) of the program on the 16 rows a wave holds
-template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false>
+template <int EPL, int STEPS2, int KIND, bool FAST, bool CTX = false, bool ODD = false>
 __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &prog, int lane, int q, float (&a)[EPL],
                                              float (&b)[EPL], float &ld2, float &umin,
                                              const float (&cx)[4] = {0.0f, 0.0f, 0.0f, 0.0f})
@@ -415,7 +415,9 @@ __device__ __forceinline__ void chain_layers(const float *lds, const ChainProg &
         for (; o < prog.n_c; ++o)
             made_lean<EPL, STEPS2 == 0 ? 1 : STEPS2, KIND, FAST>(lds + prog.offset[o], lane, q, a, b, ld2, umin);
     } else {
-        const unsigned long long mv = prog.move_mask;          // (0 for even event sizes: the branches below are uniform)
+        // (ODD: its own instantiation -- as uniform run-time branches the moves cost the even-size programs 2 %: 248.1 / 246.1
+        // against 242.8 / 241.3 us per RealNVP-64 step on the same box)
+        const unsigned long long mv = ODD ? prog.move_mask : 0ull;
         if (prog.first_src == 1 && prog.n_c > 0) {
             if (mv & 1ull) move_middle<EPL>(q, a, b);
             couple_fmt<EPL, STEPS2, KIND, FAST, CTX>(lds + prog.offset[0], lane, q, b, a, ld2, umin, cx, cs);
@@ -584,7 +586,7 @@ __device__ __forceinline__ void chain_layers_stream(float *buf0, const float *__
 #define TFK_CHAIN_ATTR
 #endif
 
-template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false, bool ODD = false>
 __global__ __launch_bounds__(BLOCK) TFK_CHAIN_ATTR
 __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 16 && BLOCK == 1024) || (EPL == 8 && CTX)) ? 4 : 1)))) void k_flow_chain(
     const float *__restrict__ x, float *z, float *logdet, const float *__restrict__ gauss_loc,
@@ -758,12 +760,12 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
             for (int i = 0; i < kChainSideOps; ++i)                   // the elementwise layers behind the couplings
                 if (prog.post_kind[i]) side_op<EPL>(prog.post_kind[i], lds + prog.post_off[i], prog.ctx_steps, lane, q, a, b, ld, cx);
         } else {
-        chain_layers<EPL, STEPS2, KIND, kShortcut>(lds, prog, lane, q, a, b, ld2, umin);
+        chain_layers<EPL, STEPS2, KIND, kShortcut, false, ODD>(lds, prog, lane, q, a, b, ld2, umin);
         if constexpr (kShortcut) {
             if (__builtin_amdgcn_ballot_w64(umin < kLogShortcutMin) != 0) {   // scales near the 1e-10 floor: with logarithms
                 load_rows();                                          // (x is still intact: z is stored below)
                 ld2 = 0.0f;
-                chain_layers<EPL, STEPS2, KIND, false>(lds, prog, lane, q, a, b, ld2, umin);
+                chain_layers<EPL, STEPS2, KIND, false, false, ODD>(lds, prog, lane, q, a, b, ld2, umin);
             }
         }
         }
@@ -844,7 +846,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
     }
 }
 
-template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false>
+template <int EPL, int BLOCK, int STEPS2, int KIND, bool STREAM = false, bool CTX = false, bool ODD = false>
 static int launch_chain_b(const float *x, float *z, float *logdet, const float *loc, const float *log_scale,
                           float *logprob, int64_t N, const float *params, int n_params, const ChainProg &prog,
                           int flags, int xw, hipStream_t s, const char *fn)
@@ -855,7 +857,7 @@ static int launch_chain_b(const float *x, float *z, float *logdet, const float *
                        + (prog.sum_ws ? (size_t)BLOCK * sizeof(double) : 0);       // one fp64 slot per thread
     if (lds > 160 * 1024)
         return fail(TFK_EINVAL, "%s: %zu bytes of parameters do not fit the 160 KiB LDS; split the program", fn, lds);
-    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM, CTX>;
+    auto kern = &k_flow_chain<EPL, BLOCK, STEPS2, KIND, STREAM, CTX, ODD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -933,6 +935,21 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
 #define TFK_CHAIN_BIG16 768
 #endif
     constexpr int BIG = (EPL == 16) ? TFK_CHAIN_BIG16 : 512;
+    if (prog.move_mask) {                                    // odd event sizes: the instantiation with the middle-element moves
+        if constexpr (KIND < 4) {
+#define TFK_CBO(BLOCK_, ST_) \
+    launch_chain_b<EPL, BLOCK_, ST_, KIND, false, false, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
+            switch (steps2) {
+            case 1: return big ? TFK_CBO(BIG, 1) : TFK_CBO(kBlock, 1);
+            case 2: return big ? TFK_CBO(BIG, 2) : TFK_CBO(kBlock, 2);
+            case 3: return big ? TFK_CBO(BIG, 3) : TFK_CBO(kBlock, 3);
+            case 4: return big ? TFK_CBO(BIG, 4) : TFK_CBO(kBlock, 4);
+            default: break;
+            }
+#undef TFK_CBO
+        }
+        return fail(TFK_EINVAL, "%s: programs of odd event sizes: affine / shift couplings with fp32 operands, 1..4 GEMM-2 steps", fn);
+    }
 #define TFK_CB(BLOCK_, ST_) \
     launch_chain_b<EPL, BLOCK_, ST_, KIND>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
     switch (steps2) {

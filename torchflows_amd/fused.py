@@ -970,7 +970,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     # bf16 x 3 operands for affine / shift chains: D = 64 only, and the whole chain must stay ONE launch (10.6 KB of
     # operands per coupling instead of 5.7): decided after a dry count of the couplings
     n_couplings = sum(isinstance(layer, CouplingBijection) for layer, _ in plan)
-    aff3 = lean_bf16x3_enabled() and Dp == 64 and 0 < n_couplings <= 13
+    aff3 = lean_bf16x3_enabled() and Dp == 64 and 0 < n_couplings <= 13 and not odd
     # (context) if a context-conditioned elementwise layer precedes the first coupling, every elementwise layer before
     # that coupling is an interpreter op of the launch in front of the chain (the inverse direction starts with a
     # constant ActNorm followed by the context-conditioned layer)
