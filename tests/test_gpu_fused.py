@@ -434,7 +434,7 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
                                              ("RealNVP", 100, 3), ("RealNVP", 200, 2),
                                              ("RealNVP", 3, 2), ("RealNVP", 7, 3), ("NICE", 21, 4), ("RealNVP", 43, 8),
                                              ("RealNVP", 63, 5), ("RealNVP", 15, 4), ("RealNVP", 31, 3), ("NICE", 5, 3),
-                                             ("RealNVP", 99, 3), ("RealNVP", 127, 2), ("NICE", 201, 3), ("CouplingRQNSF", 22, 3), ("CouplingRQNSF", 8, 2),
+                                             ("RealNVP", 99, 3), ("RealNVP", 127, 2), ("NICE", 201, 3), ("RealNVP", 201, 9), ("CouplingRQNSF", 22, 3), ("CouplingRQNSF", 8, 2),
                                              ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2), ("CouplingRQNSF", 7, 2),
                                              ("CouplingRQNSF", 63, 3), ("CouplingRQNSF", 99, 2),
                                              ("MAF", 6, 2), ("MAF", 21, 3), ("MAF", 43, 2), ("MAF", 100, 2),
@@ -482,8 +482,10 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
         flow.invalidate_native_caches()            # (the cache remembers that the chain was declined without padding)
         chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
         want_w = next(w for w in ((32, 64, 128) if "RQ" in arch else (16, 32, 64, 128, 256)) if (D + 1) // 2 <= w // 2)
-        assert chain is not None and chain.D == want_w and len(chain.segments) == 1, (chain.D, len(chain.segments))
-        assert res["1"][5] == 3
+        # (RealNVP(201, 9 layers): 198 KB of operands at 256 columns -- odd sizes keep them resident, so two launches per pass)
+        n_seg = 2 if (D, n_layers) == (201, 9) else 1
+        assert chain is not None and chain.D == want_w and len(chain.segments) == n_seg, (chain.D, len(chain.segments))
+        assert res["1"][5] == 3 * n_seg
         monkeypatch.setenv("TORCHFLOWS_AMD_ODD_LEAN", "0")
         flow.invalidate_native_caches()
         with torch.no_grad():
