@@ -93,20 +93,21 @@ def _run_bench(args, env, timeout=900):
 def test_bench_four_ranks_rehearsal():
     """The path the driver's 1 / 2 / 4 / 8-GPU scaling run takes, rehearsed with everything but RCCL: four ranks that
     share this box's one card (the pool allows at most 6 GPU processes; the 8-rank launch is the driver's) over gloo,
-    started by `python bench.py --gpus 4` itself.  Config 2 weak scaling, then config 4's strong-scaling form, whose
+    started by `python bench.py --gpus 4` itself: config 4's strong-scaling form, whose
     all-reduced log-likelihood must equal the ONE-rank value of the same global data set to 1e-9 and be the sum of the
     ranks' shards; every rank reports its own step time (a straggler would show as max >> min)."""
     env = dict(os.environ, TORCHFLOWS_AMD_DIST_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    d = _run_bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--rows", "16384", "--stats-steps", "0"], env)
-    assert d["n_gpus"] == d["rccl_ranks"] == 4 and d["rows_all_ranks"] == 4 * 16384 and d["scaling"] == "weak"
-    assert len(d["rank_ms_per_step"]["per_rank"]) == 4 and 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"]
-    assert abs(sum(d["log_likelihood_shards"]) - d["log_likelihood_sum"]) <= 1e-9 * abs(d["log_likelihood_sum"])
+    # (config 2's weak-scaling form with several ranks is test_bench_starts_its_own_ranks' 2-rank run -- the same code path;
+    # every launch of four ranks costs a minute of interpreter start-up on a fresh box, so the 4-rank launch here is the
+    # strong-scaling one, which checks more)
     strong = ["--workload", "realnvp256", "--total-rows", "131072", "--steps", "2", "--warmup", "1", "--stats-steps", "0",
               "--no-sample", "--no-train", "--no-cpu-baseline"]
     one = _run_bench(["--gpus", "1"] + strong, env)
     four = _run_bench(["--gpus", "4"] + strong, env)
+    assert len(four["rank_ms_per_step"]["per_rank"]) == 4
+    assert 0 < four["rank_ms_per_step"]["min"] <= four["rank_ms_per_step"]["max"]
     assert four["n_gpus"] == four["rccl_ranks"] == 4 and four["scaling"] == "strong"
     assert four["rows_all_ranks"] == one["rows_all_ranks"] == 131072 and four["config"]["rows_per_gpu"] == 32768
     assert abs(four["log_likelihood_sum"] - one["log_likelihood_sum"]) <= 1e-9 * abs(one["log_likelihood_sum"])

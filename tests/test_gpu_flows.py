@@ -359,7 +359,7 @@ def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch
     flow = pkg.Flow(getattr(pkg, arch)(D, **kw))
     flow.train()
     with torch.no_grad():          # (Inverse* presets: log_prob is the D-pass sequential map on the host -- a small batch)
-        flow.log_prob(torch.randn(2048 if (arch.startswith("Masked") or D < 64) else 192, D))
+        flow.log_prob(torch.randn(2048 if arch.startswith("Masked") else 192, D))
     flow.eval()
     sd = {k: v.numpy() for k, v in flow.state_dict().items()}
     ref = oracle.preset_from_state_dict(arch, D, 2, sd)

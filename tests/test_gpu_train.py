@@ -255,7 +255,20 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     with torch.no_grad():
         before = float(flow.log_prob(x).mean())
     host, dev = copy.deepcopy(flow), copy.deepcopy(flow).cuda()
-    host.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
+    if (arch, D) == ("CouplingRQNSF", 64):
+        # (five epochs of the 64-wide spline flow take 20 s on the host: here the reference trajectory is the EAGER
+        # device fit -- which the 8-wide case above holds against the host)
+        import os
+        host = host.cuda()
+        os.environ["TORCHFLOWS_AMD_GRAPH"] = "0"
+        try:
+            host.fit(x.cuda(), n_epochs=5, lr=lr, x_val=x[:1024].cuda(), shuffle=False)
+        finally:
+            del os.environ["TORCHFLOWS_AMD_GRAPH"]
+        assert host._fit_stats["graph_captures"] == 0
+        host = host.cpu()
+    else:
+        host.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     calls = native.calls
     dev.fit(x, n_epochs=5, lr=lr, x_val=x[:1024], shuffle=False)
     assert native.calls > calls
