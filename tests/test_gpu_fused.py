@@ -439,7 +439,7 @@ def test_sample_log_prob_rides_in_the_inverse_program(pkg, oracle, arch, D):
                                              ("RealNVP", 99, 3), ("RealNVP", 127, 2), ("NICE", 201, 3), ("RealNVP", 201, 9), ("CouplingRQNSF", 22, 3), ("CouplingRQNSF", 8, 2),
                                              ("CouplingRQNSF", 21, 2), ("CouplingRQNSF", 100, 2), ("CouplingRQNSF", 7, 2),
                                              ("CouplingRQNSF", 63, 3), ("CouplingRQNSF", 99, 2),
-                                             ("MAF", 6, 2), ("MAF", 21, 3), ("MAF", 43, 2), ("MAF", 100, 2),
+                                             ("MAF", 6, 2), ("MAF", 21, 3), ("MAF", 43, 2), ("MAF", 100, 2), ("MAF", 7, 2), ("MAF", 99, 2),
                                              ("MaskedAutoregressiveRQNSF", 22, 2)])
 def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, arch, D, n_layers):
     """Event sizes other than 64 / 128 / 256.  Even: both halves of the row are padded to the next supported
@@ -501,6 +501,18 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
         with torch.no_grad():                      # the sampled rows evaluate to the density the other route returned
             x_back, ld_back = flow.bijection.inverse(flow.bijection.forward(xs)[0])
         assert normwise(x_back.cpu().numpy(), xs.cpu().numpy()) < 1e-4
+    if D % 2 and arch == "MAF":
+        # odd MAF: any layout serves a MADE layer (every element is read and transformed), so the density direction is the
+        # lean chain at the next row width, read in place -- ONE launch per log_prob
+        from torchflows_amd import fused as fz
+        flow.invalidate_native_caches()
+        chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
+        assert chain is not None and chain.D == next(w for w in (32, 64, 128) if (D + 1) // 2 <= w // 2)
+        assert len(chain.segments) == 1 and chain.segments[0].ops[0][0] == fz.OP_MADE_FWD_LEAN
+        before = native.calls
+        with torch.no_grad():
+            lp_again = flow.log_prob(x.cuda())
+        assert native.calls - before == 1 and torch.equal(lp_again, lp)
     tol = 4e-5 if "RQ" in arch else 1e-5
     assert max(e["lp"], e["lp_lw"], e["ld_lw"]) < tol * max(1.0, D / 64) and e["z"] < 2 * tol
     assert e["round_trip"] < 10 * tol and e["ld_sum"] < 1e-4

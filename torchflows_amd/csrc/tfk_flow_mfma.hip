@@ -338,7 +338,8 @@ static int flow_run_mfma_impl(const float *x, int32_t x_width, float *z, float *
     const bool odd_ok = (x_width & 1) && x_width >= 3 && (x_width + 1) / 2 <= D / 2 &&
                         ((first_kind >= TFK_OP_AFFINE_FWD_LEAN && first_kind <= TFK_OP_SHIFT_INV_LEAN) ||
                          first_kind == TFK_OP_RQS_FWD_LEAN || first_kind == TFK_OP_RQS_INV_LEAN ||
-                         first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN);
+                         first_kind == TFK_OP_LRS_FWD_LEAN || first_kind == TFK_OP_LRS_INV_LEAN ||
+                         first_kind == TFK_OP_MADE_FWD_LEAN || first_kind == TFK_OP_MADE_INV_LEAN);
     if (x_width != D && (!lean || x_width < 2 || x_width > D || ((x_width & 1) && !odd_ok)))
         return fail(TFK_EINVAL, "%s: x_width = %d: narrower input rows need a lean program and an even width <= D = %d "
                     "(odd: a chain of couplings, (x_width + 1) / 2 <= D / 2)", fn, x_width, D);

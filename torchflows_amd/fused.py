@@ -1061,8 +1061,9 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
                     t[pos] = alpha * t[pos] + beta
                     ld_const = ld_const + torch.log(alpha).sum()
             elif isinstance(layer, MaskedAutoregressiveBijection):
-                if context or Dp < 32 or odd:
-                    return None
+                if context or Dp < 32:
+                    return None                              # (odd event sizes: any layout serves a MADE layer -- the
+                                                             # conditioner reads and transforms every element; no moves)
                 got = _lean_made(layer, d, pos, D, Dp)       # MAF density / IAF sampling: the parallel map
                 if got is None:
                     return None
@@ -1603,7 +1604,8 @@ def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=No
     # start with an op below OP_AFFINE_FWD_LEAN and take the padding pass)
     narrow_in = (padded and n_seg > 0 and chain.segments[0].mfma and context is None
                  and (chain.D_log % 2 == 0 or OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_SHIFT_INV_LEAN
-                      or chain.segments[0].ops[0][0] in (OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN))
+                      or chain.segments[0].ops[0][0] in (OP_RQS_FWD_LEAN, OP_RQS_INV_LEAN, OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN,
+                                                         OP_MADE_FWD_LEAN, OP_MADE_INV_LEAN))
                  and (OP_AFFINE_FWD_LEAN <= chain.segments[0].ops[0][0] <= OP_RQS_INV_LEAN
                       or chain.segments[0].ops[0][0] in (OP_LRS_FWD_LEAN, OP_LRS_INV_LEAN)) and narrow_enabled())
     if padded and not narrow_in:                 # (N, D_log) -> (N, D): each half at the head of its plane
