@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full parametric grids of the GPU suite (deselected unless --runslow)")
+
+
+def free_port() -> str:
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous of the multi-process tests: no hard-coded ports)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
 
 
 def load_golden(name):

@@ -657,11 +657,13 @@ def test_sharded_fit_two_ranks_on_one_card(native):
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_fit_gpu_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    from conftest import free_port
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29671", script],
+                          "--master-addr", "127.0.0.1", "--master-port", port, script],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "DIST_FIT_GPU_OK" in out.stdout

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_golden, state_dict_of
+from conftest import ROOT, free_port, load_golden, state_dict_of
 
 import torchflows_amd as tfa
 from torchflows_amd import native
@@ -320,7 +320,7 @@ def test_sharded_log_likelihood_two_ranks_gloo(world):
     """N > 1 path on CPU: each rank evaluates its shard, one all-reduce of the fp64 sum.  world = 8 is the rank count
     of the driver's scaling run (1001 rows: shards of 126 / 125 rows): every rank must hold the 1-process total."""
     script = os.path.join(ROOT, "tests", "dist_worker.py")
-    port = str(29653 + world)
+    port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1" if world > 2 else "2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", port,
@@ -333,9 +333,10 @@ def test_sharded_fit_two_ranks_gloo():
     """Data-parallel training on CPU: per-rank shards, one all-reduce of the flat gradient per step,
     ActNorm statistics of the global first batch; must reproduce the one-process run."""
     script = os.path.join(ROOT, "tests", "dist_fit_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", OMP_NUM_THREADS="2")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29655",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", port,
                           script], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_FIT_OK" in out.stdout
@@ -467,6 +468,60 @@ def test_torchflows_import_alias_resolves_to_the_build():
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
     assert out.returncode == 0 and "ALIAS_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_reference_spelled_package_imports_and_kl_fit():
+    """the reference re-exports its presets from the PACKAGES
+    (bijections/finite/autoregressive/__init__.py:1-22, multiscale/__init__.py:1-16, matrix/__init__.py:4); every
+    in-scope name resolves by that spelling through the ``torchflows`` alias to this build's class.  And
+    ``BaseFlow.fit_kl_p_to_q`` / ``_loss_kl_p_to_q`` (flows.py:79-197) exist and train: forward KL to a Gaussian target
+    falls and the flow is left in eval mode."""
+    code = (
+        "import torch\n"
+        "from torchflows.bijections.finite.autoregressive import (NICE, RealNVP, MAF, IAF, CouplingRQNSF,\n"
+        "    MaskedAutoregressiveRQNSF, InverseAutoregressiveRQNSF, CouplingLRS, MaskedAutoregressiveLRS,\n"
+        "    InverseAutoregressiveLRS)\n"
+        "from torchflows.bijections.finite.multiscale import MultiscaleNICE, MultiscaleRealNVP, AffineGlow, ShiftGlow\n"
+        "from torchflows.bijections.finite.matrix import ReversePermutationMatrix, RandomPermutationMatrix\n"
+        "from torchflows.flows import Flow, BaseFlow, FlowMixture\n"
+        "import torchflows_amd as tfa\n"
+        "import torchflows_amd.bijections.finite.multiscale.architectures as ms\n"
+        "assert RealNVP is tfa.RealNVP and NICE is tfa.NICE and CouplingRQNSF is tfa.CouplingRQNSF\n"
+        "assert AffineGlow is ms.AffineGlow and MultiscaleRealNVP is ms.MultiscaleRealNVP\n"
+        "try:\n"
+        "    from torchflows.bijections.finite.autoregressive import UMNNMAF\n"
+        "    raise SystemExit('out-of-scope preset resolved')\n"
+        "except ImportError:\n"
+        "    pass\n"
+        "torch.manual_seed(0)\n"
+        "flow = Flow(RealNVP(4, n_layers=2))\n"
+        "tgt = torch.distributions.MultivariateNormal(torch.full((4,), 1.5), 0.25 * torch.eye(4))\n"
+        "xt, xv = tgt.sample((512,)), tgt.sample((128,))\n"
+        "nlp = lambda x: -tgt.log_prob(x)\n"
+        "with torch.no_grad():\n"
+        "    before = float(flow._loss_kl_p_to_q(xv, -nlp(xv), use_regularization=False))\n"
+        "flow.fit_kl_p_to_q(xt, xv, nlp, n_epochs=40, lr=0.02, batch_size=128)\n"
+        "assert not flow.training\n"
+        "with torch.no_grad():\n"
+        "    after = float(flow._loss_kl_p_to_q(xv, -nlp(xv), use_regularization=False))\n"
+        "assert after < 0.25 * before, (before, after)\n"
+        "print('SPELLING_OK', before, after)\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert out.returncode == 0 and "SPELLING_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_kept_optimizer_is_never_captured():
+    """``fit(reset_optimizer=False)`` keeps whatever optimiser an earlier fit built.  A FlatAdamW counts its
+    steps on the host, so (i) ``Flow.fit`` must not capture a step of it into a hipGraph -- ``_optimizer_capturable`` is
+    the gate -- and (ii) torch's own AdamW qualifies only with ``capturable=True`` in every group."""
+    from torchflows_amd.flat_optim import FlatAdamW
+    from torchflows_amd.flows import _optimizer_capturable
+    ps = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(3, 2))]
+    assert not _optimizer_capturable(FlatAdamW(ps, lr=1e-3))
+    assert not _optimizer_capturable(torch.optim.AdamW(ps, lr=1e-3))
+    if torch.cuda.is_available():
+        assert _optimizer_capturable(torch.optim.AdamW([p.cuda() for p in ps], lr=1e-3, capturable=True))
 
 
 @pytest.mark.parametrize("arch,D,n_layers,direction", [("RealNVP", 64, 8, 0), ("RealNVP", 64, 3, 1), ("NICE", 64, 4, 0),
@@ -661,6 +716,17 @@ def test_compiled_programs_retire_on_replacement_move_and_context_width():
         assert chain.ctx_width == 3
         with pytest.raises(ValueError):
             fused.run_chain(chain, torch.zeros(4, 64), want_rows=True, context=torch.zeros(4, 4))
+    # (iii-b) a hand-built composition whose FIRST layer takes no context (an ActNorm in front): the
+    # composition's own context_shape is None (bijections/base.py:203-209) and the width comes from the couplings
+    from torchflows_amd.bijections.base import BijectiveComposition
+    from torchflows_amd.bijections.finite.autoregressive.layers import ActNorm
+    layers = list(cflow.bijection.layers)
+    first = next(i for i, l in enumerate(layers) if isinstance(l, ActNorm))
+    reordered = BijectiveComposition([layers[first]] + layers[:first] + layers[first + 1:]).eval()
+    assert reordered.context_shape is None
+    chain = fused.get_compiled(reordered, 0, cpu, context=True)                # (raised TypeError before)
+    if chain is not None:
+        assert chain.ctx_width == 3
     # (iv)
     small = tfa.Flow(tfa.RealNVP(4, n_layers=1))
     losses = sharded_fit(small, torch.randn(40, 4), n_epochs=3, batch_size=16, lr=1e-3)

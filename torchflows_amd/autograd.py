@@ -605,6 +605,12 @@ class _PlanPacks:
         all gradients of the plan then come out of libtfk accumulators and can leave as slices of one buffer."""
         if not self.layers and not self.rqs_layers:
             return False
+        # ONE layer object (or one parameter tensor) twice in the chain (shared weights): grad_src maps a slot of the parameter buffer to exactly
+        # one accumulator position, so the second use would overwrite the first instead of adding to it -- such a plan
+        # keeps the per-tensor route, where autograd sums the per-step gradients (ADVICE r3)
+        ids = [id(p) for layer, _, kind in self.plan for p in _layer_params(layer, kind)]
+        if len(ids) != len(set(ids)):
+            return False
         outer = rows_outer_enabled()
         for i, (layer, d, kind) in enumerate(self.plan):
             if kind in ("perm", "elementwise") or (kind == "coupling" and i in self.slot):

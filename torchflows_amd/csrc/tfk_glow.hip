@@ -673,17 +673,15 @@ int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tf
     const int64_t tiles = (N + g.tile_rows - 1) / g.tile_rows;
     int64_t grid = layer->grid > 0 ? layer->grid : (int64_t)cu_count() * wgs_per_cu;
     if (grid > tiles) grid = tiles;
-    static bool attr_done[6] = {false, false, false, false, false, false};
+    // (the attribute is per DEVICE: set on every call like the other launchers -- a process-wide "done" flag skipped it
+    // on a second GPU, whose launch then failed for more than 64 KB of LDS)
 #define TFK_GLOW(K, I)                                                                                               \
     do {                                                                                                             \
         auto kern = k_glow_coupling<K, I>;                                                                           \
-        if (!attr_done[2 * K + I]) {                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    kGlowLdsBytes) != hipSuccess)                                                    \
-                return fail(TFK_ELAUNCH, "%s: cannot raise the dynamic LDS limit: %s", fn,                           \
-                            hipGetErrorString(hipGetLastError()));                                                   \
-            attr_done[2 * K + I] = true;                                                                             \
-        }                                                                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                kGlowLdsBytes) != hipSuccess)                                                        \
+            return fail(TFK_ELAUNCH, "%s: cannot raise the dynamic LDS limit: %s", fn,                               \
+                        hipGetErrorString(hipGetLastError()));                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, s, rows, logdet, (long long)N, g,           \
                            layer->src_idx, reinterpret_cast<const float2 *>(layer->src_st), layer->tgt_idx,          \
                            reinterpret_cast<const float2 *>(layer->tgt_st), layer->weights, layer->bg1, layer->bg2,  \

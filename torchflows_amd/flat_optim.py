@@ -148,6 +148,11 @@ class FlatAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._trainable and self._trainable[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # the step count and the bias corrections are host numbers: a captured step would replay ONE step's
+            # corrections for ever (torch's own _cuda_graph_capture_health_check, for the same reason)
+            raise RuntimeError("FlatAdamW.step() cannot be captured into a hipGraph: build the optimiser with "
+                               "make_adamw(..., capturable=True)")
         fb = self._flat
         if fb is None or not fb.intact():
             self._rehome()

@@ -34,6 +34,15 @@ GRAPH_AUTO_MIN_STEPS = 32
 GRAPH_LOSS_LAG = 16
 
 
+def _optimizer_capturable(opt) -> bool:
+    """True for an optimiser whose step may be captured into a hipGraph: torch's own with ``capturable=True`` in every
+    parameter group (its step counters then live on the device).  FlatAdamW keeps its step count on the host."""
+    from torchflows_amd.flat_optim import FlatAdamW
+    if isinstance(opt, FlatAdamW):
+        return False
+    return all(bool(g.get("capturable", False)) for g in opt.param_groups)
+
+
 def _drop_native_caches(module, incompatible_keys=None) -> None:
     module.invalidate_native_caches()
 
@@ -88,6 +97,74 @@ class BaseFlow(nn.Module):
 
     def regularization(self, *args, **kwargs) -> torch.Tensor:
         return torch.tensor(0.0)
+
+    # -- forward-KL fit against a known target density (reference flows.py:79-197) ------------------------------------
+    def _loss_kl_p_to_q(self, data: torch.Tensor, log_prob_target_data: torch.Tensor,
+                        use_regularization: bool = True) -> torch.Tensor:
+        """``mean(log p(x) - log q(x)) [+ regularization]`` on one batch (reference :79-94)."""
+        dev = self.get_device()
+        loss = torch.mean(log_prob_target_data.to(dev) - self.log_prob(data.to(dev)))
+        if use_regularization:
+            loss = loss + self.regularization()
+        return loss
+
+    def fit_kl_p_to_q(self, x_train: torch.Tensor, x_val: torch.Tensor, neg_log_prob_target, n_epochs: int = 500,
+                      lr: float = 0.05, batch_size: int = 1024, show_progress: bool = False,
+                      keep_best_weights: bool = True, early_stopping: bool = False, early_stopping_threshold: int = 50,
+                      time_limit_seconds: float = None, reset_optimizer: bool = True):
+        """Fit by minimising KL(p || q) on samples of p whose (negative) log-density is known; arguments, loss and
+        bookkeeping as the reference's (:96-197): batches in data order (its DataLoader does not shuffle), the
+        validation loss is the SUM of the batch means without the regularisation term, best weights by that sum,
+        early stopping on it, ``eval()`` on return.  As in ``fit`` the two sets and their target log-densities live on
+        the flow's device for the whole call; ``log_prob`` with gradients runs on the reverse-mode kernels there."""
+        if len(list(self.parameters())) == 0:
+            return
+        dev = self.get_device()
+        with torch.no_grad():
+            train = (x_train.to(dev), (-neg_log_prob_target(x_train)).detach().to(dev))
+            val = (x_val.to(dev), (-neg_log_prob_target(x_val)).detach().to(dev))
+        self.train()
+        t0 = time.time()
+        if self._optimizer is None or reset_optimizer:
+            self._optimizer = make_adamw(self.parameters(), lr)
+
+        def snapshot():
+            return {k: v.detach().clone() for k, v in self.state_dict().items()}
+
+        def in_batches(pair):
+            for lo in range(0, len(pair[0]), batch_size):
+                yield pair[0][lo:lo + batch_size], pair[1][lo:lo + batch_size]
+
+        val_loss, best_val, best_epoch, best_weights = None, float("inf"), 0, snapshot()
+        epochs, pbar = range(n_epochs), None
+        if show_progress:
+            from tqdm import tqdm
+            epochs = pbar = tqdm(epochs, desc="Fitting NF")
+        for epoch in epochs:
+            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                print("Training time limit exceeded")
+                break
+            for xb, tb in in_batches(train):
+                self._optimizer.zero_grad()
+                train_loss = self._loss_kl_p_to_q(xb, tb)
+                train_loss.backward()
+                self._optimizer.step()
+                if pbar is not None:
+                    tail = "" if val_loss is None else (f", Validation loss: {val_loss:.4f} "
+                                                        f"[best: {best_val:.4f} @ {best_epoch}]")
+                    pbar.set_postfix_str(f"Training loss (batch): {float(train_loss):.4f}" + tail)
+            with torch.no_grad():
+                total = sum(self._loss_kl_p_to_q(xb, tb, use_regularization=False) for xb, tb in in_batches(val))
+            val_loss = float(total)                    # (one transfer per epoch)
+            if val_loss < best_val:
+                best_val, best_epoch = val_loss, epoch
+                if keep_best_weights:
+                    best_weights = snapshot()
+            if early_stopping and epoch - best_epoch > early_stopping_threshold:
+                break
+        if keep_best_weights:
+            self.load_state_dict(best_weights)
+        self.eval()
 
 
 class Flow(BaseFlow):
@@ -313,6 +390,11 @@ class Flow(BaseFlow):
             use_graph = (not adaptive) and n_epochs * (n_train // max(int(batch_size), 1)) >= GRAPH_AUTO_MIN_STEPS
         if self._optimizer is None or reset_optimizer:
             self._optimizer = make_adamw(self.parameters(), lr, capturable=use_graph)
+        elif use_graph and not _optimizer_capturable(self._optimizer):
+            # fit(reset_optimizer=False) behind variational_fit or a short eager fit keeps THAT optimiser: a FlatAdamW (or a
+            # non-capturable AdamW) counts its steps on the host, and a captured step would replay one step's bias
+            # corrections for ever -- a silently wrong trajectory.  Such a fit runs eager steps.
+            use_graph = False
         graphed = None               # (batch size, graph, static x, static w, static loss, tensor addresses)
         stats = {"eager_steps": 0, "graph_replays": 0, "graph_captures": 0}
         self._fit_stats = stats

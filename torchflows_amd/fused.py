@@ -1458,6 +1458,20 @@ def _live_checksum(module: nn.Module) -> float:
     return acc
 
 
+def _context_width(composition) -> Optional[int]:
+    """Elements per context row the packed weights expect.  A hand-built composition takes its ``context_shape`` from
+    its FIRST layer (bijections/base.py:203-209), which is None when an ActNorm or a permutation stands in front of the
+    context-conditioned couplings: the width comes from the first layer that does define one (None if none does)."""
+    from torchflows_amd.utils import event_size
+    if composition.context_shape is not None:
+        return event_size(composition.context_shape)
+    for m in composition.modules():
+        cs = getattr(m, "context_shape", None)
+        if m is not composition and cs is not None:
+            return event_size(cs)
+    return None
+
+
 def get_compiled(composition, direction: int, device: torch.device, context: bool = False) -> Optional[CompiledChain]:
     """Cached ``compile_chain``; recompiles when a parameter / buffer was modified in place."""
     cache = composition.__dict__.setdefault("_tfk_compiled", {})
@@ -1477,8 +1491,7 @@ def get_compiled(composition, direction: int, device: torch.device, context: boo
         return hit[1]
     chain = compile_chain(composition, direction, device, context=context)
     if chain is not None and context:
-        from torchflows_amd.utils import event_size
-        chain.ctx_width = event_size(composition.context_shape)
+        chain.ctx_width = _context_width(composition)
     cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
     if chain is None:
         warn_declined(composition, direction)

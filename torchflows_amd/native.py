@@ -565,6 +565,31 @@ def rqs_coupling_train_bwd(x, g, gld, params, gemm2_steps, gh_perm, gpre_perm, n
 _rows_outer_ws = {}
 
 
+def _rows_outer_workspace(device, M: int, stream: int):
+    """ONE workspace per (device, M) -- about 25 MB at M = 768 -- whatever the stream: every graph-mode ``Flow.fit`` runs
+    on a fresh side stream, and a copy per stream pinned up to ~0.8 GB for the life of the process.  The
+    buffer is never freed (a captured training step bakes in its address).  A use on ANOTHER stream than the last one
+    first waits for that stream's tail, so two streams never hold the partial sums at the same time; only a stream that
+    is being captured and finds the buffer last used elsewhere gets a private copy (a capture cannot wait on work outside
+    it)."""
+    key = (device.index, M)
+    entry = _rows_outer_ws.get(key)
+    if entry is None:
+        entry = _rows_outer_ws[key] = [torch.empty(int(lib().tfk_rows_outer_workspace_bytes(M)) // 4,
+                                                   dtype=torch.float32, device=device), stream]
+    elif entry[1] != stream:
+        if torch.cuda.is_current_stream_capturing():
+            pkey = (device.index, M, stream)
+            private = _rows_outer_ws.get(pkey)
+            if private is None:
+                private = _rows_outer_ws[pkey] = [torch.empty_like(entry[0]), stream]
+            return private[0]
+        prev = torch.cuda.ExternalStream(entry[1], device=device) if entry[1] else torch.cuda.default_stream(device)
+        torch.cuda.current_stream(device).wait_stream(prev)
+        entry[1] = stream
+    return entry[0]
+
+
 def rows_outer(A, M, B, out):
     """out[M * 16] (accumulator order, include/tfk.h) = sum over the rows of A[n, :M]^T B[n, :16] (tfk_rows_outer):
     the weight-gradient products that contract over the batch rows, deterministic, no GEMM-library call."""
@@ -573,11 +598,7 @@ def rows_outer(A, M, B, out):
     N, lda = _rows(A, name)
     if B.shape != (N, 16) or out.numel() != M * 16 or not out.is_contiguous():
         raise NativeError(f"{name}: B must be (N, 16) and out hold M * 16 = {M * 16} contiguous floats")
-    key = (A.device.index, int(M), _stream(A))
-    ws = _rows_outer_ws.get(key)
-    if ws is None:
-        ws = _rows_outer_ws[key] = torch.empty(int(lib().tfk_rows_outer_workspace_bytes(int(M))) // 4,
-                                               dtype=torch.float32, device=A.device)
+    ws = _rows_outer_workspace(A.device, int(M), _stream(A))
     with _device_guard(A):
         rc = lib().tfk_rows_outer(_f32(A, name), int(lda), int(M), _f32(B, name), _f32(out, name), _f32(ws, name), N,
                                   _stream(A))
