@@ -117,6 +117,9 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     # max(1e-5, 2 x the reference's own fp32 distance), and by the triangle inequality within 1e-5 + 3 x floor of the
     # fp32 value.
     e_lp64 = rel(lp.cpu().numpy(), g("log_prob64"))
+    if e_lp >= 1e-5:
+        import conftest
+        conftest.PARITY_NOTES.append(f"{name[:-4]} {variant} {e_lp:.2e} / {floor_lp:.2e}")
     print(f"    log_prob vs the reference in fp64: {e_lp64:.2e}")
     # Elementwise accuracy where fp32 itself is the limit (spline knots = 100 * cumsum(softmax) - 50: one ulp of a logit
     # moves a knot by up to 1e-5): two independent fp32 evaluations differ from EACH OTHER by the sum of their distances
@@ -128,7 +131,8 @@ def test_flow_golden_on_hip(pkg, name, arch, n_layers, ctx_shape, spline, varian
     pr_x, pr_x_ref = pass_rate(xr.cpu().numpy(), g("x_inv64")), pass_rate(g("x_inv"), g("x_inv64"))
     print(f"    elementwise 1e-5 pass rate vs the reference in fp64: z {pr_z:.4f} (reference's fp32 {pr_z_ref:.4f}), "
           f"x_inv {pr_x:.4f} (reference's fp32 {pr_x_ref:.4f})")
-    slack = 0.05 + 1.5 / np.sqrt(z.numel())           # (+ sampling noise of the small fixtures: 120 elements in flow_ma*5)
+    slack = 0.05 + 1.5 / np.sqrt(z.numel())           # (+ sampling noise; round 4: every spline sibling fixture holds >= 5 625
+                                                      #  elements, so the slack is <= 0.07 -- it was 0.19 on 120 elements)
     assert pr_z >= pr_z_ref - slack and pr_x >= pr_x_ref - slack, (pr_z, pr_z_ref, pr_x, pr_x_ref)
     if variant == "init" and name in ("flow_realnvp3.npz", "flow_realnvp64.npz", "flow_nsf64.npz", "flow_realnvp256.npz"):
         assert e_lp < 1e-5, e_lp

@@ -130,11 +130,16 @@ def test_affine_glow_config5_golden_on_hip(native):
     e = dict(log_prob=rel(lp.cpu().numpy(), fx["log_prob"]), z=rel(z.cpu().numpy(), fx["z"]),
              log_det=rel(ld.cpu().numpy(), fx["log_det"]), x_inv=rel(xr.cpu().numpy(), fx["x_inv"]),
              log_det_inv=rel(ldr.cpu().numpy(), fx["log_det_inv"]))
-    floor = dict(log_prob=rel(fx["log_prob"], fx["log_prob64"]), z=rel(fx["z"], fx["z64"]),
-                 log_det=rel(fx["log_det"], fx["log_det64"]))
-    print("glow32 vs reference:", e, "reference fp32-vs-fp64:", floor)
-    assert e["log_prob"] < 1e-5 and e["log_det"] < 1e-5 and e["log_det_inv"] < 1e-5, e
-    assert e["z"] < 2e-5 and e["x_inv"] < 2e-5, e
+    floor = dict(log_prob=rel(fx["log_prob"], fx["log_prob64"]), z=float(fx["floor_z"]),
+                 log_det=rel(fx["log_det"], fx["log_det64"]), x_inv=float(fx["floor_x_inv"]),
+                 log_det_inv=rel(fx["log_det_inv"], fx["log_det_inv64"]))
+    # per group of rows: 0..31 standard normal, 32..47 scaled x 4 (the conditioner's sigmoid bound), 48..63 scaled x 0.01
+    groups = {"std": slice(0, 32), "x4": slice(32, 48), "x0.01": slice(48, 64)}
+    per = {g: dict(log_prob=rel(lp.cpu().numpy()[s], fx["log_prob"][s]), z=rel(z.cpu().numpy()[s], fx["z"][s]))
+           for g, s in groups.items()}
+    print("glow32 vs reference (64 rows):", e, "reference fp32-vs-fp64:", floor, "per row group:", per)
+    # < 1e-5 on ALL of them, stress rows included (round 3: 8 standard rows, z / x at 2e-5)
+    assert max(e.values()) < 1e-5, e
 
 
 def test_affine_glow_config5_full_size_properties(native):

@@ -34,12 +34,16 @@ def test_glow32_program_matches_reference_fp64(libtfk):
     assert prog is not None and len(prog.steps) == 19 and prog.flush is not None
     kinds = [s.info["kind"] for s in prog.steps]
     assert kinds.count("conv1x1") == 3 and kinds[3:9:2] == ["conv1x1"] * 3       # only the top block's
-    z, ld = ge.run_program(prog, torch.from_numpy(fx["x"]))
-    assert rel(z.numpy(), fx["z64"]) < 2e-6 and rel(ld.numpy(), fx["log_det64"]) < 1e-7
+    # (the emulator is a float64 python loop: 8 standard rows, 4 of the x 4 and 4 of the x 0.01 stress rows; z64 is stored
+    # for the first 8 rows, the log-det's fp64 value for all of them)
+    pick = list(range(8)) + [32, 33, 40, 47] + [48, 49, 56, 63]
+    z, ld = ge.run_program(prog, torch.from_numpy(fx["x"][pick]))
+    assert rel(z.numpy()[:8], fx["z64"]) < 2e-6 and rel(ld.numpy(), fx["log_det64"][pick]) < 1e-7
+    assert rel(z.numpy(), fx["z"][pick]) < 1e-5
     inv = image_program.compile_program(flow.bijection, 1, torch.device("cpu"))
     assert [s.inverse for s in inv.steps] == [True] * 19
-    x, ldi = ge.run_program(inv, torch.from_numpy(fx["z_in"]))
-    assert rel(x.numpy(), fx["x_inv"]) < 5e-6 and rel(ldi.numpy(), fx["log_det_inv"]) < 1e-6
+    x, ldi = ge.run_program(inv, torch.from_numpy(fx["z_in"][pick]))
+    assert rel(x.numpy(), fx["x_inv"][pick]) < 5e-6 and rel(ldi.numpy(), fx["log_det_inv64"][pick]) < 1e-7
     # the index tables of a step partition the positions the layer touches; targets are listed in ascending order
     for s in prog.steps:
         src, tgt = s.keep[0][: s.layer.c_in * s.layer.hi * s.layer.wi], s.keep[2][: s.layer.T]
