@@ -633,15 +633,17 @@ def main():
             torch.cuda.synchronize()
             step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.stats_steps))
     rows_total = world * rows
-    rank_ms, rank_sums = [1e3 * elapsed / args.steps], None
+    rank_ms, rank_sums, rank_devices = [1e3 * elapsed / args.steps], None, [local_dev]
     if world > 1:
         # every rank's own step time (a straggler shows as max >> min) and its shard of the log-likelihood (the shards
         # must add up to the all-reduced total): two small all-gathers AFTER the timed region
-        mine = torch.tensor([elapsed, float(native.sum_f32(lp).item())], dtype=torch.float64, device=dev)
-        both = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        mine = torch.tensor([elapsed, float(native.sum_f32(lp).item()), float(torch.cuda.current_device())],
+                            dtype=torch.float64, device=dev)
+        both = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
         dist.all_gather(both, mine)
         rank_ms = [1e3 * float(b[0]) / args.steps for b in both]
         rank_sums = [float(b[1]) for b in both]
+        rank_devices = [int(b[2]) for b in both]             # the HIP device every rank is bound to (rank r -> device r)
         t = torch.tensor([elapsed, float(rows)], dtype=torch.float64, device=dev)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         r = t[1:].clone()
@@ -777,6 +779,7 @@ def main():
             "log_likelihood_sum": float(total.item()),
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "log_likelihood_shards": rank_sums,
+            "rank_devices": rank_devices, "devices_visible": torch.cuda.device_count(),
             "step_stats": ({"steps": len(step_ms), "median_ms": step_ms[len(step_ms) // 2], "min_ms": step_ms[0],
                             "max_ms": step_ms[-1], "p10_ms": step_ms[len(step_ms) // 10],
                             "p90_ms": step_ms[(9 * len(step_ms)) // 10],
@@ -931,6 +934,18 @@ def main():
                                                                       + proc.stderr.strip()[-200:]}
                 except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as exc:
                     result["train"]["fit_batch_1024"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                # the reference's only published timings: the tqdm rates in its notebooks (hardware
+                # not stated) -- the same calls on this build, a few seconds each, in a child process
+                try:
+                    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "notebook_probe.py"), "3.0"],
+                                          capture_output=True, text=True, timeout=300)
+                    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("NOTEBOOK_JSON ")]
+                    if proc.returncode == 0 and line:
+                        result["train"].update(json.loads(line[-1][len("NOTEBOOK_JSON "):]))
+                    else:
+                        result["train"]["notebook_error"] = f"exit code {proc.returncode}: " + proc.stderr.strip()[-300:]
+                except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
+                    result["train"]["notebook_error"] = f"{type(exc).__name__}: {exc}"[:300]
             rb = tk.get("rqs_coupling_train_bwd")
             if rb is not None:
                 result["train"]["roofline_fused_bwd"] = {

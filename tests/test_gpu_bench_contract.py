@@ -108,6 +108,12 @@ def test_bench_four_ranks_rehearsal():
     four = _run_bench(["--gpus", "4"] + strong, env)
     assert len(four["rank_ms_per_step"]["per_rank"]) == 4
     assert 0 < four["rank_ms_per_step"]["min"] <= four["rank_ms_per_step"]["max"]
+    assert four["rank_ms_per_step"]["min"] == min(four["rank_ms_per_step"]["per_rank"])
+    assert four["rank_ms_per_step"]["max"] == max(four["rank_ms_per_step"]["per_rank"])
+    # rank r is bound to device r % device_count (gloo rehearsal: one card, so all four report device 0; under RCCL on
+    # the driver's node device_count is 8 and rank r owns GPU r) -- pinned so that the scaling run works first time
+    assert four["rank_devices"] == [r % four["devices_visible"] for r in range(4)], four["rank_devices"]
+    assert one["rank_devices"] == [0]
     assert four["n_gpus"] == four["rccl_ranks"] == 4 and four["scaling"] == "strong"
     assert four["rows_all_ranks"] == one["rows_all_ranks"] == 131072 and four["config"]["rows_per_gpu"] == 32768
     assert abs(four["log_likelihood_sum"] - one["log_likelihood_sum"]) <= 1e-9 * abs(one["log_likelihood_sum"])

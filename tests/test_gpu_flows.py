@@ -348,9 +348,13 @@ def test_made_sequential_map_in_one_launch(pkg, oracle, arch, D, n_hidden):
     assert max(e.values()) < 1e-5 * max(1.0, D / 64), e
 
 
-@pytest.mark.parametrize("arch", ["MaskedAutoregressiveRQNSF", "InverseAutoregressiveRQNSF",
-                                  "MaskedAutoregressiveLRS", "InverseAutoregressiveLRS"])
-@pytest.mark.parametrize("D,n_hidden", [(5, None), (16, 12), (64, None)])
+_MADE_SPLINES = ["MaskedAutoregressiveRQNSF", "InverseAutoregressiveRQNSF", "MaskedAutoregressiveLRS", "InverseAutoregressiveLRS"]
+
+
+# (D = 64: the host's fp64 D-pass truth takes 10-30 s per preset; the default run keeps one of the four, --runslow all)
+@pytest.mark.parametrize("D,n_hidden,arch", [(D, h, a) for D, h in ((5, None), (16, 12)) for a in _MADE_SPLINES]
+                         + [(64, None, "MaskedAutoregressiveRQNSF")]
+                         + [pytest.param(64, None, a, marks=pytest.mark.slow) for a in _MADE_SPLINES[1:]])
 def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch, D, n_hidden):
     """The sequential map of MADE-based spline layers as ONE launch per layer (tfk_made_{rqs,lrs}_sequential),
     including the reference's last-pass log-det (layers_base.py:213-221): parity with the oracle's D-pass

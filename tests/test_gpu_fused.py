@@ -347,7 +347,8 @@ def test_views_into_larger_buffers(pkg, oracle, monkeypatch, arch, D):
         assert torch.equal(x2, x3)
 
 
-@pytest.mark.parametrize("arch,D,n_hidden", [("MaskedAutoregressiveRQNSF", 64, None), ("InverseAutoregressiveRQNSF", 64, None),
+@pytest.mark.parametrize("arch,D,n_hidden", [("MaskedAutoregressiveRQNSF", 64, None),
+                                             pytest.param("InverseAutoregressiveRQNSF", 64, None, marks=pytest.mark.slow),
                                              ("MaskedAutoregressiveRQNSF", 128, None)])
 def test_made_spline_parallel_map_as_flow_program(pkg, oracle, monkeypatch, arch, D, n_hidden):
     """The parallel map of MADE-based RQ-spline layers (MA-RQNSF density, IA-RQNSF sampling) as matrix-core
@@ -931,9 +932,11 @@ def test_conditional_spline_chain_is_three_launches(arch, D, C, n_hidden):
     assert torch.allclose(xr.cpu(), x, atol=2e-3, rtol=1e-5) and torch.allclose(ld_d, -ldr, atol=1e-3)
 
 
-@pytest.mark.parametrize("arch,D,n_layers", [("MaskedAutoregressiveRQNSF", 64, 4), ("InverseAutoregressiveRQNSF", 64, 3),
+@pytest.mark.parametrize("arch,D,n_layers", [("MaskedAutoregressiveRQNSF", 64, 4),
+                                             pytest.param("InverseAutoregressiveRQNSF", 64, 3, marks=pytest.mark.slow),
                                              ("MaskedAutoregressiveLRS", 64, 3), ("MaskedAutoregressiveRQNSF", 128, 2),
-                                             ("MaskedAutoregressiveRQNSF", 22, 3), ("InverseAutoregressiveLRS", 64, 2)])
+                                             ("MaskedAutoregressiveRQNSF", 22, 3),
+                                             pytest.param("InverseAutoregressiveLRS", 64, 2, marks=pytest.mark.slow)])
 def test_made_spline_chain_is_one_launch(arch, D, n_layers):
     """The parallel map of MADE-based spline flows (MA-RQNSF / MA-LRS density, IA-* sampling direction) as ONE launch of
     the spline chain kernel (TFK_OP_MADE_{RQS,LRS}_FWD_LEAN: both planes feed GEMM 1, every element is a target).

@@ -579,6 +579,8 @@ class Flow(BaseFlow):
 
         initial, best = snapshot(), snapshot()
         best_loss, best_epoch, n_div, gave_up = float("inf"), 0, 0, False
+        stats = {"eager_steps": 0}
+        self._fit_stats = stats
         epochs = range(n_epochs)
         pbar = None
         if show_progress:
@@ -601,6 +603,7 @@ class Flow(BaseFlow):
                 if not diverged:
                     loss.backward()
                     self._optimizer.step()
+                    stats["eager_steps"] += 1
                     value = float(loss.detach())
                     if value < best_loss:
                         best_loss, best_epoch = value, epoch
