@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 27
+#define TFK_ABI_VERSION 28
 
 enum {
     TFK_OK = 0,
@@ -478,6 +478,44 @@ int tfk_glow_plan(const tfk_glow_layer *layer, int32_t D, int32_t *slots, int32_
                   int32_t *lds_bytes, int32_t *tile_rows);
 int tfk_glow_coupling(float *rows, float *logdet, int64_t N, int32_t D, const tfk_glow_layer *layer, int32_t inverse,
                       void *stream);
+
+/* ---- SEVERAL consecutive couplings of an image flow in ONE launch, the rows held in the LDS (round 4) -------------
+ * The couplings of one level of a multiscale flow (multiscale/base.py:249-296: the checkerboard layers, then -- squeezed
+ * -- the channel-wise layers) all work on the same set of row elements.  tfk_glow_level runs a list of them back to back
+ * for a few samples at a time: the samples' elements of that set are read from HBM once into the LDS (`row_idx`:
+ * their physical positions in ascending order, NULL = the whole row), every coupling of the list reads its sources
+ * and transforms its targets there, and the elements are written back once -- instead of one read of the sources and one
+ * read + write of the targets PER coupling (AffineGlow (3, 32, 32): 19 couplings = 240 KB per row; as three level
+ * launches 72 KB).  Semantics = tfk_glow_coupling applied step by step (same tables, same pending maps, the per-sample
+ * log-det added in the same order).
+ * A step is a tfk_glow_layer plus the positions of its elements INSIDE the level's element list:
+ *   src_loc   device uint16[c_in * hi * wi], the order of layer.src_idx
+ *   tgt_loc   device uint16[T'], the order of layer.tgt_idx; affine / shift: ascending, T' = T padded to a multiple of 64
+ *             (layer.tgt_st padded likewise); 1x1 convolution: T' = T
+ *   w4, b4    affine / shift: the Linear layer for v_mfma_f32_4x4x1 (4 samples x 64 parameters per instruction, no padding
+ *             of the sample axis): w4 = rows of log2(e) W_eff (R, 16) row-major, b4 = log2(e) b_eff (R), R = n_params padded to
+ *             a multiple of 64, in the order [u of target 0, beta of target 0, u of target 1, ...] (affine; = the order of h
+ *             after sorting the targets) or [shift of target 0, 1, ...] (shift).  1x1 convolution: NULL (layer.w_eff is used).
+ *   weights_host  the floats of layer.weights in HOST memory (layer.weights itself is not read by the level kernel)
+ * The launch shape and everything else derived from the geometry (LDS layout, which cells of the activation buffers hold the
+ * sample-independent background) are packed ONCE on the host into a caller-owned blob (tfk_glow_level_blob_bytes,
+ * tfk_glow_level_pack), which the caller uploads; tfk_glow_level takes both copies (the host copy for the launch shape).
+ * samples = 0 / block = 0: the library's choice (samples in {4, 8} resident per workgroup, 256 / 512 / 1024 threads).
+ * rows_in may differ from rows_out only when row_idx is NULL (the level covers every element: no clone of the input). */
+typedef struct tfk_glow_level_step {
+    tfk_glow_layer layer;
+    int32_t inverse, reserved;
+    const uint16_t *src_loc, *tgt_loc;
+    const float *w4, *b4;
+    const float *weights_host;      /* HOST copy of layer.weights: packed into the blob (the kernel reads the conv weights as scalar loads through it) */
+} tfk_glow_level_step;
+int64_t tfk_glow_level_blob_bytes(const tfk_glow_level_step *steps, int32_t n_steps, int32_t D, int32_t D_level,
+                                  int32_t samples, int32_t block);
+int tfk_glow_level_pack(const tfk_glow_level_step *steps, int32_t n_steps, int32_t D, int32_t D_level, int32_t samples,
+                        int32_t block, void *blob_host, int64_t blob_bytes);
+int tfk_glow_level_info(const void *blob_host, int32_t *samples, int32_t *block, int32_t *lds_bytes, int32_t *wgs_per_cu);
+int tfk_glow_level(const float *rows_in, float *rows_out, float *logdet, int64_t N, int32_t D, const int32_t *row_idx,
+                   const void *blob_host, const void *blob_dev, void *stream);
 
 /* rows[n, d] = st[2 d] * rows[n, d] + st[2 d + 1] in place: the flush of the pending maps behind the last coupling. */
 int tfk_rows_fma(float *rows, const float *st, int64_t N, int32_t D, void *stream);

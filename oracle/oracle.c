@@ -246,13 +246,16 @@ static void rqs_bins(const float *u, int K, float minimum, float maximum,
     const float rsum = 1.0f / sum;
     const float scale = (float)(1.0 - 1e-3 * (double)K); /* python double, cast once */
     const float span = (float)((double)maximum - (double)minimum);
-    float run = 0.0f;
+    /* torch.cumsum on the CPU accumulates fp32 inputs in DOUBLE and rounds every prefix once (ATen
+     * ReduceOpsKernel.cpp, cumsum_cpu_kernel: acc_type<float, false>; checked in the build container:
+     * torch.cumsum(fp32) == (fp32) numpy.cumsum(fp64) on 100 % of 8-term rows, the fp32 running sum on 80 %) */
+    double run = 0.0;
     bins[0] = 0.0f;                                  /* F.pad(..., (1, 0)) :49 */
     for (int j = 0; j < K; ++j) {
         const float sm = e[j] * rsum;                /* :46 */
         const float w = RQS_MIN_BIN + scale * sm;    /* :47 */
-        run = run + w;                               /* cumsum :48 */
-        bins[j + 1] = run;
+        run = run + (double)w;                       /* cumsum :48 */
+        bins[j + 1] = (float)run;
     }
     for (int j = 0; j <= K; ++j)
         bins[j] = span * bins[j] + minimum;          /* :50 */
@@ -431,11 +434,11 @@ static void lrs_bins(const float *u, int K, float minimum, float maximum, float 
     const float rsum = 1.0f / sum;
     const float scale = (float)(1.0 - 1e-2 * (double)K);
     const float span = (float)((double)maximum - (double)minimum);
-    float run = 0.0f;
+    double run = 0.0;                                /* cumsum :71 accumulates in double on the CPU (see rqs_bins) */
     bins[0] = 0.0f;
     for (int j = 0; j < K; ++j) {
-        run = run + (LRS_MIN_BIN + scale * (e[j] * rsum));
-        bins[j + 1] = run;
+        run = run + (double)(LRS_MIN_BIN + scale * (e[j] * rsum));
+        bins[j + 1] = (float)run;
     }
     for (int j = 0; j <= K; ++j) bins[j] = span * bins[j] + minimum;
     bins[0] = minimum;

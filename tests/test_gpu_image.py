@@ -143,7 +143,7 @@ def test_affine_glow_config5_golden_on_hip(native):
 
 
 def test_affine_glow_config5_full_size_properties(native):
-    """Config 5 at its full size, N = 2^18 rows of (3, 32, 32) (3 GiB) evaluated in chunks: the first 8 rows ARE
+    """Config 5 at its full size, N = 2^18 rows of (3, 32, 32) (3 GiB) evaluated in chunks: the first 64 rows ARE
     the fixture's (reference log_prob within 1e-5), chunk-size invariance, round trip, ld_fwd = -ld_inv, and the
     fp64 sum of the log-likelihood against a host fp64 sum."""
     from golden_util import load_glow32
@@ -153,10 +153,11 @@ def test_affine_glow_config5_full_size_properties(native):
     N = 1 << 18
     g = torch.Generator(device="cuda").manual_seed(99)
     x = torch.randn(N, 3, 32, 32, device="cuda", generator=g)
-    x[:8] = torch.from_numpy(fx["x"]).cuda()
+    n_fx = fx["x"].shape[0]                                       # the fixture's 64 rows, stress rows included
+    x[:n_fx] = torch.from_numpy(fx["x"]).cuda()
     with torch.no_grad():
         lp, total = sharded_log_likelihood(flow, x, chunk_rows=1 << 13)
-        assert rel(lp[:8].cpu().numpy(), fx["log_prob"]) < 1e-5
+        assert rel(lp[:n_fx].cpu().numpy(), fx["log_prob"]) < 1e-5
         assert torch.isfinite(lp).all()
         host_sum = float(lp.cpu().double().sum())
         assert abs(float(total) - host_sum) <= 1e-9 * abs(host_sum)
@@ -286,6 +287,44 @@ def test_image_programs_other_presets_vs_host(native, cls_name, event_shape, n_l
     assert rel(z.cpu().numpy(), z_h.numpy()) < 1e-5 and rel(ld.cpu().numpy(), ld_h.numpy()) < 1e-5
     assert rel(lp.cpu().numpy(), lp_h.numpy()) < 1e-5
     assert rel(xr.cpu().numpy(), x.numpy()) < 1e-4 and rel((-ldr).cpu().numpy(), ld.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cls_name,event_shape,n_layers", [("AffineGlow", (3, 32, 32), None), ("AffineGlow", (3, 16, 16), None),
+                                                          ("MultiscaleRealNVP", (1, 28, 28), None), ("ShiftGlow", (3, 16, 16), None),
+                                                          ("AffineGlow", (6, 16, 8), 2)])
+def test_level_launches_equal_the_coupling_launches(native, monkeypatch, cls_name, event_shape, n_layers):
+    """tfk_glow_level (round 4, opt-in: TORCHFLOWS_AMD_GLOW_LEVELS=1): the couplings of one level of the multiscale
+    recursion back to back on rows held in the LDS -- same tables, same pending maps, the Linear layer on
+    v_mfma_f32_4x4x1 instead of 16x16x4.  Its rows must equal those of the one-launch-per-coupling route BIT FOR BIT
+    (every per-element operation is the same fp32 sequence; the MFMA variants add the 16 products in the same order),
+    the log-det to one rounding (summed per level before it meets the running value), forward and inverse, affine /
+    shift / 1x1-convolution couplings, the 2-wide modifier kernel of 28-pixel images, and batch sizes that leave a partial
+    group of four samples."""
+    import torchflows_amd as tfa
+    from torchflows_amd import image_program
+    from torchflows_amd.bijections.finite import multiscale
+    torch.manual_seed(11)
+    flow = tfa.Flow(getattr(multiscale, cls_name)(event_shape, n_layers=n_layers))
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(torch.randn(48, *event_shape))
+    flow = flow.eval().cuda()
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("TORCHFLOWS_AMD_GLOW_LEVELS", "1")
+    for d in (0, 1):
+        prog = image_program.compile_program(flow.bijection, d, dev)
+        assert prog is not None and prog.levels is not None
+        assert sum(lv.count for lv in prog.levels) == len(prog.steps) and len(prog.levels) < len(prog.steps)
+        for n in (1, 5, 64, 131):
+            x = torch.randn(n, *event_shape, device=dev) * (1.0 if d == 0 else 0.7)
+            before = native.calls
+            out_l, ld_l = image_program.run(prog, x, event_shape)
+            assert native.calls - before == len(prog.levels) + (1 if prog.flush is not None else 0)
+            levels, prog.levels = prog.levels, None
+            out_s, ld_s = image_program.run(prog, x, event_shape)
+            prog.levels = levels
+            assert torch.equal(out_l, out_s), (cls_name, d, n, float((out_l - out_s).abs().max()))
+            assert rel(ld_l.cpu().numpy(), ld_s.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])

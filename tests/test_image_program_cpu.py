@@ -116,3 +116,26 @@ def test_program_declines_what_it_does_not_cover(libtfk):
     assert image_program.compile_program(ok, 0, cpu) is not None
     ok.checkerboard_layers[0].invert()
     assert image_program.compile_program(ok, 0, cpu) is None
+
+
+def test_level_programs_pack_on_the_host(libtfk, monkeypatch):
+    """The opt-in level route (tfk_glow_level): config 5's 19 couplings group into three levels (9 on all 3 072 elements,
+    6 on 1 536, 4 on 768 -- multiscale/base.py:249-296), the inverse program in the opposite order; the blobs are packed
+    by libtfk on the host (launch shape, geometry, background cell lists, a copy of the conv weights), no GPU needed."""
+    from golden_util import load_glow32
+    from torchflows_amd import image_program, native
+    monkeypatch.setenv("TORCHFLOWS_AMD_GLOW_LEVELS", "1")
+    flow, _ = load_glow32()
+    fwd = image_program.compile_program(flow.bijection, 0, torch.device("cpu"))
+    inv = image_program.compile_program(flow.bijection, 1, torch.device("cpu"))
+    assert [(lv.count, lv.D_level) for lv in fwd.levels] == [(9, 3072), (6, 1536), (4, 768)]
+    assert [(lv.count, lv.D_level) for lv in inv.levels] == [(4, 768), (6, 1536), (9, 3072)]
+    assert fwd.levels[0].row_idx is None and fwd.levels[1].row_idx.numel() == 1536
+    for lv in fwd.levels:
+        info = native.glow_level_info(lv.blob_host)
+        assert info["samples"] == 4 and info["lds_bytes"] <= 160 * 1024 and info["wgs_per_cu"] >= 1
+        idx = lv.row_idx
+        if idx is not None:
+            assert bool((idx[1:] > idx[:-1]).all())
+    monkeypatch.setenv("TORCHFLOWS_AMD_GLOW_LEVELS", "0")
+    assert image_program.compile_program(flow.bijection, 0, torch.device("cpu")).levels is None

@@ -46,14 +46,16 @@ __device__ __forceinline__ void lrs_eval(const float *p, float v, const LrsConst
     const float rx = 1.0f / sx, ry = 1.0f / sy;
     int k = 0;
     float xk = C.minimum, xk1 = C.maximum, yk = C.minimum, yk1 = C.maximum;
-    float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+    // (torch.cumsum on the CPU accumulates fp32 inputs in double and rounds every prefix once: tfk_spline.h)
+    double runx = 0.0, runy = 0.0;
+    float prevx = C.minimum, prevy = C.minimum;
     bool prev_below = true;
 #pragma unroll
     for (int j = 1; j <= KT; ++j) {
-        runx = runx + (kLrsMinBin + C.scale * (ex[j - 1] * rx));    // :69-71
-        runy = runy + (kLrsMinBin + C.scale * (ey[j - 1] * ry));
-        const float kx = (j == KT) ? C.maximum : C.span * runx + C.minimum;
-        const float ky = (j == KT) ? C.maximum : C.span * runy + C.minimum;
+        runx = runx + (double)(kLrsMinBin + C.scale * (ex[j - 1] * rx));    // :69-71
+        runy = runy + (double)(kLrsMinBin + C.scale * (ey[j - 1] * ry));
+        const float kx = (j == KT) ? C.maximum : C.span * (float)runx + C.minimum;
+        const float ky = (j == KT) ? C.maximum : C.span * (float)runy + C.minimum;
         const bool below = (INVERSE ? ky : kx) < v;                 // searchsorted left, :105 / :150
         const bool sel = prev_below && !below;
         k = sel ? j - 1 : k;

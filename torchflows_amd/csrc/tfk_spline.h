@@ -5,6 +5,8 @@
 // including ATen's CPU softmax form e * (1 / sum).
 #pragma once
 
+#include <type_traits>
+
 #include "tfk_common.h"
 
 namespace tfk {
@@ -80,14 +82,19 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
             sy += ey[j];
         }
         const float rx = div_fast(1.0f, sx), ry = div_fast(1.0f, sy);
-        float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+        // torch.cumsum on the CPU -- the reference's path -- accumulates fp32 inputs in DOUBLE and rounds every prefix once
+        // (ATen ReduceOpsKernel.cpp: acc_type<float, false>); the per-layer kernels (HBM-bound) do the same, the
+        // VALU-bound flow programs (REGS) keep the fp32 running sum
+        typedef typename std::conditional<REGS, float, double>::type run_t;
+        run_t runx = 0, runy = 0;
+        float prevx = C.minimum, prevy = C.minimum;
         bool prev_below = true;                            // knot 0 = minimum < v (in box)
 #pragma unroll
         for (int j = 1; j <= KT; ++j) {
-            runx = runx + (kRqsMinBin + C.scale * (ex[j - 1] * rx));   // :47-48
-            runy = runy + (kRqsMinBin + C.scale * (ey[j - 1] * ry));
-            const float kx = (j == KT) ? C.maximum : C.span * runx + C.minimum;   // :50-52
-            const float ky = (j == KT) ? C.maximum : C.span * runy + C.minimum;
+            runx = runx + (run_t)(kRqsMinBin + C.scale * (ex[j - 1] * rx));   // :47-48
+            runy = runy + (run_t)(kRqsMinBin + C.scale * (ey[j - 1] * ry));
+            const float kx = (j == KT) ? C.maximum : C.span * (float)runx + C.minimum;   // :50-52
+            const float ky = (j == KT) ? C.maximum : C.span * (float)runy + C.minimum;
             // searchsorted(knots, v) - 1, right=False: last knot strictly below v (:82/:147)
             const bool below = (INVERSE ? ky : kx) < v;
             const bool sel = prev_below && !below;
@@ -112,15 +119,16 @@ __device__ __forceinline__ void rqs_eval(const PT &p, int Krt, float v, const Rq
             sy += exp_noovf((p[j] + div_1000(p[K + j])) - my);
         }
         const float rx = div_fast(1.0f, sx), ry = div_fast(1.0f, sy);
-        float runx = 0.0f, runy = 0.0f, prevx = C.minimum, prevy = C.minimum;
+        double runx = 0.0, runy = 0.0;                      // (double accumulator: see above)
+        float prevx = C.minimum, prevy = C.minimum;
         bool prev_below = true;
         for (int j = 1; j <= K; ++j) {
             const float e_x = exp_noovf(p[j - 1] - mx);
             const float e_y = exp_noovf((p[j - 1] + div_1000(p[K + j - 1])) - my);
-            runx = runx + (kRqsMinBin + C.scale * (e_x * rx));
-            runy = runy + (kRqsMinBin + C.scale * (e_y * ry));
-            const float kx = (j == K) ? C.maximum : C.span * runx + C.minimum;
-            const float ky = (j == K) ? C.maximum : C.span * runy + C.minimum;
+            runx = runx + (double)(kRqsMinBin + C.scale * (e_x * rx));
+            runy = runy + (double)(kRqsMinBin + C.scale * (e_y * ry));
+            const float kx = (j == K) ? C.maximum : C.span * (float)runx + C.minimum;
+            const float ky = (j == K) ? C.maximum : C.span * (float)runy + C.minimum;
             const bool below = (INVERSE ? ky : kx) < v;
             const bool sel = prev_below && !below;
             k = sel ? j - 1 : k;

@@ -45,12 +45,26 @@ class Step:
 
 
 @dataclass
+class Level:
+    """Consecutive steps that work on the same set of row elements: ONE tfk_glow_level launch (rows held in the LDS)."""
+    first: int                       # steps[first : first + count]
+    count: int
+    row_idx: Optional[torch.Tensor]  # device int32 (D_level,), ascending physical positions; None = the whole row
+    D_level: int
+    blob_host: torch.Tensor          # uint8, launch shape + geometry + background cell lists (native.glow_level_pack)
+    blob_dev: torch.Tensor
+    keep: tuple                      # device tensors the blob points into
+    info: dict = field(default_factory=dict)
+
+
+@dataclass
 class ImageProgram:
     D: int
     steps: List[Step]
     ld_const: float
     flush: Optional[torch.Tensor]    # (D, 2) pending maps left behind the last layer, None if all identity
     version: int
+    levels: Optional[List[Level]] = None     # the same steps grouped into level launches (None: one launch per step)
 
 
 class _Decline(Exception):
@@ -59,6 +73,15 @@ class _Decline(Exception):
 
 def enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_IMAGE_PROGRAM", "1") != "0"
+
+
+def levels_enabled() -> bool:
+    """TORCHFLOWS_AMD_GLOW_LEVELS=1: one launch per LEVEL (tfk_glow_level: the level's row elements held in the LDS, HBM
+    traffic 240 -> ~100 KB per row) instead of one per coupling.  OFF by default: measured on MI355X (round 4, 65 536 rows
+    of AffineGlow((3, 32, 32)), same box) the three level launches take 20.2 ms against 14.2 ms for the 19 coupling
+    launches -- four resident samples per workgroup (12 KB of row + 23.5 KB of activations each at the first level) leave
+    one workgroup per CU, whose stages run back to back instead of overlapping."""
+    return os.environ.get("TORCHFLOWS_AMD_GLOW_LEVELS", "0") == "1"
 
 
 def _bn_affine(bn: nn.BatchNorm2d):
@@ -232,14 +255,21 @@ class _Builder:
             raise _Decline("source mask does not fill the conditioner image")
         dev = self.device
         st = lambda idx: torch.stack([self.s[idx], self.t[idx]], dim=1).float().contiguous()
+        log2e = 1.4426950408889634
+        aux = dict(src=src.clone(), tgt=tgt.clone(), W4=None, b4=None, weights=pk["weights"].contiguous())
         if kind == "shift":                                # one tile per 16 targets (sorted by position): their shifts
             order = torch.argsort(tgt, stable=True)
             tgt_k = tgt[order]
             n_groups = (T + 15) // 16
             w_tiles, b_tiles = _tile_pack(pk["W_eff"][order], pk["b_eff"][order])
-            pad = 16 * n_groups - T
+            pad = (-T) % 64                                # (whole tiles of the level kernel: 64 parameters)
             tgt_i = torch.cat([tgt_k.to(torch.int32), torch.zeros(pad, dtype=torch.int32)])
             tgt_m = torch.cat([st(tgt_k), torch.zeros(pad, 2)])
+            R = T + pad
+            W4 = torch.zeros(R, 16, dtype=torch.float64)
+            b4 = torch.zeros(R, dtype=torch.float64)
+            W4[:T], b4[:T] = pk["W_eff"][order] * log2e, pk["b_eff"][order] * log2e
+            aux.update(tgt=tgt_k.clone(), W4=W4.float().contiguous(), b4=b4.float().contiguous())
         elif kind == "affine":
             # the kernel takes the targets in any order: ascending physical position, so that the 16 targets of a tile
             # pair are neighbours in the row; tile 2 m = their scale logits (h[..., t, 0]), tile 2 m + 1 their shifts
@@ -253,9 +283,16 @@ class _Builder:
             Wk[row_u], bk[row_u] = pk["W_eff"][2 * order], pk["b_eff"][2 * order]
             Wk[row_u + 16], bk[row_u + 16] = pk["W_eff"][2 * order + 1], pk["b_eff"][2 * order + 1]
             w_tiles, b_tiles = _tile_pack(Wk, bk)
-            pad = 16 * n_groups - T                        # the kernel reads the tables in whole groups of 16 targets
+            pad = (-T) % 64                                # the kernels read the tables in whole groups of 16 / 32 targets
             tgt_i = torch.cat([tgt_k.to(torch.int32), torch.zeros(pad, dtype=torch.int32)])
             tgt_m = torch.cat([st(tgt_k), torch.zeros(pad, 2)])
+            # the level kernel's operands: rows [u of target 0, beta of target 0, u of target 1, ...] in sorted order
+            R = 2 * (T + pad)
+            W4 = torch.zeros(R, 16, dtype=torch.float64)
+            b4 = torch.zeros(R, dtype=torch.float64)
+            W4[:2 * T] = (pk["W_eff"].view(T, 2, 16)[order] * log2e).reshape(2 * T, 16)
+            b4[:2 * T] = (pk["b_eff"].view(T, 2)[order] * log2e).reshape(2 * T)
+            aux.update(tgt=tgt_k.clone(), W4=W4.float().contiguous(), b4=b4.float().contiguous())
         else:
             w_tiles, b_tiles = _tile_pack(pk["W_eff"], pk["b_eff"])
             tgt_i, tgt_m = tgt.to(torch.int32), st(tgt)
@@ -270,7 +307,7 @@ class _Builder:
                              bg2=keep[6].data_ptr(), w_eff=keep[7].data_ptr(), b_eff=keep[8].data_ptr())
         plan = native.glow_plan(L, self.D)                # validates the shape (raises NativeError otherwise)
         self.steps.append(Step(L, d == INVERSE, keep,
-                               dict(kind=kind, image=(c_in, hi, wi), at=(pk["oy"], pk["ox"]), T=T, **plan)))
+                               dict(kind=kind, image=(c_in, hi, wi), at=(pk["oy"], pk["ox"]), T=T, aux=aux, **plan)))
         self.s[tgt] = 1.0                                  # targets are stored in final form
         self.t[tgt] = 0.0
 
@@ -316,6 +353,62 @@ def _walk(b: _Builder, module, d: int, M: torch.Tensor) -> None:
         raise _Decline(f"no fused launch for {type(module).__name__}")
 
 
+def _u16(values: torch.Tensor, device, pad_to: int = 4) -> torch.Tensor:
+    """int64 values < 65536 as a device tensor of uint16 bit patterns (int16 storage), zero-padded to a multiple of
+    ``pad_to`` entries (the kernel reads the target positions two or four at a time)."""
+    import numpy as np
+    a = values.numpy().astype(np.uint16)
+    if a.size % pad_to:
+        a = np.concatenate([a, np.zeros(pad_to - a.size % pad_to, np.uint16)])
+    return torch.from_numpy(a.view(np.int16).copy()).to(device)
+
+
+def build_levels(steps: List[Step], D: int, device: torch.device) -> Optional[List[Level]]:
+    """Group consecutive steps with the same element footprint (sources + targets) into level launches; None when a
+    level does not fit the level kernel (then the program keeps one launch per step)."""
+    import ctypes as C
+    env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_LEVEL_" + k, "0") or 0)
+    groups, foot = [], None
+    for i, step in enumerate(steps):
+        aux = step.info["aux"]
+        f = torch.unique(torch.cat([aux["src"], aux["tgt"]]))            # ascending
+        if foot is not None and f.numel() == foot.numel() and bool((f == foot).all()):
+            groups[-1][1].append(i)
+        else:
+            groups.append((f, [i]))
+            foot = f
+    levels = []
+    for foot, idxs in groups:
+        Dl = int(foot.numel())
+        if Dl > 65535:
+            return None
+        whole = Dl == D
+        where = torch.full((D,), -1, dtype=torch.long)
+        where[foot] = torch.arange(Dl)
+        arr = (native.GlowLevelStep * len(idxs))()
+        keep = []
+        for k, i in enumerate(idxs):
+            step, aux = steps[i], steps[i].info["aux"]
+            src_loc, tgt_loc = _u16(where[aux["src"]], device), _u16(where[aux["tgt"]], device, 64)
+            C.memmove(C.byref(arr[k].layer), C.byref(step.layer), C.sizeof(step.layer))
+            arr[k].inverse = 1 if step.inverse else 0
+            arr[k].src_loc, arr[k].tgt_loc = src_loc.data_ptr(), tgt_loc.data_ptr()
+            arr[k].weights_host = aux["weights"].data_ptr()            # (CPU tensor, kept alive by the step's info)
+            keep += [src_loc, tgt_loc]
+            if aux["W4"] is not None:
+                w4, b4 = aux["W4"].to(device), aux["b4"].to(device)
+                arr[k].w4, arr[k].b4 = w4.data_ptr(), b4.data_ptr()
+                keep += [w4, b4]
+        try:
+            blob = native.glow_level_pack(arr, D, Dl, env("SAMPLES"), env("BLOCK"))
+        except native.NativeError:
+            return None
+        row_idx = None if whole else foot.to(torch.int32).to(device)
+        levels.append(Level(idxs[0], len(idxs), row_idx, Dl, blob, blob.to(device), tuple(keep),
+                            dict(native.glow_level_info(blob), steps=len(idxs), D_level=Dl)))
+    return levels
+
+
 def compile_program(module, d: int, device: torch.device) -> Optional[ImageProgram]:
     from torchflows_amd import fused
     if not enabled() or len(module.event_shape) != 3:
@@ -331,7 +424,8 @@ def compile_program(module, d: int, device: torch.device) -> Optional[ImageProgr
         return None
     pending = bool((b.s != 1.0).any() or (b.t != 0.0).any())
     flush = torch.stack([b.s, b.t], dim=1).float().contiguous().to(device) if pending else None
-    return ImageProgram(D, b.steps, b.ld, flush, fused._params_version(module))
+    levels = build_levels(b.steps, D, device) if levels_enabled() else None
+    return ImageProgram(D, b.steps, b.ld, flush, fused._params_version(module), levels)
 
 
 def get_program(module, d: int, device: torch.device) -> Optional[ImageProgram]:
@@ -352,6 +446,21 @@ def run(prog: ImageProgram, x: torch.Tensor, event_shape):
     """(z, log_det) of the compiled chain on ``x`` (never modified: the launches work on a copy)."""
     n_event = len(event_shape)
     batch = x.shape[:x.dim() - n_event]
+    if prog.levels is not None and x.device.type == "cuda":
+        # one launch per level; a first level that covers the whole row reads the caller's tensor and writes the working
+        # copy itself (no clone)
+        src = x.reshape(-1, prog.D)
+        if not src.is_contiguous():
+            src = src.contiguous()
+        first = prog.levels[0]
+        rows = torch.empty_like(src) if first.row_idx is None else src.clone()
+        logdet = torch.full((rows.shape[0],), prog.ld_const, dtype=torch.float32, device=x.device)
+        for k, lv in enumerate(prog.levels):
+            native.glow_level(src if (k == 0 and lv.row_idx is None) else rows, rows, logdet, lv.row_idx,
+                              lv.blob_host, lv.blob_dev)
+        if prog.flush is not None:
+            native.rows_fma(rows, prog.flush)
+        return rows.view(x.shape), logdet.view(batch)
     rows = x.reshape(-1, prog.D).clone(memory_format=torch.contiguous_format)
     logdet = torch.full((rows.shape[0],), prog.ld_const, dtype=torch.float32, device=x.device)
     for step in prog.steps:

@@ -47,9 +47,10 @@ SYMBOLS = (
     "tfk_made_lrs_sequential_lds_bytes", "tfk_made_lrs_sequential",
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
+    "tfk_glow_level_blob_bytes", "tfk_glow_level_pack", "tfk_glow_level_info", "tfk_glow_level",
 )
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 class NativeError(RuntimeError):
@@ -70,6 +71,12 @@ class GlowLayer(C.Structure):
                 ("slots", _i32), ("block", _i32), ("cg1", _i32), ("cg2", _i32), ("grid", _i32),
                 ("src_idx", _vp), ("src_st", _vp), ("tgt_idx", _vp), ("tgt_st", _vp),
                 ("weights", _vp), ("bg1", _vp), ("bg2", _vp), ("w_eff", _vp), ("b_eff", _vp)]
+
+
+class GlowLevelStep(C.Structure):
+    """``tfk_glow_level_step`` of include/tfk.h: a coupling inside a level program (tfk_glow_level)."""
+    _fields_ = [("layer", GlowLayer), ("inverse", _i32), ("reserved", _i32), ("src_loc", _vp), ("tgt_loc", _vp),
+                ("w4", _vp), ("b4", _vp), ("weights_host", _vp)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -162,6 +169,12 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_glow_plan.argtypes = [C.POINTER(GlowLayer), _i32, pi, pi, pi, pi, pi, pi]
     L.tfk_glow_coupling.argtypes = [_vp, _vp, _i64, _i32, C.POINTER(GlowLayer), _i32, _vp]
     L.tfk_rows_fma.argtypes = [_vp, _vp, _i64, _i32, _vp]
+    ps = C.POINTER(GlowLevelStep)
+    L.tfk_glow_level_blob_bytes.argtypes = [ps, _i32, _i32, _i32, _i32, _i32]
+    L.tfk_glow_level_blob_bytes.restype = _i64
+    L.tfk_glow_level_pack.argtypes = [ps, _i32, _i32, _i32, _i32, _i32, _vp, _i64]
+    L.tfk_glow_level_info.argtypes = [_vp, pi, pi, pi, pi]
+    L.tfk_glow_level.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -866,6 +879,46 @@ def glow_coupling(rows: torch.Tensor, logdet: torch.Tensor, layer: GlowLayer, in
                                      C.byref(layer), 1 if inverse else 0, _stream(rows))
     calls += 1
     _check(rc, "tfk_glow_coupling")
+
+
+def glow_level_pack(steps, D: int, D_level: int, samples: int = 0, block: int = 0) -> torch.Tensor:
+    """The host copy of a level program's blob (uint8 CPU tensor): launch shape, geometry and background cell lists of
+    ``steps`` (a ctypes array of GlowLevelStep whose pointers are DEVICE pointers).  Pure host work, no GPU needed."""
+    n = len(steps)
+    nbytes = int(lib().tfk_glow_level_blob_bytes(steps, n, int(D), int(D_level), int(samples), int(block)))
+    if nbytes <= 0:
+        _check(-nbytes if nbytes < 0 else 1, "tfk_glow_level_blob_bytes")
+    blob = torch.zeros(nbytes, dtype=torch.uint8)
+    rc = lib().tfk_glow_level_pack(steps, n, int(D), int(D_level), int(samples), int(block), blob.data_ptr(), nbytes)
+    _check(rc, "tfk_glow_level_pack")
+    return blob
+
+
+def glow_level_info(blob_host: torch.Tensor) -> dict:
+    vals = [_i32(0) for _ in range(4)]
+    rc = lib().tfk_glow_level_info(blob_host.data_ptr(), *[C.byref(v) for v in vals])
+    _check(rc, "tfk_glow_level_info")
+    return dict(zip(("samples", "block", "lds_bytes", "wgs_per_cu"), (int(v.value) for v in vals)))
+
+
+def glow_level(rows_in: torch.Tensor, rows_out: torch.Tensor, logdet: torch.Tensor, row_idx: Optional[torch.Tensor],
+               blob_host: torch.Tensor, blob_dev: torch.Tensor) -> None:
+    """The couplings of one level back to back on rows held in the LDS (in place unless the level covers the whole row)."""
+    global calls
+    name = "tfk_glow_level"
+    N, D = _rows(rows_out, name)
+    if rows_in.shape != rows_out.shape or logdet.numel() != N:
+        raise NativeError(f"{name}: rows_in {tuple(rows_in.shape)}, rows_out {tuple(rows_out.shape)}, logdet {logdet.numel()}")
+    if row_idx is not None and (row_idx.dtype != torch.int32 or row_idx.device != rows_out.device):
+        raise NativeError(f"{name}: row_idx must be an int32 tensor on the rows' device")
+    if blob_host.device.type != "cpu" or blob_dev.device != rows_out.device:
+        raise NativeError(f"{name}: the blob's two copies must live on the host and on the rows' device")
+    with _device_guard(rows_out):
+        rc = lib().tfk_glow_level(_f32(rows_in, name), _f32(rows_out, name), _f32(logdet, name), N, D,
+                                  None if row_idx is None else row_idx.data_ptr(), blob_host.data_ptr(),
+                                  blob_dev.data_ptr(), _stream(rows_out))
+    calls += 1
+    _check(rc, name)
 
 
 def rows_fma(rows: torch.Tensor, st: torch.Tensor) -> None:
