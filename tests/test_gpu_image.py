@@ -324,7 +324,7 @@ def test_level_launches_equal_the_coupling_launches(native, monkeypatch, cls_nam
             out_s, ld_s = image_program.run(prog, x, event_shape)
             prog.levels = levels
             assert torch.equal(out_l, out_s), (cls_name, d, n, float((out_l - out_s).abs().max()))
-            assert rel(ld_l.cpu().numpy(), ld_s.cpu().numpy()) < 1e-6
+            assert rel(ld_l.cpu().numpy(), ld_s.cpu().numpy()) < 5e-6     # (partial sums of ~1e2 cancel to ~1e-1: a few ulps of those)
 
 
 @pytest.mark.parametrize("event_shape,n", [((3, 32, 32), 64), ((1, 28, 28), 16), ((3, 16, 16), 33)])
