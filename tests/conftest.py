@@ -43,6 +43,25 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                     "(error / reference's own fp32-vs-fp64 floor): " + "; ".join(PARITY_NOTES))
 
 
+def set_debug(monkeypatch, **switches) -> None:
+    """Set (value) or clear (None) route / tuning switches inside TORCHFLOWS_AMD_DEBUG="key=value,..." (torchflows_amd/
+    utils.py: debug_switch), keeping the switches other calls of the same test have set."""
+    cur = {}
+    for item in os.environ.get("TORCHFLOWS_AMD_DEBUG", "").split(","):
+        k, _, v = item.partition("=")
+        if k.strip():
+            cur[k.strip().lower()] = v.strip()
+    for k, v in switches.items():
+        if v is None:
+            cur.pop(k.lower(), None)
+        else:
+            cur[k.lower()] = str(v)
+    if cur:
+        monkeypatch.setenv("TORCHFLOWS_AMD_DEBUG", ",".join(f"{k}={v}" for k, v in cur.items()))
+    else:
+        monkeypatch.delenv("TORCHFLOWS_AMD_DEBUG", raising=False)
+
+
 def free_port() -> str:
     """A TCP port that is free on 127.0.0.1 right now (rendezvous of the multi-process tests: no hard-coded ports)."""
     import socket

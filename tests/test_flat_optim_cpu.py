@@ -3,6 +3,8 @@ update bit-identical to torch.optim.AdamW whichever way the gradients arrive."""
 import copy
 
 import pytest
+
+from conftest import set_debug
 import torch
 
 from torchflows_amd.flat_optim import FlatAdamW, FlatParams, lookup
@@ -87,11 +89,11 @@ def test_missing_gradients_are_skipped_like_torch_does():
 def test_make_adamw_picks_it_only_where_it_pays(monkeypatch):
     from torchflows_amd.utils import make_adamw
     net, _ = _nets()
-    monkeypatch.delenv("TORCHFLOWS_AMD_FLAT_ADAMW", raising=False)
+    set_debug(monkeypatch, flat_adamw=None)
     assert type(make_adamw(net.parameters(), 0.1)) is torch.optim.AdamW          # host parameters: torch's own
-    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "1")
+    set_debug(monkeypatch, flat_adamw="1")
     assert isinstance(make_adamw(net.parameters(), 0.1), FlatAdamW)
-    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "0")
+    set_debug(monkeypatch, flat_adamw="0")
     assert type(make_adamw(net.parameters(), 0.1)) is torch.optim.AdamW
 
 
@@ -103,10 +105,10 @@ def test_fit_on_the_host_with_the_flat_optimiser_matches(monkeypatch):
     x = torch.randn(512, 6) * 0.5 + 1.0
     a = Flow(RealNVP(6, n_layers=2))
     b = copy.deepcopy(a)
-    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "1")
+    set_debug(monkeypatch, flat_adamw="1")
     a.fit(x, n_epochs=4, lr=0.01, batch_size=128, shuffle=False, x_val=x[:64])
     assert isinstance(a._optimizer, FlatAdamW) and a._optimizer.flat.intact()
-    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "0")
+    set_debug(monkeypatch, flat_adamw="0")
     b.fit(x, n_epochs=4, lr=0.01, batch_size=128, shuffle=False, x_val=x[:64])
     for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert torch.equal(pa, pb), n
@@ -122,7 +124,7 @@ def test_flows_and_their_optimiser_survive_deepcopy_and_pickle(monkeypatch):
     torch.manual_seed(2)
     x = torch.randn(256, 6)
     flow = Flow(RealNVP(6, n_layers=2))
-    monkeypatch.setenv("TORCHFLOWS_AMD_FLAT_ADAMW", "1")
+    set_debug(monkeypatch, flat_adamw="1")
     flow.fit(x, n_epochs=2, lr=0.01, batch_size=128, shuffle=False)
     assert isinstance(flow._optimizer, FlatAdamW)
     anchor = torch.nn.Linear(1, 1)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, state_dict_of
+from conftest import load_golden, state_dict_of, set_debug
 
 pytestmark = pytest.mark.gpu
 
@@ -388,9 +388,9 @@ def test_made_spline_sequential_map_in_one_launch(pkg, oracle, monkeypatch, arch
 
     (y, ld), launches = run()
     assert launches <= 2 * len(flow.bijection.layers), launches          # no D-pass loops
-    monkeypatch.setenv("TORCHFLOWS_AMD_MADE_FUSED", "0")
+    set_debug(monkeypatch, made_fused="0")
     (y_loop, ld_loop), launches_loop = run()
-    monkeypatch.setenv("TORCHFLOWS_AMD_MADE_FUSED", "1")
+    set_debug(monkeypatch, made_fused="1")
     assert launches_loop >= 2 * D
     y_ref, ld_ref = getattr(ref, seq)(x.numpy())
     e = dict(y=rel(y.cpu().numpy(), y64.numpy()), ld=rel(ld.cpu().numpy(), ld64.numpy()),

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, state_dict_of
+from conftest import load_golden, state_dict_of, set_debug
 
 pytestmark = pytest.mark.gpu
 
@@ -460,7 +460,7 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
     flow = flow.cuda()
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("TORCHFLOWS_AMD_FUSED_PAD", mode)
+        set_debug(monkeypatch, fused_pad=mode)
         flow.bijection.__dict__.pop("_tfk_compiled", None)
         before = native.calls
         with torch.no_grad():
@@ -468,7 +468,7 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
             z, ld = flow.bijection.forward(x.cuda())
             xr, ldi = flow.bijection.inverse(z)
         res[mode] = (lp, z, ld, xr, ldi, native.calls - before)
-    monkeypatch.setenv("TORCHFLOWS_AMD_FUSED_PAD", "1")
+    set_debug(monkeypatch, fused_pad="1")
     assert res["1"][5] < res["0"][5] and res["1"][5] <= 3 * 4 + (n_layers if "M" == arch[0] else 0), (res["1"][5], res["0"][5])
     z_ref, lp_ref = ref.log_prob(x.numpy(), return_z=True)
     lp, z, ld, xr, ldi, _ = res["1"]
@@ -480,7 +480,7 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
     if D % 2 and arch in ("RealNVP", "NICE", "CouplingRQNSF"):
         # odd event sizes of affine / shift chains: the straight-line kernel with the middle element changing planes
         # (round 3) -- ONE launch per pass at the narrowest row width that holds (D + 1) / 2 columns per plane; against the
-        # interpreter's plane-per-element route (TORCHFLOWS_AMD_ODD_LEAN=0) to fp32 rounding
+        # interpreter's plane-per-element route (TORCHFLOWS_AMD_DEBUG=odd_lean=0) to fp32 rounding
         from torchflows_amd import fused as fz
         flow.invalidate_native_caches()            # (the cache remembers that the chain was declined without padding)
         chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
@@ -489,13 +489,13 @@ def test_even_event_sizes_run_as_padded_flow_programs(pkg, oracle, monkeypatch, 
         n_seg = 2 if (D, n_layers) == (201, 9) else 1
         assert chain is not None and chain.D == want_w and len(chain.segments) == n_seg, (chain.D, len(chain.segments))
         assert res["1"][5] == 3 * n_seg
-        monkeypatch.setenv("TORCHFLOWS_AMD_ODD_LEAN", "0")
+        set_debug(monkeypatch, odd_lean="0")
         flow.invalidate_native_caches()
         with torch.no_grad():
             lp_i = flow.log_prob(x.cuda())
             z_i, ld_i = flow.bijection.forward(x.cuda())
             xs, lps = flow.sample((300,), return_log_prob=True)
-        monkeypatch.delenv("TORCHFLOWS_AMD_ODD_LEAN")
+        set_debug(monkeypatch, odd_lean=None)
         flow.invalidate_native_caches()
         tol_i = 4e-5 if "RQ" in arch else 1e-5
         assert rel(lp.cpu().numpy(), lp_i.cpu().numpy()) < tol_i and normwise(z.cpu().numpy(), z_i.cpu().numpy()) < tol_i
@@ -649,7 +649,7 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
         z1, lp1 = flow.forward_with_log_prob(xd)
         n_calls = native.calls - before
         xr1, ld1 = flow.bijection.inverse(z1)
-        monkeypatch.setenv("TORCHFLOWS_AMD_NARROW_IN", "0")
+        set_debug(monkeypatch, narrow_in="0")
         z0, lp0 = flow.forward_with_log_prob(xd)
     assert n_calls == 1                                         # one launch, no padding kernels
     tol = 4e-5 if "RQ" in arch else 1e-5
@@ -660,7 +660,7 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
         # affine / shift chains on event sizes <= 16 run at row width 16 (two row elements per lane and plane); the same
         # values as at width 32 up to the order of the (zero) padding terms, and Flow.sample's inverse launch as well
         from torchflows_amd import fused as fz
-        monkeypatch.delenv("TORCHFLOWS_AMD_NARROW_IN")
+        set_debug(monkeypatch, narrow_in=None)
         chain = fz.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
         assert chain is not None and chain.D == 16 and len(chain.segments) == 1
         with torch.no_grad():
@@ -668,7 +668,7 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
             torch.manual_seed(11)
             xs, lps = flow.sample((500,), return_log_prob=True)
             assert native.calls - before <= 2
-            monkeypatch.setenv("TORCHFLOWS_AMD_ROWS16", "0")
+            set_debug(monkeypatch, rows16="0")
             flow.invalidate_native_caches()
             z32, lp32 = flow.forward_with_log_prob(xd)
             xr32, _ = flow.bijection.inverse(z1)
@@ -681,7 +681,7 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
 
 
 def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):
-    """TORCHFLOWS_AMD_LEAN_BF16X3=1: GEMM 2 of RealNVP-64 chains on the bf16 matrix pipe at fp32 accuracy (opt-in: no
+    """TORCHFLOWS_AMD_DEBUG=lean_bf16x3=1: GEMM 2 of RealNVP-64 chains on the bf16 matrix pipe at fp32 accuracy (opt-in: no
     faster than fp32 operands for affine chains, fused.lean_bf16x3_enabled) -- same values as the default format to
     fp32 rounding, and as the host."""
     import torchflows_amd as tfa
@@ -696,7 +696,7 @@ def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):
         lp_h = flow.log_prob(x)
         flow = flow.cuda()
         lp0 = flow.log_prob(x.cuda())
-        monkeypatch.setenv("TORCHFLOWS_AMD_LEAN_BF16X3", "1")
+        set_debug(monkeypatch, lean_bf16x3="1")
         flow.invalidate_native_caches()
         lp1 = flow.log_prob(x.cuda())
         z1, ld1 = flow.bijection.forward(x.cuda())
@@ -859,10 +859,10 @@ def test_log_likelihood_sum_rides_in_the_log_prob_launch(arch, D, N, monkeypatch
     """Flow.log_prob_and_sum: the fp64 sum of the log-probabilities comes out of the SAME launch (tfk_flow_run_mfma_sum:
     one partial per workgroup, the last workgroup adds them in index order and resets the workspace) -- equal to the
     fp64 sum of the returned vector to rounding, bitwise reproducible, and correct call after call.  (Opt-in:
-    TORCHFLOWS_AMD_SUM_IN_KERNEL=1; by default log_prob_and_sum is log_prob + tfk_sum_f32.)"""
+    TORCHFLOWS_AMD_DEBUG=sum_in_kernel=1; by default log_prob_and_sum is log_prob + tfk_sum_f32.)"""
     import torchflows_amd as tfa
     from torchflows_amd import native
-    monkeypatch.setenv("TORCHFLOWS_AMD_SUM_IN_KERNEL", "1")
+    set_debug(monkeypatch, sum_in_kernel="1")
     torch.manual_seed(11)
     flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=4))
     flow.train()
@@ -969,3 +969,43 @@ def test_made_spline_chain_is_one_launch(arch, D, n_layers):
     e_z, e_ld = normwise(z_d.cpu().numpy(), z_h.numpy()), rel(ld_d.cpu().numpy(), ld_h.numpy())
     print(f"{arch}({D}, {n_layers} layers): z nw {e_z:.2e}, log_det {e_ld:.2e}")
     assert e_z < 2e-5 and e_ld < 4e-5                       # (D log-det terms per layer that largely cancel)
+
+
+def test_data_edits_are_noticed_without_a_host_sync(monkeypatch):
+    """``p.data.mul_(...)`` moves no version counter, so a compiled program would serve the old weights
+    for ever.  Default guard (fused._Guard): every GUARD_EVERY-th hit enqueues a device-side checksum comparison whose
+    verdict is read on a later hit -- no synchronisation on the hit path; within ~2 GUARD_EVERY calls the stale program is
+    dropped (StaleProgramWarning) and the results are those of the live weights.  RealNVP-64 (flow program) and an image
+    flow (image program)."""
+    import warnings
+    import torchflows_amd as tfa
+    from torchflows_amd import fused
+    from torchflows_amd.bijections.finite.multiscale import AffineGlow
+    monkeypatch.setattr(fused, "GUARD_EVERY", 4)
+    for make, shape in ((lambda: tfa.RealNVP(64, n_layers=2), (64,)), (lambda: AffineGlow((3, 8, 8), n_layers=1), (3, 8, 8))):
+        torch.manual_seed(2)
+        flow = tfa.Flow(make())
+        flow.train()
+        with torch.no_grad():
+            flow.log_prob(torch.randn(256, *shape))
+        flow = flow.eval().cuda()
+        x = torch.randn(64, *shape, device="cuda")
+        with torch.no_grad():
+            before = flow.log_prob(x).clone()
+            lin = [m for m in flow.modules() if isinstance(m, torch.nn.Linear)][-1]
+            lin.bias.data.add_(0.05)                                   # no version counter moves
+            ref = None
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                seen = None
+                for i in range(40):
+                    lp = flow.log_prob(x)
+                    torch.cuda.synchronize()
+                    if not torch.equal(lp, before):
+                        seen = i
+                        break
+            assert seen is not None and seen <= 3 * 4 + 2, seen
+            assert any(issubclass(m.category, fused.StaleProgramWarning) for m in w)
+            flow.invalidate_native_caches()
+            ref = flow.log_prob(x)
+            assert torch.equal(lp, ref)

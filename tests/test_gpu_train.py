@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, state_dict_of
+from conftest import load_golden, state_dict_of, set_debug
 from test_grads_cpu import FLOWS, MADE_FLOWS, _mirror_flow, _param_of, normwise
 
 pytestmark = pytest.mark.gpu
@@ -329,11 +329,11 @@ def test_fused_training_backward_matches_layerwise(native, monkeypatch, D, N, la
 
     truth = grads(copy.deepcopy(comp).double(), x.double(), wz.double(), wl.double())
     dev = copy.deepcopy(comp).cuda()
-    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_FUSED", "0")
+    set_debug(monkeypatch, train_fused="0")
     before = native.calls
     split = grads(dev, x.cuda(), wz.cuda(), wl.cuda())
     n_split = native.calls - before
-    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_FUSED", "1")
+    set_debug(monkeypatch, train_fused="1")
     before = native.calls
     fused = grads(dev, x.cuda(), wz.cuda(), wl.cuda())
     assert 0 < native.calls - before <= n_split           # fewer launches: the reversal rides along
@@ -401,7 +401,7 @@ def test_context_conditioned_flows_train_on_the_hip_path(native, arch, D, C):
 def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeypatch, arch, D):
     """make_adamw on the device homes the parameters in ONE buffer (flat_optim.py); the chain's autograd node then packs
     its operands by one gather, evaluates the L2 penalty itself and returns every gradient as a slice of one buffer,
-    which FlatAdamW updates with torch's own _foreach calls.  Against the per-tensor route (TORCHFLOWS_AMD_FLAT=0 and
+    which FlatAdamW updates with torch's own _foreach calls.  Against the per-tensor route (TORCHFLOWS_AMD_DEBUG=flat=0 and
     torch.optim.AdamW): identical gradients (the same kernels filled the same accumulators; the penalty's term is added
     in the same precision), a bit-identical trajectory over 6 steps, every update on the fast path, and an eval-mode
     log_prob afterwards that sees the trained weights (the version counters moved with the buffer)."""
@@ -425,11 +425,11 @@ def test_parameters_in_one_buffer_same_gradients_same_trajectory(native, monkeyp
     assert isinstance(oa, FlatAdamW) and oa.flat.intact()
     ob = torch.optim.AdamW(b.parameters(), 0.01)
     for step in range(6):
-        monkeypatch.setenv("TORCHFLOWS_AMD_FLAT", "1")
+        set_debug(monkeypatch, flat="1")
         oa.zero_grad()
         la = a._base_batch_loss((x, w))
         la.backward()
-        monkeypatch.setenv("TORCHFLOWS_AMD_FLAT", "0")
+        set_debug(monkeypatch, flat="0")
         ob.zero_grad()
         lb = b._base_batch_loss((x, w))
         lb.backward()
@@ -554,11 +554,11 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
     fused = True                                           # (NICE: shift couplings = the affine launches with a zero scale logit)
     for inverse in (False, True):
         want = grads(ref, x.double(), inverse)
-        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
+        set_debug(monkeypatch, train_pad="1")
         before = native.calls
         got = grads(dev, x.cuda(), inverse)
         n_pad = native.calls - before
-        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "0")
+        set_debug(monkeypatch, train_pad="0")
         before = native.calls
         plain = grads(dev, x.cuda(), inverse)
         n_plain = native.calls - before
@@ -572,7 +572,7 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
             assert n_pad < n_plain or D in (64, 128) or D % 2, (n_pad, n_plain)
             # fwd + bwd: 3 blocks, <= 6 unfolded elementwise / reversal steps (odd sizes: 3 more reversals each way)
             assert n_pad <= 2 * (3 + 6) + 4 + (6 if D % 2 else 0), n_pad
-    monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN_PAD", "1")
+    set_debug(monkeypatch, train_pad="1")
     plan = ag.training_plan(dev.bijection, 0)
     assert ag.fully_fused(plan, D) and ag.plan_width(plan, D) in (64, 128)
     if "RQ" in arch:
@@ -615,7 +615,7 @@ def test_rows_outer_vs_float64(native, M, lda, N):
 def test_spline_training_step_without_gemm_library_calls(native, monkeypatch):
     """CouplingRQNSF(64): the fused spline backward also writes the hidden activations it re-evaluates, and the three
     products that contract over the batch rows run on tfk_rows_outer -- same gradients as the split-K GEMM route
-    (TORCHFLOWS_AMD_ROWS_OUTER=0) and as the host graph in float64, fewer launches."""
+    (TORCHFLOWS_AMD_DEBUG=rows_outer=0) and as the host graph in float64, fewer launches."""
     import copy
     from torchflows_amd.flows import Flow
     from torchflows_amd.bijections.finite.autoregressive import architectures as A
@@ -633,11 +633,11 @@ def test_spline_training_step_without_gemm_library_calls(native, monkeypatch):
         xx = xx.clone().requires_grad_(True)
         return torch.autograd.grad(f.log_prob(xx).sum(), [xx] + [p for n, p in f.named_parameters() if n in names])
     want = grads(ref, x.double())
-    monkeypatch.setenv("TORCHFLOWS_AMD_ROWS_OUTER", "1")
+    set_debug(monkeypatch, rows_outer="1")
     before = native.calls
     got = grads(dev, x.cuda())
     n_new = native.calls - before
-    monkeypatch.setenv("TORCHFLOWS_AMD_ROWS_OUTER", "0")
+    set_debug(monkeypatch, rows_outer="0")
     before = native.calls
     old = grads(dev, x.cuda())
     n_old = native.calls - before

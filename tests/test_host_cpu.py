@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, free_port, load_golden, state_dict_of
+from conftest import ROOT, free_port, load_golden, state_dict_of, set_debug
 
 import torchflows_amd as tfa
 from torchflows_amd import native
@@ -552,8 +552,8 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
         pytest.skip("spline chains at row width 32: bf16 x 3 operands only")
     if bf16x3 == "0" and "RQ" not in arch and "LRS" not in arch and D not in (64, 22, 8):
         pytest.skip("the operand format only concerns spline chains and 64-wide affine chains")
-    monkeypatch.setenv("TORCHFLOWS_AMD_RQS_BF16X3", bf16x3)
-    monkeypatch.setenv("TORCHFLOWS_AMD_LEAN_BF16X3", bf16x3)
+    set_debug(monkeypatch, rqs_bf16x3=bf16x3)
+    set_debug(monkeypatch, lean_bf16x3=bf16x3)
     torch.manual_seed(3)
     kw = {}
     if "-h" in arch:                                          # wider conditioner: two hidden tiles (bf16 x 3 format only)

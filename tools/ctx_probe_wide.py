@@ -12,7 +12,7 @@ for arch, D, C in (("RealNVP", 256, 8), ("RealNVP", 128, 8), ("NICE", 64, 8)):
     flow = flow.eval().cuda()
     x, c = torch.randn(N, D, device="cuda"), torch.randn(N, C, device="cuda")
     for lean in ("1", "0"):
-        os.environ["TORCHFLOWS_AMD_LEAN"] = lean
+        os.environ["TORCHFLOWS_AMD_DEBUG"] = "lean=" + str(lean)
         flow.invalidate_native_caches()
         with torch.no_grad():
             before = native.calls

@@ -15,7 +15,7 @@ for n in (1024, 1 << 16, 1 << 20):
     for mode in ("1", "0"):
         if mode == "0" and n > (1 << 16):
             continue
-        os.environ["TORCHFLOWS_AMD_MADE_FUSED"] = mode
+        os.environ["TORCHFLOWS_AMD_DEBUG"] = "made_fused=" + str(mode)
         with torch.no_grad():
             flow.sample((n,))
             torch.cuda.synchronize()
@@ -26,7 +26,7 @@ for n in (1024, 1 << 16, 1 << 20):
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         print(f"N={n}: {'one launch per layer' if mode == '1' else 'D passes per layer'}: {1e3 * dt:.2f} ms per call, {n / dt:.3e} samples/s")
-os.environ["TORCHFLOWS_AMD_MADE_FUSED"] = "1"
+os.environ["TORCHFLOWS_AMD_DEBUG"] = "made_fused=" + str("1")
 x = torch.randn(1 << 20, 64, device="cuda")
 with torch.no_grad():
     flow.log_prob(x); torch.cuda.synchronize(); t0 = time.perf_counter()

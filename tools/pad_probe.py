@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Event sizes that are not 64 / 128 / 256 (N = 2^20 rows): padded flow programs with the rows read as they are
-(tfk_flow_run_mfma_in), with the host-side padding pass (TORCHFLOWS_AMD_NARROW_IN=0), and layer by layer; the
+(tfk_flow_run_mfma_in), with the host-side padding pass (TORCHFLOWS_AMD_DEBUG=narrow_in=0), and layer by layer; the
 per-element rate is compared with D = 64's (within 1.3x)."""
 import os, sys, time, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
@@ -16,9 +16,9 @@ for D in sizes:
         flow.log_prob(torch.randn(4096, D))
     flow = flow.eval().cuda()
     x = torch.randn(1 << 20, D, device="cuda")
-    for mode, env in (("rows as they are", dict(TORCHFLOWS_AMD_FUSED_PAD="1", TORCHFLOWS_AMD_NARROW_IN="1")),
-                      ("host padding pass", dict(TORCHFLOWS_AMD_FUSED_PAD="1", TORCHFLOWS_AMD_NARROW_IN="0")),
-                      ("layer by layer", dict(TORCHFLOWS_AMD_FUSED_PAD="0", TORCHFLOWS_AMD_FUSED="0" if D == 64 else "1"))):
+    for mode, env in (("rows as they are", dict(TORCHFLOWS_AMD_DEBUG="fused_pad=1,narrow_in=1", TORCHFLOWS_AMD_FUSED="1")),
+                      ("host padding pass", dict(TORCHFLOWS_AMD_DEBUG="fused_pad=1,narrow_in=0", TORCHFLOWS_AMD_FUSED="1")),
+                      ("layer by layer", dict(TORCHFLOWS_AMD_DEBUG="fused_pad=0", TORCHFLOWS_AMD_FUSED="0" if D == 64 else "1"))):
         os.environ.update(env)
         flow.invalidate_native_caches()
         import warnings

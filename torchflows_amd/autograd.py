@@ -24,6 +24,8 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from torchflows_amd.utils import debug_switch
+
 from torchflows_amd import native
 
 FORWARD, INVERSE = 0, 1
@@ -387,24 +389,24 @@ def _fused_rqs_layer(layer, D: int):
 
 def flat_enabled() -> bool:
     """Operands gathered from / gradients returned as slices of ONE buffer when the parameters live in one
-    (torchflows_amd/flat_optim.py; TORCHFLOWS_AMD_FLAT=0: always the per-tensor route)."""
-    return os.environ.get("TORCHFLOWS_AMD_FLAT", "1") != "0"
+    (torchflows_amd/flat_optim.py; TORCHFLOWS_AMD_DEBUG=flat=0: always the per-tensor route)."""
+    return debug_switch("flat", "1") != "0"
 
 
 def rows_outer_enabled() -> bool:
-    """The weight-gradient products of the fused spline training step on tfk_rows_outer (TORCHFLOWS_AMD_ROWS_OUTER=0:
+    """The weight-gradient products of the fused spline training step on tfk_rows_outer (TORCHFLOWS_AMD_DEBUG=rows_outer=0:
     split-K batched GEMMs on the GEMM library, as before round 3)."""
-    return os.environ.get("TORCHFLOWS_AMD_ROWS_OUTER", "1") != "0"
+    return debug_switch("rows_outer", "1") != "0"
 
 
 def fused_train_enabled() -> bool:
-    return os.environ.get("TORCHFLOWS_AMD_TRAIN_FUSED", "1") != "0"
+    return debug_switch("train_fused", "1") != "0"
 
 
 def padded_train_enabled() -> bool:
     """Fused training launches for even event sizes below 128 that are not 64 / 128, on rows padded to the next of the
-    two (TORCHFLOWS_AMD_TRAIN_PAD=0: the layer-by-layer reverse mode, as before round 3)."""
-    return os.environ.get("TORCHFLOWS_AMD_TRAIN_PAD", "1") != "0"
+    two (TORCHFLOWS_AMD_DEBUG=train_pad=0: the layer-by-layer reverse mode, as before round 3)."""
+    return debug_switch("train_pad", "1") != "0"
 
 
 def train_width(D: int) -> Optional[int]:

@@ -273,10 +273,10 @@ class MaskedAutoregressiveBijection(AutoregressiveBijection):
         transposed, zero-padded to 8 / 16 / 32 / 64 hidden units -- when the layer qualifies (affine or
         8-bin RQ-spline transformer, MADE with two masked linear layers and no global parameters); cached
         until a weight changes."""
-        import os
         import torch.nn as nn
         from torchflows_amd import fused
-        if os.environ.get("TORCHFLOWS_AMD_MADE_FUSED", "1") == "0":      # (comparison runs)
+        from torchflows_amd.utils import debug_switch
+        if debug_switch("made_fused", "1") == "0":      # (comparison runs)
             return None
         ct = self.conditioner_transform
         kind = self.transformer.native_kind

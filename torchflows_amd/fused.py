@@ -37,6 +37,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from torchflows_amd.utils import debug_switch
+
 from torchflows_amd import native
 
 OP_EW_MULADD, OP_EW_SUBDIV, OP_AFFINE_FWD, OP_AFFINE_INV, OP_SHIFT_FWD, OP_SHIFT_INV, \
@@ -54,10 +56,10 @@ FORWARD, INVERSE = 0, 1
 
 # parameters staged in LDS per launch; 40 KB keeps 4 workgroups (16 waves) per CU and holds
 # the whole RealNVP(64, n_layers=8) program (35.8 KB)
-MAX_PARAM_BYTES = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS", 40 * 1024))
+MAX_PARAM_BYTES = 40 * 1024
 # the matrix-core layout stores MFMA A-operands per lane (zero-padded to 16 hidden units):
 # RealNVP(64, n_layers=8) is 49 KB; its kernel runs 512-thread workgroups, 2 per CU (register-bound)
-MAX_PARAM_BYTES_MFMA = int(os.environ.get("TORCHFLOWS_AMD_FUSED_LDS_MFMA", 52 * 1024))
+MAX_PARAM_BYTES_MFMA = 52 * 1024
 # wider rows hold more registers per lane, so fewer workgroups fit a CU whatever the LDS use:
 # D = 128 (120 VGPRs) runs 2 x 512 threads per CU, D = 256 (179 VGPRs) one -- their launches may
 # stage more of the program (each extra launch re-reads and re-writes all the rows)
@@ -582,7 +584,7 @@ def _made_rqs_op(layer, mods, pos: torch.Tensor, D: int, H: int, Dp: Optional[in
 # lean chains (csrc/tfk_flow_chain.h): couplings of one kind, elementwise layers deferred
 # ---------------------------------------------------------------------------------------------
 def lean_enabled() -> bool:
-    return os.environ.get("TORCHFLOWS_AMD_LEAN", "1") != "0"
+    return debug_switch("lean", "1") != "0"
 
 
 def _lean_elementwise(layer, d: int, D: int):
@@ -666,7 +668,7 @@ def lean_bf16x3_enabled() -> bool:
     rows): 252.0 us per launch against 255.8 us with fp32 operands.  The 12 f32 MFMAs it removes (384 matrix cycles per
     wave-layer) come back as 12 bf16 MFMAs (~192) + 22 vector instructions for the split + a 1024-thread workgroup per
     CU (85 KB of operands).  It pays for spline chains (24 -> 18 MFMAs per element, split amortised over 8 elements)."""
-    return os.environ.get("TORCHFLOWS_AMD_LEAN_BF16X3", "0") == "1"
+    return debug_switch("lean_bf16x3", "0") == "1"
 
 
 def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3: bool = False, W1c=None) -> torch.Tensor:
@@ -745,7 +747,7 @@ def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3
 
 
 def rqs_bf16x3_enabled() -> bool:
-    return os.environ.get("TORCHFLOWS_AMD_RQS_BF16X3", "1") != "0"
+    return debug_switch("rqs_bf16x3", "1") != "0"
 
 
 def _bf16_pieces(w: torch.Tensor):
@@ -983,7 +985,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
               if first_c < len(plan) and isinstance(plan[first_c][0], CouplingBijection) else None)
     inline = (context and (kind_c in ("affine", "inverse_affine", "shift")
                            or (kind_c in ("rqs", "lrs") and Dp <= 128 and rqs_bf16x3_enabled()))
-              and os.environ.get("TORCHFLOWS_AMD_CTX_INLINE", "1") != "0")
+              )
     if inline and Dp == 256 and kind_c not in ("rqs", "lrs"):
         # the context variant of the 256-wide chain kernel spills (660 B of scratch at the 256-VGPR cap): measured
         # 1.8e8 evals/s against the interpreter's 3.5e8 on a conditional RealNVP(256) -- the interpreter keeps that size
@@ -1381,33 +1383,33 @@ def compile_chain(composition, direction: int, device: torch.device,
 
 
 def narrow_enabled() -> bool:
-    return os.environ.get("TORCHFLOWS_AMD_NARROW_IN", "1") != "0"
+    return debug_switch("narrow_in", "1") != "0"
 
 
 def stream_chain_enabled() -> bool:
-    """One launch with streamed operands for affine / shift chains that do not fit the LDS (TORCHFLOWS_AMD_STREAM_CHAIN=0:
+    """One launch with streamed operands for affine / shift chains that do not fit the LDS (TORCHFLOWS_AMD_DEBUG=stream_chain=0:
     one launch per LDS-full of couplings, as before)."""
-    return os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") != "0"
+    return debug_switch("stream_chain", "1") != "0"
 
 
 def odd_lean_enabled() -> bool:
-    """Odd event sizes on the straight-line chain kernels (TORCHFLOWS_AMD_ODD_LEAN=0: the interpreter with a plane per
+    """Odd event sizes on the straight-line chain kernels (TORCHFLOWS_AMD_DEBUG=odd_lean=0: the interpreter with a plane per
     element, as before round 3)."""
-    return os.environ.get("TORCHFLOWS_AMD_ODD_LEAN", "1") != "0"
+    return debug_switch("odd_lean", "1") != "0"
 
 
 def rows16_enabled() -> bool:
-    """Row width 16 for affine / shift chains on event sizes <= 16 (TORCHFLOWS_AMD_ROWS16=0: width 32 as before)."""
-    return os.environ.get("TORCHFLOWS_AMD_ROWS16", "1") != "0"
+    """Row width 16 for affine / shift chains on event sizes <= 16 (TORCHFLOWS_AMD_DEBUG=rows16=0: width 32 as before)."""
+    return debug_switch("rows16", "1") != "0"
 
 
 def narrow_rows_enabled() -> bool:
-    """Row width 32 for event sizes <= 32 (TORCHFLOWS_AMD_ROWS32=0: pad them to 64 as before)."""
-    return os.environ.get("TORCHFLOWS_AMD_ROWS32", "1") != "0"
+    """Row width 32 for event sizes <= 32 (always since round 4; the switch that padded them to 64 instead is retired)."""
+    return True
 
 
 def padded_enabled(D: int, Dp: int) -> bool:
-    return Dp == D or os.environ.get("TORCHFLOWS_AMD_FUSED_PAD", "1") != "0"
+    return Dp == D or debug_switch("fused_pad", "1") != "0"
 
 
 def sample_ready(chain: Optional[CompiledChain]) -> bool:
@@ -1445,8 +1447,63 @@ _STRUCTURAL_CACHES = ("_tfk_plan_packs", "_tfk_slots", "_tfk_declined_warned")
 # tensors and are rebuilt in microseconds: invalidate() drops them like any other cache)
 
 
-_CACHE_CHECK = int(os.environ.get("TORCHFLOWS_AMD_CACHE_CHECK", "0") or 0)
+_CACHE_CHECK = int(debug_switch("cache_check", "0") or 0)
 _cache_calls = 0
+
+# Edits through ``.data`` (``p.data.mul_(...)``) move no version counter: a compiled program would go on serving the old
+# weights in silence -- a hazard the reference does not have (it reads the live tensors on every call).  Default guard,
+# WITHOUT a host synchronisation on the hit path: every GUARD_EVERY-th hit of a compiled program on a HIP device enqueues a
+# checksum of the live tensors (two multi-tensor kernels), its comparison with the checksum taken when the program was
+# packed, and a copy of the verdict into pinned host memory; the verdict is READ on a later hit, once its event has
+# completed.  A mismatch drops every packed copy below the composition, warns, and recompiles in the same call.  A stale
+# program can therefore serve at most ~2 GUARD_EVERY calls after such an edit (TORCHFLOWS_AMD_DEBUG=guard_every=N; 0 = off);
+# ``invalidate_native_caches()`` right after the edit stays the way to serve none.
+GUARD_EVERY = int(debug_switch("guard_every", "64") or 0)
+
+
+class StaleProgramWarning(UserWarning):
+    """Parameters changed without their version counters moving (an edit through ``.data``); the packed copies were
+    dropped and rebuilt."""
+
+
+def _device_checksum(module: nn.Module) -> Optional[torch.Tensor]:
+    """0-dim fp64 device tensor: a position-weighted checksum of every fp32 parameter / buffer below ``module``."""
+    ts = [t.detach() for t in list(module.parameters()) + list(module.buffers())
+          if t.is_floating_point() and t.numel() and t.is_cuda]
+    if not ts:
+        return None
+    n1 = torch.stack(torch._foreach_norm(ts, 1)).double()          # sum |x|
+    n2 = torch.stack(torch._foreach_norm(ts, 2)).double()          # sqrt(sum x^2)
+    w = torch.arange(1, len(ts) + 1, dtype=torch.float64, device=n1.device)
+    return (n1 * w).sum() + 3.0 * (n2 * w).sum()
+
+
+class _Guard:
+    __slots__ = ("packed", "hits", "flag", "event")
+
+    def __init__(self, module: nn.Module):
+        self.packed = _device_checksum(module)
+        self.hits, self.flag, self.event = 0, None, None
+
+    def stale(self, module: nn.Module) -> bool:
+        """Called on every cache hit.  True when an EARLIER check has come back with a mismatch."""
+        if self.packed is None or GUARD_EVERY <= 0:
+            return False
+        if self.event is not None and self.event.query():
+            bad = bool(self.flag.item())                              # (pinned host memory, the copy has completed)
+            self.event = None
+            if bad:
+                return True
+        self.hits += 1
+        if self.hits % GUARD_EVERY == 0 and self.event is None and not torch.cuda.is_current_stream_capturing():
+            live = _device_checksum(module)
+            if live is not None and live.device == self.packed.device:
+                if self.flag is None:
+                    self.flag = torch.zeros((), dtype=torch.bool).pin_memory()
+                self.flag.copy_(live != self.packed, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record()
+        return False
 
 
 def _live_checksum(module: nn.Module) -> float:
@@ -1478,13 +1535,21 @@ def get_compiled(composition, direction: int, device: torch.device, context: boo
     key = (direction, str(device), bool(composition.training), bool(context))
     hit = cache.get(key)
     version = _params_version(composition)
+    if hit is not None and hit[0] == version and device.type == "cuda" and len(hit) > 3 and hit[3].stale(composition):
+        warnings.warn("torchflows_amd: parameters below this composition changed without their version counters moving "
+                      "(an in-place edit through .data?); the packed copies were served stale for up to "
+                      f"{2 * GUARD_EVERY} calls and are rebuilt now -- call invalidate_native_caches() right after such "
+                      "edits", StaleProgramWarning, stacklevel=3)
+        invalidate(composition)
+        cache = composition.__dict__.setdefault("_tfk_compiled", {})
+        hit = None
     if hit is not None and hit[0] == version:
         if _CACHE_CHECK:
-            # opt-in debug check (TORCHFLOWS_AMD_CACHE_CHECK=N): every N-th hit compares a checksum of the LIVE
+            # opt-in debug check (TORCHFLOWS_AMD_DEBUG=cache_check=N): every N-th hit compares a checksum of the LIVE
             # tensors with the one taken when the program was packed -- catches edits through ``.data``
             global _cache_calls
             _cache_calls += 1
-            if _cache_calls % _CACHE_CHECK == 0 and len(hit) > 2 and hit[2] != _live_checksum(composition):
+            if _cache_calls % _CACHE_CHECK == 0 and hit[2] is not None and hit[2] != _live_checksum(composition):
                 raise RuntimeError(
                     "torchflows_amd: parameters below this composition changed without their version counters "
                     "moving (an in-place edit through .data?): call invalidate_native_caches() after such edits")
@@ -1492,7 +1557,8 @@ def get_compiled(composition, direction: int, device: torch.device, context: boo
     chain = compile_chain(composition, direction, device, context=context)
     if chain is not None and context:
         chain.ctx_width = _context_width(composition)
-    cache[key] = (version, chain, _live_checksum(composition)) if _CACHE_CHECK else (version, chain)
+    guard = _Guard(composition) if (device.type == "cuda" and chain is not None and GUARD_EVERY > 0) else None
+    cache[key] = (version, chain, _live_checksum(composition) if _CACHE_CHECK else None, guard)
     if chain is None:
         warn_declined(composition, direction)
     return chain
@@ -1573,12 +1639,12 @@ _LEAN_KINDS = frozenset((OP_AFFINE_FWD_LEAN, OP_AFFINE_INV_LEAN, OP_SHIFT_FWD_LE
 
 def sum_ready(chain: Optional[CompiledChain]) -> bool:
     """One LEAN launch: the fp64 sum of the log-probabilities can ride along (tfk_flow_run_mfma_sum).  Opt-in
-    (TORCHFLOWS_AMD_SUM_IN_KERNEL=1): measured on RealNVP-64, 2^20 rows, it removes the reduction's two launches (~8 us
+    (TORCHFLOWS_AMD_DEBUG=sum_in_kernel=1): measured on RealNVP-64, 2^20 rows, it removes the reduction's two launches (~8 us
     of a 261 us step) and adds ~6 us to the kernel (one agent-scope ticket per workgroup, 3 072 of them): 263.7 against
     261.2 us per step over 20 steps, 239.3 against 241.3 us at the median of 100 -- a wash."""
     return (chain is not None and len(chain.segments) == 1 and chain.segments[0].mfma
             and chain.segments[0].ops[0][0] in _LEAN_KINDS
-            and os.environ.get("TORCHFLOWS_AMD_SUM_IN_KERNEL", "0") == "1")
+            and debug_switch("sum_in_kernel", "0") == "1")
 
 
 def run_chain(chain: CompiledChain, rows: torch.Tensor, want_rows: bool, base=None, base_of_input: bool = False,

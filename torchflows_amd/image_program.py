@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from torchflows_amd import native
+from torchflows_amd.utils import debug_switch
 
 FORWARD, INVERSE = 0, 1
 
@@ -298,7 +299,7 @@ class _Builder:
             tgt_i, tgt_m = tgt.to(torch.int32), st(tgt)
         keep = (src.to(torch.int32).to(dev), st(src).to(dev), tgt_i.to(dev), tgt_m.to(dev),
                 pk["weights"].to(dev), pk["bg1"].to(dev), pk["bg2"].to(dev), w_tiles.to(dev), b_tiles.to(dev))
-        env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_" + k, "0") or 0)
+        env = lambda k: int(debug_switch("glow_" + k.lower(), "0") or 0)
         L = native.GlowLayer(kind={"affine": 0, "conv1x1": 1, "shift": 2}[kind], c_in=c_in, hi=hi, wi=wi, oy=pk["oy"], ox=pk["ox"],
                              kh=pk["kh"], kw=pk["kw"], T=T, n_params=pk["n_params"], n_ch=n_ch, hw=hw, slots=env("SLOTS"), block=env("BLOCK"),
                              cg1=env("CG1"), cg2=env("CG2"), grid=env("GRID"),
@@ -367,7 +368,7 @@ def build_levels(steps: List[Step], D: int, device: torch.device) -> Optional[Li
     """Group consecutive steps with the same element footprint (sources + targets) into level launches; None when a
     level does not fit the level kernel (then the program keeps one launch per step)."""
     import ctypes as C
-    env = lambda k: int(os.environ.get("TORCHFLOWS_AMD_GLOW_LEVEL_" + k, "0") or 0)
+    env = lambda k: int(debug_switch("glow_level_" + k.lower(), "0") or 0)
     groups, foot = [], None
     for i, step in enumerate(steps):
         aux = step.info["aux"]
@@ -435,10 +436,19 @@ def get_program(module, d: int, device: torch.device) -> Optional[ImageProgram]:
     key = (d, device.index)
     version = fused._params_version(module)
     hit = cache.get(key)
+    if hit is not None and hit[0] == version and hit[2] is not None and hit[2].stale(module):
+        import warnings                                  # (the asynchronous .data-edit guard of fused.get_compiled)
+        warnings.warn("torchflows_amd: parameters below this image flow changed without their version counters moving "
+                      "(an in-place edit through .data?); the compiled program is rebuilt", fused.StaleProgramWarning,
+                      stacklevel=3)
+        fused.invalidate(module)
+        cache = module.__dict__.setdefault("_tfk_image_programs", {})
+        hit = None
     if hit is not None and hit[0] == version:
         return hit[1]
     prog = compile_program(module, d, device)
-    cache[key] = (version, prog)
+    guard = fused._Guard(module) if (prog is not None and device.type == "cuda" and fused.GUARD_EVERY > 0) else None
+    cache[key] = (version, prog, guard)
     return prog
 
 

@@ -768,8 +768,9 @@ def flow_run(x, z, logdet, gauss_loc, gauss_log_scale, logprob, ops, params, acc
 
 def _stream_flag() -> int:
     """Flag bit 3 of tfk_flow_run_mfma: stream the operands of an affine / shift chain (D >= 128) even if they fit the LDS
-    (tuning: TORCHFLOWS_AMD_STREAM_CHAIN=force)."""
-    return 8 if os.environ.get("TORCHFLOWS_AMD_STREAM_CHAIN", "1") == "force" else 0
+    (tuning: TORCHFLOWS_AMD_DEBUG=stream_chain=force)."""
+    from torchflows_amd.utils import debug_switch
+    return 8 if debug_switch("stream_chain", "1") == "force" else 0
 
 
 _sum_ws = {}      # (device index, stream handle) -> zero-initialised workspace of tfk_flow_run_mfma_sum (resets itself)

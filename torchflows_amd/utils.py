@@ -46,28 +46,36 @@ def as_rows(x: torch.Tensor, event_shape: Sequence[int]) -> Tuple[torch.Tensor, 
     return rows, batch
 
 
+def debug_switch(name: str, default: str) -> str:
+    """Route / tuning switches of the A/B tests and tools, all behind ONE environment variable:
+    ``TORCHFLOWS_AMD_DEBUG="rows16=0,flat=0,glow_block=512"`` (comma-separated ``key=value``; README lists the keys).
+    The documented environment variables proper are TORCHFLOWS_AMD_{LIB, FUSED, MFMA, TRAIN, GRAPH, IMAGE_PROGRAM,
+    GLOW_LEVELS, DIST_BACKEND}; everything else that used to be a variable of its own (round 3: 28 of them) lives here."""
+    import os
+    spec = os.environ.get("TORCHFLOWS_AMD_DEBUG", "")
+    if spec:
+        for item in spec.split(","):
+            k, _, v = item.partition("=")
+            if k.strip().lower() == name:
+                return v.strip()
+    return default
+
+
 def make_adamw(params, lr: float, capturable: bool = False):
-    """AdamW as the reference's ``fit`` builds it (flows.py:268).  TORCHFLOWS_AMD_FUSED_ADAMW=1 selects PyTorch's
-    single-kernel ``fused`` implementation where every parameter lives on the GPU -- opt-in: on this stack it measured
-    SLOWER for a 40-tensor flow (2.67 against 2.52 ms per eager RealNVP-64 step) and its rounding differs from the default
-    implementation's, which the host-trajectory test pins."""
+    """AdamW as the reference's ``fit`` builds it (flows.py:268).  (PyTorch's single-kernel ``fused`` implementation was an
+    opt-in switch until round 3: on this stack it measured SLOWER for a 40-tensor flow -- 2.67 against 2.52 ms per eager
+    RealNVP-64 step -- and its rounding differs from the default implementation's, which the host-trajectory test pins;
+    the switch is retired.)"""
     import os
     import torch
     params = list(params)
     # every parameter fp32 on one GPU: the same update over ONE buffer (flat_optim.py: torch's own _foreach calls on
-    # one-element lists, bit-identical trajectories, a tenth of the host time).  TORCHFLOWS_AMD_FLAT_ADAMW=0 turns it
+    # one-element lists, bit-identical trajectories, a tenth of the host time).  TORCHFLOWS_AMD_DEBUG=flat_adamw=0 turns it
     # off, =1 forces it on the host as well (tests).
-    flat = os.environ.get("TORCHFLOWS_AMD_FLAT_ADAMW", "")
+    flat = debug_switch("flat_adamw", "")
     trainable = [p for p in params if p.requires_grad]
     if (not capturable and flat != "0" and trainable and len({p.device for p in trainable}) == 1
             and all(p.dtype == torch.float32 for p in trainable) and (trainable[0].is_cuda or flat == "1")):
         from torchflows_amd.flat_optim import FlatAdamW
         return FlatAdamW(params, lr=lr)
-    fused = (os.environ.get("TORCHFLOWS_AMD_FUSED_ADAMW", "0") == "1" and len(params) > 0
-             and all(p.is_cuda and torch.is_floating_point(p) for p in params))
-    if fused:
-        try:
-            return torch.optim.AdamW(params, lr=lr, fused=True, capturable=capturable)
-        except (RuntimeError, TypeError):          # (a PyTorch build without the fused kernel)
-            pass
     return torch.optim.AdamW(params, lr=lr, capturable=capturable)
