@@ -680,29 +680,47 @@ def test_narrow_rows_are_read_in_place(monkeypatch, arch, D):
         assert normwise(xs.cpu().numpy(), xs32.cpu().numpy()) < 2e-6 and rel(lps.cpu().numpy(), lps32.cpu().numpy()) < 2e-6
 
 
-def test_affine_chain_bf16x3_operands_opt_in(monkeypatch):
-    """TORCHFLOWS_AMD_DEBUG=lean_bf16x3=1: GEMM 2 of RealNVP-64 chains on the bf16 matrix pipe at fp32 accuracy (opt-in: no
-    faster than fp32 operands for affine chains, fused.lean_bf16x3_enabled) -- same values as the default format to
-    fp32 rounding, and as the host."""
+@pytest.mark.parametrize("arch,D,n_layers", [("RealNVP", 64, 4), ("RealNVP", 256, 8), ("NICE", 256, 8), ("RealNVP", 256, 2)])
+def test_affine_chain_bf16x3_operands(monkeypatch, arch, D, n_layers):
+    """GEMM 2 of affine / shift chains on the bf16 matrix pipe at fp32 accuracy (three bf16 pieces per operand, six of the
+    nine piece products).  D = 64: opt-in (TORCHFLOWS_AMD_DEBUG=lean_bf16x3=1, no faster than fp32 operands there); D = 256:
+    the default since round 4 (streamed 42 KB blocks, 617 -> 545 us per RealNVP-256 launch).  Same values as the fp32 operand
+    format to fp32 rounding, the host's fp64 evaluation within 1e-5, one launch per log_prob, the inverse undoes the forward."""
+    import copy
     import torchflows_amd as tfa
+    from torchflows_amd import fused, native
     torch.manual_seed(2)
-    flow = tfa.Flow(tfa.RealNVP(64, n_layers=4))
+    flow = tfa.Flow(getattr(tfa, arch)(D, n_layers=n_layers))
     flow.train()
     with torch.no_grad():
-        flow.log_prob(torch.randn(1024, 64))
+        flow.log_prob(torch.randn(1024, D))
     flow.eval()
-    x = torch.randn(2000, 64)
+    x = torch.randn(2000, D)
+    x[:100] *= 4.0
     with torch.no_grad():
-        lp_h = flow.log_prob(x)
+        lp_h = copy.deepcopy(flow).double().log_prob(x.double())
         flow = flow.cuda()
+        set_debug(monkeypatch, lean_bf16x3="0")
         lp0 = flow.log_prob(x.cuda())
         set_debug(monkeypatch, lean_bf16x3="1")
         flow.invalidate_native_caches()
+        chain = fused.get_compiled(flow.bijection, 0, torch.device("cuda", 0))
+        is3 = any(len(op) > 4 and int(op[4]) == 256 for seg in chain.segments for op in seg.ops)
+        # (D = 256: the format exists as streamed operands only -- a chain of two couplings keeps its fp32 blocks resident)
+        assert is3 == (not (D == 256 and n_layers == 2)), "operand format"
+        before = native.calls
         lp1 = flow.log_prob(x.cuda())
+        assert native.calls - before == 1
         z1, ld1 = flow.bijection.forward(x.cuda())
-        xr, _ = flow.bijection.inverse(z1)
-    assert rel(lp1.cpu().numpy(), lp_h.numpy()) < 1e-5 and rel(lp1.cpu().numpy(), lp0.cpu().numpy()) < 2e-6
-    assert torch.allclose(xr.cpu(), x, atol=1e-4)
+        xr, ldr = flow.bijection.inverse(z1)
+        if D == 256:                                        # the default picks the format by itself
+            set_debug(monkeypatch, lean_bf16x3=None)
+            flow.invalidate_native_caches()
+            assert torch.equal(flow.log_prob(x.cuda()), lp1)
+    e_h, e_0 = rel(lp1.cpu().numpy(), lp_h.numpy()), rel(lp1.cpu().numpy(), lp0.cpu().numpy())
+    print(f"{arch}({D}) bf16 x 3 operands: log_prob vs fp64 host {e_h:.2e}, vs the fp32 operand format {e_0:.2e}")
+    assert e_h < 1e-5 and e_0 < 2e-6
+    assert torch.allclose(xr.cpu(), x, atol=2e-4) and torch.allclose(ld1, -ldr, atol=1e-3)
 
 
 @pytest.mark.parametrize("D,n_hidden", [(64, 24), (64, 31), (128, None), (256, None), (22, 20)])

@@ -550,7 +550,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
     import torchflows_amd as tfa
     if "@" in arch and bf16x3 == "0" and ("RQ" in arch or "LRS" in arch):
         pytest.skip("spline chains at row width 32: bf16 x 3 operands only")
-    if bf16x3 == "0" and "RQ" not in arch and "LRS" not in arch and D not in (64, 22, 8):
+    if bf16x3 == "0" and "RQ" not in arch and "LRS" not in arch and D not in (64, 22, 8, 256):
         pytest.skip("the operand format only concerns spline chains and 64-wide affine chains")
     set_debug(monkeypatch, rqs_bf16x3=bf16x3)
     set_debug(monkeypatch, lean_bf16x3=bf16x3)
@@ -561,7 +561,7 @@ def test_lean_chain_packer_against_fp64_emulator(arch, D, n_layers, direction, b
         kw = dict(conditioner_kwargs=dict(n_hidden=int(h)))
         if bf16x3 == "0":
             pytest.skip("fp32 operands stop at hidden width 16")
-    if D == 256 and bf16x3 == "0":
+    if D == 256 and bf16x3 == "0" and "RQ" in arch:
         pytest.skip("CouplingRQNSF(256) has hidden width 17: bf16 x 3 operands only")
     if ("LRS" in arch or "Autoregressive" in arch) and bf16x3 == "0":
         pytest.skip("lean linear rational splines and MADE spline layers: bf16 x 3 operands only")

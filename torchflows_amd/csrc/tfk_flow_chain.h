@@ -250,27 +250,32 @@ __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, 
     const int ll01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302), ll23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302);
     const li32x4 B1 = {hh01, hh23, hh01, hh23}, B2 = {mm01, mm23, mm01, mm23}, B3 = {hh01, hh23, ll01, ll23};
 
-    // the tiles side by side, product by product (a tile's three MFMAs must not follow each other back to back)
+    // the tiles side by side, product by product (a tile's three MFMAs must not follow each other back to back), in groups
+    // of four: 32 operand / accumulator registers whatever the row width (D = 256 has 16 tiles per coupling)
+    constexpr int GT3 = T2 < 4 ? T2 : 4;
+    static_assert(T2 % GT3 == 0, "tile groups");
+#pragma unroll
+  for (int g0 = 0; g0 < T2; g0 += GT3) {
     cf32x4 o[T2];
-    li32x4 a1[T2];
+    li32x4 a1[GT3];
 #pragma unroll
-    for (int t = 0; t < T2; ++t) {
-        o[t] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        a1[t] = A23[(t * 2) * 64 + lane];
+    for (int tt = 0; tt < GT3; ++tt) {
+        o[g0 + tt] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        a1[tt] = A23[((g0 + tt) * 2) * 64 + lane];
     }
 #pragma unroll
-    for (int t = 0; t < T2; ++t)
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[t]), __builtin_bit_cast(lbf16x8, B1), o[t], 0, 0, 0);
+    for (int tt = 0; tt < GT3; ++tt)
+        o[g0 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[tt]), __builtin_bit_cast(lbf16x8, B1), o[g0 + tt], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < T2; ++t)
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[t]), __builtin_bit_cast(lbf16x8, B2), o[t], 0, 0, 0);
+    for (int tt = 0; tt < GT3; ++tt)
+        o[g0 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a1[tt]), __builtin_bit_cast(lbf16x8, B2), o[g0 + tt], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < T2; ++t) {
-        const li32x4 a2 = A23[(t * 2 + 1) * 64 + lane];
-        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a2), __builtin_bit_cast(lbf16x8, B3), o[t], 0, 0, 0);
+    for (int tt = 0; tt < GT3; ++tt) {
+        const li32x4 a2 = A23[((g0 + tt) * 2 + 1) * 64 + lane];
+        o[g0 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, a2), __builtin_bit_cast(lbf16x8, B3), o[g0 + tt], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < T2; ++t) {
+    for (int t = g0; t < g0 + GT3; ++t) {
         if constexpr (affine) {
             if constexpr (FAST && KIND == 1) {
                 ld2 += log2_scales<true>(o[t][0], o[t][2], 0.0f, 0.0f, umin);
@@ -296,6 +301,7 @@ __device__ __forceinline__ void couple_lean3(const float *prm, int lane, int q, 
             }
         }
     }
+  }
 }
 
 
@@ -515,7 +521,9 @@ template <int EPL, int STEPS2, int KIND>
 constexpr int chain_block_floats()
 {
     constexpr int T2 = KIND < 2 ? EPL / 2 : (EPL + 3) / 4;
-    constexpr int NA2 = (T2 * (STEPS2 == 0 ? 1 : STEPS2) + 3) & ~3;
+    if constexpr (STEPS2 == 0)                               // bf16 x 3 operands: A1 | b1 | A23[T2][2][64][4 dwords] | pre_s | pre_t
+        return EPL * 64 + 16 + T2 * 2 * 64 * 4 + 8 * EPL;
+    constexpr int NA2 = (T2 * STEPS2 + 3) & ~3;
     return EPL * 64 + 16 + NA2 * 64 + T2 * 16 + 8 * EPL;
 }
 
@@ -600,7 +608,7 @@ __attribute__((amdgpu_waves_per_eu((EPL == 16 && BLOCK == 768) ? 3 : (((EPL == 1
     const bool base_of_input = (flags & 4) != 0;
     // resident: the whole parameter block; streamed: two coupling blocks | the closing TFK_OP_EW_FMA block
     constexpr int LB = chain_block_floats<EPL, STEPS2, KIND>();
-    static_assert(!STREAM || (KIND < 4 && STEPS2 != 0), "streamed operands: affine / shift couplings, fp32 format");
+    static_assert(!STREAM || KIND < 4, "streamed operands: affine / shift couplings");
     static_assert(!CTX || (KIND < 4 && STEPS2 != 0 && !STREAM), "context: affine / shift couplings, fp32 format, resident");
     float *ew_s = STREAM ? lds + kStreamBufs * LB : lds + (prog.ew_offset >= 0 ? prog.ew_offset : 0);
     if constexpr (STREAM) {
@@ -887,7 +895,7 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
                           int steps2, int flags, int xw, hipStream_t s, const char *fn)
 {
     // operands that do not fit the LDS beside each other are streamed (chain_layers_stream): D >= 128, fp32 format
-    if ((size_t)n_params + 16 * EPL + 4 > 160 * 1024 / sizeof(float) || ((flags & 8) && EPL >= 16 && KIND < 4 && steps2 != 0)) {
+    if ((size_t)n_params + 16 * EPL + 4 > 160 * 1024 / sizeof(float) || ((flags & 8) && EPL >= 16 && KIND < 4 && (steps2 != 0 || EPL == 32))) {
         if (prog.move_mask)
             return fail(TFK_EINVAL, "%s: programs of odd event sizes keep their operands resident (no streaming)", fn);
         if constexpr (EPL >= 16 && KIND < 4) {
@@ -897,6 +905,9 @@ static int launch_chain_k(const float *x, float *z, float *logdet, const float *
 #define TFK_CS(ST_) \
     launch_chain_b<EPL, TFK_STREAM_BLOCK, ST_, KIND, true>(x, z, logdet, loc, log_scale, logprob, N, params, n_params, prog, flags, xw, s, fn)
             switch (steps2) {
+            case 0:                 // bf16 x 3 operands (round 4): 42 KB per coupling at D = 256, two blocks resident
+                if constexpr (EPL == 32) return TFK_CS(0);
+                break;
             case 1: return TFK_CS(1);
             case 2: return TFK_CS(2);
             case 3: return TFK_CS(3);

@@ -663,12 +663,16 @@ def _lean_coupling(layer, d: int, pos: torch.Tensor, D: int, Dp: int, allow_ctx:
     return lk, plane, H, W1t, b1, W2p, b2p
 
 
-def lean_bf16x3_enabled() -> bool:
-    """bf16 x 3 operands for GEMM 2 of affine / shift chains at D = 64: OFF by default -- measured on RealNVP-64 (2^20
-    rows): 252.0 us per launch against 255.8 us with fp32 operands.  The 12 f32 MFMAs it removes (384 matrix cycles per
-    wave-layer) come back as 12 bf16 MFMAs (~192) + 22 vector instructions for the split + a 1024-thread workgroup per
-    CU (85 KB of operands).  It pays for spline chains (24 -> 18 MFMAs per element, split amortised over 8 elements)."""
-    return debug_switch("lean_bf16x3", "0") == "1"
+def lean_bf16x3_enabled(Dp: int = 64) -> bool:
+    """bf16 x 3 operands for GEMM 2 of affine / shift chains (TORCHFLOWS_AMD_DEBUG=lean_bf16x3=0 / 1; default "auto").
+    D = 64: OFF unless forced -- measured on RealNVP-64 (2^20 rows): 252.0 us per launch against 255.8 us with fp32
+    operands.  The 12 f32 MFMAs it removes (384 matrix cycles per wave-layer) come back as 12 bf16 MFMAs (~192) + 22 vector
+    instructions for the split + a 1024-thread workgroup per CU (85 KB of operands).
+    D = 256 (streamed operands): ON -- round 4, RealNVP-256 on 2^19 rows, same box, alternating: 617 -> 545 us per launch
+    (8.25 -> 9.34e8 evals/s, +13 %): 48 f32 MFMAs per wave-layer (1 536 matrix cycles of the layer's 2 560) become 48 bf16
+    ones (~770) for the same 22-instruction split; parity unchanged (tests/test_gpu_fused.py)."""
+    mode = debug_switch("lean_bf16x3", "auto")
+    return mode == "1" or (mode == "auto" and Dp == 256)
 
 
 def _pack_lean(lk: int, H: int, Dp: int, W1t, b1, W2p, b2p, pre_s, pre_t, bf16x3: bool = False, W1c=None) -> torch.Tensor:
@@ -938,7 +942,7 @@ def _pack_lean_made(H: int, Dp: int, W1f, b1f, W2p, b2p, pre_s, pre_t) -> torch.
 
 
 def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor, pos_in: torch.Tensor,
-                  context: bool = False, odd: bool = False):
+                  context: bool = False, odd: bool = False, allow_aff3: bool = True):
     """The chain as LEAN flow programs (csrc/tfk_flow_chain.h), or None: elementwise layers with global parameters,
     folded reversals and affine / shift couplings of one kind and one hidden width <= 16 whose source plane
     alternates -- every RealNVP / NICE preset.  The elementwise layers are deferred: physical column c carries a
@@ -972,7 +976,9 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     # bf16 x 3 operands for affine / shift chains: D = 64 only, and the whole chain must stay ONE launch (10.6 KB of
     # operands per coupling instead of 5.7): decided after a dry count of the couplings
     n_couplings = sum(isinstance(layer, CouplingBijection) for layer, _ in plan)
-    aff3 = lean_bf16x3_enabled() and Dp == 64 and 0 < n_couplings <= 13 and not odd
+    aff3 = allow_aff3 and lean_bf16x3_enabled(Dp) and not odd and ((Dp == 64 and 0 < n_couplings <= 13)
+                                                    or (Dp == 256 and not context and stream_chain_enabled()))
+    # (D = 256, round 4: the streamed chain takes the bf16 x 3 format too -- 42 KB per coupling, two blocks resident)
     # (context) if a context-conditioned elementwise layer precedes the first coupling, every elementwise layer before
     # that coupling is an interpreter op of the launch in front of the chain (the inverse direction starts with a
     # constant ActNorm followed by the context-conditioned layer)
@@ -1211,9 +1217,15 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     # affine / shift chains whose blocks do not fit the LDS together (D = 256: 22 KB per coupling): ONE launch with the
     # operands streamed block by block (csrc/tfk_flow_chain.h: chain_layers_stream) instead of one launch per LDS-full
     total = sum(block.numel() for _, _, _, block, _ in items) * 4
+    fmt3_all = all(extra == (256,) for k_, _, _, _, extra in items if k_ != OP_EW_FMA)
     if (not streamed and not context and kind0 in (0, 1, 2, 3) and Dp >= 128 and stream_chain_enabled() and len(items) <= 61
-            and total > 158 * 1024 and not any(extra for *_, extra in items) and not odd):
+            and total > 158 * 1024 and not odd
+            and (not any(extra for *_, extra in items) or (Dp == 256 and fmt3_all))):
         streamed = True
+    elif Dp == 256 and any(extra == (256,) for *_, extra in items):
+        # bf16 x 3 blocks at D = 256 exist as STREAMED operands only: a chain short enough to keep its blocks resident
+        # (three couplings) is packed again in the fp32 format
+        return _compile_lean(composition, plan, device, D, Dp, pos, pos_in, context=context, odd=odd, allow_aff3=False)
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
     for kind, plane, steps2, block, extra in items:
@@ -1535,7 +1547,8 @@ def get_compiled(composition, direction: int, device: torch.device, context: boo
     key = (direction, str(device), bool(composition.training), bool(context))
     hit = cache.get(key)
     version = _params_version(composition)
-    if hit is not None and hit[0] == version and device.type == "cuda" and len(hit) > 3 and hit[3].stale(composition):
+    if (hit is not None and hit[0] == version and device.type == "cuda" and len(hit) > 3 and hit[3] is not None
+            and hit[3].stale(composition)):
         warnings.warn("torchflows_amd: parameters below this composition changed without their version counters moving "
                       "(an in-place edit through .data?); the packed copies were served stale for up to "
                       f"{2 * GUARD_EVERY} calls and are rebuilt now -- call invalidate_native_caches() right after such "
