@@ -957,6 +957,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
         CouplingBijection, ElementwiseBijection, MaskedAutoregressiveBijection)
     from torchflows_amd.bijections.finite.matrix.permutation import PermutationMatrix
     hp = Dp // 2
+    pos_arg = pos                                            # (the walk below rebinds ``pos`` at every permutation)
     if odd:
         # ODD event sizes (affine / shift chains): HalfSplit has one target more than sources, and with the reversals the
         # MIDDLE element is a target of every coupling -- it has to sit in whichever plane is being transformed.  Both
@@ -1225,7 +1226,7 @@ def _compile_lean(composition, plan, device, D: int, Dp: int, pos: torch.Tensor,
     elif Dp == 256 and any(extra == (256,) for *_, extra in items):
         # bf16 x 3 blocks at D = 256 exist as STREAMED operands only: a chain short enough to keep its blocks resident
         # (three couplings) is packed again in the fp32 format
-        return _compile_lean(composition, plan, device, D, Dp, pos, pos_in, context=context, odd=odd, allow_aff3=False)
+        return _compile_lean(composition, plan, device, D, Dp, pos_arg, pos_in, context=context, odd=odd, allow_aff3=False)
     segments: List[Segment] = []
     ops, blocks, used = [], [], 0
     for kind, plane, steps2, block, extra in items:
