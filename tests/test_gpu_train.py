@@ -70,6 +70,38 @@ def test_flow_grads_golden_on_hip(native, fname, arch, es, n_layers):
     print(f"{fname}: worst parameter gradient {worst:.2e}")
 
 
+def test_realnvp256_trains_on_the_fused_launches(native):
+    """config 4's own preset (RealNVP(256): hidden width 12) on the fused training launches --
+    tfk_affine_coupling_train_bwd at D = 256 (round 4: 256 VGPRs + 166 AGPRs, one wave per SIMD, the dL/dh transpose tile
+    staged in two halves) -- with the weights of tests/golden/flow_realnvp256.npz: the plan is fully fused (hipGraph-capturable:
+    no GEMM-library call), one backward launch + one column sum per coupling, and the gradients of sum(w log_prob) match
+    fp64 autograd on the host."""
+    import copy
+    from conftest import load_golden, state_dict_of
+    import torchflows_amd as tfa
+    from torchflows_amd import autograd as ag
+    from torchflows_amd.bijections.base import method_direction
+    fx = load_golden("flow_realnvp256.npz")
+    flow = tfa.Flow(tfa.RealNVP(256, n_layers=8))
+    flow.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict_of(fx, "init").items()})
+    flow.eval()
+    x = torch.from_numpy(fx["x"])
+    w = torch.rand(x.shape[0], generator=torch.Generator().manual_seed(5)) + 0.5
+    _, gx_t, grads_t = hip_grads(copy.deepcopy(flow).double(), x.double(), w.double())
+    flow = flow.cuda()
+    plan = ag.training_plan(flow.bijection, method_direction(flow.bijection.forward))
+    assert plan is not None and ag.fully_fused(plan, 256) and ag.plan_width(plan, 256) == 256
+    before = native.calls
+    lp, gx, grads = hip_grads(flow, x.cuda(), w.cuda())
+    launches = native.calls - before
+    assert launches <= 8 * 3 + 30, launches                  # forward program + fused backward + column sum per coupling
+    assert np.max(np.abs(lp.detach().cpu().numpy() - fx["init/log_prob"]) / np.maximum(1, np.abs(fx["init/log_prob"]))) < 1e-5
+    e = normwise(gx.cpu().numpy(), gx_t.numpy())
+    worst = max(normwise(g.cpu().numpy(), grads_t[n].numpy()) for n, g in grads.items() if g is not None and g.numel())
+    print(f"RealNVP(256) fused training launches: {launches} libtfk calls, gx {e:.2e}, worst parameter gradient {worst:.2e}")
+    assert e < 1e-5 and worst < 1e-4
+
+
 @pytest.mark.parametrize("arch,D,n_layers", [("RealNVP", 64, 8), ("NICE", 64, 8), ("CouplingRQNSF", 64, 8),
                                              ("RealNVP", 256, 8)])
 def test_flow_grads_vs_oracle_large_batch(native, oracle, arch, D, n_layers):
@@ -303,7 +335,7 @@ def test_fit_with_hipgraph_replay_in_a_subprocess(native):
     assert abs(out["after_graph"] - out["after_eager"]) < 1e-3 * max(1.0, abs(out["after_eager"]))
 
 
-@pytest.mark.parametrize("D,N", [(64, 4099), (64, 17), (64, 1), (128, 2050)])
+@pytest.mark.parametrize("D,N", [(64, 4099), (64, 17), (64, 1), (128, 2050), (256, 1031), (256, 5)])
 @pytest.mark.parametrize("layer_cls", ["AffineCoupling", "InverseAffineCoupling"])
 def test_fused_training_backward_matches_layerwise(native, monkeypatch, D, N, layer_cls):
     """tfk_affine_coupling_train_bwd (conditioner + transform + MLP backward + weight-gradient sums

@@ -662,7 +662,10 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
     // half-wave touch 32 different banks: blocks of 16 rows x 4 floats every 72 floats (bank =
     // 8*block + 4*q + r), x rows every HALF + 16 floats (bank = 16*q + column).
     constexpr int BLK = 72, XROW = HALF + 16;
-    constexpr int SCR_H = 4 * BLK, SCR_G = T2 * 4 * BLK, SCR_X = 16 * XROW;
+    // D = 256 (round 4): the dL/dh tile is staged in two halves of T2 / 2 tiles (16 tiles at once would take the LDS to
+    // 166 KB with four waves per workgroup)
+    constexpr int GH = (EPL == 32) ? 2 : 1, TG = T2 / GH;
+    constexpr int SCR_H = 4 * BLK, SCR_G = TG * 4 * BLK, SCR_X = 16 * XROW;
     constexpr int M = T2 * 256 + T1 * 256 + 16;
     constexpr int SCR = (2 * SCR_H + SCR_G + SCR_X) > M ? (2 * SCR_H + SCR_G + SCR_X) : M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
             make_float4(hid[0], hid[1], hid[2], q == 3 ? 1.0f : hid[3]);
         *reinterpret_cast<float4 *>(scr_p + q * BLK + j * 4) = make_float4(gpre[0], gpre[1], gpre[2], gpre[3]);
 #pragma unroll
-        for (int t = 0; t < T2; ++t)
+        for (int t = 0; t < TG; ++t)
             *reinterpret_cast<float4 *>(scr_g + (t * 4 + q) * BLK + j * 4) =
                 make_float4(ghv[t][0], ghv[t][1], ghv[t][2], ghv[t][3]);
 #pragma unroll
@@ -846,11 +849,22 @@ __global__ __launch_bounds__(kBlock) void k_affine_coupling_train_bwd(
             bp[s] = scr_p[(j & 3) * BLK + (4 * s + q) * 4 + (j >> 2)];
         }
 #pragma unroll
-        for (int t = 0; t < T2; ++t)
+        for (int h = 0; h < GH; ++h) {
+            if (h > 0) {                    // the second half of the dL/dh tiles takes the first one's place
+                wave_lds_sync();
 #pragma unroll
-            for (int s = 0; s < 4; ++s)     // A-operand: [D-row j of tile t][k = row 4s+q]
-                accW2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                    scr_g[(t * 4 + (j >> 2)) * BLK + (4 * s + q) * 4 + (j & 3)], bh[s], accW2[t], 0, 0, 0);
+                for (int t = 0; t < TG; ++t)
+                    *reinterpret_cast<float4 *>(scr_g + (t * 4 + q) * BLK + j * 4) =
+                        make_float4(ghv[h * TG + t][0], ghv[h * TG + t][1], ghv[h * TG + t][2], ghv[h * TG + t][3]);
+                wave_lds_sync();
+            }
+#pragma unroll
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)     // A-operand: [D-row j of tile t][k = row 4s+q]
+                    accW2[h * TG + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        scr_g[(t * 4 + (j >> 2)) * BLK + (4 * s + q) * 4 + (j & 3)], bh[s], accW2[h * TG + t], 0, 0, 0);
+        }
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
@@ -915,7 +929,7 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
                             const float *gscale, int g_reversed, hipStream_t s, const char *fn)
 {
     constexpr int M = (EPL / 2) * 256 + (EPL / 4) * 256 + 16;
-    constexpr int TILES = 2 * 4 * 72 + (EPL / 2) * 4 * 72 + 16 * (4 * EPL + 16);
+    constexpr int TILES = 2 * 4 * 72 + ((EPL / 2) / (EPL == 32 ? 2 : 1)) * 4 * 72 + 16 * (4 * EPL + 16);
     constexpr int SCR = TILES > M ? TILES : M;                    // as in the kernel
     const size_t lds = ((size_t)n_params + (kBlock / 64) * SCR) * sizeof(float);
     if (lds > 160 * 1024) return fail(TFK_EINVAL, "%s: %zu bytes of LDS needed", fn, lds);
@@ -952,7 +966,7 @@ static int launch_train_bwd(const float *x, float *g, const float *gld, const fl
 
 extern "C" {
 
-int tfk_coupling_train_bwd_supported(int32_t D) { return (D == 64 || D == 128) ? 1 : 0; }
+int tfk_coupling_train_bwd_supported(int32_t D) { return (D == 64 || D == 128 || D == 256) ? 1 : 0; }
 
 int64_t tfk_coupling_train_bwd_out_floats(int32_t D)
 {
@@ -973,7 +987,7 @@ int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, co
 {
     const char *fn = "tfk_affine_coupling_train_bwd";
     if (N < 1) return fail(TFK_EINVAL, "%s: N = %lld < 1", fn, (long long)N);
-    if (!tfk_coupling_train_bwd_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64 or 128", fn, D);
+    if (!tfk_coupling_train_bwd_supported(D)) return fail(TFK_EINVAL, "%s: D = %d must be 64, 128 or 256", fn, D);
     if (gemm2_steps < 1 || gemm2_steps > 4) return fail(TFK_EINVAL, "%s: GEMM-2 steps %d not in [1, 4]", fn, gemm2_steps);
     const int EPL = D / 8, T2 = EPL / 2, T1 = EPL / 4;
     const int64_t need = (int64_t)EPL * 64 + 16 + (int64_t)T2 * gemm2_steps * 64 + T2 * 16 + T2 * 4 * 64 + T1 * 4 * 64;
@@ -986,6 +1000,9 @@ int tfk_affine_coupling_train_bwd(const float *x, float *g, const float *gld, co
     if (EPL == 8)
         return launch_train_bwd<8>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form,
                                    gscale, g_reversed ? 1 : 0, s, fn);
+    if (EPL == 32)
+        return launch_train_bwd<32>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form,
+                                    gscale, g_reversed ? 1 : 0, s, fn);
     return launch_train_bwd<16>(x, g, gld, params, (int)n_params, gemm2_steps, out, workspace, N, inverse_form,
                                 gscale, g_reversed ? 1 : 0, s, fn);
 }
