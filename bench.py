@@ -91,7 +91,9 @@ class KernelTimer:
                             ("bounded_sigmoid", lambda a, k: 8 * a[0].numel()),
                             # image flows, one launch per coupling (csrc/tfk_glow.hip): args (rows, logdet, layer, inverse)
                             ("glow_coupling", self._glow_bytes),
-                            ("rows_fma", lambda a, k: 8 * a[0].numel())):
+                            ("rows_fma", lambda a, k: 8 * a[0].numel()),
+                            # flush + base density of an image program in one read-only pass (round 4)
+                            ("rows_fma_gauss_logprob", lambda a, k: 4 * a[0].numel() + 8 * a[0].shape[0])):
             self._wrap(fn, byte_fn)
 
     @staticmethod
@@ -194,10 +196,11 @@ class KernelTimer:
         for op in ops:
             kind, steps2 = op[0], op[2]
             HT = 1 if steps2 <= 4 else (2 if steps2 <= 8 else 4)
+            f3_lean = kind in (12, 13, 14, 15) and len(op) > 4 and int(op[4]) == 256      # bf16 x 3 operands: GEMM 1 only
             if kind in (2, 3, 12, 13):
-                per_wave += EPL * HT + (EPL // 2) * steps2
+                per_wave += EPL * HT + (0 if f3_lean else (EPL // 2) * steps2)
             elif kind in (4, 5, 14, 15):
-                per_wave += EPL * HT + (EPL // 4) * steps2
+                per_wave += EPL * HT + (0 if f3_lean else (EPL // 4) * steps2)
             elif kind in (17, 18, 23, 24) and len(op) > 4 and (int(op[4]) >> 8) == 1:
                 per_wave += EPL * (2 if steps2 > 4 else 1)      # GEMM 1 only: GEMM 2 runs as bf16 MFMAs (_flow_mfmas_bf16)
             elif kind in (6, 7, 17, 18):
@@ -221,6 +224,9 @@ class KernelTimer:
         for op in ops:
             if op[0] in (17, 18, 23, 24) and len(op) > 4 and (int(op[4]) >> 8) == 1:
                 per_wave += (24 if op[0] >= 23 else 18) * EPL * (2 if op[2] > 4 else 1)
+            elif op[0] in (12, 13, 14, 15) and len(op) > 4 and int(op[4]) == 256:
+                # lean affine / shift couplings in the bf16 x 3 format (D = 256 by default): 3 per GEMM-2 tile
+                per_wave += 3 * (EPL // 2 if op[0] in (12, 13) else EPL // 4)
         return per_wave * ((N + 15) // 16)
 
     @staticmethod

@@ -520,6 +520,13 @@ int tfk_glow_level(const float *rows_in, float *rows_out, float *logdet, int64_t
 /* rows[n, d] = st[2 d] * rows[n, d] + st[2 d + 1] in place: the flush of the pending maps behind the last coupling. */
 int tfk_rows_fma(float *rows, const float *st, int64_t N, int32_t D, void *stream);
 
+/* out[n] = DiagonalGaussian(loc, exp(log_scale)).log_prob(st[2 d] * rows[n, d] + st[2 d + 1]) [+ logdet_in[n]]: the flush
+ * of an image program's pending maps (tfk_rows_fma) and the base density of Flow.log_prob (tfk_diag_gauss_logprob; gaussian.py:
+ * 46-54, flows.py:647-648) as ONE read of the rows, which are not written (the mapped values are rounded as tfk_rows_fma
+ * rounds them).  D <= 3276 (20 D bytes of LDS). */
+int tfk_rows_fma_gauss_logprob(const float *rows, const float *st, const float *loc, const float *log_scale,
+                               const float *logdet_in, float *out, int64_t N, int32_t D, void *stream);
+
 /* ---- reverse mode of the layer kernels ------------------------------------
  * The reference has no backward code; these replace what torch.autograd derives from
  * affine.py:36-59, spline/base.py:53-72 + rational_quadratic.py:45-200, layers_base.py:237-318

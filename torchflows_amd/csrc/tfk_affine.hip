@@ -316,18 +316,26 @@ __global__ __launch_bounds__(kBlock) void k_permute(
 // DiagonalGaussian.log_prob (+ log_det).  gaussian.py:46-54, flows.py:647-648.
 // Dynamic LDS: 3*D floats (loc | scale | log_scale).
 // ---------------------------------------------------------------------------
-template <bool VEC4>
+// FMA: the rows carry a pending per-column map v = s * raw + t (the deferred ActNorm layers of an image program,
+// tfk_glow.hip): tfk_rows_fma_gauss_logprob evaluates the density of the mapped values without writing them -- the flush
+// pass (read + write of every row) and the density pass (another read) of Flow.log_prob become ONE read.
+template <bool VEC4, bool FMA = false>
 __global__ __launch_bounds__(kBlock) void k_diag_gauss(
     const float *__restrict__ z, const float *__restrict__ loc,
     const float *__restrict__ log_scale, const float *logdet_in, float *out,
-    long long N, int D, int G)
+    long long N, int D, int G, const float2 *__restrict__ st = nullptr)
 {
     extern __shared__ float smem[];
     float *loc_s = smem, *scale_s = smem + D, *ls_s = smem + 2 * D;
+    float *s_s = smem + 3 * D, *t_s = smem + 4 * D;      // (FMA only)
     for (int e = threadIdx.x; e < D; e += kBlock) {
         loc_s[e] = loc[e];
         ls_s[e] = log_scale[e];
         scale_s[e] = expf(log_scale[e]);              // gaussian.py:37-38
+        if (FMA) {
+            const float2 m = st[e];
+            s_s[e] = m.x, t_s[e] = m.y;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & (G - 1);
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_diag_gauss(
          row += stride) {
         float acc = 0.0f;
         auto term = [&](float v, int e) {
+            if (FMA) v = fmaf(s_s[e], v, t_s[e]);        // (the flush's own rounding: tfk_rows_fma)
             const float t = (v - loc_s[e]) / scale_s[e];
             float q = 0.5f * (t * t);
             q = q + kHalfLog2Pi;
@@ -679,6 +688,31 @@ int tfk_diag_gauss_logprob(const float *z, const float *loc, const float *log_sc
     else
         hipLaunchKernelGGL((k_diag_gauss<false>), dim3(grid), dim3(kBlock), lds, s, z, loc, log_scale,
                            logdet_in, out, (long long)N, D, G);
+    return check_launch(fn);
+}
+
+int tfk_rows_fma_gauss_logprob(const float *rows, const float *st, const float *loc, const float *log_scale,
+                               const float *logdet_in, float *out, int64_t N, int32_t D, void *stream)
+{
+    const char *fn = "tfk_rows_fma_gauss_logprob";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (D <= 0) return fail(TFK_EINVAL, "%s: D = %d must be positive", fn, D);
+    if (N == 0) return TFK_OK;
+    if (!rows || !st || !loc || !log_scale || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (reinterpret_cast<uintptr_t>(st) & 7u) return fail(TFK_EINVAL, "%s: st needs 8-byte alignment", fn);
+    const size_t lds = (size_t)5 * D * sizeof(float);
+    if (lds > 64 * 1024) return fail(TFK_EINVAL, "%s: D = %d (the base parameters and the pending maps take 20 D bytes of LDS: D <= 3276)", fn, D);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = (D % 4 == 0) && aligned16(rows);
+    const int G = lanes_per_row(vec ? D / 4 : D);
+    const int grid = grid_for(N, kBlock / G);
+    const float2 *st2 = reinterpret_cast<const float2 *>(st);
+    if (vec)
+        hipLaunchKernelGGL((k_diag_gauss<true, true>), dim3(grid), dim3(kBlock), lds, s, rows, loc, log_scale,
+                           logdet_in, out, (long long)N, D, G, st2);
+    else
+        hipLaunchKernelGGL((k_diag_gauss<false, true>), dim3(grid), dim3(kBlock), lds, s, rows, loc, log_scale,
+                           logdet_in, out, (long long)N, D, G, st2);
     return check_launch(fn);
 }
 

@@ -629,7 +629,30 @@ class Flow(BaseFlow):
         fused_out = self._fused_log_prob(x.to(self.get_device()), want_z=False, context=ctx)
         if fused_out is not None:
             return fused_out[1]
+        got = self._image_log_prob(x, ctx)
+        if got is not None:
+            return got
         return self.forward_with_log_prob(x, context)[1]
+
+    def _image_log_prob(self, x: torch.Tensor, context):
+        """``log_prob`` of an image flow whose bijection compiles to an image program (image_program.py): the couplings, then
+        the deferred ActNorm maps and the base density in ONE read of the rows (tfk_rows_fma_gauss_logprob) -- z is never
+        written.  None when that route does not apply."""
+        from torchflows_amd import image_program, native
+        from torchflows_amd.bijections.base import _params_ok, method_direction
+        from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection
+        b = self.bijection
+        if (context is not None or not isinstance(b, MultiscaleBijection) or not isinstance(self.base, DiagonalGaussian)
+                or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.parameters())))):
+            return None
+        x = x.to(self.get_device())
+        if x.numel() == 0 or not native.eligible(x, self.base.loc, self.base.log_scale) or not _params_ok(self):
+            return None
+        d = method_direction(b.forward)
+        prog = None if d is None else image_program.get_program(b, d, x.device)
+        if prog is None:
+            return None
+        return image_program.log_prob(prog, x, self.event_shape, self.base.loc.detach(), self.base.log_scale.detach())
 
     def sample(self, sample_shape: Union[int, torch.Size, Tuple[int, ...]],
                context: torch.Tensor = None, no_grad: bool = False,

@@ -452,13 +452,27 @@ def get_program(module, d: int, device: torch.device) -> Optional[ImageProgram]:
     return prog
 
 
-def run(prog: ImageProgram, x: torch.Tensor, event_shape):
-    """(z, log_det) of the compiled chain on ``x`` (never modified: the launches work on a copy)."""
+def log_prob(prog: ImageProgram, x: torch.Tensor, event_shape, loc: torch.Tensor, log_scale: torch.Tensor) -> torch.Tensor:
+    """``base.log_prob(z) + log_det`` of the compiled chain without materialising z: the couplings, then ONE pass that
+    applies the pending maps and evaluates the diagonal Gaussian (tfk_rows_fma_gauss_logprob) -- the flush's read + write and
+    the density's read of every row become one read.  Rows wider than the fused kernel's LDS budget take ``run`` + the
+    separate density kernel."""
     n_event = len(event_shape)
     batch = x.shape[:x.dim() - n_event]
+    if prog.flush is None or prog.D > 3276:
+        z, ld = run(prog, x, event_shape)
+        out = torch.empty(ld.numel(), dtype=torch.float32, device=x.device)
+        native.diag_gauss_logprob(z.reshape(-1, prog.D), loc, log_scale, ld.reshape(-1), out)
+        return out.view(batch)
+    rows, logdet = _couplings(prog, x)
+    out = torch.empty(rows.shape[0], dtype=torch.float32, device=x.device)
+    native.rows_fma_gauss_logprob(rows, prog.flush, loc, log_scale, logdet, out)
+    return out.view(batch)
+
+
+def _couplings(prog: ImageProgram, x: torch.Tensor):
+    """(rows, logdet) behind the last coupling, pending maps NOT flushed."""
     if prog.levels is not None and x.device.type == "cuda":
-        # one launch per level; a first level that covers the whole row reads the caller's tensor and writes the working
-        # copy itself (no clone)
         src = x.reshape(-1, prog.D)
         if not src.is_contiguous():
             src = src.contiguous()
@@ -468,13 +482,19 @@ def run(prog: ImageProgram, x: torch.Tensor, event_shape):
         for k, lv in enumerate(prog.levels):
             native.glow_level(src if (k == 0 and lv.row_idx is None) else rows, rows, logdet, lv.row_idx,
                               lv.blob_host, lv.blob_dev)
-        if prog.flush is not None:
-            native.rows_fma(rows, prog.flush)
-        return rows.view(x.shape), logdet.view(batch)
+        return rows, logdet
     rows = x.reshape(-1, prog.D).clone(memory_format=torch.contiguous_format)
     logdet = torch.full((rows.shape[0],), prog.ld_const, dtype=torch.float32, device=x.device)
     for step in prog.steps:
         native.glow_coupling(rows, logdet, step.layer, inverse=step.inverse)
+    return rows, logdet
+
+
+def run(prog: ImageProgram, x: torch.Tensor, event_shape):
+    """(z, log_det) of the compiled chain on ``x`` (never modified: the launches work on a copy)."""
+    n_event = len(event_shape)
+    batch = x.shape[:x.dim() - n_event]
+    rows, logdet = _couplings(prog, x)
     if prog.flush is not None:
         native.rows_fma(rows, prog.flush)
     return rows.view(x.shape), logdet.view(batch)

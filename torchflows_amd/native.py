@@ -48,6 +48,7 @@ SYMBOLS = (
     "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
     "tfk_glow_level_blob_bytes", "tfk_glow_level_pack", "tfk_glow_level_info", "tfk_glow_level",
+    "tfk_rows_fma_gauss_logprob",
 )
 
 ABI_VERSION = 28
@@ -169,6 +170,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_glow_plan.argtypes = [C.POINTER(GlowLayer), _i32, pi, pi, pi, pi, pi, pi]
     L.tfk_glow_coupling.argtypes = [_vp, _vp, _i64, _i32, C.POINTER(GlowLayer), _i32, _vp]
     L.tfk_rows_fma.argtypes = [_vp, _vp, _i64, _i32, _vp]
+    L.tfk_rows_fma_gauss_logprob.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
     ps = C.POINTER(GlowLevelStep)
     L.tfk_glow_level_blob_bytes.argtypes = [ps, _i32, _i32, _i32, _i32, _i32]
     L.tfk_glow_level_blob_bytes.restype = _i64
@@ -932,6 +934,20 @@ def rows_fma(rows: torch.Tensor, st: torch.Tensor) -> None:
         rc = lib().tfk_rows_fma(_f32(rows, "tfk_rows_fma"), _f32(st, "tfk_rows_fma"), N, D, _stream(rows))
     calls += 1
     _check(rc, "tfk_rows_fma")
+
+
+def rows_fma_gauss_logprob(rows, st, loc, log_scale, logdet_in, out) -> None:
+    """out[n] = base log-density of st[d, 0] * rows[n, d] + st[d, 1] (+ logdet_in[n]); the rows are only read."""
+    global calls
+    name = "tfk_rows_fma_gauss_logprob"
+    N, D = _rows(rows, name)
+    if st.numel() != 2 * D or loc.numel() != D or log_scale.numel() != D or out.numel() != N:
+        raise NativeError(f"{name}: bad parameter / out shape")
+    with _device_guard(rows):
+        rc = lib().tfk_rows_fma_gauss_logprob(_f32(rows, name), _f32(st, name), _f32(loc, name), _f32(log_scale, name),
+                                              _f32(logdet_in, name), _f32(out, name), N, D, _stream(rows))
+    calls += 1
+    _check(rc, name)
 
 
 def sum_f32(values: torch.Tensor) -> torch.Tensor:
