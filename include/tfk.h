@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 28
+#define TFK_ABI_VERSION 29
 
 enum {
     TFK_OK = 0,
@@ -421,6 +421,64 @@ int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, con
 /* Bounded conditioner output (conditioning/transforms.py:107-113, used by ConvNetConditioner with (-2, 2)):
  * out = lo + (hi - lo) * sigmoid(h) over n floats, the three roundings of the reference kept; h may alias out. */
 int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float hi, void *stream);
+
+/* ---- The ConvNet conditioner in TRAINING (classic.py:45-122 under Flow.fit: BatchNorm2d with batch statistics) ----
+ * One forward and one reverse-mode launch per block (csrc/tfk_convtrain.hip); every sum over the batch is a
+ * fixed-order sum of per-workgroup partials finished by the last workgroup of the SAME launch (no reduction launches).
+ * workspace: tfk_convnet_train_workspace_bytes() bytes, ZEROED once by the caller (its first 8 bytes are the
+ * ticket counter, left at zero by every launch), used by one stream at a time.
+ *
+ * BatchNorm tensors: `stats` (4 c floats: scale | shift | mean | 1/std of the normalisation the forward applied,
+ * scale = weight / std, shift = bias - mean * scale); `coef` (3 c floats: d(loss)/d(input) = c1 g + c2 y + c3, the
+ * batch-statistics backward folded into three per-channel numbers). */
+int64_t tfk_convnet_train_workspace_bytes(void);
+int tfk_convnet_train_block_supported(int32_t c_in, int32_t c_out, int32_t H);
+/* conv3x3 (padding 1; input = in_affine applied to x inside the image, in_affine = scale | shift of the BatchNorm
+ * in front or NULL) -> ReLU -> MaxPool2d(2): y (N, c_out, H/2, W/2) BEFORE normalisation, argmax (same shape, the
+ * position 0..3 of the maximum in its 2x2 window), and the BatchNorm behind the block: training != 0 -> batch
+ * statistics (biased variance), running statistics updated as torch.nn.functional.batch_norm does when
+ * update_running != 0 (num_batches_tracked may be NULL); training == 0 -> the running statistics. */
+int tfk_convnet_train_block_fwd(const float *x, const float *in_affine, const float *weight, const float *bias,
+                                float *y, uint8_t *argmax, const float *bn_weight, const float *bn_bias,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float eps,
+                                float momentum, int32_t training, int32_t update_running, float *stats,
+                                void *workspace, int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W,
+                                void *stream);
+/* Reverse mode of the block: gz = d(loss)/d(BatchNorm output) (N, c_out, H/2, H/2), coef of that BatchNorm, y /
+ * argmax / x / in_affine / weight as in the forward (square planes, tfk_convnet_train_block_supported).
+ * g_in (N, c_in, H, H) = d(loss)/d(the affine'd input).  sums: weight gradient (c_out x c_in x 9) | bias gradient
+ * (c_out).  If the input came through a BatchNorm (bn_stats = its `stats`, else NULL): its coef, weight and bias
+ * gradients are written too (bn_training: batch statistics were used). */
+int tfk_convnet_train_block_bwd(const float *gz, const float *coef, const float *y, const uint8_t *argmax,
+                                const float *x, const float *in_affine, const float *weight, float *g_in, float *sums,
+                                const float *bn_stats, float *bn_coef, float *bn_dweight, float *bn_dbias,
+                                int32_t bn_training, void *workspace, int64_t N, int32_t c_in, int32_t c_out, int32_t H,
+                                void *stream);
+/* ConvModifier (classic.py:8-42): ONE convolution with a kh x kw kernel (1 or 2 per axis; 2 where the size difference
+ * is odd) whose padding (H_out - H + kh - 1) / 2 is >= kh - 1, so the (H, W) image lands inside an (H_out, W_out) frame
+ * that holds the bias; weight (c_out, c_in, kh, kw), c_out 1 or 4; the BatchNorm in front applied on load (in_affine or
+ * NULL).  Reverse mode: g_in (N, c_in, H, W) = d(loss)/d(the affine'd input); sums: weight gradient (c_out x c_in x kh
+ * x kw) | sum g_in (c_in) | sum g_in x (c_in) | bias gradient (c_out); BatchNorm outputs as above. */
+int tfk_convnet_train_frame_fwd(const float *x, const float *in_affine, const float *weight, const float *bias,
+                                float *out, int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W,
+                                int32_t H_out, int32_t W_out, int32_t kh, int32_t kw, void *stream);
+int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float *in_affine, const float *weight,
+                                float *g_in, float *sums, const float *bn_stats, float *bn_coef, float *bn_dweight,
+                                float *bn_dbias, int32_t bn_training, void *workspace, int64_t N, int32_t c_in,
+                                int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out, int32_t kh,
+                                int32_t kw, void *stream);
+/* The Linear layer behind the second ConvModifier without a GEMM-library call (so that a training step of an image
+ * flow can be captured into a hipGraph): out (N, M) = a (N, F) weight^T + bias, weight (M, F), F <= 128; and its input
+ * gradient g_a (N, F) = g (N, M) weight. */
+int tfk_convnet_train_linear_fwd(const float *a, const float *weight, const float *bias, float *out, int64_t N, int32_t M,
+                                 int32_t F, void *stream);
+int tfk_convnet_train_linear_bwd_input(const float *g, const float *weight, float *g_a, int64_t N, int32_t M, int32_t F,
+                                       void *stream);
+/* Weight and bias gradient of the Linear layer behind the second ConvModifier: g (N, M) = d(loss)/d(output),
+ * a (N, H_out x W_out) its input, equal to *frame_bias outside the 4 x 4 interior: dW (M, H_out x W_out), db (M);
+ * rows in order, deterministic, no GEMM-library call. */
+int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *frame_bias, float *dW, float *db,
+                                   int64_t N, int32_t M, int32_t H_out, int32_t W_out, void *stream);
 
 /* ---- a whole convolutional coupling of the image / multiscale flows in ONE launch (config 5) -----------------
  * Replaces, for one coupling of multiscale/base.py:19-114 (CheckerboardCoupling, ChannelWiseCoupling,

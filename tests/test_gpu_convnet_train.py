@@ -1,0 +1,129 @@
+"""The ConvNet conditioner with gradients on libtfk (torchflows_amd/convnet_train.py, csrc/tfk_convtrain.hip) against
+the ATen composite path -- the reference's own op chain (multiscale/conditioning/classic.py:45-122) -- evaluated in
+float64 on the CPU; the bar for every quantity is the larger of an absolute floor and three times the distance of the
+fp32 ATen/MIOpen route from that float64 value."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import set_debug
+
+pytestmark = pytest.mark.gpu
+
+
+def normwise(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def native():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from torchflows_amd import native as nat
+    nat.lib()
+    return nat
+
+
+def _net(shape, n_out, seed=0):
+    from torchflows_amd.bijections.finite.multiscale.conditioning.classic import ConvNet
+    torch.manual_seed(seed)
+    net = ConvNet(shape, n_out)
+    with torch.no_grad():               # non-trivial BatchNorm state
+        for blk in list(net.blocks)[1:4]:
+            blk.bn.weight.uniform_(0.5, 1.5)
+            blk.bn.bias.uniform_(-0.3, 0.3)
+            blk.bn.running_mean.uniform_(-0.2, 0.4)
+            blk.bn.running_var.uniform_(0.5, 2.0)
+    return net
+
+
+def _evaluate(net, x, g, training):
+    net.train(training)
+    x = x.clone().requires_grad_(True)
+    out = net(x)
+    grads = torch.autograd.grad(out, [x] + list(net.parameters()), g)
+    state = {k: v.detach().cpu().double().numpy() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+    return (out.detach().cpu().double().numpy(), [t.detach().cpu().double().numpy() for t in grads], state)
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["batch-statistics", "running-statistics"])
+@pytest.mark.parametrize("shape,N", [((1, 14, 28), 37), ((3, 16, 32), 19), ((6, 16, 16), 64), ((12, 8, 8), 5),
+                                     ((2, 32, 32), 3), ((2, 7, 14), 21), ((4, 7, 7), 33), ((24, 3, 3), 9)])
+def test_convnet_forward_and_gradients(native, monkeypatch, shape, N, training):
+    n_out = 2 * int(np.prod(shape))
+    ref = _net(shape, n_out)
+    torch.manual_seed(1)
+    x = torch.randn(N, *shape) * 1.5 + 0.2
+    g = torch.randn(N, n_out)
+    want = _evaluate(copy.deepcopy(ref).double(), x.double(), g.double(), training)          # float64, CPU, ATen
+    set_debug(monkeypatch, convnet_train="0")
+    aten = _evaluate(copy.deepcopy(ref).cuda(), x.cuda(), g.cuda(), training)                 # fp32 ATen / MIOpen
+    set_debug(monkeypatch, convnet_train=None)
+    before = native.calls
+    got = _evaluate(copy.deepcopy(ref).cuda(), x.cuda(), g.cuda(), training)                  # fp32 libtfk
+    assert native.calls - before == 6 + 7, "one forward launch per block / modifier, one reverse-mode launch each + linear"
+    names = ["x"] + [k for k, _ in ref.named_parameters()]
+    assert normwise(got[0], want[0]) < max(2e-6, 3 * normwise(aten[0], want[0]))
+    worst = 0.0
+    for name, a, b, c in zip(names, got[1], want[1], aten[1]):
+        assert a.shape == b.shape, name
+        e, bar = normwise(a, b), max(2e-5, 3 * normwise(c, b))
+        worst = max(worst, e / bar)
+        assert e < bar, (name, e, bar)
+    for k in want[2]:
+        if "num_batches" in k:
+            assert got[2][k] == want[2][k], k
+        else:
+            assert normwise(got[2][k], want[2][k]) < 1e-5, k
+    print(f"convnet {shape} N={N} training={training}: worst gradient error / bar = {worst:.3f}")
+
+
+def test_convnet_gradients_are_deterministic(native):
+    net = _net((3, 16, 32), 96).cuda().train()
+    torch.manual_seed(3)
+    x = torch.randn(300, 3, 16, 32, device="cuda")
+    g = torch.randn(300, 96, device="cuda")
+    runs = []
+    for _ in range(2):
+        m = copy.deepcopy(net)
+        xr = x.clone().requires_grad_(True)
+        runs.append(torch.autograd.grad(m(xr), [xr] + list(m.parameters()), g))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+def test_coupling_training_step_counts_the_batch_once(native, monkeypatch):
+    """A training-mode coupling through the reverse-mode chain (autograd.ChainFunction re-evaluates the conditioner in its
+    backward): gradients equal the plain autograd graph's, and the BatchNorm running statistics move ONCE per step."""
+    from torchflows_amd.bijections.finite.multiscale.base import NormalizedCheckerboardCoupling
+    from torchflows_amd.bijections.finite.autoregressive.transformers.linear.affine import Affine
+    torch.manual_seed(0)
+    layer = NormalizedCheckerboardCoupling((1, 28, 28), transformer_class=Affine).cuda()
+    x = torch.randn(50, 1, 28, 28, device="cuda")
+    with torch.no_grad():
+        layer.train()
+        layer(x)                      # ActNorm takes its statistics
+    counted = {k: int(v) for k, v in layer.state_dict().items() if "num_batches" in k}
+    results = []
+    for route in ("hip", "aten"):
+        m = copy.deepcopy(layer).train()
+        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN", "1" if route == "hip" else "0")
+        set_debug(monkeypatch, convnet_train=None if route == "hip" else "0")
+        before = native.calls
+        z, ld = m(x)
+        loss = (z ** 2).sum() * 0.5 - ld.sum()
+        grads = torch.autograd.grad(loss, [p for p in m.parameters() if p.requires_grad and p.numel()])
+        results.append((grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k},
+                        native.calls - before))
+    (g_hip, s_hip, n_hip), (g_aten, s_aten, _) = results
+    for a, b in zip(g_hip, g_aten):
+        assert normwise(a.cpu().numpy(), b.cpu().numpy()) < 2e-4
+    for k in s_aten:
+        if "num_batches" in k:
+            assert int(s_hip[k]) == int(s_aten[k]) == counted[k] + 1, k
+        else:
+            assert normwise(s_hip[k].cpu().numpy(), s_aten[k].cpu().numpy()) < 1e-5, k
+    assert n_hip <= 30, f"{n_hip} libtfk launches for one coupling's training step"

@@ -167,6 +167,13 @@ def _layer_context(layer, context):
     return context if (context is not None and layer.context_shape is not None) else None
 
 
+def _keeps_graph(layer) -> bool:
+    """Couplings whose conditioner is evaluated once per step with its autograd graph kept for the backward pass,
+    instead of being re-evaluated there: the convolutional conditioners of the image flows."""
+    from torchflows_amd.bijections.finite.multiscale.conditioning.classic import ConvNetConditioner
+    return isinstance(layer.conditioner_transform, ConvNetConditioner)
+
+
 def _plain_mlp(layer):
     """(Linear, Linear) when the conditioner is the default FeedForward: Linear, Tanh, Linear on
     x_A alone (transforms.py:274-307), no global parameters, unbounded output -- the case whose
@@ -908,6 +915,7 @@ class ChainFunction(torch.autograd.Function):
         if W != D:                   # padded training layout: every kernel below sees (N, W) rows
             cur, cur_is_saved = packs.pad_rows(rows), False
         rqs_blocks = {}
+        kept = {}                    # step -> (conditioner input, its output WITH graph) of the couplings that keep one
         for step, (layer, d, kind) in enumerate(plan):
             if step in packs.folded_steps:
                 saved.append(None)          # ran inside the preceding coupling's flow program
@@ -998,7 +1006,20 @@ class ChainFunction(torch.autograd.Function):
                 rqs_blocks[step] = block
                 cur, cur_is_saved = out, False
             else:
-                h = _conditioner(layer, cur, plan.context).reshape(N, -1).contiguous()
+                if _keeps_graph(layer):
+                    # a convolutional conditioner: evaluated ONCE, with its graph (the activations it saves are what a
+                    # re-evaluation in the backward pass would produce again -- and a BatchNorm in training mode counts
+                    # the batch once, as the reference's single forward does)
+                    S = layer.coupling.source_event_size
+                    x_a = cur[:, :S] if layer._source_is_head else cur.index_select(1, layer._source_index)
+                    x_a = x_a.detach().requires_grad_(True)
+                    with torch.enable_grad():
+                        h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
+                                                         context=_layer_context(layer, plan.context)).reshape(N, -1)
+                    kept[step] = (x_a, h2)
+                    h = h2.detach().contiguous()
+                else:
+                    h = _conditioner(layer, cur, plan.context).reshape(N, -1).contiguous()
                 out = torch.empty_like(cur)
                 T = layer.coupling.target_event_size
                 tgt = None if layer._target_is_tail else layer._target_index32
@@ -1031,6 +1052,7 @@ class ChainFunction(torch.autograd.Function):
         ctx.n_params = len(params)
         ctx.packs, ctx.packed = packs, packed
         ctx.rqs_blocks = rqs_blocks
+        ctx.kept = kept
         ctx.flat, ctx.flat_maps, ctx.l2vec = fb, maps, l2vec
         if l2vec is not None:
             # sum_coef coef * sum_p ||p||^2 (layers_base.py:38-48) over the buffer: the gradient joins the flat one
@@ -1218,10 +1240,15 @@ class ChainFunction(torch.autograd.Function):
                     lin1, lin2 = mlp
                     a1 = torch.tanh(torch.addmm(lin1.bias, x_a, lin1.weight.t()))
                     hc = torch.addmm(lin2.bias, a1, lin2.weight.t())
+                elif ctx.kept.get(i) is not None:      # the forward pass kept the conditioner's graph (used once)
+                    x_a, h2 = ctx.kept[i]
+                    ctx.kept[i] = None
+                    hc = h2.detach().contiguous()
                 else:                          # any other conditioner: re-evaluate with a graph
                     x_a = x_a.detach().requires_grad_(True)
-                    with torch.enable_grad():
-                        h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),
+                    from torchflows_amd import convnet_train
+                    with torch.enable_grad(), convnet_train.recomputing():      # (same batch again: BatchNorm's running
+                        h2 = layer.conditioner_transform(x_a.reshape(N, *layer.coupling.constant_shape),   # statistics stay)
                                                          context=_layer_context(layer, plan.context)).reshape(N, -1)
                     hc = h2.detach().contiguous()
                 gh = torch.empty_like(hc)

@@ -180,8 +180,8 @@ class MultiscaleBijection(Bijection):
     def _run_program(self, x: torch.Tensor, context, d: int):
         """The whole recursion as one libtfk launch per coupling, in place on one row buffer (image_program.py:
         squeeze / chunk as index tables, ActNorm layers deferred); None when the compiler does not cover this model."""
-        if context is not None or x.numel() == 0 or not native.eligible(x) or not _params_ok(self):
-            return None
+        if self.training or context is not None or x.numel() == 0 or not native.eligible(x) or not _params_ok(self):
+            return None     # (training mode: BatchNorm takes batch statistics, nothing to fold -- and no compile attempt per step)
         from torchflows_amd import image_program
         prog = image_program.get_program(self, d, x.device)
         return None if prog is None else image_program.run(prog, x, self.event_shape)

@@ -5,8 +5,10 @@
 ``ConvModifier`` brings any image to ``(4, 32, 32)`` with one convolution, three
 ``conv3x3 -> ReLU -> maxpool -> BatchNorm`` blocks follow, a second modifier maps to
 ``(1, 10, 10)`` and a linear layer produces the parameters, squashed into (-2, 2) by a
-sigmoid.  All of it stays on PyTorch-ROCm (MIOpen convolutions); module and attribute names
-match the reference so state dicts carry over.
+sigmoid.  Inference folds BatchNorm and runs a block per launch (csrc/tfk_convblock.hip) or a whole coupling
+per launch (image_program.py); with gradients or in training mode the network runs on csrc/tfk_convtrain.hip
+(convnet_train.py); other shapes stay on PyTorch-ROCm (MIOpen).  Module and attribute names match the
+reference so state dicts carry over.
 """
 from __future__ import annotations
 
@@ -113,6 +115,11 @@ class ConvNet(nn.Module):
                                                        hit[1], hit[2])
             y = self.pool(torch.relu(self.conv(x)))
             if bn.training or not bn.track_running_stats or y.device.type != "cuda":
+                from torchflows_amd import convnet_train
+                if bn.training and convnet_train.is_recomputing():
+                    # the second evaluation of one batch (the conditioner re-evaluated for its gradient): batch statistics
+                    # as before, the running ones have already counted this batch
+                    return nn.functional.batch_norm(y, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
                 return bn(y)
             # inference-mode BatchNorm is a per-channel scale and shift: one elementwise kernel at HBM
             # speed (MIOpenBatchNormFwdInferSpatialEst ran at ~28 GB/s on these shapes: 2.4 ms per call,
@@ -141,6 +148,9 @@ class ConvNet(nn.Module):
     def forward(self, x):
         lead = x.shape[:-3]
         x = x.reshape(-1, *x.shape[-3:])            # conv2d wants exactly one batch axis
+        from torchflows_amd import convnet_train
+        if convnet_train.usable(self, x):           # gradients and / or batch statistics: one launch per block
+            return convnet_train.apply(self, x).reshape(*lead, -1)
         for block in self.blocks:
             x = block(x)
         return self.linear(x.reshape(*lead, -1))

@@ -1,0 +1,187 @@
+"""The ConvNet conditioner of the image couplings with gradients, on libtfk (csrc/tfk_convtrain.hip).
+
+Reference ``multiscale/conditioning/classic.py:45-122``: ConvModifier -> 3 x [conv3x3 -> ReLU -> MaxPool2d(2) ->
+BatchNorm2d] -> ConvModifier -> Linear.  ``Flow.fit`` runs it in training mode (flows.py:333), i.e. every BatchNorm
+normalises with the statistics of the batch and updates its running ones: a block's output depends on all samples, so the
+unit of fusion is the block, not the coupling (``image_program`` fuses a whole coupling only because inference folds
+BatchNorm into a per-channel scale / shift).  One ``torch.autograd.Function`` covers the network:
+
+  forward   frame (ConvModifier) | block 1 | block 2 | block 3 | frame (+ BatchNorm 3 on load) | linear           6 launches
+  backward  linear input gradient | linear weight gradient | frame_bwd | block_bwd x 3 | frame_bwd              7 launches
+
+against ~70 ATen / MIOpen launches.  Each block launch writes the pooled activation BEFORE normalisation and the arg-max
+byte of every pooling window; the normalisation is applied by whoever reads it next.  The batch sums (statistics in the
+forward; weight gradients and the two sums a BatchNorm backward needs in the reverse pass) are fixed-order sums of
+per-workgroup partials finished inside the same launch.
+
+Only the reference's own network shape is covered (``supported``); anything else keeps the ATen composite path.
+"""
+from __future__ import annotations
+
+import contextlib
+import threading
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from torchflows_amd import native
+
+_state = threading.local()
+
+
+@contextlib.contextmanager
+def recomputing():
+    """Inside: a forward pass that REPEATS one already made on the same batch (``autograd.ChainFunction.backward``
+    re-evaluates the conditioner to differentiate it).  BatchNorm layers in training mode normalise with the batch
+    statistics as before but leave their running statistics alone -- the first pass has counted this batch."""
+    prev = getattr(_state, "recompute", False)
+    _state.recompute = True
+    try:
+        yield
+    finally:
+        _state.recompute = prev
+
+
+def is_recomputing() -> bool:
+    return getattr(_state, "recompute", False)
+
+
+def enabled() -> bool:
+    from torchflows_amd.utils import debug_switch
+    return debug_switch("convnet_train", "1") != "0"
+
+
+def _modifier_ok(mod, c_out: int) -> bool:
+    conv = mod.conv
+    kh, kw = conv.weight.shape[2:]
+    return (kh in (1, 2) and kw in (1, 2) and conv.weight.shape[0] == c_out and conv.bias is not None
+            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.padding[0] >= kh - 1 and conv.padding[1] >= kw - 1 and conv.padding_mode == "zeros")
+
+
+def structure_ok(net) -> bool:
+    """The reference's default ConvNet: (c, h, w) -> modifier (a 1- or 2-wide kernel per axis) to (4, 32, 32) -> blocks
+    4->8->8->4 with pooling -> 1x1 modifier to (1, 10, 10) -> Linear(100, n); cached on the module (the structure does
+    not change)."""
+    hit = net.__dict__.get("_tfk_ct_structure")
+    if hit is not None:
+        return hit
+    ok = False
+    try:
+        blocks = list(net.blocks)
+        if len(blocks) == 5 and isinstance(net.linear, nn.Linear) and net.linear.bias is not None:
+            first, last = blocks[0], blocks[4]
+            chans = [(4, 8, 32), (8, 8, 16), (8, 4, 8)]
+            ok = (_modifier_ok(first, 4) and tuple(first.output_shape) == (4, 32, 32)
+                  and _modifier_ok(last, 1) and tuple(last.output_shape) == (1, 10, 10)
+                  and tuple(last.conv.weight.shape[1:]) == (4, 1, 1) and net.linear.in_features == 100)
+            for blk, (ci, co, h) in zip(blocks[1:4], chans):
+                bn = blk.bn
+                ok = ok and (isinstance(blk.pool, nn.MaxPool2d) and blk.conv.in_channels == ci
+                             and blk.conv.out_channels == co and tuple(blk.conv.kernel_size) == (3, 3)
+                             and tuple(blk.conv.padding) == (1, 1) and blk.conv.bias is not None
+                             and isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.track_running_stats
+                             and bn.momentum is not None
+                             and bool(native.lib().tfk_convnet_train_block_supported(ci, co, h)))
+    except (AttributeError, native.NativeError):
+        ok = False
+    net.__dict__["_tfk_ct_structure"] = ok
+    return ok
+
+
+def _params(net) -> List[torch.Tensor]:
+    b = net.blocks
+    out = [b[0].conv.weight, b[0].conv.bias]
+    for blk in (b[1], b[2], b[3]):
+        out += [blk.conv.weight, blk.conv.bias, blk.bn.weight, blk.bn.bias]
+    out += [b[4].conv.weight, b[4].conv.bias, net.linear.weight, net.linear.bias]
+    return out
+
+
+def _frame_ok(net, c: int, h: int, w: int) -> bool:
+    kh, kw = net.blocks[0].conv.weight.shape[2:]
+    return not (h > 32 or w > 32 or (32 - h + kh - 1) % 2 or (32 - w + kw - 1) % 2
+                or net.blocks[0].conv.weight.shape[1] != c or (4 * kh * kw + 2) * c + 4 > 640
+                or (4 * (h + 1) * (w + 1) + 2 * c * h * w) * 4 > 120 * 1024)
+
+
+def static_usable(net, device) -> bool:
+    """``usable`` for every batch the network will see on ``device``, judged from the module alone (the input frame
+    follows from the first modifier's kernel and padding): what ``Flow.fit`` asks before it captures a training step."""
+    if not enabled() or not structure_ok(net):
+        return False
+    conv = net.blocks[0].conv
+    kh, kw = conv.weight.shape[2:]
+    h, w = 32 - 2 * conv.padding[0] + kh - 1, 32 - 2 * conv.padding[1] + kw - 1
+    if h < 1 or w < 1 or not _frame_ok(net, conv.weight.shape[1], h, w):
+        return False
+    return all(p.device == device and p.dtype == torch.float32 for p in _params(net))
+
+
+def usable(net, x: torch.Tensor) -> bool:
+    """fp32 on a HIP device, the default network, an input frame the 1x1 modifier covers, and either a gradient to
+    compute or batch statistics to take (training mode)."""
+    if not enabled() or x.dim() != 4 or x.device.type != "cuda" or x.dtype != torch.float32 or x.shape[0] == 0:
+        return False
+    if not structure_ok(net):
+        return False
+    _, c, h, w = x.shape
+    if not _frame_ok(net, c, h, w):
+        return False
+    params = _params(net)
+    if any(p.device != x.device or p.dtype != torch.float32 for p in params):
+        return False
+    training = net.blocks[1].bn.training
+    if any(blk.bn.training != training for blk in (net.blocks[2], net.blocks[3])):
+        return False
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return needs_grad or training
+
+
+def apply(net, x: torch.Tensor) -> torch.Tensor:
+    """theta (N, n_outputs) of ``net`` on images x (N, c, h, w)."""
+    training = net.blocks[1].bn.training
+    update = training and not is_recomputing()
+    return ConvNetFunction.apply(net, training, update, x.contiguous(), *_params(net))
+
+
+class ConvNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, training: bool, update: bool, x: torch.Tensor, *params: torch.Tensor):
+        (w_m1, b_m1, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w_m2, b_m2, w_lin, b_lin) = \
+            [p.detach() for p in params]
+        N = x.shape[0]
+        blocks = net.blocks
+        a0 = native.convnet_train_frame_fwd(x, None, w_m1, b_m1, 32, 32)
+        y1, i1, s1 = native.convnet_train_block_fwd(a0, None, w1, b1, blocks[1].bn, training, update)
+        y2, i2, s2 = native.convnet_train_block_fwd(y1, s1, w2, b2, blocks[2].bn, training, update)
+        y3, i3, s3 = native.convnet_train_block_fwd(y2, s2, w3, b3, blocks[3].bn, training, update)
+        a4 = native.convnet_train_frame_fwd(y3, s3, w_m2, b_m2, 10, 10).view(N, 100)
+        theta = native.convnet_train_linear_fwd(a4, w_lin, b_lin)
+        ctx.training = training
+        ctx.save_for_backward(x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a4, w_m1, w1, w2, w3, w_m2, b_m2, w_lin)
+        return theta
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_theta: torch.Tensor):
+        (x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a4, w_m1, w1, w2, w3, w_m2, b_m2, w_lin) = ctx.saved_tensors
+        tr = ctx.training
+        N = x.shape[0]
+        g_theta = g_theta.contiguous()
+        g_a4 = native.convnet_train_linear_bwd_input(g_theta, w_lin)          # (N, 100)
+        dW_lin, db_lin = native.convnet_train_linear_wgrad(g_theta, a4, b_m2, 10, 10)
+        gz3, dw_m2, db_m2, bn3 = native.convnet_train_frame_bwd(g_a4.view(N, 1, 10, 10), y3, s3, w_m2, s3, tr)
+        gz2, dW3, db3, bn2 = native.convnet_train_block_bwd(gz3, bn3[0], y3, i3, y2, s2, w3, s2, tr)
+        gz1, dW2, db2, bn1 = native.convnet_train_block_bwd(gz2, bn2[0], y2, i2, y1, s1, w2, s1, tr)
+        g_a0, dW1, db1, _ = native.convnet_train_block_bwd(gz1, bn1[0], y1, i1, a0, None, w1, None, tr)
+        g_x, dw_m1, db_m1, _ = native.convnet_train_frame_bwd(g_a0, x, None, w_m1, None, tr)
+        grads = [dw_m1, db_m1,
+                 dW1, db1, bn1[1], bn1[2],
+                 dW2, db2, bn2[1], bn2[2],
+                 dW3, db3, bn3[1], bn3[2],
+                 dw_m2, db_m2, dW_lin, db_lin]
+        need = ctx.needs_input_grad
+        return (None, None, None, g_x if need[3] else None,
+                *[g if need[4 + k] else None for k, g in enumerate(grads)])

@@ -1,0 +1,861 @@
+// tfk_convtrain.hip -- the Glow ConvNet conditioner in TRAINING: forward with batch statistics and reverse mode
+// (reference multiscale/conditioning/classic.py:45-122: ConvModifier -> 3 x [conv3x3 -> ReLU -> MaxPool2d(2) ->
+// BatchNorm2d] -> ConvModifier -> Linear; `Flow.fit` runs it with BatchNorm in training mode, flows.py:333).
+//
+// The library route is ~70 launches per coupling and step (MIOpen Winograd + layout transposes, ReLU, pooling, three
+// BatchNorm kernels per block and their backward counterparts, a 958 us weight-gradient GEMM for the Linear layer whose
+// contraction runs over the batch): 22 ms per step of MultiscaleRealNVP((1, 28, 28)) on 1 000 images, all of it tiny
+// kernels.  Here a block is ONE forward launch and ONE reverse-mode launch:
+//   forward   conv3x3 (+ the previous block's BatchNorm applied on load) -> ReLU -> max-pool, pooled pre-normalisation
+//             output + the arg-max of every 2x2 window (one byte) written once; per-channel sum / sum of squares handed in
+//             per workgroup, and the LAST workgroup to finish (ticket counter) adds them in index order, in fp64, and
+//             leaves the BatchNorm's scale / shift / mean / 1/std (and the running statistics' update) for the next launch
+//   backward  BatchNorm backward as dy = c1 g + c2 y + c3 per channel (c1..c3 from the batch sums the PRODUCER of g handed
+//             in), routed to the arg-max where the pooled output is positive, then the convolution's three gradients from
+//             LDS: dW (thread per (c_out, c_in) pair x 9 taps, sparse in the pooled cells), db, dX (dense gather), and
+//             the batch sums the previous BatchNorm's backward needs -- again finished by the last workgroup.
+// Every sum over the batch is a fixed-order sum of per-workgroup partials: deterministic for a given grid.
+// Batch-coupled quantities (BatchNorm statistics) are why this is a launch per BLOCK and not per coupling: each block's
+// output depends on every sample of the batch through the normalisation that precedes the next block.
+#include "tfk_common.h"
+
+namespace tfk {
+
+constexpr int kCtMaxGrid = 1024;          // workgroups that hand in partial sums (rows of the workspace)
+constexpr int kCtMaxK = 640;              // floats per workgroup (block backward 8 -> 8: 576 + 8 + 16)
+
+// Every workgroup hands in K floats (vals, LDS); true in the last workgroup to finish, with tot[k] = the sum over the
+// workgroups in index order (fp64).  Visibility across the XCDs' L2s as in finish_sum_f64 (tfk_common.h): agent-scope
+// atomic stores, awaited before the agent-scope ticket; the last workgroup reads with agent-scope atomic loads.
+template <int BLOCK>
+__device__ __forceinline__ bool hand_in(const float *vals, int K, float *partial, unsigned long long *counter,
+                                        double *tot, int *flag)
+{
+    __syncthreads();
+    float *mine = partial + (size_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += BLOCK)
+        __hip_atomic_store(mine + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket =
+            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (ticket == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*flag) return false;
+    // the last workgroup: column k of the (workgroups x K) partial sums by S = BLOCK / min(K, BLOCK) lanes, each a fixed
+    // slice of the rows with eight loads in flight (an agent-scope load is ~0.2 us: one lane walking 1 000 rows of a
+    // column alone cost more than the convolution itself), slices added in order
+    __shared__ double part[BLOCK];
+    const int CP = K < BLOCK ? K : BLOCK, S = BLOCK / CP;
+    const int c = threadIdx.x % CP, sl = threadIdx.x / CP;
+    const unsigned G = gridDim.x;
+    for (int k0 = 0; k0 < K; k0 += CP) {
+        const int k = k0 + c;
+        double a = 0.0;
+        if (k < K && sl < S) {
+            unsigned p = (unsigned)sl;
+            for (; p + 7u * (unsigned)S < G; p += 8u * (unsigned)S) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = __hip_atomic_load(partial + (size_t)(p + (unsigned)(j * S)) * K + k, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += (double)v[j];
+            }
+            for (; p < G; p += (unsigned)S)
+                a += (double)__hip_atomic_load(partial + (size_t)p * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (k < K && sl == 0) {
+            double t = 0.0;
+            for (int q = 0; q < S; ++q) t += part[q * CP + c];
+            tot[k] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+}
+
+// sum of v over the workgroup's lanes -> dst[k] (LDS), K values; wred: 4 x K floats of LDS
+template <int K>
+__device__ __forceinline__ void block_sums(const float (&v)[K], float *wred, float *dst)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+        if (lane == 0) wred[wave * K + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K)
+        dst[threadIdx.x] = (wred[threadIdx.x] + wred[K + threadIdx.x]) + (wred[2 * K + threadIdx.x] + wred[3 * K + threadIdx.x]);
+    __syncthreads();
+}
+
+struct BnFwd {              // the BatchNorm2d behind a block (functional.py batch_norm semantics)
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches;
+    float *stats;           // out: scale | shift | mean | 1/std, 4 * C floats
+    float eps, momentum;
+    int training, update;
+};
+
+struct BnBwd {              // the BatchNorm2d whose OUTPUT gradient a backward launch produces
+    const float *stats;     // its forward's scale | shift | mean | 1/std (null: none)
+    float *coef;            // out: c1 | c2 | c3 with d(loss)/d(input) = c1 g + c2 y + c3
+    float *dgamma, *dbeta;  // out
+    double count;           // elements per channel in the batch
+    int training;
+};
+
+// sg[c] = sum g, sgy[c] = sum g * y (y = the BatchNorm's input), over the batch
+__device__ __forceinline__ void bn_backward_finish(const double *sg, const double *sgy, int C, const BnBwd &bn)
+{
+    if (!bn.stats) return;
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        const double scale = bn.stats[c], mean = bn.stats[2 * C + c], invstd = bn.stats[3 * C + c];
+        const double dbeta = sg[c], dgamma = invstd * (sgy[c] - mean * sg[c]);
+        bn.dbeta[c] = (float)dbeta;
+        bn.dgamma[c] = (float)dgamma;
+        double c2 = 0.0, c3 = 0.0;
+        if (bn.training) {      // dy = scale (g - mean(g) - xhat mean(g xhat)),  xhat = (y - mean) / std
+            const double mg = dbeta / bn.count, mgx = dgamma / bn.count;
+            c2 = -scale * invstd * mgx;
+            c3 = -scale * mg + scale * invstd * mgx * mean;
+        }
+        bn.coef[c] = (float)scale;
+        bn.coef[C + c] = (float)c2;
+        bn.coef[2 * C + c] = (float)c3;
+    }
+}
+
+// ---- forward of one block ---------------------------------------------------------------------------------------
+// one lane per pooled pixel, all output channels (as k_conv3x3_relu_pool_affine, tfk_convblock.hip); in_aff: the previous
+// BatchNorm's scale | shift applied to the input inside the image (the zero padding stays zero), or null.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_ct_block_fwd(
+    const float *__restrict__ x, const float *__restrict__ in_aff, const float *__restrict__ w,
+    const float *__restrict__ bias, float *__restrict__ y, unsigned char *__restrict__ amax, float *partial,
+    unsigned long long *counter, BnFwd bn, long long N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) float ws[CIN * COUT * 12];
+    __shared__ float bs[COUT], ia[2 * CIN], vals[2 * COUT], wred[4 * 2 * COUT];
+    __shared__ double tot[2 * COUT];
+    __shared__ int flag;
+    for (int i = threadIdx.x; i < CIN * COUT * 12; i += kBlock) {
+        const int tap = i % 12, co = (i / 12) % COUT, ci = i / (12 * COUT);
+        ws[i] = tap < 9 ? w[(co * CIN + ci) * 9 + tap] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < COUT; i += kBlock) bs[i] = bias[i];
+    for (int i = threadIdx.x; i < CIN; i += kBlock) {
+        ia[i] = in_aff ? in_aff[i] : 1.0f;
+        ia[CIN + i] = in_aff ? in_aff[CIN + i] : 0.0f;
+    }
+    __syncthreads();
+    const int PH = H >> 1, PW = W >> 1;
+    const long long total = N * (long long)PH * PW;
+    const long long plane = (long long)H * W;
+    float s[2 * COUT];
+#pragma unroll
+    for (int k = 0; k < 2 * COUT; ++k) s[k] = 0.0f;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const int pw = (int)(idx % PW);
+        const int ph = (int)((idx / PW) % PH);
+        const long long n = idx / ((long long)PW * PH);
+        float acc[COUT][2][2];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox) acc[co][oy][ox] = bs[co];
+        const int ih0 = 2 * ph - 1, iw0 = 2 * pw - 1;
+#pragma unroll 1
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *src = x + (n * CIN + ci) * plane;
+            const float sc = ia[ci], sh = ia[CIN + ci];
+            float p[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ih = ih0 + r;
+                const bool rok = (ih >= 0) && (ih < H);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int iw = iw0 + c;
+                    p[r][c] = (rok && iw >= 0 && iw < W) ? fmaf(src[(long long)ih * W + iw], sc, sh) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12);
+                const float4 w1 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12 + 4);
+                const float4 w2 = *reinterpret_cast<const float4 *>(ws + (ci * COUT + co) * 12 + 8);
+                const float k[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        float a = acc[co][oy][ox];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a = fmaf(k[3 * ky + kx], p[oy + ky][ox + kx], a);
+                        acc[co][oy][ox] = a;
+                    }
+            }
+        }
+        const long long o0 = (n * COUT) * (long long)PH * PW + (long long)ph * PW + pw;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float m = acc[co][0][0];
+            int a = 0;
+            if (acc[co][0][1] > m) { m = acc[co][0][1]; a = 1; }
+            if (acc[co][1][0] > m) { m = acc[co][1][0]; a = 2; }
+            if (acc[co][1][1] > m) { m = acc[co][1][1]; a = 3; }
+            const float v = fmaxf(m, 0.0f);                      // relu and max commute
+            y[o0 + (long long)co * PH * PW] = v;
+            amax[o0 + (long long)co * PH * PW] = (unsigned char)a;
+            s[co] += v;
+            s[COUT + co] = fmaf(v, v, s[COUT + co]);
+        }
+    }
+    if (!bn.training) {             // inference statistics: nothing to add up
+        if (blockIdx.x == 0 && threadIdx.x < COUT) {
+            const int c = threadIdx.x;
+            const float invstd = 1.0f / sqrtf(bn.running_var[c] + bn.eps);
+            const float scale = bn.gamma[c] * invstd;
+            bn.stats[c] = scale;
+            bn.stats[COUT + c] = bn.beta[c] - bn.running_mean[c] * scale;
+            bn.stats[2 * COUT + c] = bn.running_mean[c];
+            bn.stats[3 * COUT + c] = invstd;
+        }
+        return;
+    }
+    block_sums<2 * COUT>(s, wred, vals);
+    if (!hand_in<kBlock>(vals, 2 * COUT, partial, counter, tot, &flag)) return;
+    if (threadIdx.x < COUT) {
+        const int c = threadIdx.x;
+        const double M = (double)total;
+        const double mean = tot[c] / M;
+        double var = tot[COUT + c] / M - mean * mean;           // biased: what the batch is normalised with
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)bn.eps);
+        const double scale = (double)bn.gamma[c] * invstd;
+        bn.stats[c] = (float)scale;
+        bn.stats[COUT + c] = (float)((double)bn.beta[c] - mean * scale);
+        bn.stats[2 * COUT + c] = (float)mean;
+        bn.stats[3 * COUT + c] = (float)invstd;
+        if (bn.update) {            // running statistics: unbiased variance, exponential average
+            const double m = bn.momentum, unb = M > 1.0 ? var * M / (M - 1.0) : var;
+            bn.running_mean[c] = (float)((1.0 - m) * (double)bn.running_mean[c] + m * mean);
+            bn.running_var[c] = (float)((1.0 - m) * (double)bn.running_var[c] + m * unb);
+        }
+    }
+    if (threadIdx.x == 0 && bn.update && bn.num_batches) bn.num_batches[0] += 1;
+}
+
+// ---- ConvModifier (classic.py:8-42): one convolution with a 1- or 2-wide kernel per axis whose padding exceeds
+// kernel - 1, i.e. channel mixing (+ a 2-tap blur on an axis whose size difference is odd) inside a frame that equals
+// the bias.  weight (COUT, C, KH, KW); out[i][j] = bias + sum w[.][dy][dx] z[i - ph + dy][j - pw + dx], z = 0 outside.
+template <int COUT>
+__global__ __launch_bounds__(kBlock) void k_ct_frame_fwd(
+    const float *__restrict__ x, const float *__restrict__ in_aff, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ out, long long N, int C, int H, int W, int HT, int WT,
+    int ph, int pw, int KH, int KW)
+{
+    const long long total = N * (long long)HT * WT;
+    const long long plane_in = (long long)H * W, plane_out = (long long)HT * WT;
+    const int T = KH * KW;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const int j = (int)(idx % WT);
+        const int i = (int)((idx / WT) % HT);
+        const long long n = idx / plane_out;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+        for (int dy = 0; dy < KH; ++dy) {
+            const int ii = i - ph + dy;
+            if (ii < 0 || ii >= H) continue;
+            for (int dx = 0; dx < KW; ++dx) {
+                const int jj = j - pw + dx;
+                if (jj < 0 || jj >= W) continue;
+                const float *src = x + n * C * plane_in + (long long)ii * W + jj;
+                for (int c = 0; c < C; ++c) {
+                    float v = src[c * plane_in];
+                    if (in_aff) v = fmaf(v, in_aff[c], in_aff[C + c]);
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+                        acc[co] = fmaf(weight[(co * C + c) * T + dy * KW + dx], v, acc[co]);
+                }
+            }
+        }
+        float *dst = out + n * COUT * plane_out + (long long)i * WT + j;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) dst[co * plane_out] = acc[co] + bias[co];
+    }
+}
+
+// Reverse mode of the above.  g_out (N, COUT, HT, WT) -> g_in (N, C, H, W) = d(loss)/d(the affine'd input); per launch
+// sums: dW (COUT x C x KH x KW) | sum g_in (C) | sum g_in x (C) | db (COUT)   [x = the RAW input: what the BatchNorm in
+// front saw].  One sample per workgroup pass; dynamic LDS: the window of g_out the input can reach (COUT x (H + KH - 1)
+// x (W + KW - 1)), x (C x HW), g_in (C x HW).  NO: sums per lane (K1 <= NO * 256).
+template <int COUT, int NO>
+__global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
+    const float *__restrict__ g_out, const float *__restrict__ x, const float *__restrict__ in_aff,
+    const float *__restrict__ weight, float *__restrict__ g_in, float *partial, unsigned long long *counter,
+    float *sums_out, BnBwd bn, long long N, int C, int H, int W, int HT, int WT, int ph, int pw, int KH, int KW)
+{
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int HW = H * W, HTWT = HT * WT, T = KH * KW;
+    const int GH = H + KH - 1, GW = W + KW - 1, GHW = GH * GW;
+    const int K1 = COUT * C * T + 2 * C, K = K1 + COUT;
+    double *tot = ldsd;                             // K doubles
+    float *gI = reinterpret_cast<float *>(tot + K), *xr = gI + COUT * GHW, *gin = xr + C * HW, *wl = gin + C * HW;
+    float *ia = wl + COUT * C * T, *vals = ia + 2 * C, *wred = vals + K;       // 2 C | K | 4 COUT floats
+    __shared__ int flag;
+    for (int i = threadIdx.x; i < COUT * C * T; i += kBlock) wl[i] = weight[i];
+    for (int i = threadIdx.x; i < C; i += kBlock) {
+        ia[i] = in_aff ? in_aff[i] : 1.0f;
+        ia[C + i] = in_aff ? in_aff[C + i] : 0.0f;
+    }
+    float dbl[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) dbl[co] = 0.0f;
+    float acc[NO];
+#pragma unroll
+    for (int q = 0; q < NO; ++q) acc[q] = 0.0f;
+    const int r0 = ph - (KH - 1), s0 = pw - (KW - 1);          // g_out position of window entry (0, 0)
+    for (long long n = blockIdx.x; n < N; n += gridDim.x) {
+        __syncthreads();                            // (the previous pass is done with the LDS; wl / ia are written)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float *src = g_out + (n * COUT + co) * HTWT;
+            for (int pos = threadIdx.x; pos < HTWT; pos += kBlock) {
+                const float g = src[pos];
+                dbl[co] += g;
+                const int r = pos / WT - r0, q = pos % WT - s0;
+                if (r >= 0 && r < GH && q >= 0 && q < GW) gI[co * GHW + r * GW + q] = g;
+            }
+        }
+        for (int i = threadIdx.x; i < C * HW; i += kBlock) xr[i] = x[n * C * HW + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * HW; i += kBlock) {
+            const int c = i / HW, pix = i - c * HW, yy = pix / W, xx = pix - yy * W;
+            float gi = 0.0f;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                for (int dy = 0; dy < KH; ++dy)
+                    for (int dx = 0; dx < KW; ++dx)
+                        gi = fmaf(wl[(co * C + c) * T + dy * KW + dx],
+                                  gI[co * GHW + (yy + KH - 1 - dy) * GW + xx + KW - 1 - dx], gi);
+            gin[i] = gi;
+            g_in[n * C * HW + i] = gi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            const int o = threadIdx.x + q * kBlock;
+            float a = acc[q];
+            if (o < COUT * C * T) {
+                const int tap = o % T, cc = o / T, co = cc / C, c = cc - co * C, dy = tap / KW, dx = tap - dy * KW;
+                const float sc = ia[c], sh = ia[C + c];
+                const float *gsrc = gI + co * GHW + (KH - 1 - dy) * GW + KW - 1 - dx;
+                for (int yy = 0; yy < H; ++yy)
+                    for (int xx = 0; xx < W; ++xx)
+                        a = fmaf(gsrc[yy * GW + xx], fmaf(xr[c * HW + yy * W + xx], sc, sh), a);
+            } else if (o < COUT * C * T + C) {
+                const int c = o - COUT * C * T;
+                for (int pix = 0; pix < HW; ++pix) a += gin[c * HW + pix];
+            } else if (o < K1) {
+                const int c = o - COUT * C * T - C;
+                for (int pix = 0; pix < HW; ++pix) a = fmaf(gin[c * HW + pix], xr[c * HW + pix], a);
+            }
+            acc[q] = a;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NO; ++q)
+        if (threadIdx.x + q * kBlock < K1) vals[threadIdx.x + q * kBlock] = acc[q];
+    block_sums<COUT>(dbl, wred, vals + K1);
+    if (!hand_in<kBlock>(vals, K, partial, counter, tot, &flag)) return;
+    for (int k = threadIdx.x; k < K; k += kBlock) sums_out[k] = (float)tot[k];
+    bn_backward_finish(tot + COUT * C * T, tot + COUT * C * T + C, C, bn);
+}
+
+// ---- reverse mode of one block ------------------------------------------------------------------------------------
+// gz (N, COUT, H/2, H/2): d(loss)/d(BatchNorm output); coef: that BatchNorm's c1 | c2 | c3; y, amax: the forward's pooled
+// output and arg-max; in (N, CIN, H, H) + in_aff: the forward's input.  Writes g_in = d(loss)/d(affine'd input) and hands
+// in dW (COUT x CIN x 9) | db (COUT) | sum g_in (CIN) | sum g_in * in (CIN).  Square planes, H in {8, 16, 32}.
+template <int CIN, int COUT, int H>
+__global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
+    const float *__restrict__ gz, const float *__restrict__ coef, const float *__restrict__ y,
+    const unsigned char *__restrict__ amax, const float *__restrict__ in, const float *__restrict__ in_aff,
+    const float *__restrict__ w, float *__restrict__ g_in, float *partial, unsigned long long *counter,
+    float *sums_out, BnBwd bn, long long N)
+{
+    constexpr int P = H + 2, PP = P * P, HP = H / 2, CELLS = HP * HP, HH = H * H;
+    constexpr int PAIRS = COUT * CIN, GROUPS = kBlock / PAIRS;
+    constexpr int K = PAIRS * 9 + COUT + 2 * CIN;
+    static_assert(GROUPS >= 1 && GROUPS * PAIRS == kBlock, "pairs must divide the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *zin = lds;                               // CIN x P x P, zero halo
+    float *dc = zin + CIN * PP;                     // COUT x P x P, zero halo: d(loss)/d(convolution output)
+    float *dv = dc + COUT * PP;                     // COUT x CELLS: the one non-zero of every 2x2 window
+    unsigned char *da = reinterpret_cast<unsigned char *>(dv + COUT * CELLS);       // its position
+    __shared__ float cf[3 * COUT], ia[2 * CIN], vals[K], wred[4 * 2 * CIN];
+    __shared__ double tot[K];
+    __shared__ int flag;
+    for (int i = threadIdx.x; i < (CIN + COUT) * PP; i += kBlock) lds[i] = 0.0f;
+    for (int i = threadIdx.x; i < 3 * COUT; i += kBlock) cf[i] = coef[i];
+    for (int i = threadIdx.x; i < CIN; i += kBlock) {
+        ia[i] = in_aff ? in_aff[i] : 1.0f;
+        ia[CIN + i] = in_aff ? in_aff[CIN + i] : 0.0f;
+    }
+    const int pair = threadIdx.x % PAIRS, grp = threadIdx.x / PAIRS;
+    const int pco = pair / CIN, pci = pair % CIN;
+    float aw[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) aw[k] = 0.0f;
+    float sg[2 * CIN];
+#pragma unroll
+    for (int k = 0; k < 2 * CIN; ++k) sg[k] = 0.0f;
+    for (long long n = blockIdx.x; n < N; n += gridDim.x) {
+        __syncthreads();
+        // (a) the convolution-output gradient: BatchNorm backward, un-pool, ReLU
+        for (int it = threadIdx.x; it < COUT * CELLS; it += kBlock) {
+            const int co = it / CELLS, cell = it - co * CELLS;
+            const long long gi = n * COUT * CELLS + it;
+            const float g = gz[gi], yv = y[gi];
+            const int a = amax[gi];
+            const float d = yv > 0.0f ? fmaf(cf[co], g, fmaf(cf[COUT + co], yv, cf[2 * COUT + co])) : 0.0f;
+            dv[it] = d;
+            da[it] = (unsigned char)a;
+            const int py = cell / HP, px = cell - py * HP;
+            float *dst = dc + co * PP + (2 * py + 1) * P + 2 * px + 1;
+            dst[0] = a == 0 ? d : 0.0f;
+            dst[1] = a == 1 ? d : 0.0f;
+            dst[P] = a == 2 ? d : 0.0f;
+            dst[P + 1] = a == 3 ? d : 0.0f;
+        }
+        for (int it = threadIdx.x; it < CIN * HH; it += kBlock) {
+            const int ci = it / HH, r = it - ci * HH, yy = r / H, xx = r - yy * H;
+            zin[ci * PP + (yy + 1) * P + xx + 1] = fmaf(in[n * CIN * HH + it], ia[ci], ia[CIN + ci]);
+        }
+        __syncthreads();
+        // (c) weight gradient: this thread's (c_out, c_in) pair, its share of the pooled cells, 9 taps
+        for (int cell = grp; cell < CELLS; cell += GROUPS) {
+            const float d = dv[pco * CELLS + cell];
+            const int a = da[pco * CELLS + cell];
+            const int py = cell / HP, px = cell - py * HP;
+            const float *src = zin + pci * PP + (2 * py + (a >> 1)) * P + 2 * px + (a & 1);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) aw[3 * ky + kx] = fmaf(d, src[ky * P + kx], aw[3 * ky + kx]);
+            aw[9] += d;
+        }
+        // (b) input gradient: full correlation with the flipped kernel, all input channels of one position
+        for (int pos = threadIdx.x; pos < HH; pos += kBlock) {
+            const int yy = pos / H, xx = pos - yy * H;
+            float gi[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) gi[ci] = 0.0f;
+#pragma unroll 1
+            for (int co = 0; co < COUT; ++co) {         // rolled: one output channel's CIN x 9 weights in SGPRs at a time
+                const float *src = dc + co * PP + yy * P + xx;
+                const float *wc = w + co * CIN * 9;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float dval = src[(2 - ky) * P + (2 - kx)];
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci)
+                            gi[ci] = fmaf(wc[(ci * 3 + ky) * 3 + kx], dval, gi[ci]);
+                    }
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const long long at = (n * CIN + ci) * HH + pos;
+                g_in[at] = gi[ci];
+                sg[ci] += gi[ci];
+                sg[CIN + ci] = fmaf(gi[ci], in[at], sg[CIN + ci]);
+            }
+        }
+    }
+    __syncthreads();
+    float *red = lds;                               // GROUPS x PAIRS x 10 (the launch reserves at least that much)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) red[(grp * PAIRS + pair) * 10 + k] = aw[k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < PAIRS * 9; o += kBlock) {
+        const int pr = o / 9, k = o - pr * 9;
+        float s = 0.0f;
+        for (int g = 0; g < GROUPS; ++g) s += red[(g * PAIRS + pr) * 10 + k];
+        vals[o] = s;
+    }
+    if (threadIdx.x < COUT) {
+        float s = 0.0f;
+        for (int g = 0; g < GROUPS; ++g) s += red[(g * PAIRS + threadIdx.x * CIN) * 10 + 9];
+        vals[PAIRS * 9 + threadIdx.x] = s;
+    }
+    block_sums<2 * CIN>(sg, wred, vals + PAIRS * 9 + COUT);
+    if (!hand_in<kBlock>(vals, K, partial, counter, tot, &flag)) return;
+    for (int k = threadIdx.x; k < PAIRS * 9 + COUT; k += kBlock) sums_out[k] = (float)tot[k];
+    bn_backward_finish(tot + PAIRS * 9 + COUT, tot + PAIRS * 9 + COUT + CIN, CIN, bn);
+}
+
+// ---- weight gradient of the Linear layer behind the second ConvModifier ---------------------------------------------
+// Its input a (N, HT x WT) equals the modifier's bias outside the H x W = 16 interior pixels, so
+//   dW[m][j] = sum_n g[n][m] a[n][j] = frame(j) ? bias * db[m] : sum_n g[n][m] a_int[n][j],   db[m] = sum_n g[n][m]:
+// a contraction over the batch with 16 columns on one side (the library GEMM runs it as one tile: 958 us at N = 1 000,
+// M = 784).  One workgroup per 16 rows m, rows n in order: deterministic.
+__global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
+    const float *__restrict__ g, const float *__restrict__ a, const float *__restrict__ frame_bias,
+    float *__restrict__ dW, float *__restrict__ db, long long N, int M, int HT, int WT, int top, int left)
+{
+    __shared__ float gs[64][17], as[64][16], sb[16];
+    const int m0 = blockIdx.x * 16, ml = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int F = HT * WT;
+    const int col = (top + (k >> 2)) * WT + left + (k & 3);     // interior pixel k of the 4 x 4 block
+    float acc = 0.0f, accb = 0.0f;
+    for (long long n0 = 0; n0 < N; n0 += 64) {
+        for (int i = threadIdx.x; i < 64 * 16; i += kBlock) {
+            const int r = i >> 4, c = i & 15;
+            const long long n = n0 + r;
+            gs[r][c] = (n < N && m0 + c < M) ? g[n * M + m0 + c] : 0.0f;
+            as[r][c] = n < N ? a[n * F + (top + (c >> 2)) * WT + left + (c & 3)] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const float gv = gs[r][ml];
+            acc = fmaf(gv, as[r][k], acc);
+            accb += gv;
+        }
+        __syncthreads();
+    }
+    if (k == 0) sb[ml] = accb;
+    __syncthreads();
+    if (m0 + ml >= M) return;
+    float *row = dW + (long long)(m0 + ml) * F;
+    row[col] = acc;
+    const float fb = frame_bias[0] * sb[ml];
+    for (int j = k; j < F; j += 16) {
+        const int ii = j / WT - top, jj = j % WT - left;
+        if (!(ii >= 0 && ii < 4 && jj >= 0 && jj < 4)) row[j] = fb;
+    }
+    if (k == 0) db[m0 + ml] = sb[ml];
+}
+
+// ---- the Linear layer behind the second ConvModifier, forward and input gradient ------------------------------------
+// (N x F) x (F x M), F = 100, and (N x M) x (M x F): skinny products the GEMM library runs fine, written out so that the
+// whole network is free of library calls (a training step with them cannot be captured into a hipGraph on this stack)
+// and deterministic.  out[n][m] = bias[m] + sum_f a[n][f] W[m][f]: a 64 x 64 output tile per workgroup, 4 x 4 per lane.
+__global__ __launch_bounds__(kBlock) void k_ct_linear_fwd(
+    const float *__restrict__ a, const float *__restrict__ Wt, const float *__restrict__ bias, float *__restrict__ out,
+    long long N, int M, int F)
+{
+    extern __shared__ __attribute__((aligned(16))) float lin[];
+    const int FP = F + 1;
+    float *as = lin, *wsm = lin + 64 * FP;
+    const long long n0 = (long long)blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * F; i += kBlock) {
+        const int r = i / F, f = i - r * F;
+        as[r * FP + f] = (n0 + r < N) ? a[(n0 + r) * F + f] : 0.0f;
+        wsm[r * FP + f] = (m0 + r < M) ? Wt[(long long)(m0 + r) * F + f] : 0.0f;
+    }
+    __syncthreads();
+    const int tn = threadIdx.x >> 4, tm = threadIdx.x & 15;      // rows tn + 16 i, columns tm + 16 j
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int f = 0; f < F; ++f) {
+        float av[4], wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = as[(tn + 16 * i) * FP + f];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = wsm[(tm + 16 * j) * FP + f];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long n = n0 + tn + 16 * i;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + tm + 16 * j;
+            if (m < M) out[n * M + m] = acc[i][j] + bias[m];
+        }
+    }
+}
+
+// g_a[n][f] = sum_m g[n][m] W[m][f]: one lane per output, the m axis walked in order with eight loads in flight (g[n][.]
+// is one address per row of lanes, W[m][.] a coalesced row that stays in L2): N x F lanes hide the latency that a
+// staged-slab version of this product (16 rows per workgroup, 64 workgroups) serialised -- 292 us against 30.
+__global__ __launch_bounds__(kBlock) void k_ct_linear_bwd_input(
+    const float *__restrict__ g, const float *__restrict__ Wt, float *__restrict__ g_a, long long N, int M, int F)
+{
+    const long long total = N * (long long)F;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const long long n = idx / F;
+        const int f = (int)(idx - n * F);
+        const float *gr = g + n * M;
+        const float *wc = Wt + f;
+        float acc = 0.0f;
+        int m = 0;
+        for (; m + 8 <= M; m += 8) {
+            float gv[8], wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gv[j] = gr[m + j];
+                wv[j] = wc[(long long)(m + j) * F];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(gv[j], wv[j], acc);
+        }
+        for (; m < M; ++m) acc = fmaf(gr[m], wc[(long long)m * F], acc);
+        g_a[idx] = acc;
+    }
+}
+
+}  // namespace tfk
+
+using namespace tfk;
+
+namespace {
+
+bool block_ok(int c_in, int c_out) { return (c_in == 4 && c_out == 8) || (c_in == 8 && c_out == 8) || (c_in == 8 && c_out == 4); }
+
+int bwd_grid(int64_t N, int per_cu)
+{
+    int64_t g = (int64_t)cu_count() * per_cu;
+    if (g > kCtMaxGrid) g = kCtMaxGrid;
+    return (int)(N < g ? N : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tfk_convnet_train_workspace_bytes(void)
+{
+    return 16 + (int64_t)kCtMaxGrid * kCtMaxK * (int64_t)sizeof(float);
+}
+
+int tfk_convnet_train_block_supported(int32_t c_in, int32_t c_out, int32_t H)
+{
+    // (the reference's network: 4 x 32 x 32 -> 8 x 16 x 16 -> 8 x 8 x 8 -> 4 x 4 x 4, classic.py:88-104)
+    return ((c_in == 4 && c_out == 8 && H == 32) || (c_in == 8 && c_out == 8 && H == 16) || (c_in == 8 && c_out == 4 && H == 8)) ? 1 : 0;
+}
+
+int tfk_convnet_train_block_fwd(const float *x, const float *in_affine, const float *weight, const float *bias,
+                                float *y, uint8_t *argmax, const float *bn_weight, const float *bn_bias,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float eps,
+                                float momentum, int32_t training, int32_t update_running, float *stats,
+                                void *workspace, int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W,
+                                void *stream)
+{
+    const char *fn = "tfk_convnet_train_block_fwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!block_ok(c_in, c_out)) return fail(TFK_EINVAL, "%s: channels %d -> %d (4->8, 8->8, 8->4)", fn, c_in, c_out);
+    if (H < 2 || W < 2 || (H & 1) || (W & 1)) return fail(TFK_EINVAL, "%s: H = %d, W = %d must be even and >= 2", fn, H, W);
+    if (N == 0) return TFK_OK;
+    if (!x || !weight || !bias || !y || !argmax || !bn_weight || !bn_bias || !running_mean || !running_var || !stats ||
+        !workspace)
+        return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t blocks = (N * (int64_t)(H / 2) * (W / 2) + kBlock - 1) / kBlock;
+    const int grid = (int)(blocks < kCtMaxGrid ? blocks : kCtMaxGrid);
+    unsigned long long *counter = static_cast<unsigned long long *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    BnFwd bn{bn_weight, bn_bias, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), stats,
+             eps, momentum, training ? 1 : 0, (training && update_running) ? 1 : 0};
+#define TFK_CT(CI, CO)                                                                                            \
+    hipLaunchKernelGGL((k_ct_block_fwd<CI, CO>), dim3(grid), dim3(kBlock), 0, s, x, in_affine, weight, bias, y, \
+                       argmax, partial, counter, bn, (long long)N, H, W)
+    if (c_in == 4) TFK_CT(4, 8);
+    else if (c_out == 8) TFK_CT(8, 8);
+    else TFK_CT(8, 4);
+#undef TFK_CT
+    return check_launch(fn);
+}
+
+// padding of the ConvModifier's convolution along one axis (classic.py:17-29): out = in + 2 pad - kernel + 1
+static bool frame_axis(int in, int out, int kernel, int *pad)
+{
+    if (kernel < 1 || kernel > 2 || out < in) return false;
+    const int twice = out - in + kernel - 1;
+    if (twice & 1) return false;
+    *pad = twice / 2;
+    return *pad >= kernel - 1;
+}
+
+int tfk_convnet_train_frame_fwd(const float *x, const float *in_affine, const float *weight, const float *bias,
+                                float *out, int64_t N, int32_t c_in, int32_t c_out, int32_t H, int32_t W,
+                                int32_t H_out, int32_t W_out, int32_t kh, int32_t kw, void *stream)
+{
+    const char *fn = "tfk_convnet_train_frame_fwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (c_out != 1 && c_out != 4) return fail(TFK_EINVAL, "%s: c_out = %d (1 or 4)", fn, c_out);
+    int ph = 0, pw = 0;
+    if (c_in < 1 || H < 1 || W < 1 || !frame_axis(H, H_out, kh, &ph) || !frame_axis(W, W_out, kw, &pw))
+        return fail(TFK_EINVAL, "%s: need c_in >= 1 and a %d x %d kernel that maps %dx%d to %dx%d with padding >= kernel - 1",
+                    fn, kh, kw, H, W, H_out, W_out);
+    if (N == 0) return TFK_OK;
+    if (!x || !weight || !bias || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(N * (int64_t)H_out * W_out, kBlock);
+    if (c_out == 4)
+        hipLaunchKernelGGL((k_ct_frame_fwd<4>), dim3(grid), dim3(kBlock), 0, s, x, in_affine, weight, bias, out,
+                           (long long)N, c_in, H, W, H_out, W_out, ph, pw, kh, kw);
+    else
+        hipLaunchKernelGGL((k_ct_frame_fwd<1>), dim3(grid), dim3(kBlock), 0, s, x, in_affine, weight, bias, out,
+                           (long long)N, c_in, H, W, H_out, W_out, ph, pw, kh, kw);
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float *in_affine, const float *weight,
+                                float *g_in, float *sums, const float *bn_stats, float *bn_coef, float *bn_dweight,
+                                float *bn_dbias, int32_t bn_training, void *workspace, int64_t N, int32_t c_in,
+                                int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out, int32_t kh,
+                                int32_t kw, void *stream)
+{
+    const char *fn = "tfk_convnet_train_frame_bwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (c_out != 1 && c_out != 4) return fail(TFK_EINVAL, "%s: c_out = %d (1 or 4)", fn, c_out);
+    int ph = 0, pw = 0;
+    if (c_in < 1 || H < 1 || W < 1 || !frame_axis(H, H_out, kh, &ph) || !frame_axis(W, W_out, kw, &pw))
+        return fail(TFK_EINVAL, "%s: need c_in >= 1 and a %d x %d kernel that maps %dx%d to %dx%d with padding >= kernel - 1",
+                    fn, kh, kw, H, W, H_out, W_out);
+    const int T = kh * kw, K1 = c_out * c_in * T + 2 * c_in, K = K1 + c_out;
+    if (K1 > 3 * kBlock || K > kCtMaxK)
+        return fail(TFK_EINVAL, "%s: %d x %d channels x %d taps: too many sums for one workgroup", fn, c_out, c_in, T);
+    const int64_t lds_floats = (int64_t)c_out * (H + kh - 1) * (W + kw - 1) + 2 * (int64_t)c_in * H * W + c_out * c_in * T +
+                               2 * c_in + K + 4 * c_out + 2 * (int64_t)K;
+    if (lds_floats * 4 > 150 * 1024) return fail(TFK_EINVAL, "%s: %d x %d x %d input does not fit the LDS", fn, c_in, H, W);
+    if (bn_stats && (!bn_coef || !bn_dweight || !bn_dbias)) return fail(TFK_EINVAL, "%s: BatchNorm outputs missing", fn);
+    if (N == 0) return TFK_OK;
+    if (!g_out || !x || !weight || !g_in || !sums || !workspace) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = bwd_grid(N, 2);
+    unsigned long long *counter = static_cast<unsigned long long *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    BnBwd bn{bn_stats, bn_coef, bn_dweight, bn_dbias, (double)N * H * W, bn_training ? 1 : 0};
+    const size_t lds = (size_t)lds_floats * 4;
+#define TFK_CT(CO, NO)                                                                                                 \
+    do {                                                                                                               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_frame_bwd<CO, NO>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);                                  \
+        hipLaunchKernelGGL((k_ct_frame_bwd<CO, NO>), dim3(grid), dim3(kBlock), lds, s, g_out, x, in_affine, weight,    \
+                           g_in, partial, counter, sums, bn, (long long)N, c_in, H, W, H_out, W_out, ph, pw, kh, kw);  \
+    } while (0)
+    if (c_out == 1) TFK_CT(1, 1);
+    else if (K1 <= kBlock) TFK_CT(4, 1);
+    else TFK_CT(4, 3);
+#undef TFK_CT
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_block_bwd(const float *gz, const float *coef, const float *y, const uint8_t *argmax,
+                                const float *x, const float *in_affine, const float *weight, float *g_in, float *sums,
+                                const float *bn_stats, float *bn_coef, float *bn_dweight, float *bn_dbias,
+                                int32_t bn_training, void *workspace, int64_t N, int32_t c_in, int32_t c_out, int32_t H,
+                                void *stream)
+{
+    const char *fn = "tfk_convnet_train_block_bwd";
+    if (N < 0) return fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    if (!tfk_convnet_train_block_supported(c_in, c_out, H))
+        return fail(TFK_EINVAL, "%s: %d -> %d channels on %d x %d planes (4->8 on 32, 8->8 on 16, 8->4 on 8)", fn, c_in, c_out, H, H);
+    if (bn_stats && (!bn_coef || !bn_dweight || !bn_dbias)) return fail(TFK_EINVAL, "%s: BatchNorm outputs missing", fn);
+    if (N == 0) return TFK_OK;
+    if (!gz || !coef || !y || !argmax || !x || !weight || !g_in || !sums || !workspace)
+        return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long *counter = static_cast<unsigned long long *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    BnBwd bn{bn_stats, bn_coef, bn_dweight, bn_dbias, (double)N * H * H, bn_training ? 1 : 0};
+    const int P = H + 2, cells = (H / 2) * (H / 2);
+    size_t lds = (size_t)(c_in + c_out) * P * P * 4 + (size_t)c_out * cells * 5 + 16;
+    if (lds < (size_t)kBlock * 10 * 4) lds = (size_t)kBlock * 10 * 4;       // (the cross-group reduction of dW)
+    const int grid = bwd_grid(N, 1);        // (fewer, longer workgroups: the last one adds up one row of sums per workgroup)
+#define TFK_CT(CI, CO, HH)                                                                                             \
+    do {                                                                                                               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_block_bwd<CI, CO, HH>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
+            return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);                                \
+        hipLaunchKernelGGL((k_ct_block_bwd<CI, CO, HH>), dim3(grid), dim3(kBlock), lds, s, gz, coef, y, argmax, x,     \
+                           in_affine, weight, g_in, partial, counter, sums, bn, (long long)N);                         \
+    } while (0)
+    if (c_in == 4) TFK_CT(4, 8, 32);
+    else if (c_out == 8) TFK_CT(8, 8, 16);
+    else TFK_CT(8, 4, 8);
+#undef TFK_CT
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_linear_fwd(const float *a, const float *weight, const float *bias, float *out, int64_t N, int32_t M,
+                                 int32_t F, void *stream)
+{
+    const char *fn = "tfk_convnet_train_linear_fwd";
+    if (N < 0 || M < 1 || F < 1 || F > 128) return fail(TFK_EINVAL, "%s: N = %lld, M = %d, F = %d (F <= 128)", fn, (long long)N, M, F);
+    if (N == 0) return TFK_OK;
+    if (!a || !weight || !bias || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)2 * 64 * (F + 1) * 4;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_linear_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
+    hipLaunchKernelGGL(k_ct_linear_fwd, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(kBlock), lds, s, a,
+                       weight, bias, out, (long long)N, M, F);
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_linear_bwd_input(const float *g, const float *weight, float *g_a, int64_t N, int32_t M, int32_t F,
+                                       void *stream)
+{
+    const char *fn = "tfk_convnet_train_linear_bwd_input";
+    if (N < 0 || M < 1 || F < 1 || F > 128) return fail(TFK_EINVAL, "%s: N = %lld, M = %d, F = %d (F <= 128)", fn, (long long)N, M, F);
+    if (N == 0) return TFK_OK;
+    if (!g || !weight || !g_a) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_ct_linear_bwd_input, dim3(grid_for(N * (int64_t)F, kBlock)), dim3(kBlock), 0, s, g, weight, g_a,
+                       (long long)N, M, F);
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *frame_bias, float *dW, float *db,
+                                   int64_t N, int32_t M, int32_t H_out, int32_t W_out, void *stream)
+{
+    const char *fn = "tfk_convnet_train_linear_wgrad";
+    if (N < 0 || M < 1) return fail(TFK_EINVAL, "%s: N = %lld, M = %d", fn, (long long)N, M);
+    if (H_out < 4 || W_out < 4 || ((H_out - 4) & 1) || ((W_out - 4) & 1))
+        return fail(TFK_EINVAL, "%s: the interior is 4 x 4 in the middle of an even frame (%d x %d)", fn, H_out, W_out);
+    if (!g || !a || !frame_bias || !dW || !db) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 15) / 16), dim3(kBlock), 0, s, g, a, frame_bias, dW, db,
+                       (long long)N, M, H_out, W_out, (H_out - 4) / 2, (W_out - 4) / 2);
+    return check_launch(fn);
+}
+
+}  // extern "C"

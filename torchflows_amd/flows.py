@@ -292,16 +292,47 @@ class Flow(BaseFlow):
         from torchflows_amd import autograd as hip_autograd
         from torchflows_amd.bijections.base import BijectiveComposition, method_direction
         b = self.bijection
-        if not (hip_autograd.enabled() and isinstance(b, BijectiveComposition)
-                and isinstance(self.base, DiagonalGaussian)):
+        if not (hip_autograd.enabled() and isinstance(self.base, DiagonalGaussian)):
             return False
-        if self.base.loc.requires_grad or self.base.log_scale.requires_grad or len(self.base.event_shape) != 1:
+        if self.base.loc.requires_grad or self.base.log_scale.requires_grad:
             return False
         if any(p.dtype != torch.float32 or p.device.type != "cuda" for p in self.parameters()):
+            return False
+        from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection
+        if isinstance(b, MultiscaleBijection):
+            return self._image_graph_safe(b)
+        if not isinstance(b, BijectiveComposition) or len(self.base.event_shape) != 1:
             return False
         d = method_direction(b.forward)
         plan = None if d is None else hip_autograd.training_plan(b, d)
         return plan is not None and hip_autograd.fully_fused(plan, b.n_dim)
+
+    def _image_graph_safe(self, b) -> bool:
+        """An image flow whose training step is libtfk launches and elementwise / index ATen ops only: every coupling on
+        the reverse-mode chain (autograd.training_plan) and every ConvNet conditioner on csrc/tfk_convtrain.hip -- no
+        MIOpen, no GEMM-library call, no host synchronisation."""
+        from torchflows_amd import autograd as hip_autograd, convnet_train
+        from torchflows_amd.bijections.base import BijectiveComposition, method_direction
+        from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection, Squeeze
+        from torchflows_amd.bijections.finite.multiscale.conditioning.classic import ConvNet
+        dev = self.get_device()
+        for m in b.modules():
+            if isinstance(m, ConvNet) and not convnet_train.static_usable(m, dev):
+                return False
+        todo = [b]
+        while todo:
+            m = todo.pop()
+            layers = list(m.checkerboard_layers) + (list(m.channel_wise_layers) if m.n_blocks > 1 else [])
+            for layer in layers:
+                d = method_direction(layer.forward)
+                if not isinstance(layer, BijectiveComposition) or d is None \
+                        or hip_autograd.training_plan(layer, d) is None:
+                    return False
+            if m.n_blocks > 1:
+                if not isinstance(m.small_bijection, MultiscaleBijection) or not isinstance(m.squeeze, Squeeze):
+                    return False
+                todo.append(m.small_bijection)
+        return True
 
     def fit(self,
             x_train: torch.Tensor,
@@ -389,7 +420,9 @@ class Flow(BaseFlow):
         if use_graph and graph_mode != "1":
             use_graph = (not adaptive) and n_epochs * (n_train // max(int(batch_size), 1)) >= GRAPH_AUTO_MIN_STEPS
         if self._optimizer is None or reset_optimizer:
-            self._optimizer = make_adamw(self.parameters(), lr, capturable=use_graph)
+            from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection
+            self._optimizer = make_adamw(self.parameters(), lr, capturable=use_graph,
+                                         fused=use_graph and isinstance(self.bijection, MultiscaleBijection))
         elif use_graph and not _optimizer_capturable(self._optimizer):
             # fit(reset_optimizer=False) behind variational_fit or a short eager fit keeps THAT optimiser: a FlatAdamW (or a
             # non-capturable AdamW) counts its steps on the host, and a captured step would replay one step's bias
@@ -419,8 +452,25 @@ class Flow(BaseFlow):
             stats["graph_captures"] += 1
             return len(xb), graph, xs, ws, static_loss, where()
 
-        def snapshot():
-            return {k: v.detach().clone() for k, v in self.state_dict().items()}
+        def snapshot(into=None):
+            """The state dict's values, copied -- into the previous snapshot's tensors when there is one (only the latest
+            kept weights are ever read back): a few multi-tensor copies instead of one launch per entry (an image flow
+            has ~350 of them; the copy per epoch was 10 % of its training step)."""
+            state = self.state_dict()
+            if into is None or into.keys() != state.keys():
+                return {k: v.detach().clone() for k, v in state.items()}
+            groups = {}
+            for k, v in state.items():
+                dst = into[k]
+                if dst.shape != v.shape or dst.dtype != v.dtype or dst.device != v.device:
+                    return {k: v.detach().clone() for k, v in state.items()}
+                groups.setdefault((v.dtype, v.device), ([], []))
+                groups[(v.dtype, v.device)][0].append(dst)
+                groups[(v.dtype, v.device)][1].append(v.detach())
+            with torch.no_grad():
+                for dsts, srcs in groups.values():
+                    torch._foreach_copy_(dsts, srcs)
+            return into
 
         best_weights = snapshot()
         best_val, best_train = float("inf"), float("inf")
@@ -530,7 +580,7 @@ class Flow(BaseFlow):
                         best_val, best_val_epoch = val_loss, epoch
                 mark = best_val_epoch if val is not None else best_train_epoch
                 if keep_best_weights and mark == epoch:
-                    best_weights = snapshot()
+                    best_weights = snapshot(best_weights)
                 if early_stopping and epoch - mark > early_stopping_threshold:
                     break
         if side is not None:
@@ -643,7 +693,7 @@ class Flow(BaseFlow):
         from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection
         b = self.bijection
         if (context is not None or not isinstance(b, MultiscaleBijection) or not isinstance(self.base, DiagonalGaussian)
-                or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.parameters())))):
+                or b.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.parameters())))):
             return None
         x = x.to(self.get_device())
         if x.numel() == 0 or not native.eligible(x, self.base.loc, self.base.log_scale) or not _params_ok(self):

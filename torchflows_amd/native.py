@@ -49,9 +49,12 @@ SYMBOLS = (
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
     "tfk_glow_level_blob_bytes", "tfk_glow_level_pack", "tfk_glow_level_info", "tfk_glow_level",
     "tfk_rows_fma_gauss_logprob",
+    "tfk_convnet_train_workspace_bytes", "tfk_convnet_train_block_supported", "tfk_convnet_train_block_fwd",
+    "tfk_convnet_train_block_bwd", "tfk_convnet_train_frame_fwd", "tfk_convnet_train_frame_bwd",
+    "tfk_convnet_train_linear_wgrad", "tfk_convnet_train_linear_fwd", "tfk_convnet_train_linear_bwd_input",
 )
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class NativeError(RuntimeError):
@@ -177,6 +180,20 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_glow_level_pack.argtypes = [ps, _i32, _i32, _i32, _i32, _i32, _vp, _i64]
     L.tfk_glow_level_info.argtypes = [_vp, pi, pi, pi, pi]
     L.tfk_glow_level.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]
+    L.tfk_convnet_train_workspace_bytes.argtypes = []
+    L.tfk_convnet_train_workspace_bytes.restype = _i64
+    L.tfk_convnet_train_block_supported.argtypes = [_i32, _i32, _i32]
+    L.tfk_convnet_train_block_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float,
+                                              _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
+    L.tfk_convnet_train_block_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
+                                              _i64, _i32, _i32, _i32, _vp]
+    L.tfk_convnet_train_frame_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                              _vp]
+    L.tfk_convnet_train_frame_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32,
+                                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
+    L.tfk_convnet_train_linear_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
+    L.tfk_convnet_train_linear_fwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]
+    L.tfk_convnet_train_linear_bwd_input.argtypes = [_vp, _vp, _vp, _i64, _i32, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -711,6 +728,161 @@ def conv1x1_frame(x, weight, bias, h_out: int, w_out: int):
     calls += 1
     _check(rc, name)
     return out
+
+
+_convnet_ws = {}      # (device index, stream handle) -> zeroed workspace of the tfk_convnet_train_* launches
+
+
+def convnet_train_workspace(t: torch.Tensor) -> torch.Tensor:
+    """The partial-sum rows + ticket counter the ConvNet training launches share, one per (device, stream): zeroed
+    once, every launch leaves the counter at zero and consumes its own partial sums before it ends."""
+    key = (t.device.index, _stream(t))
+    ws = _convnet_ws.get(key)
+    if ws is None:
+        ws = _convnet_ws[key] = torch.zeros(int(lib().tfk_convnet_train_workspace_bytes()) // 4, dtype=torch.float32,
+                                            device=t.device)
+    return ws
+
+
+def convnet_train_block_fwd(x, in_affine, weight, bias, bn, training: bool, update_running: bool):
+    """One ConvNetBlock (conv3x3 -> ReLU -> MaxPool2d(2)) ahead of its BatchNorm ``bn``: returns (y before
+    normalisation, argmax bytes, stats = scale | shift | mean | 1/std of that BatchNorm); ``in_affine``: the scale | shift
+    of the BatchNorm in front of the block (applied on load) or None."""
+    global calls
+    name = "tfk_convnet_train_block_fwd"
+    N, c_in, H, W = x.shape
+    c_out = weight.shape[0]
+    y = torch.empty(N, c_out, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    amax = torch.empty(N, c_out, H // 2, W // 2, dtype=torch.uint8, device=x.device)
+    stats = torch.empty(4 * c_out, dtype=torch.float32, device=x.device)
+    nb = bn.num_batches_tracked
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    ws = convnet_train_workspace(x)
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_block_fwd(
+            _f32(x, name), _f32(in_affine, name), _f32(weight, name), _f32(bias, name), _f32(y, name), amax.data_ptr(),
+            _f32(bn.weight, name), _f32(bn.bias, name), _f32(bn.running_mean, name), _f32(bn.running_var, name),
+            None if nb is None else nb.data_ptr(), float(bn.eps), momentum, 1 if training else 0,
+            1 if update_running else 0, _f32(stats, name), ws.data_ptr(), N, c_in, c_out, H, W, _stream(x))
+    calls += 1
+    _check(rc, name)
+    return y, amax, stats
+
+
+def convnet_train_block_bwd(gz, coef, y, amax, x, in_affine, weight, bn_stats, bn_training: bool):
+    """Reverse mode of the block: returns (g_in, weight gradient, bias gradient, and -- when the input came through a
+    BatchNorm with ``bn_stats`` -- (coef, d weight, d bias) of that BatchNorm, else None)."""
+    global calls
+    name = "tfk_convnet_train_block_bwd"
+    N, c_in, H, _ = x.shape
+    c_out = weight.shape[0]
+    g_in = torch.empty_like(x)
+    sums = torch.empty(c_out * c_in * 9 + c_out, dtype=torch.float32, device=x.device)
+    bnout = None
+    if bn_stats is not None:
+        bnout = torch.empty(5 * c_in, dtype=torch.float32, device=x.device)
+    ws = convnet_train_workspace(x)
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_block_bwd(
+            _f32(gz, name), _f32(coef, name), _f32(y, name), amax.data_ptr(), _f32(x, name), _f32(in_affine, name),
+            _f32(weight, name), _f32(g_in, name), _f32(sums, name), _f32(bn_stats, name),
+            None if bnout is None else bnout.data_ptr(), None if bnout is None else bnout[3 * c_in:].data_ptr(),
+            None if bnout is None else bnout[4 * c_in:].data_ptr(), 1 if bn_training else 0, ws.data_ptr(), N, c_in,
+            c_out, H, _stream(x))
+    calls += 1
+    _check(rc, name)
+    dW, db = sums[:c_out * c_in * 9].view(c_out, c_in, 3, 3), sums[c_out * c_in * 9:]
+    prev = None if bnout is None else (bnout[:3 * c_in], bnout[3 * c_in:4 * c_in], bnout[4 * c_in:])
+    return g_in, dW, db, prev
+
+
+def convnet_train_frame_fwd(x, in_affine, weight, bias, h_out: int, w_out: int):
+    """ConvModifier (weight (c_out, c_in, kh, kw), kh / kw 1 or 2), the BatchNorm in front applied on load."""
+    global calls
+    name = "tfk_convnet_train_frame_fwd"
+    N, c_in, H, W = x.shape
+    c_out, _, kh, kw = weight.shape
+    out = torch.empty(N, c_out, h_out, w_out, dtype=torch.float32, device=x.device)
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_frame_fwd(_f32(x, name), _f32(in_affine, name), _f32(weight, name), _f32(bias, name),
+                                               _f32(out, name), N, c_in, c_out, H, W, h_out, w_out, kh, kw, _stream(x))
+    calls += 1
+    _check(rc, name)
+    return out
+
+
+def convnet_train_frame_bwd(g_out, x, in_affine, weight, bn_stats, bn_training: bool):
+    """Reverse mode of the ConvModifier: (g_in, weight gradient (c_out, c_in, kh, kw), bias gradient (c_out), BatchNorm
+    triple or None as in ``convnet_train_block_bwd``)."""
+    global calls
+    name = "tfk_convnet_train_frame_bwd"
+    N, c_in, H, W = x.shape
+    _, c_out, h_out, w_out = g_out.shape
+    kh, kw = weight.shape[2:]
+    g_in = torch.empty_like(x)
+    K0 = c_out * c_in * kh * kw
+    K1 = K0 + 2 * c_in
+    sums = torch.empty(K1 + c_out, dtype=torch.float32, device=x.device)
+    bnout = None
+    if bn_stats is not None:
+        bnout = torch.empty(5 * c_in, dtype=torch.float32, device=x.device)
+    ws = convnet_train_workspace(x)
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_frame_bwd(
+            _f32(g_out, name), _f32(x, name), _f32(in_affine, name), _f32(weight, name), _f32(g_in, name),
+            _f32(sums, name), _f32(bn_stats, name), None if bnout is None else bnout.data_ptr(),
+            None if bnout is None else bnout[3 * c_in:].data_ptr(), None if bnout is None else bnout[4 * c_in:].data_ptr(),
+            1 if bn_training else 0, ws.data_ptr(), N, c_in, c_out, H, W, h_out, w_out, kh, kw, _stream(x))
+    calls += 1
+    _check(rc, name)
+    prev = None if bnout is None else (bnout[:3 * c_in], bnout[3 * c_in:4 * c_in], bnout[4 * c_in:])
+    return g_in, sums[:K0].view(c_out, c_in, kh, kw), sums[K1:], prev
+
+
+def convnet_train_linear_fwd(a, weight, bias):
+    """a (N, F) weight (M, F)^T + bias -> (N, M), no GEMM-library call."""
+    global calls
+    name = "tfk_convnet_train_linear_fwd"
+    N, F = a.shape
+    M = weight.shape[0]
+    out = torch.empty(N, M, dtype=torch.float32, device=a.device)
+    with _device_guard(a):
+        rc = lib().tfk_convnet_train_linear_fwd(_f32(a, name), _f32(weight, name), _f32(bias, name), _f32(out, name), N, M,
+                                                F, _stream(a))
+    calls += 1
+    _check(rc, name)
+    return out
+
+
+def convnet_train_linear_bwd_input(g, weight):
+    """g (N, M) weight (M, F) -> (N, F), no GEMM-library call."""
+    global calls
+    name = "tfk_convnet_train_linear_bwd_input"
+    N, M = g.shape
+    F = weight.shape[1]
+    g_a = torch.empty(N, F, dtype=torch.float32, device=g.device)
+    with _device_guard(g):
+        rc = lib().tfk_convnet_train_linear_bwd_input(_f32(g, name), _f32(weight, name), _f32(g_a, name), N, M, F,
+                                                      _stream(g))
+    calls += 1
+    _check(rc, name)
+    return g_a
+
+
+def convnet_train_linear_wgrad(g, a, frame_bias, h_out: int, w_out: int):
+    """(dW (M, h_out * w_out), db (M)) of the Linear layer behind the second ConvModifier; ``a`` (N, h_out * w_out) equals
+    ``frame_bias`` outside its 4 x 4 interior."""
+    global calls
+    name = "tfk_convnet_train_linear_wgrad"
+    N, M = g.shape
+    dW = torch.empty(M, h_out * w_out, dtype=torch.float32, device=g.device)
+    db = torch.empty(M, dtype=torch.float32, device=g.device)
+    with _device_guard(g):
+        rc = lib().tfk_convnet_train_linear_wgrad(_f32(g, name), _f32(a, name), _f32(frame_bias, name), _f32(dW, name),
+                                                  _f32(db, name), N, M, h_out, w_out, _stream(g))
+    calls += 1
+    _check(rc, name)
+    return dW, db
 
 
 def _pack_ops(ops):

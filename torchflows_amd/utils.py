@@ -61,7 +61,7 @@ def debug_switch(name: str, default: str) -> str:
     return default
 
 
-def make_adamw(params, lr: float, capturable: bool = False):
+def make_adamw(params, lr: float, capturable: bool = False, fused: bool = False):
     """AdamW as the reference's ``fit`` builds it (flows.py:268).  (PyTorch's single-kernel ``fused`` implementation was an
     opt-in switch until round 3: on this stack it measured SLOWER for a 40-tensor flow -- 2.67 against 2.52 ms per eager
     RealNVP-64 step -- and its rounding differs from the default implementation's, which the host-trajectory test pins;
@@ -78,4 +78,9 @@ def make_adamw(params, lr: float, capturable: bool = False):
             and all(p.dtype == torch.float32 for p in trainable) and (trainable[0].is_cuda or flat == "1")):
         from torchflows_amd.flat_optim import FlatAdamW
         return FlatAdamW(params, lr=lr)
+    if fused and capturable:
+        # inside a captured step there is no host cost to save, only launches: the default implementation with
+        # capturable=True raises its betas to the step count with one tiny kernel PER PARAMETER (327 of them in
+        # MultiscaleRealNVP((1, 28, 28)): 1 ms of a 10 ms replay), the single-kernel implementation does not
+        return torch.optim.AdamW(params, lr=lr, capturable=True, fused=True)
     return torch.optim.AdamW(params, lr=lr, capturable=capturable)
