@@ -467,17 +467,19 @@ int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float 
                                 float *bn_dbias, int32_t bn_training, void *workspace, int64_t N, int32_t c_in,
                                 int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out, int32_t kh,
                                 int32_t kw, void *stream);
-/* The Linear layer behind the second ConvModifier without a GEMM-library call (so that a training step of an image
- * flow can be captured into a hipGraph): out (N, M) = a (N, F) weight^T + bias, weight (M, F), F <= 128; and its input
- * gradient g_a (N, F) = g (N, M) weight. */
-int tfk_convnet_train_linear_fwd(const float *a, const float *weight, const float *bias, float *out, int64_t N, int32_t M,
-                                 int32_t F, void *stream);
-int tfk_convnet_train_linear_bwd_input(const float *g, const float *weight, float *g_a, int64_t N, int32_t M, int32_t F,
-                                       void *stream);
-/* Weight and bias gradient of the Linear layer behind the second ConvModifier: g (N, M) = d(loss)/d(output),
- * a (N, H_out x W_out) its input, equal to *frame_bias outside the 4 x 4 interior: dW (M, H_out x W_out), db (M);
- * rows in order, deterministic, no GEMM-library call. */
-int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *frame_bias, float *dW, float *db,
+/* The Linear layer behind the second ConvModifier.  Its input equals the modifier's bias (*frame_bias) outside the 4 x 4
+ * interior of the (H_out, W_out) frame, so the layer is a 16-term product: prep folds the weight (M, H_out * W_out) into
+ * W16 (M, 16) = its interior columns, w_frame (M) = the sum of the others, b_eff (M) = bias + *frame_bias * w_frame;
+ * fwd: out (N, M) = b_eff + a16 (N, 16) W16^T;  bwd_input: g16 (N, 16) = g (N, M) W16;  wgrad: dW (M, H_out * W_out)
+ * (interior columns sum_n g a16, the others *frame_bias * db) and db (M) = sum_n g.  No GEMM-library call (a training
+ * step with one cannot be captured into a hipGraph on this stack); rows in order, deterministic.
+ * d(loss)/d(*frame_bias) = dot(db, w_frame) joins the modifier's own bias gradient. */
+int tfk_convnet_train_linear_prep(const float *weight, const float *bias, const float *frame_bias, float *W16,
+                                  float *b_eff, float *w_frame, int32_t M, int32_t H_out, int32_t W_out, void *stream);
+int tfk_convnet_train_linear_fwd(const float *a16, const float *W16, const float *b_eff, float *out, int64_t N, int32_t M,
+                                 void *stream);
+int tfk_convnet_train_linear_bwd_input(const float *g, const float *W16, float *g16, int64_t N, int32_t M, void *stream);
+int tfk_convnet_train_linear_wgrad(const float *g, const float *a16, const float *frame_bias, float *dW, float *db,
                                    int64_t N, int32_t M, int32_t H_out, int32_t W_out, void *stream);
 
 /* ---- a whole convolutional coupling of the image / multiscale flows in ONE launch (config 5) -----------------

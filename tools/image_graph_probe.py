@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does Flow.fit capture the training step of an image flow into a hipGraph, and what does a replayed step cost?
-   python tools/image_graph_probe.py [epochs]        (TORCHFLOWS_AMD_GRAPH=1 forces the capture, 0 forbids it)"""
+   python tools/image_graph_probe.py [epochs] [glow]     (TORCHFLOWS_AMD_GRAPH=1 forces the capture, 0 forbids it)"""
 import sys
 import time
 
@@ -13,11 +13,16 @@ from torchflows.architectures import MultiscaleRealNVP  # noqa: E402
 
 dev = torch.device("cuda:0")
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+glow = len(sys.argv) > 2 and sys.argv[2] == "glow"          # AffineGlow((3, 32, 32)), config 5's model
 g = torch.Generator().manual_seed(1)
-img = torch.randn(1024, 1, 28, 28, generator=g)
+img = torch.randn(1024, *((3, 32, 32) if glow else (1, 28, 28)), generator=g)
 img = (img - img.mean()) / img.std()
 torch.manual_seed(0)
-flow = Flow(MultiscaleRealNVP((1, 28, 28))).to(dev)
+if glow:
+    from torchflows.bijections.finite.multiscale.architectures import AffineGlow
+    flow = Flow(AffineGlow((3, 32, 32))).to(dev)
+else:
+    flow = Flow(MultiscaleRealNVP((1, 28, 28))).to(dev)
 print("graph safe:", flow._graph_safe(), flush=True)
 flow.fit(img, n_epochs=4)
 torch.cuda.synchronize()

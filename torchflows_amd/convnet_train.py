@@ -6,8 +6,12 @@ normalises with the statistics of the batch and updates its running ones: a bloc
 unit of fusion is the block, not the coupling (``image_program`` fuses a whole coupling only because inference folds
 BatchNorm into a per-channel scale / shift).  One ``torch.autograd.Function`` covers the network:
 
-  forward   frame (ConvModifier) | block 1 | block 2 | block 3 | frame (+ BatchNorm 3 on load) | linear           6 launches
+  forward   frame (ConvModifier) | block 1 | block 2 | block 3 | frame (+ BatchNorm 3 on load) | fold | linear    7 launches
   backward  linear input gradient | linear weight gradient | frame_bwd | block_bwd x 3 | frame_bwd              7 launches
+            (+ one dot product and one add for the second modifier's bias)
+
+The Linear layer sees the second modifier's bias on 84 of its 100 inputs: it is evaluated as a 16-term product with an
+effective bias (``linear_prep``), as ``image_program`` does at inference.
 
 against ~70 ATen / MIOpen launches.  Each block launch writes the pooled activation BEFORE normalisation and the arg-max
 byte of every pooling window; the normalisation is applied by whoever reads it next.  The batch sums (statistics in the
@@ -157,22 +161,24 @@ class ConvNetFunction(torch.autograd.Function):
         y1, i1, s1 = native.convnet_train_block_fwd(a0, None, w1, b1, blocks[1].bn, training, update)
         y2, i2, s2 = native.convnet_train_block_fwd(y1, s1, w2, b2, blocks[2].bn, training, update)
         y3, i3, s3 = native.convnet_train_block_fwd(y2, s2, w3, b3, blocks[3].bn, training, update)
-        a4 = native.convnet_train_frame_fwd(y3, s3, w_m2, b_m2, 10, 10).view(N, 100)
-        theta = native.convnet_train_linear_fwd(a4, w_lin, b_lin)
+        a16 = native.convnet_train_frame_fwd(y3, s3, w_m2, b_m2, 4, 4).view(N, 16)     # (the frame around it == b_m2)
+        W16, b_eff, w_frame = native.convnet_train_linear_prep(w_lin, b_lin, b_m2, 10, 10)
+        theta = native.convnet_train_linear_fwd(a16, W16, b_eff)
         ctx.training = training
-        ctx.save_for_backward(x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a4, w_m1, w1, w2, w3, w_m2, b_m2, w_lin)
+        ctx.save_for_backward(x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame)
         return theta
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_theta: torch.Tensor):
-        (x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a4, w_m1, w1, w2, w3, w_m2, b_m2, w_lin) = ctx.saved_tensors
+        (x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame) = ctx.saved_tensors
         tr = ctx.training
         N = x.shape[0]
         g_theta = g_theta.contiguous()
-        g_a4 = native.convnet_train_linear_bwd_input(g_theta, w_lin)          # (N, 100)
-        dW_lin, db_lin = native.convnet_train_linear_wgrad(g_theta, a4, b_m2, 10, 10)
-        gz3, dw_m2, db_m2, bn3 = native.convnet_train_frame_bwd(g_a4.view(N, 1, 10, 10), y3, s3, w_m2, s3, tr)
+        g16 = native.convnet_train_linear_bwd_input(g_theta, W16)             # (N, 16): the interior of d/d(Linear input)
+        dW_lin, db_lin = native.convnet_train_linear_wgrad(g_theta, a16, b_m2, 10, 10)
+        gz3, dw_m2, db_m2, bn3 = native.convnet_train_frame_bwd(g16.view(N, 1, 4, 4), y3, s3, w_m2, s3, tr)
+        db_m2 = db_m2 + torch.dot(db_lin, w_frame)                            # (+ the frame: 84 inputs that equal b_m2)
         gz2, dW3, db3, bn2 = native.convnet_train_block_bwd(gz3, bn3[0], y3, i3, y2, s2, w3, s2, tr)
         gz1, dW2, db2, bn1 = native.convnet_train_block_bwd(gz2, bn2[0], y2, i2, y1, s1, w2, s1, tr)
         g_a0, dW1, db1, _ = native.convnet_train_block_bwd(gz1, bn1[0], y1, i1, a0, None, w1, None, tr)

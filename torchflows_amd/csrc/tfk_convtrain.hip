@@ -18,67 +18,89 @@
 // Batch-coupled quantities (BatchNorm statistics) are why this is a launch per BLOCK and not per coupling: each block's
 // output depends on every sample of the batch through the normalisation that precedes the next block.
 #include "tfk_common.h"
+#include <stdlib.h>
 
 namespace tfk {
 
 constexpr int kCtMaxGrid = 1024;          // workgroups that hand in partial sums (rows of the workspace)
 constexpr int kCtMaxK = 640;              // floats per workgroup (block backward 8 -> 8: 576 + 8 + 16)
+constexpr int kCtHeaderBytes = 1024;      // ticket counters: 1 + kCtMaxGrid / kCtCluster of them
 
-// Every workgroup hands in K floats (vals, LDS); true in the last workgroup to finish, with tot[k] = the sum over the
-// workgroups in index order (fp64).  Visibility across the XCDs' L2s as in finish_sum_f64 (tfk_common.h): agent-scope
-// atomic stores, awaited before the agent-scope ticket; the last workgroup reads with agent-scope atomic loads.
+// Every workgroup hands in K floats (vals, LDS); true in the last workgroup to finish, with tot[k] = the sum over all
+// workgroups (fp64) in a FIXED order.  Two levels, because one workgroup walking a thousand rows of partial sums costs
+// more than the convolution it follows (an agent-scope load is ~0.6 us, measured: 37 us for 256 rows x 312 columns):
+// workgroups form clusters of kCtCluster; the last one of a cluster to finish adds the cluster's rows in index order and
+// hands in ONE row for the cluster; the last cluster to do so adds the cluster rows in index order.  The result does not
+// depend on which workgroup came last at either level.
+// Visibility across the XCDs' L2s as in finish_sum_f64 (tfk_common.h): agent-scope atomic stores, awaited before the
+// agent-scope ticket; the adding workgroup reads with agent-scope atomic loads.  counters: [0] = top level, [1 + c] =
+// cluster c; all left at zero.  partial: gridDim.x rows, then ceil(gridDim.x / kCtCluster) cluster rows.
+constexpr int kCtCluster = 16;
+
 template <int BLOCK>
-__device__ __forceinline__ bool hand_in(const float *vals, int K, float *partial, unsigned long long *counter,
+__device__ __forceinline__ void ct_store_row(float *row, const float *vals, int K)
+{
+    for (int k = threadIdx.x; k < K; k += BLOCK)
+        __hip_atomic_store(row + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// tot[k] = rows[0][k] + rows[1][k] + ... (R <= 64 rows of K floats), every lane a column, 16 loads in flight
+template <int BLOCK>
+__device__ __forceinline__ void ct_add_rows(const float *rows, int R, int K, double *tot)
+{
+    for (int k = threadIdx.x; k < K; k += BLOCK) {
+        double a = 0.0;
+        int r = 0;
+        for (; r + 16 <= R; r += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = __hip_atomic_load(rows + (size_t)(r + j) * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a += (double)v[j];
+        }
+        for (; r < R; ++r)
+            a += (double)__hip_atomic_load(rows + (size_t)r * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[k] = a;
+    }
+    __syncthreads();
+}
+
+template <int BLOCK>
+__device__ __forceinline__ bool hand_in(float *vals, int K, float *partial, unsigned long long *counters,
                                         double *tot, int *flag)
 {
     __syncthreads();
-    float *mine = partial + (size_t)blockIdx.x * K;
-    for (int k = threadIdx.x; k < K; k += BLOCK)
-        __hip_atomic_store(mine + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const unsigned G = gridDim.x, NC = (G + kCtCluster - 1) / kCtCluster;
+    const unsigned cluster = blockIdx.x / kCtCluster;
+    const unsigned first = cluster * kCtCluster, members = (first + kCtCluster <= G) ? kCtCluster : G - first;
+    ct_store_row<BLOCK>(partial + (size_t)blockIdx.x * K, vals, K);
     if (threadIdx.x == 0) {
         const unsigned long long ticket =
-            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = (ticket == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+            __hip_atomic_fetch_add(counters + 1 + cluster, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (ticket == (unsigned long long)members - 1ull) ? 1 : 0;
     }
     __syncthreads();
     if (!*flag) return false;
-    // the last workgroup: column k of the (workgroups x K) partial sums by S = BLOCK / min(K, BLOCK) lanes, each a fixed
-    // slice of the rows with eight loads in flight (an agent-scope load is ~0.2 us: one lane walking 1 000 rows of a
-    // column alone cost more than the convolution itself), slices added in order
-    __shared__ double part[BLOCK];
-    const int CP = K < BLOCK ? K : BLOCK, S = BLOCK / CP;
-    const int c = threadIdx.x % CP, sl = threadIdx.x / CP;
-    const unsigned G = gridDim.x;
-    for (int k0 = 0; k0 < K; k0 += CP) {
-        const int k = k0 + c;
-        double a = 0.0;
-        if (k < K && sl < S) {
-            unsigned p = (unsigned)sl;
-            for (; p + 7u * (unsigned)S < G; p += 8u * (unsigned)S) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = __hip_atomic_load(partial + (size_t)(p + (unsigned)(j * S)) * K + k, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a += (double)v[j];
-            }
-            for (; p < G; p += (unsigned)S)
-                a += (double)__hip_atomic_load(partial + (size_t)p * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        part[threadIdx.x] = a;
-        __syncthreads();
-        if (k < K && sl == 0) {
-            double t = 0.0;
-            for (int q = 0; q < S; ++q) t += part[q * CP + c];
-            tot[k] = t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // last of its cluster
+    if (threadIdx.x == 0) __hip_atomic_store(counters + 1 + cluster, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ct_add_rows<BLOCK>(partial + (size_t)first * K, (int)members, K, tot);
+    if (NC == 1) return true;
+    for (int k = threadIdx.x; k < K; k += BLOCK) vals[k] = (float)tot[k];
     __syncthreads();
+    float *crows = partial + (size_t)G * K;
+    ct_store_row<BLOCK>(crows + (size_t)cluster * K, vals, K);
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket =
+            __hip_atomic_fetch_add(counters, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (ticket == (unsigned long long)NC - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*flag) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counters, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ct_add_rows<BLOCK>(crows, (int)NC, K, tot);
     return true;
 }
 
@@ -320,6 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
     const int HW = H * W, HTWT = HT * WT, T = KH * KW;
     const int GH = H + KH - 1, GW = W + KW - 1, GHW = GH * GW;
     const int K1 = COUT * C * T + 2 * C, K = K1 + COUT;
+    const int SL = (NO == 1) ? kBlock / K1 : 1;     // slices of the pixels per sum
     double *tot = ldsd;                             // K doubles
     float *gI = reinterpret_cast<float *>(tot + K), *xr = gI + COUT * GHW, *gin = xr + C * HW, *wl = gin + C * HW;
     float *ia = wl + COUT * C * T, *vals = ia + 2 * C, *wred = vals + K;       // 2 C | K | 4 COUT floats
@@ -365,29 +388,45 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NO; ++q) {
-            const int o = threadIdx.x + q * kBlock;
+            // sum number o: NO == 1 -> its pixels in SL slices over the lanes (o = lane % K1, slice = lane / K1)
+            const int o = (NO == 1) ? (int)threadIdx.x % K1 : (int)threadIdx.x + q * kBlock;
+            const int sl = (NO == 1) ? (int)threadIdx.x / K1 : 0;
             float a = acc[q];
-            if (o < COUT * C * T) {
+            if (sl >= SL) {
+            } else if (o < COUT * C * T) {
                 const int tap = o % T, cc = o / T, co = cc / C, c = cc - co * C, dy = tap / KW, dx = tap - dy * KW;
                 const float sc = ia[c], sh = ia[C + c];
                 const float *gsrc = gI + co * GHW + (KH - 1 - dy) * GW + KW - 1 - dx;
-                for (int yy = 0; yy < H; ++yy)
-                    for (int xx = 0; xx < W; ++xx)
-                        a = fmaf(gsrc[yy * GW + xx], fmaf(xr[c * HW + yy * W + xx], sc, sh), a);
+                for (int pix = sl; pix < HW; pix += SL) {
+                    const int yy = pix / W, xx = pix - yy * W;
+                    a = fmaf(gsrc[yy * GW + xx], fmaf(xr[c * HW + pix], sc, sh), a);
+                }
             } else if (o < COUT * C * T + C) {
                 const int c = o - COUT * C * T;
-                for (int pix = 0; pix < HW; ++pix) a += gin[c * HW + pix];
+                for (int pix = sl; pix < HW; pix += SL) a += gin[c * HW + pix];
             } else if (o < K1) {
                 const int c = o - COUT * C * T - C;
-                for (int pix = 0; pix < HW; ++pix) a = fmaf(gin[c * HW + pix], xr[c * HW + pix], a);
+                for (int pix = sl; pix < HW; pix += SL) a = fmaf(gin[c * HW + pix], xr[c * HW + pix], a);
             }
             acc[q] = a;
         }
     }
     __syncthreads();
+    if (NO == 1) {          // slices of one sum, added in order
+        float *red = wred + 4 * COUT;       // kBlock floats behind the rest
+        red[threadIdx.x] = acc[0];
+        __syncthreads();
+        if ((int)threadIdx.x < K1) {
+            float t = 0.0f;
+            for (int q = 0; q < SL; ++q) t += red[q * K1 + threadIdx.x];
+            vals[threadIdx.x] = t;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int q = 0; q < NO; ++q)
-        if (threadIdx.x + q * kBlock < K1) vals[threadIdx.x + q * kBlock] = acc[q];
+        for (int q = 0; q < NO; ++q)
+            if ((int)threadIdx.x + q * kBlock < K1) vals[threadIdx.x + q * kBlock] = acc[q];
+    }
     block_sums<COUT>(dbl, wred, vals + K1);
     if (!hand_in<kBlock>(vals, K, partial, counter, tot, &flag)) return;
     for (int k = threadIdx.x; k < K; k += kBlock) sums_out[k] = (float)tot[k];
@@ -518,8 +557,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
 }
 
 // ---- weight gradient of the Linear layer behind the second ConvModifier ---------------------------------------------
-// Its input a (N, HT x WT) equals the modifier's bias outside the H x W = 16 interior pixels, so
-//   dW[m][j] = sum_n g[n][m] a[n][j] = frame(j) ? bias * db[m] : sum_n g[n][m] a_int[n][j],   db[m] = sum_n g[n][m]:
+// Its input equals the modifier's bias outside the 16 interior pixels a (N, 16), so
+//   dW[m][j] = frame(j) ? bias * db[m] : sum_n g[n][m] a[n][interior index of j],   db[m] = sum_n g[n][m]:
 // a contraction over the batch with 16 columns on one side (the library GEMM runs it as one tile: 958 us at N = 1 000,
 // M = 784).  One workgroup per 16 rows m, rows n in order: deterministic.
 __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
             const int r = i >> 4, c = i & 15;
             const long long n = n0 + r;
             gs[r][c] = (n < N && m0 + c < M) ? g[n * M + m0 + c] : 0.0f;
-            as[r][c] = n < N ? a[n * F + (top + (c >> 2)) * WT + left + (c & 3)] : 0.0f;
+            as[r][c] = n < N ? a[n * 16 + c] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -561,81 +600,91 @@ __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
 }
 
 // ---- the Linear layer behind the second ConvModifier, forward and input gradient ------------------------------------
-// (N x F) x (F x M), F = 100, and (N x M) x (M x F): skinny products the GEMM library runs fine, written out so that the
-// whole network is free of library calls (a training step with them cannot be captured into a hipGraph on this stack)
-// and deterministic.  out[n][m] = bias[m] + sum_f a[n][f] W[m][f]: a 64 x 64 output tile per workgroup, 4 x 4 per lane.
-__global__ __launch_bounds__(kBlock) void k_ct_linear_fwd(
-    const float *__restrict__ a, const float *__restrict__ Wt, const float *__restrict__ bias, float *__restrict__ out,
-    long long N, int M, int F)
+// Its input is the modifier's bias outside the 4 x 4 interior, so out[n][m] = b_eff[m] + sum_{j<16} a16[n][j] W16[m][j]
+// with W16 = the 16 interior columns of the weight and b_eff = bias + frame_bias * (sum of the other columns): a
+// 16-term product instead of a 100-term one (the same fold image_program.py applies at inference), written out so
+// that the network has no GEMM-library call (a training step with them cannot be captured into a hipGraph on this stack)
+// and every sum has a fixed order.
+__global__ __launch_bounds__(kBlock) void k_ct_linear_prep(
+    const float *__restrict__ Wt, const float *__restrict__ bias, const float *__restrict__ frame_bias,
+    float *__restrict__ W16, float *__restrict__ b_eff, float *__restrict__ wfr, int M, int HT, int WT, int top, int left)
 {
-    extern __shared__ __attribute__((aligned(16))) float lin[];
-    const int FP = F + 1;
-    float *as = lin, *wsm = lin + 64 * FP;
-    const long long n0 = (long long)blockIdx.x * 64;
-    const int m0 = blockIdx.y * 64;
-    for (int i = threadIdx.x; i < 64 * F; i += kBlock) {
-        const int r = i / F, f = i - r * F;
-        as[r * FP + f] = (n0 + r < N) ? a[(n0 + r) * F + f] : 0.0f;
-        wsm[r * FP + f] = (m0 + r < M) ? Wt[(long long)(m0 + r) * F + f] : 0.0f;
-    }
-    __syncthreads();
-    const int tn = threadIdx.x >> 4, tm = threadIdx.x & 15;      // rows tn + 16 i, columns tm + 16 j
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-    for (int f = 0; f < F; ++f) {
-        float av[4], wv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = as[(tn + 16 * i) * FP + f];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wv[j] = wsm[(tm + 16 * j) * FP + f];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+    // one wavefront per output row m: its F weights read coalesced, the frame columns added over the lanes
+    const int m = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const int F = HT * WT;
+    const float *row = Wt + (long long)m * F;
+    float fr = 0.0f;
+    for (int f = lane; f < F; f += kWave) {
+        const int ii = f / WT - top, jj = f % WT - left;
+        const float v = row[f];
+        if (ii >= 0 && ii < 4 && jj >= 0 && jj < 4) W16[m * 16 + ii * 4 + jj] = v;
+        else fr += v;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long n = n0 + tn + 16 * i;
-        if (n >= N) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + tm + 16 * j;
-            if (m < M) out[n * M + m] = acc[i][j] + bias[m];
-        }
+    for (int o = 32; o > 0; o >>= 1) fr += __shfl_xor(fr, o, kWave);
+    if (lane == 0) {
+        wfr[m] = fr;
+        b_eff[m] = bias[m] + frame_bias[0] * fr;
     }
 }
 
-// g_a[n][f] = sum_m g[n][m] W[m][f]: one lane per output, the m axis walked in order with eight loads in flight (g[n][.]
-// is one address per row of lanes, W[m][.] a coalesced row that stays in L2): N x F lanes hide the latency that a
-// staged-slab version of this product (16 rows per workgroup, 64 workgroups) serialised -- 292 us against 30.
-__global__ __launch_bounds__(kBlock) void k_ct_linear_bwd_input(
-    const float *__restrict__ g, const float *__restrict__ Wt, float *__restrict__ g_a, long long N, int M, int F)
+// out[n][m] = b_eff[m] + sum_j a16[n][j] W16[m][j]: a lane keeps ITS row of W16 in registers and walks 16 rows n (their
+// a16 rows are one address per wavefront); the write of out is the traffic that counts.
+__global__ __launch_bounds__(kBlock) void k_ct_linear16_fwd(
+    const float *__restrict__ a16, const float *__restrict__ W16, const float *__restrict__ b_eff,
+    float *__restrict__ out, long long N, int M)
 {
-    const long long total = N * (long long)F;
-    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * kBlock) {
-        const long long n = idx / F;
-        const int f = (int)(idx - n * F);
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= M) return;
+    const float4 *wr = reinterpret_cast<const float4 *>(W16 + (long long)m * 16);
+    const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+    const float be = b_eff[m];
+    const long long n0 = (long long)blockIdx.y * 16;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const long long n = n0 + r;
+        if (n >= N) break;
+        const float4 *ar = reinterpret_cast<const float4 *>(a16 + n * 16);
+        const float4 a0 = ar[0], a1 = ar[1], a2 = ar[2], a3 = ar[3];
+        float acc = be;
+        acc = fmaf(a0.x, w0.x, acc); acc = fmaf(a0.y, w0.y, acc); acc = fmaf(a0.z, w0.z, acc); acc = fmaf(a0.w, w0.w, acc);
+        acc = fmaf(a1.x, w1.x, acc); acc = fmaf(a1.y, w1.y, acc); acc = fmaf(a1.z, w1.z, acc); acc = fmaf(a1.w, w1.w, acc);
+        acc = fmaf(a2.x, w2.x, acc); acc = fmaf(a2.y, w2.y, acc); acc = fmaf(a2.z, w2.z, acc); acc = fmaf(a2.w, w2.w, acc);
+        acc = fmaf(a3.x, w3.x, acc); acc = fmaf(a3.y, w3.y, acc); acc = fmaf(a3.z, w3.z, acc); acc = fmaf(a3.w, w3.w, acc);
+        out[n * M + m] = acc;
+    }
+}
+
+// g16[n][j] = sum_m g[n][m] W16[m][j]: a workgroup takes 4 rows n; wavefront w walks the m with m / 8 % 4 == w (eight
+// loads in flight per lane), lane (row, j); the four partial sums are added in wavefront order.
+__global__ __launch_bounds__(kBlock) void k_ct_linear16_bwd_input(
+    const float *__restrict__ g, const float *__restrict__ W16, float *__restrict__ g16, long long N, int M)
+{
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (lane >> 4);
+    const int j = lane & 15;
+    float acc = 0.0f;
+    if (n < N) {
         const float *gr = g + n * M;
-        const float *wc = Wt + f;
-        float acc = 0.0f;
-        int m = 0;
-        for (; m + 8 <= M; m += 8) {
+        const float *wc = W16 + j;
+        int m = wave * 8;
+        for (; m + 8 <= M; m += 32) {
             float gv[8], wv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                gv[j] = gr[m + j];
-                wv[j] = wc[(long long)(m + j) * F];
+            for (int q = 0; q < 8; ++q) {
+                gv[q] = gr[m + q];
+                wv[q] = wc[(m + q) * 16];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(gv[j], wv[j], acc);
+            for (int q = 0; q < 8; ++q) acc = fmaf(gv[q], wv[q], acc);
         }
-        for (; m < M; ++m) acc = fmaf(gr[m], wc[(long long)m * F], acc);
-        g_a[idx] = acc;
+        for (; m < M; ++m) acc = fmaf(gr[m], wc[m * 16], acc);      // (the ragged last block of 8, if it is this wavefront's)
     }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && n < N) g16[n * 16 + j] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 }  // namespace tfk
@@ -649,6 +698,7 @@ bool block_ok(int c_in, int c_out) { return (c_in == 4 && c_out == 8) || (c_in =
 int bwd_grid(int64_t N, int per_cu)
 {
     int64_t g = (int64_t)cu_count() * per_cu;
+    if (const char *e = getenv("TFK_CT_GRID")) g = atoi(e);       // EXPERIMENT
     if (g > kCtMaxGrid) g = kCtMaxGrid;
     return (int)(N < g ? N : g);
 }
@@ -659,7 +709,7 @@ extern "C" {
 
 int64_t tfk_convnet_train_workspace_bytes(void)
 {
-    return 16 + (int64_t)kCtMaxGrid * kCtMaxK * (int64_t)sizeof(float);
+    return kCtHeaderBytes + (int64_t)(kCtMaxGrid + kCtMaxGrid / kCtCluster) * kCtMaxK * (int64_t)sizeof(float);
 }
 
 int tfk_convnet_train_block_supported(int32_t c_in, int32_t c_out, int32_t H)
@@ -687,7 +737,7 @@ int tfk_convnet_train_block_fwd(const float *x, const float *in_affine, const fl
     int64_t blocks = (N * (int64_t)(H / 2) * (W / 2) + kBlock - 1) / kBlock;
     const int grid = (int)(blocks < kCtMaxGrid ? blocks : kCtMaxGrid);
     unsigned long long *counter = static_cast<unsigned long long *>(workspace);
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCtHeaderBytes);
     BnFwd bn{bn_weight, bn_bias, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), stats,
              eps, momentum, training ? 1 : 0, (training && update_running) ? 1 : 0};
 #define TFK_CT(CI, CO)                                                                                            \
@@ -751,15 +801,15 @@ int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float 
     if (K1 > 3 * kBlock || K > kCtMaxK)
         return fail(TFK_EINVAL, "%s: %d x %d channels x %d taps: too many sums for one workgroup", fn, c_out, c_in, T);
     const int64_t lds_floats = (int64_t)c_out * (H + kh - 1) * (W + kw - 1) + 2 * (int64_t)c_in * H * W + c_out * c_in * T +
-                               2 * c_in + K + 4 * c_out + 2 * (int64_t)K;
+                               2 * c_in + K + 4 * c_out + 2 * (int64_t)K + kBlock;
     if (lds_floats * 4 > 150 * 1024) return fail(TFK_EINVAL, "%s: %d x %d x %d input does not fit the LDS", fn, c_in, H, W);
     if (bn_stats && (!bn_coef || !bn_dweight || !bn_dbias)) return fail(TFK_EINVAL, "%s: BatchNorm outputs missing", fn);
     if (N == 0) return TFK_OK;
     if (!g_out || !x || !weight || !g_in || !sums || !workspace) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = bwd_grid(N, 2);
+    const int grid = bwd_grid(N, 4);            // (few sums per workgroup: the work per sample decides)
     unsigned long long *counter = static_cast<unsigned long long *>(workspace);
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCtHeaderBytes);
     BnBwd bn{bn_stats, bn_coef, bn_dweight, bn_dbias, (double)N * H * W, bn_training ? 1 : 0};
     const size_t lds = (size_t)lds_floats * 4;
 #define TFK_CT(CO, NO)                                                                                                 \
@@ -793,12 +843,12 @@ int tfk_convnet_train_block_bwd(const float *gz, const float *coef, const float 
         return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned long long *counter = static_cast<unsigned long long *>(workspace);
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + 16);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCtHeaderBytes);
     BnBwd bn{bn_stats, bn_coef, bn_dweight, bn_dbias, (double)N * H * H, bn_training ? 1 : 0};
     const int P = H + 2, cells = (H / 2) * (H / 2);
     size_t lds = (size_t)(c_in + c_out) * P * P * 4 + (size_t)c_out * cells * 5 + 16;
     if (lds < (size_t)kBlock * 10 * 4) lds = (size_t)kBlock * 10 * 4;       // (the cross-group reduction of dW)
-    const int grid = bwd_grid(N, 1);        // (fewer, longer workgroups: the last one adds up one row of sums per workgroup)
+    const int grid = bwd_grid(N, 2);        // (two workgroups per CU fit the LDS; measured 71 -> 49 us at 1 024 samples)
 #define TFK_CT(CI, CO, HH)                                                                                             \
     do {                                                                                                               \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_block_bwd<CI, CO, HH>),                            \
@@ -814,33 +864,40 @@ int tfk_convnet_train_block_bwd(const float *gz, const float *coef, const float 
     return check_launch(fn);
 }
 
-int tfk_convnet_train_linear_fwd(const float *a, const float *weight, const float *bias, float *out, int64_t N, int32_t M,
-                                 int32_t F, void *stream)
+int tfk_convnet_train_linear_prep(const float *weight, const float *bias, const float *frame_bias, float *W16,
+                                  float *b_eff, float *w_frame, int32_t M, int32_t H_out, int32_t W_out, void *stream)
 {
-    const char *fn = "tfk_convnet_train_linear_fwd";
-    if (N < 0 || M < 1 || F < 1 || F > 128) return fail(TFK_EINVAL, "%s: N = %lld, M = %d, F = %d (F <= 128)", fn, (long long)N, M, F);
-    if (N == 0) return TFK_OK;
-    if (!a || !weight || !bias || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)2 * 64 * (F + 1) * 4;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_linear_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
-    hipLaunchKernelGGL(k_ct_linear_fwd, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(kBlock), lds, s, a,
-                       weight, bias, out, (long long)N, M, F);
+    const char *fn = "tfk_convnet_train_linear_prep";
+    if (M < 1 || H_out < 4 || W_out < 4 || ((H_out - 4) & 1) || ((W_out - 4) & 1))
+        return fail(TFK_EINVAL, "%s: M = %d, a 4 x 4 interior in the middle of an even frame (%d x %d)", fn, M, H_out, W_out);
+    if (!weight || !bias || !frame_bias || !W16 || !b_eff || !w_frame) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(k_ct_linear_prep, dim3((M + 3) / 4), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       weight, bias, frame_bias, W16, b_eff, w_frame, M, H_out, W_out, (H_out - 4) / 2, (W_out - 4) / 2);
     return check_launch(fn);
 }
 
-int tfk_convnet_train_linear_bwd_input(const float *g, const float *weight, float *g_a, int64_t N, int32_t M, int32_t F,
-                                       void *stream)
+int tfk_convnet_train_linear_fwd(const float *a16, const float *W16, const float *b_eff, float *out, int64_t N, int32_t M,
+                                 void *stream)
+{
+    const char *fn = "tfk_convnet_train_linear_fwd";
+    if (N < 0 || M < 1) return fail(TFK_EINVAL, "%s: N = %lld, M = %d", fn, (long long)N, M);
+    if (N == 0) return TFK_OK;
+    if (!a16 || !W16 || !b_eff || !out) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (!aligned16(a16) || !aligned16(W16)) return fail(TFK_EINVAL, "%s: a16 / W16 must be 16-byte aligned", fn);
+    if ((N + 15) / 16 > 65535) return fail(TFK_EINVAL, "%s: N = %lld (at most 16 * 65535 rows per call)", fn, (long long)N);
+    hipLaunchKernelGGL(k_ct_linear16_fwd, dim3((unsigned)((M + kBlock - 1) / kBlock), (unsigned)((N + 15) / 16)), dim3(kBlock),
+                       0, static_cast<hipStream_t>(stream), a16, W16, b_eff, out, (long long)N, M);
+    return check_launch(fn);
+}
+
+int tfk_convnet_train_linear_bwd_input(const float *g, const float *W16, float *g16, int64_t N, int32_t M, void *stream)
 {
     const char *fn = "tfk_convnet_train_linear_bwd_input";
-    if (N < 0 || M < 1 || F < 1 || F > 128) return fail(TFK_EINVAL, "%s: N = %lld, M = %d, F = %d (F <= 128)", fn, (long long)N, M, F);
+    if (N < 0 || M < 1) return fail(TFK_EINVAL, "%s: N = %lld, M = %d", fn, (long long)N, M);
     if (N == 0) return TFK_OK;
-    if (!g || !weight || !g_a) return fail(TFK_EINVAL, "%s: null pointer", fn);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_ct_linear_bwd_input, dim3(grid_for(N * (int64_t)F, kBlock)), dim3(kBlock), 0, s, g, weight, g_a,
-                       (long long)N, M, F);
+    if (!g || !W16 || !g16) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(k_ct_linear16_bwd_input, dim3((unsigned)((N + 3) / 4)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), g, W16, g16, (long long)N, M);
     return check_launch(fn);
 }
 

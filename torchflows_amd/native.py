@@ -52,6 +52,7 @@ SYMBOLS = (
     "tfk_convnet_train_workspace_bytes", "tfk_convnet_train_block_supported", "tfk_convnet_train_block_fwd",
     "tfk_convnet_train_block_bwd", "tfk_convnet_train_frame_fwd", "tfk_convnet_train_frame_bwd",
     "tfk_convnet_train_linear_wgrad", "tfk_convnet_train_linear_fwd", "tfk_convnet_train_linear_bwd_input",
+    "tfk_convnet_train_linear_prep",
 )
 
 ABI_VERSION = 29
@@ -192,8 +193,9 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_convnet_train_frame_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32,
                                               _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
     L.tfk_convnet_train_linear_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
-    L.tfk_convnet_train_linear_fwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]
-    L.tfk_convnet_train_linear_bwd_input.argtypes = [_vp, _vp, _vp, _i64, _i32, _i32, _vp]
+    L.tfk_convnet_train_linear_prep.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    L.tfk_convnet_train_linear_fwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp]
+    L.tfk_convnet_train_linear_bwd_input.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
     L.tfk_device_info.argtypes = [C.c_char_p, _i32, C.POINTER(_i32)]
 
@@ -839,46 +841,60 @@ def convnet_train_frame_bwd(g_out, x, in_affine, weight, bn_stats, bn_training: 
     return g_in, sums[:K0].view(c_out, c_in, kh, kw), sums[K1:], prev
 
 
-def convnet_train_linear_fwd(a, weight, bias):
-    """a (N, F) weight (M, F)^T + bias -> (N, M), no GEMM-library call."""
+def convnet_train_linear_prep(weight, bias, frame_bias, h_out: int, w_out: int):
+    """The Linear layer behind the second ConvModifier folded to its 16 interior inputs: (W16 (M, 16), b_eff (M), w_frame
+    (M)); weight (M, h_out * w_out), ``frame_bias`` the modifier's bias (1 element)."""
+    global calls
+    name = "tfk_convnet_train_linear_prep"
+    M = weight.shape[0]
+    buf = torch.empty(M * 18, dtype=torch.float32, device=weight.device)
+    W16, b_eff, w_frame = buf[:M * 16].view(M, 16), buf[M * 16:M * 17], buf[M * 17:]
+    with _device_guard(weight):
+        rc = lib().tfk_convnet_train_linear_prep(_f32(weight, name), _f32(bias, name), _f32(frame_bias, name),
+                                                 W16.data_ptr(), b_eff.data_ptr(), w_frame.data_ptr(), M, h_out, w_out,
+                                                 _stream(weight))
+    calls += 1
+    _check(rc, name)
+    return W16, b_eff, w_frame
+
+
+def convnet_train_linear_fwd(a16, W16, b_eff):
+    """b_eff + a16 (N, 16) W16 (M, 16)^T -> (N, M)."""
     global calls
     name = "tfk_convnet_train_linear_fwd"
-    N, F = a.shape
-    M = weight.shape[0]
-    out = torch.empty(N, M, dtype=torch.float32, device=a.device)
-    with _device_guard(a):
-        rc = lib().tfk_convnet_train_linear_fwd(_f32(a, name), _f32(weight, name), _f32(bias, name), _f32(out, name), N, M,
-                                                F, _stream(a))
+    N, M = a16.shape[0], W16.shape[0]
+    out = torch.empty(N, M, dtype=torch.float32, device=a16.device)
+    with _device_guard(a16):
+        rc = lib().tfk_convnet_train_linear_fwd(_f32(a16, name), W16.data_ptr(), b_eff.data_ptr(), _f32(out, name), N, M,
+                                                _stream(a16))
     calls += 1
     _check(rc, name)
     return out
 
 
-def convnet_train_linear_bwd_input(g, weight):
-    """g (N, M) weight (M, F) -> (N, F), no GEMM-library call."""
+def convnet_train_linear_bwd_input(g, W16):
+    """g (N, M) W16 (M, 16) -> (N, 16)."""
     global calls
     name = "tfk_convnet_train_linear_bwd_input"
     N, M = g.shape
-    F = weight.shape[1]
-    g_a = torch.empty(N, F, dtype=torch.float32, device=g.device)
+    g16 = torch.empty(N, 16, dtype=torch.float32, device=g.device)
     with _device_guard(g):
-        rc = lib().tfk_convnet_train_linear_bwd_input(_f32(g, name), _f32(weight, name), _f32(g_a, name), N, M, F,
-                                                      _stream(g))
+        rc = lib().tfk_convnet_train_linear_bwd_input(_f32(g, name), W16.data_ptr(), _f32(g16, name), N, M, _stream(g))
     calls += 1
     _check(rc, name)
-    return g_a
+    return g16
 
 
-def convnet_train_linear_wgrad(g, a, frame_bias, h_out: int, w_out: int):
-    """(dW (M, h_out * w_out), db (M)) of the Linear layer behind the second ConvModifier; ``a`` (N, h_out * w_out) equals
-    ``frame_bias`` outside its 4 x 4 interior."""
+def convnet_train_linear_wgrad(g, a16, frame_bias, h_out: int, w_out: int):
+    """(dW (M, h_out * w_out), db (M)) of the Linear layer behind the second ConvModifier, whose input equals
+    ``frame_bias`` outside the 4 x 4 interior a16 (N, 16)."""
     global calls
     name = "tfk_convnet_train_linear_wgrad"
     N, M = g.shape
     dW = torch.empty(M, h_out * w_out, dtype=torch.float32, device=g.device)
     db = torch.empty(M, dtype=torch.float32, device=g.device)
     with _device_guard(g):
-        rc = lib().tfk_convnet_train_linear_wgrad(_f32(g, name), _f32(a, name), _f32(frame_bias, name), _f32(dW, name),
+        rc = lib().tfk_convnet_train_linear_wgrad(_f32(g, name), _f32(a16, name), _f32(frame_bias, name), _f32(dW, name),
                                                   _f32(db, name), N, M, h_out, w_out, _stream(g))
     calls += 1
     _check(rc, name)
