@@ -558,45 +558,70 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
 
 // ---- weight gradient of the Linear layer behind the second ConvModifier ---------------------------------------------
 // Its input equals the modifier's bias outside the 16 interior pixels a (N, 16), so
-//   dW[m][j] = frame(j) ? bias * db[m] : sum_n g[n][m] a[n][interior index of j],   db[m] = sum_n g[n][m]:
+//   dW[m][f] = frame(f) ? bias * db[m] : sum_n g[n][m] a[n][interior index of f],   db[m] = sum_n g[n][m]:
 // a contraction over the batch with 16 columns on one side (the library GEMM runs it as one tile: 958 us at N = 1 000,
-// M = 784).  One workgroup per 16 rows m, rows n in order: deterministic.
+// M = 784).  A lane owns one output row m and keeps its 16 sums in registers: g[n][m .. m + 63] is one coalesced load
+// per wavefront and row, a[n][0..15] the same 64 bytes for every lane (scalar loads).  The four wavefronts of a workgroup
+// take a quarter of the rows each, in order, and their sums are added in wavefront order: deterministic.  The
+// workgroup's 64 x F block of dW is assembled in LDS and written as one contiguous stretch.
 __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
     const float *__restrict__ g, const float *__restrict__ a, const float *__restrict__ frame_bias,
     float *__restrict__ dW, float *__restrict__ db, long long N, int M, int HT, int WT, int top, int left)
 {
-    __shared__ float gs[64][17], as[64][16], sb[16];
-    const int m0 = blockIdx.x * 16, ml = threadIdx.x >> 4, k = threadIdx.x & 15;
+    extern __shared__ __attribute__((aligned(16))) float lw[];
     const int F = HT * WT;
-    const int col = (top + (k >> 2)) * WT + left + (k & 3);     // interior pixel k of the 4 x 4 block
-    float acc = 0.0f, accb = 0.0f;
-    for (long long n0 = 0; n0 < N; n0 += 64) {
-        for (int i = threadIdx.x; i < 64 * 16; i += kBlock) {
-            const int r = i >> 4, c = i & 15;
-            const long long n = n0 + r;
-            gs[r][c] = (n < N && m0 + c < M) ? g[n * M + m0 + c] : 0.0f;
-            as[r][c] = n < N ? a[n * 16 + c] : 0.0f;
+    float *part = lw;                       // 4 x 64 x 17: per wavefront, per lane: 16 sums + the plain sum
+    float *tile = lw + 4 * 64 * 17;         // 64 x F
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m0 = blockIdx.x * 64, m = m0 + lane;
+    const long long per = (N + 3) / 4, lo = wave * per, hi = (lo + per < N) ? lo + per : N;
+    float acc[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) acc[j] = 0.0f;
+    if (m < M) {
+        long long n = lo;
+        for (; n + 4 <= hi; n += 4) {
+            float gv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[q] = g[(n + q) * M + m];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float *ar = a + (n + q) * 16;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(gv[q], ar[j], acc[j]);
+                acc[16] += gv[q];
+            }
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) {
-            const float gv = gs[r][ml];
-            acc = fmaf(gv, as[r][k], acc);
-            accb += gv;
+        for (; n < hi; ++n) {
+            const float gv = g[n * M + m];
+            const float *ar = a + n * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(gv, ar[j], acc[j]);
+            acc[16] += gv;
         }
-        __syncthreads();
     }
-    if (k == 0) sb[ml] = accb;
+#pragma unroll
+    for (int j = 0; j < 17; ++j) part[(wave * 64 + lane) * 17 + j] = acc[j];
     __syncthreads();
-    if (m0 + ml >= M) return;
-    float *row = dW + (long long)(m0 + ml) * F;
-    row[col] = acc;
-    const float fb = frame_bias[0] * sb[ml];
-    for (int j = k; j < F; j += 16) {
-        const int ii = j / WT - top, jj = j % WT - left;
-        if (!(ii >= 0 && ii < 4 && jj >= 0 && jj < 4)) row[j] = fb;
+    const float fb = frame_bias[0];
+    // lane (row r = thread / 4, quarter of the columns): sums in wavefront order, then the row of the tile
+    for (int i = threadIdx.x; i < 64 * 17; i += kBlock) {
+        const int r = i / 17, j = i - r * 17;
+        const float t = (part[(0 * 64 + r) * 17 + j] + part[(1 * 64 + r) * 17 + j]) +
+                        (part[(2 * 64 + r) * 17 + j] + part[(3 * 64 + r) * 17 + j]);
+        part[r * 17 + j] = t;               // (wavefront 0's slot: read above by this lane only)
     }
-    if (k == 0) db[m0 + ml] = sb[ml];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * F; i += kBlock) {
+        const int r = i / F, f = i - r * F;
+        const int ii = f / WT - top, jj = f % WT - left;
+        tile[i] = (ii >= 0 && ii < 4 && jj >= 0 && jj < 4) ? part[r * 17 + ii * 4 + jj] : fb * part[r * 17 + 16];
+    }
+    __syncthreads();
+    const int rows = (M - m0 < 64) ? M - m0 : 64;
+    float *dst = dW + (long long)m0 * F;
+    for (int i = threadIdx.x; i < rows * F; i += kBlock) dst[i] = tile[i];
+    if (threadIdx.x < rows) db[m0 + threadIdx.x] = part[threadIdx.x * 17 + 16];
 }
 
 // ---- the Linear layer behind the second ConvModifier, forward and input gradient ------------------------------------
@@ -910,7 +935,9 @@ int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *
         return fail(TFK_EINVAL, "%s: the interior is 4 x 4 in the middle of an even frame (%d x %d)", fn, H_out, W_out);
     if (!g || !a || !frame_bias || !dW || !db) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 15) / 16), dim3(kBlock), 0, s, g, a, frame_bias, dW, db,
+    const size_t lds = (size_t)(4 * 64 * 17 + 64 * H_out * W_out) * 4;
+    if (lds > 64 * 1024) return fail(TFK_EINVAL, "%s: a %d x %d frame does not fit the LDS tile", fn, H_out, W_out);
+    hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 63) / 64), dim3(kBlock), lds, s, g, a, frame_bias, dW, db,
                        (long long)N, M, H_out, W_out, (H_out - 4) / 2, (W_out - 4) / 2);
     return check_launch(fn);
 }
