@@ -952,6 +952,18 @@ def main():
                         result["train"]["notebook_error"] = f"exit code {proc.returncode}: " + proc.stderr.strip()[-300:]
                 except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
                     result["train"]["notebook_error"] = f"{type(exc).__name__}: {exc}"[:300]
+                # config 5's model in TRAINING at Flow.fit's default batch size: the ConvNet conditioner on ATen / MIOpen
+                # (the route of rounds 1-3) against csrc/tfk_convtrain.hip, eager and captured (child process, ~20 s)
+                try:
+                    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "glow_train_probe.py"), "20"],
+                                          capture_output=True, text=True, timeout=300)
+                    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("GLOW_TRAIN_JSON ")]
+                    if proc.returncode == 0 and line:
+                        result["train"]["glow32"] = json.loads(line[-1][len("GLOW_TRAIN_JSON "):])
+                    else:
+                        result["train"]["glow32"] = {"error": f"exit code {proc.returncode}: " + proc.stderr.strip()[-300:]}
+                except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
+                    result["train"]["glow32"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             rb = tk.get("rqs_coupling_train_bwd")
             if rb is not None:
                 result["train"]["roofline_fused_bwd"] = {

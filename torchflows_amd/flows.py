@@ -392,6 +392,9 @@ class Flow(BaseFlow):
         n_train = len(x_train)
 
         adaptive, max_batch_size = False, None
+        if isinstance(batch_size, int) and batch_size > n_train > 0:
+            batch_size = n_train         # (the same batches; lets a data set smaller than one batch -- the reference's
+                                         # notebooks: 1 000 rows, batch size 1 024 -- count as full-size steps below)
         if batch_size is None:
             batch_size = n_train
         elif isinstance(batch_size, str):
