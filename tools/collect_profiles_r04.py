@@ -24,7 +24,8 @@ def head(src, dst, n):
 
 
 def main():
-    for name, pmc in (("lean", True), ("nsf", True), ("rnvp256", True), ("glow32", True), ("sample", False), ("train", False)):
+    for name, pmc in (("lean", True), ("nsf", True), ("rnvp256", True), ("glow32", True), ("sample", False), ("train", False),
+                      ("train_glow", False)):
         s, d = os.path.join(SRC, f"prof_r04_{name}"), os.path.join(DST, name)
         os.makedirs(d, exist_ok=True)
         shutil.copy(os.path.join(s, "csrc_sha256.txt"), os.path.join(d, "csrc_sha256.txt"))
@@ -36,6 +37,11 @@ def main():
             with open(os.path.join(d, "pmc_summary.csv"), "w") as f:
                 f.writelines(keep)
     shutil.copy(os.path.join(SRC, "prof_r04_train", "probe.txt"), os.path.join(DST, "train", "probe.txt"))
+    for f in ("probe.txt", "convtrain_bench.txt"):
+        with open(os.path.join(SRC, "prof_r04_train_glow", f)) as fh:
+            keep = [ln for ln in fh if "amdgpu.ids" not in ln]
+        with open(os.path.join(DST, "train_glow", f), "w") as fh:
+            fh.writelines(keep)
     glow = {}
     for step, label in (("step0", "affine 3x16x32"), ("step3", "conv1x1 6x16x16")):
         src = os.path.join(SRC, "prof_r04_glow32", f"{step}_pmc.txt")
