@@ -421,6 +421,8 @@ int tfk_conv1x1_frame(const float *x, int64_t x_stride, const float *weight, con
 /* Bounded conditioner output (conditioning/transforms.py:107-113, used by ConvNetConditioner with (-2, 2)):
  * out = lo + (hi - lo) * sigmoid(h) over n floats, the three roundings of the reference kept; h may alias out. */
 int tfk_bounded_sigmoid(const float *h, float *out, int64_t n, float lo, float hi, void *stream);
+/* Its reverse mode from the OUTPUT alone: g_in = g * (hi - lo) * s (1 - s), s = (out - lo) / (hi - lo); g_in may alias g. */
+int tfk_bounded_sigmoid_bwd(const float *out, const float *g, float *g_in, int64_t n, float lo, float hi, void *stream);
 
 /* ---- The ConvNet conditioner in TRAINING (classic.py:45-122 under Flow.fit: BatchNorm2d with batch statistics) ----
  * One forward and one reverse-mode launch per block (csrc/tfk_convtrain.hip); every sum over the batch is a

@@ -172,6 +172,18 @@ __global__ __launch_bounds__(kBlock) void k_bounded_sigmoid(const float *in, flo
     }
 }
 
+// Reverse mode of the bounded output: d/dh [lo + range * sigmoid(h)] = range * s (1 - s), s recovered from the OUTPUT
+// ((out - lo) / range: within 1e-7 of the sigmoid the forward pass rounded), so nothing but the output is kept.
+__global__ __launch_bounds__(kBlock) void k_bounded_sigmoid_bwd(const float *__restrict__ out, const float *__restrict__ g,
+                                                                float *__restrict__ g_in, long long n, float lo, float range)
+{
+    const float inv = 1.0f / range;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float s = (out[i] - lo) * inv;
+        g_in[i] = g[i] * (range * (s * (1.0f - s)));
+    }
+}
+
 }  // namespace tfk
 
 using namespace tfk;
@@ -252,6 +264,18 @@ int tfk_bounded_sigmoid(const float *in, float *h, int64_t n, float lo, float hi
     else
         hipLaunchKernelGGL((k_bounded_sigmoid<1>), dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, in, h,
                            (long long)n, lo, hi - lo);
+    return check_launch(fn);
+}
+
+int tfk_bounded_sigmoid_bwd(const float *out, const float *g, float *g_in, int64_t n, float lo, float hi, void *stream)
+{
+    const char *fn = "tfk_bounded_sigmoid_bwd";
+    if (n < 0) return fail(TFK_EINVAL, "%s: n = %lld < 0", fn, (long long)n);
+    if (!(lo < hi)) return fail(TFK_EINVAL, "%s: need lo < hi", fn);
+    if (n == 0) return TFK_OK;
+    if (!out || !g || !g_in) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(k_bounded_sigmoid_bwd, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       out, g, g_in, (long long)n, lo, hi - lo);
     return check_launch(fn);
 }
 

@@ -45,7 +45,7 @@ SYMBOLS = (
     "tfk_rows_outer_workspace_bytes", "tfk_rows_outer",
     "tfk_made_affine_sequential", "tfk_made_rqs_sequential_lds_bytes", "tfk_made_rqs_sequential",
     "tfk_made_lrs_sequential_lds_bytes", "tfk_made_lrs_sequential",
-    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid",
+    "tfk_conv3x3_block_supported", "tfk_conv3x3_relu_pool_affine", "tfk_conv1x1_frame", "tfk_bounded_sigmoid", "tfk_bounded_sigmoid_bwd",
     "tfk_glow_weight_floats", "tfk_glow_plan", "tfk_glow_coupling", "tfk_rows_fma",
     "tfk_glow_level_blob_bytes", "tfk_glow_level_pack", "tfk_glow_level_info", "tfk_glow_level",
     "tfk_rows_fma_gauss_logprob",
@@ -167,6 +167,7 @@ def _bind(L: C.CDLL) -> None:
     L.tfk_conv3x3_block_supported.argtypes = [_i32, _i32]
     L.tfk_conv3x3_relu_pool_affine.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
     L.tfk_bounded_sigmoid.argtypes = [_vp, _vp, _i64, C.c_float, C.c_float, _vp]
+    L.tfk_bounded_sigmoid_bwd.argtypes = [_vp, _vp, _vp, _i64, C.c_float, C.c_float, _vp]
     L.tfk_conv1x1_frame.argtypes = [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
     L.tfk_glow_weight_floats.argtypes = [_i32]
     L.tfk_glow_weight_floats.restype = _i64
@@ -707,6 +708,19 @@ def bounded_sigmoid(h: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
     calls += 1
     _check(rc, name)
     return out
+
+
+def bounded_sigmoid_bwd(out: torch.Tensor, g: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """d(loss)/dh of ``out = lo + (hi - lo) * sigmoid(h)`` from ``out`` and d(loss)/d(out), one pass."""
+    global calls
+    name = "tfk_bounded_sigmoid_bwd"
+    g_in = torch.empty_like(out)
+    with _device_guard(out):
+        rc = lib().tfk_bounded_sigmoid_bwd(_f32(out, name), _f32(g, name), _f32(g_in, name), out.numel(), float(lo),
+                                           float(hi), _stream(out))
+    calls += 1
+    _check(rc, name)
+    return g_in
 
 
 def conv1x1_frame(x, weight, bias, h_out: int, w_out: int):
