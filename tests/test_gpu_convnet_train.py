@@ -181,3 +181,33 @@ def test_bounded_output_one_launch_each_way(native):
     (second,) = torch.autograd.grad(first.sum(), h)
     s = torch.sigmoid(h.detach())
     assert float((second - 4.0 * s * (1 - s) * (1 - 2 * s)).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("training", [False, True], ids=["eval", "train"])
+def test_image_flow_inverse_direction_gradients(native, monkeypatch, training):
+    """The sampling direction with gradients (variational_fit on an image flow): bijection.inverse through the reverse-mode
+    chain + the libtfk conditioner against the plain ATen autograd graph of the same modules."""
+    from torchflows_amd.bijections.finite.multiscale.architectures import AffineGlow
+    torch.manual_seed(0)
+    bij = AffineGlow((3, 8, 8), n_layers=2).cuda()
+    z = torch.randn(24, 3, 8, 8, device="cuda")
+    with torch.no_grad():
+        bij.train()
+        bij.forward(torch.randn(24, 3, 8, 8, device="cuda"))       # ActNorm statistics
+    bij.train(training)
+    got = {}
+    for route in ("hip", "aten"):
+        m = copy.deepcopy(bij)
+        monkeypatch.setenv("TORCHFLOWS_AMD_TRAIN", "1" if route == "hip" else "0")
+        set_debug(monkeypatch, convnet_train=None if route == "hip" else "0")
+        x, ld = m.inverse(z)
+        loss = (x ** 2).sum() * 0.5 - ld.sum()
+        params = [p for p in m.parameters() if p.requires_grad and p.numel()]
+        got[route] = (x.detach(), ld.detach(), torch.autograd.grad(loss, params, allow_unused=True))
+    assert normwise(got["hip"][0].cpu().numpy(), got["aten"][0].cpu().numpy()) < 1e-5
+    assert normwise(got["hip"][1].cpu().numpy(), got["aten"][1].cpu().numpy()) < 1e-5
+    for a, b in zip(got["hip"][2], got["aten"][2]):
+        if a is None or b is None:
+            assert a is None and b is None
+            continue
+        assert normwise(a.cpu().numpy(), b.cpu().numpy()) < 5e-4

@@ -561,40 +561,60 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
 //   dW[m][f] = frame(f) ? bias * db[m] : sum_n g[n][m] a[n][interior index of f],   db[m] = sum_n g[n][m]:
 // a contraction over the batch with 16 columns on one side (the library GEMM runs it as one tile: 958 us at N = 1 000,
 // M = 784).  A lane owns one output row m and keeps its 16 sums in registers: g[n][m .. m + 63] is one coalesced load
-// per wavefront and row, a[n][0..15] the same 64 bytes for every lane (scalar loads).  The four wavefronts of a workgroup
-// take a quarter of the rows each, in order, and their sums are added in wavefront order: deterministic.  The
-// workgroup's 64 x F block of dW is assembled in LDS and written as one contiguous stretch.
-__global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
+// per wavefront and row, a[n][0..15] the same 64 bytes for every lane (staged 64 rows at a time in the wavefront's own LDS
+// tile, read back as broadcasts).  The eight wavefronts of a workgroup take an eighth of the rows each, in order, and
+// their sums are added in wavefront order: deterministic.  The workgroup's 64 x F block of dW is assembled in LDS and
+// written as one contiguous stretch.
+constexpr int kWgradWaves = 8;      // wavefronts (row slices) per workgroup of k_ct_linear_wgrad
+
+__global__ __launch_bounds__(kWgradWaves * 64) void k_ct_linear_wgrad(
     const float *__restrict__ g, const float *__restrict__ a, const float *__restrict__ frame_bias,
     float *__restrict__ dW, float *__restrict__ db, long long N, int M, int HT, int WT, int top, int left)
 {
     extern __shared__ __attribute__((aligned(16))) float lw[];
+    constexpr int NW = kWgradWaves, BLOCK = NW * 64;
     const int F = HT * WT;
-    float *part = lw;                       // 4 x 64 x 17: per wavefront, per lane: 16 sums + the plain sum
-    float *tile = lw + 4 * 64 * 17;         // 64 x F
+    float *part = lw;                       // NW x 64 x 17: per wavefront, per lane: 16 sums + the plain sum
+    float *atile = lw + NW * 64 * 17;       // NW x 64 x 16: the wavefront's current 64 rows of a
+    float *tile = atile + NW * 64 * 16;     // 64 x F
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int m0 = blockIdx.x * 64, m = m0 + lane;
-    const long long per = (N + 3) / 4, lo = wave * per, hi = (lo + per < N) ? lo + per : N;
+    const bool live = m < M;
+    const long long per = (N + NW - 1) / NW, lo = wave * per, hi = (lo + per < N) ? lo + per : N;
     float acc[17];
 #pragma unroll
     for (int j = 0; j < 17; ++j) acc[j] = 0.0f;
-    if (m < M) {
-        long long n = lo;
-        for (; n + 4 <= hi; n += 4) {
-            float gv[4];
+    float4 *mine = reinterpret_cast<float4 *>(atile + (wave * 64 + lane) * 16);
+    const float4 *rows4 = reinterpret_cast<const float4 *>(atile + wave * 64 * 16);
+    for (long long c0 = 0; c0 < per; c0 += 64) {        // (the same trip count in every wavefront: barriers inside)
+        const long long n0 = lo + c0;
+        __syncthreads();
+        if (n0 + lane < hi) {
+            const float4 *src = reinterpret_cast<const float4 *>(a + (n0 + lane) * 16);
+            mine[0] = src[0]; mine[1] = src[1]; mine[2] = src[2]; mine[3] = src[3];
+        }
+        __syncthreads();
+        const int cnt = (hi - n0 >= 64) ? 64 : (hi > n0 ? (int)(hi - n0) : 0);
+        if (!live) continue;
+        int r = 0;
+        for (; r + 8 <= cnt; r += 8) {
+            float gv[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gv[q] = g[(n + q) * M + m];
+            for (int q = 0; q < 8; ++q) gv[q] = g[(n0 + r + q) * M + m];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float *ar = a + (n + q) * 16;
+            for (int q = 0; q < 8; ++q) {
+                const float4 a0 = rows4[(r + q) * 4], a1 = rows4[(r + q) * 4 + 1], a2 = rows4[(r + q) * 4 + 2],
+                             a3 = rows4[(r + q) * 4 + 3];
+                const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
+                                      a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = fmaf(gv[q], ar[j], acc[j]);
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(gv[q], av[j], acc[j]);
                 acc[16] += gv[q];
             }
         }
-        for (; n < hi; ++n) {
-            const float gv = g[n * M + m];
-            const float *ar = a + n * 16;
+        for (; r < cnt; ++r) {
+            const float gv = g[(n0 + r) * M + m];
+            const float *ar = atile + (wave * 64 + r) * 16;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = fmaf(gv, ar[j], acc[j]);
             acc[16] += gv;
@@ -604,15 +624,15 @@ __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
     for (int j = 0; j < 17; ++j) part[(wave * 64 + lane) * 17 + j] = acc[j];
     __syncthreads();
     const float fb = frame_bias[0];
-    // lane (row r = thread / 4, quarter of the columns): sums in wavefront order, then the row of the tile
-    for (int i = threadIdx.x; i < 64 * 17; i += kBlock) {
+    for (int i = threadIdx.x; i < 64 * 17; i += BLOCK) {       // the slices' sums, added in wavefront order
         const int r = i / 17, j = i - r * 17;
-        const float t = (part[(0 * 64 + r) * 17 + j] + part[(1 * 64 + r) * 17 + j]) +
-                        (part[(2 * 64 + r) * 17 + j] + part[(3 * 64 + r) * 17 + j]);
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += part[(w * 64 + r) * 17 + j];
         part[r * 17 + j] = t;               // (wavefront 0's slot: read above by this lane only)
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * F; i += kBlock) {
+    for (int i = threadIdx.x; i < 64 * F; i += BLOCK) {
         const int r = i / F, f = i - r * F;
         const int ii = f / WT - top, jj = f % WT - left;
         tile[i] = (ii >= 0 && ii < 4 && jj >= 0 && jj < 4) ? part[r * 17 + ii * 4 + jj] : fb * part[r * 17 + 16];
@@ -620,8 +640,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_linear_wgrad(
     __syncthreads();
     const int rows = (M - m0 < 64) ? M - m0 : 64;
     float *dst = dW + (long long)m0 * F;
-    for (int i = threadIdx.x; i < rows * F; i += kBlock) dst[i] = tile[i];
-    if (threadIdx.x < rows) db[m0 + threadIdx.x] = part[threadIdx.x * 17 + 16];
+    for (int i = threadIdx.x; i < rows * F; i += BLOCK) dst[i] = tile[i];
+    if ((int)threadIdx.x < rows) db[m0 + threadIdx.x] = part[threadIdx.x * 17 + 16];
 }
 
 // ---- the Linear layer behind the second ConvModifier, forward and input gradient ------------------------------------
@@ -935,9 +955,13 @@ int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *
         return fail(TFK_EINVAL, "%s: the interior is 4 x 4 in the middle of an even frame (%d x %d)", fn, H_out, W_out);
     if (!g || !a || !frame_bias || !dW || !db) return fail(TFK_EINVAL, "%s: null pointer", fn);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)(4 * 64 * 17 + 64 * H_out * W_out) * 4;
-    if (lds > 64 * 1024) return fail(TFK_EINVAL, "%s: a %d x %d frame does not fit the LDS tile", fn, H_out, W_out);
-    hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 63) / 64), dim3(kBlock), lds, s, g, a, frame_bias, dW, db,
+    const size_t lds = (size_t)(kWgradWaves * 64 * (17 + 16) + 64 * H_out * W_out) * 4;
+    if (lds > 150 * 1024) return fail(TFK_EINVAL, "%s: a %d x %d frame does not fit the LDS tile", fn, H_out, W_out);
+    if (N > 0 && !aligned16(a)) return fail(TFK_EINVAL, "%s: a16 must be 16-byte aligned", fn);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_linear_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return fail(TFK_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", fn, lds);
+    hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 63) / 64), dim3(kWgradWaves * 64), lds, s, g, a, frame_bias, dW, db,
                        (long long)N, M, H_out, W_out, (H_out - 4) / 2, (W_out - 4) / 2);
     return check_launch(fn);
 }
