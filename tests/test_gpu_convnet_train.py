@@ -211,3 +211,38 @@ def test_image_flow_inverse_direction_gradients(native, monkeypatch, training):
             assert a is None and b is None
             continue
         assert normwise(a.cpu().numpy(), b.cpu().numpy()) < 5e-4
+
+
+def test_config5_model_training_step_matches_the_library_route(native, monkeypatch):
+    """One maximum-likelihood step of AffineGlow((3, 32, 32)) -- config 5's model, training mode -- loss and every gradient:
+    ConvNet conditioners on csrc/tfk_convtrain.hip against the same chain with the conditioners on ATen / MIOpen."""
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.multiscale.architectures import AffineGlow
+    torch.manual_seed(0)
+    flow = tfa.Flow(AffineGlow((3, 32, 32))).cuda()
+    x = torch.randn(48, 3, 32, 32, device="cuda")
+    flow.train()
+    with torch.no_grad():
+        flow.log_prob(x)                  # ActNorm statistics
+    out = {}
+    for route in ("libtfk", "library"):
+        m = copy.deepcopy(flow).train()
+        set_debug(monkeypatch, convnet_train=None if route == "libtfk" else "0")
+        before = native.calls
+        loss = -m.log_prob(x).mean() / 3072
+        params = [(k, p) for k, p in m.named_parameters() if p.requires_grad and p.numel()]
+        grads = torch.autograd.grad(loss, [p for _, p in params], allow_unused=True)
+        out[route] = (float(loss), {k: g for (k, _), g in zip(params, grads)}, native.calls - before)
+    assert abs(out["libtfk"][0] - out["library"][0]) < 1e-5 * abs(out["library"][0])
+    worst = ("", 0.0)
+    for k, g in out["library"][1].items():
+        h = out["libtfk"][1][k]
+        assert (g is None) == (h is None), k
+        if g is None:
+            continue
+        e = normwise(h.cpu().numpy(), g.cpu().numpy())
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-3, worst       # (fp32 noise of two different summation orders through 19 normalised couplings)
+    print(f"config-5 training step: loss {out['libtfk'][0]:.6f}, worst gradient distance between routes {worst[1]:.2e} "
+          f"({worst[0]}); libtfk launches {out['libtfk'][2]} vs {out['library'][2]}")

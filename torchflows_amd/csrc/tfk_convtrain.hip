@@ -18,7 +18,6 @@
 // Batch-coupled quantities (BatchNorm statistics) are why this is a launch per BLOCK and not per coupling: each block's
 // output depends on every sample of the batch through the normalisation that precedes the next block.
 #include "tfk_common.h"
-#include <stdlib.h>
 
 namespace tfk {
 
@@ -743,7 +742,6 @@ bool block_ok(int c_in, int c_out) { return (c_in == 4 && c_out == 8) || (c_in =
 int bwd_grid(int64_t N, int per_cu)
 {
     int64_t g = (int64_t)cu_count() * per_cu;
-    if (const char *e = getenv("TFK_CT_GRID")) g = atoi(e);       // EXPERIMENT
     if (g > kCtMaxGrid) g = kCtMaxGrid;
     return (int)(N < g ? N : g);
 }
