@@ -469,6 +469,41 @@ int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float 
                                 float *bn_dbias, int32_t bn_training, void *workspace, int64_t N, int32_t c_in,
                                 int32_t c_out, int32_t H, int32_t W, int32_t H_out, int32_t W_out, int32_t kh,
                                 int32_t kw, void *stream);
+/* The WHOLE network in one call each way (the launches above in sequence + the dot product that completes the second
+ * modifier's bias gradient): what a host in an interpreted language wants -- one FFI crossing per pass instead of seven.
+ * The network is the reference's default ConvNet: modifier (4, c, kh, kw) -> blocks 4->8 @32, 8->8 @16, 8->4 @8 ->
+ * modifier (1, 4, 1, 1) -> Linear (M, 100).  All pointers are device pointers the caller owns; `acts` are written by
+ * the forward pass and read by the backward pass. */
+typedef struct tfk_convnet_train_plan {
+    const float *mod1_w, *mod1_b;
+    const float *conv_w[3], *conv_b[3];
+    const float *bn_w[3], *bn_b[3];
+    float *bn_mean[3], *bn_var[3];          /* running statistics */
+    int64_t *bn_count[3];                   /* num_batches_tracked, may be NULL */
+    float bn_eps[3], bn_momentum[3];
+    const float *mod2_w, *mod2_b;
+    const float *lin_w, *lin_b;
+    int32_t c, h, w, kh, kw, M;
+    /* activations: a0 (N, 4, 32, 32); y[k] / amax[k] (N, 8, 16, 16), (N, 8, 8, 8), (N, 4, 4, 4); stats[k] 4 C_k floats;
+     * a16 (N, 16); lin_fold 18 M floats (W16 | b_eff | w_frame) */
+    float *a0, *y[3];
+    uint8_t *amax[3];
+    float *stats[3];
+    float *a16, *lin_fold;
+    void *workspace;                        /* tfk_convnet_train_workspace_bytes(), zeroed once */
+} tfk_convnet_train_plan;
+/* theta (N, M) = net(x), x (N, c, h, w). */
+int tfk_convnet_train_forward(const tfk_convnet_train_plan *plan, const float *x, float *theta, int64_t N,
+                              int32_t training, int32_t update_running, void *stream);
+/* Reverse pass from g_theta (N, M).  g_x (N, c, h, w); scratch: N * 6736 floats; bn_out: 100 floats (per BatchNorm k:
+ * coef 3 C_k | d weight C_k | d bias C_k, at offsets 0, 40, 80); sums: the launches' sums back to back --
+ *   modifier 1 [dW 4 c kh kw | 2 c (ignore) | db 4]  block 1 [dW 288 | db 8]  block 2 [dW 576 | db 8]  block 3 [dW 288 | db 4]
+ *   modifier 2 [dW 4 | 8 (ignore) | db 1]  Linear [dW 100 M | db M]
+ * = tfk_convnet_train_sums_floats(c, kh, kw, M) floats. */
+int64_t tfk_convnet_train_sums_floats(int32_t c, int32_t kh, int32_t kw, int32_t M);
+int tfk_convnet_train_backward(const tfk_convnet_train_plan *plan, const float *x, const float *g_theta, float *g_x,
+                               float *scratch, float *bn_out, float *sums, int64_t N, int32_t training, void *stream);
+
 /* The Linear layer behind the second ConvModifier.  Its input equals the modifier's bias (*frame_bias) outside the 4 x 4
  * interior of the (H_out, W_out) frame, so the layer is a 16-term product: prep folds the weight (M, H_out * W_out) into
  * W16 (M, 16) = its interior columns, w_frame (M) = the sum of the others, b_eff (M) = bias + *frame_bias * w_frame;

@@ -246,3 +246,27 @@ def test_config5_model_training_step_matches_the_library_route(native, monkeypat
     assert worst[1] < 2e-3, worst       # (fp32 noise of two different summation orders through 19 normalised couplings)
     print(f"config-5 training step: loss {out['libtfk'][0]:.6f}, worst gradient distance between routes {worst[1]:.2e} "
           f"({worst[0]}); libtfk launches {out['libtfk'][2]} vs {out['library'][2]}")
+
+
+def test_one_call_and_launch_by_launch_routes_agree_bitwise(native, monkeypatch):
+    """tfk_convnet_train_forward / _backward issue the same launches as the per-launch entry points called from Python."""
+    net = _net((3, 16, 32), 96).cuda().train()
+    torch.manual_seed(5)
+    x = torch.randn(70, 3, 16, 32, device="cuda")
+    g = torch.randn(70, 96, device="cuda")
+    runs = []
+    for mode in (None, "each"):
+        set_debug(monkeypatch, convnet_calls=mode)
+        m = copy.deepcopy(net)
+        xr = x.clone().requires_grad_(True)
+        out = m(xr)
+        runs.append((out.detach(), torch.autograd.grad(out, [xr] + list(m.parameters()), g),
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for i, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
+        if i == 16:       # the second modifier's bias: its frame share is a dot product, summed by libtfk here, rocBLAS there
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        else:
+            assert torch.equal(a, b), i
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k

@@ -151,43 +151,80 @@ def apply(net, x: torch.Tensor) -> torch.Tensor:
 
 
 class ConvNetFunction(torch.autograd.Function):
+    """One call into libtfk per pass (tfk_convnet_train_forward / _backward: the launches listed at the top, in sequence);
+    ``TORCHFLOWS_AMD_DEBUG=convnet_calls=each`` issues them one by one from Python instead (the per-launch entry points
+    the tests and tools/convtrain_bench.py also use)."""
+
     @staticmethod
     def forward(ctx, net, training: bool, update: bool, x: torch.Tensor, *params: torch.Tensor):
-        (w_m1, b_m1, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w_m2, b_m2, w_lin, b_lin) = \
-            [p.detach() for p in params]
-        N = x.shape[0]
-        blocks = net.blocks
-        a0 = native.convnet_train_frame_fwd(x, None, w_m1, b_m1, 32, 32)
-        y1, i1, s1 = native.convnet_train_block_fwd(a0, None, w1, b1, blocks[1].bn, training, update)
-        y2, i2, s2 = native.convnet_train_block_fwd(y1, s1, w2, b2, blocks[2].bn, training, update)
-        y3, i3, s3 = native.convnet_train_block_fwd(y2, s2, w3, b3, blocks[3].bn, training, update)
-        a16 = native.convnet_train_frame_fwd(y3, s3, w_m2, b_m2, 4, 4).view(N, 16)     # (the frame around it == b_m2)
-        W16, b_eff, w_frame = native.convnet_train_linear_prep(w_lin, b_lin, b_m2, 10, 10)
-        theta = native.convnet_train_linear_fwd(a16, W16, b_eff)
+        from torchflows_amd.utils import debug_switch
+        params = [p.detach() for p in params]
         ctx.training = training
-        ctx.save_for_backward(x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame)
+        if debug_switch("convnet_calls", "one") == "each":
+            return _forward_each(ctx, net, training, update, x, params)
+        plan = native.ConvNetTrainPlan()
+        bns = (net.blocks[1].bn, net.blocks[2].bn, net.blocks[3].bn)
+        theta, acts, amax = native.convnet_train_forward(plan, params, bns, x, training, update)
+        ctx.plan = plan
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(x, acts, amax, *params)          # (the parameters: their version counters guard the pointers)
         return theta
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_theta: torch.Tensor):
-        (x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame) = ctx.saved_tensors
-        tr = ctx.training
-        N = x.shape[0]
-        g_theta = g_theta.contiguous()
-        g16 = native.convnet_train_linear_bwd_input(g_theta, W16)             # (N, 16): the interior of d/d(Linear input)
-        dW_lin, db_lin = native.convnet_train_linear_wgrad(g_theta, a16, b_m2, 10, 10)
-        gz3, dw_m2, db_m2, bn3 = native.convnet_train_frame_bwd(g16.view(N, 1, 4, 4), y3, s3, w_m2, s3, tr)
-        db_m2 = db_m2 + torch.dot(db_lin, w_frame)                            # (+ the frame: 84 inputs that equal b_m2)
-        gz2, dW3, db3, bn2 = native.convnet_train_block_bwd(gz3, bn3[0], y3, i3, y2, s2, w3, s2, tr)
-        gz1, dW2, db2, bn1 = native.convnet_train_block_bwd(gz2, bn2[0], y2, i2, y1, s1, w2, s1, tr)
-        g_a0, dW1, db1, _ = native.convnet_train_block_bwd(gz1, bn1[0], y1, i1, a0, None, w1, None, tr)
-        g_x, dw_m1, db_m1, _ = native.convnet_train_frame_bwd(g_a0, x, None, w_m1, None, tr)
-        grads = [dw_m1, db_m1,
+        need = ctx.needs_input_grad
+        if getattr(ctx, "plan", None) is None:
+            g_x, grads = _backward_each(ctx, g_theta)
+        else:
+            x = ctx.saved_tensors[0]            # (also checks that no saved tensor was modified in place)
+            p, sh = ctx.plan, ctx.shapes
+            g_x, bn, sums = native.convnet_train_backward(p, x, g_theta.contiguous(), ctx.training)
+            M, n_m1 = p.M, 4 * p.c * p.kh * p.kw
+            o1 = n_m1 + 2 * p.c + 4
+            o2, o3, o4 = o1 + 296, o1 + 296 + 584, o1 + 296 + 584 + 292
+            oL = o4 + 13
+            grads = [sums[:n_m1].view(sh[0]), sums[o1 - 4:o1],
+                     sums[o1:o1 + 288].view(sh[2]), sums[o1 + 288:o2], bn[24:32], bn[32:40],
+                     sums[o2:o2 + 576].view(sh[6]), sums[o2 + 576:o3], bn[64:72], bn[72:80],
+                     sums[o3:o3 + 288].view(sh[10]), sums[o3 + 288:o4], bn[92:96], bn[96:100],
+                     sums[o4:o4 + 4].view(sh[14]), sums[o4 + 12:o4 + 13],
+                     sums[oL:oL + 100 * M].view(sh[16]), sums[oL + 100 * M:oL + 101 * M]]
+        return (None, None, None, g_x if need[3] else None,
+                *[g if need[4 + k] else None for k, g in enumerate(grads)])
+
+
+def _forward_each(ctx, net, training, update, x, params):
+    (w_m1, b_m1, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w_m2, b_m2, w_lin, b_lin) = params
+    N = x.shape[0]
+    blocks = net.blocks
+    a0 = native.convnet_train_frame_fwd(x, None, w_m1, b_m1, 32, 32)
+    y1, i1, s1 = native.convnet_train_block_fwd(a0, None, w1, b1, blocks[1].bn, training, update)
+    y2, i2, s2 = native.convnet_train_block_fwd(y1, s1, w2, b2, blocks[2].bn, training, update)
+    y3, i3, s3 = native.convnet_train_block_fwd(y2, s2, w3, b3, blocks[3].bn, training, update)
+    a16 = native.convnet_train_frame_fwd(y3, s3, w_m2, b_m2, 4, 4).view(N, 16)     # (the frame around it == b_m2)
+    W16, b_eff, w_frame = native.convnet_train_linear_prep(w_lin, b_lin, b_m2, 10, 10)
+    theta = native.convnet_train_linear_fwd(a16, W16, b_eff)
+    ctx.plan = None
+    ctx.save_for_backward(x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame)
+    return theta
+
+
+def _backward_each(ctx, g_theta):
+    (x, a0, y1, i1, s1, y2, i2, s2, y3, i3, s3, a16, w_m1, w1, w2, w3, w_m2, b_m2, W16, w_frame) = ctx.saved_tensors
+    tr = ctx.training
+    N = x.shape[0]
+    g_theta = g_theta.contiguous()
+    g16 = native.convnet_train_linear_bwd_input(g_theta, W16)             # (N, 16): the interior of d/d(Linear input)
+    dW_lin, db_lin = native.convnet_train_linear_wgrad(g_theta, a16, b_m2, 10, 10)
+    gz3, dw_m2, db_m2, bn3 = native.convnet_train_frame_bwd(g16.view(N, 1, 4, 4), y3, s3, w_m2, s3, tr)
+    db_m2 = db_m2 + torch.dot(db_lin, w_frame)                            # (+ the frame: 84 inputs that equal b_m2)
+    gz2, dW3, db3, bn2 = native.convnet_train_block_bwd(gz3, bn3[0], y3, i3, y2, s2, w3, s2, tr)
+    gz1, dW2, db2, bn1 = native.convnet_train_block_bwd(gz2, bn2[0], y2, i2, y1, s1, w2, s1, tr)
+    g_a0, dW1, db1, _ = native.convnet_train_block_bwd(gz1, bn1[0], y1, i1, a0, None, w1, None, tr)
+    g_x, dw_m1, db_m1, _ = native.convnet_train_frame_bwd(g_a0, x, None, w_m1, None, tr)
+    return g_x, [dw_m1, db_m1,
                  dW1, db1, bn1[1], bn1[2],
                  dW2, db2, bn2[1], bn2[2],
                  dW3, db3, bn3[1], bn3[2],
                  dw_m2, db_m2, dW_lin, db_lin]
-        need = ctx.needs_input_grad
-        return (None, None, None, g_x if need[3] else None,
-                *[g if need[4 + k] else None for k, g in enumerate(grads)])

@@ -731,6 +731,22 @@ __global__ __launch_bounds__(kBlock) void k_ct_linear16_bwd_input(
     if (wave == 0 && n < N) g16[n * 16 + j] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// out[0] += sum_m a[m] b[m], one workgroup, lanes in index order then a fixed tree: deterministic
+__global__ __launch_bounds__(kBlock) void k_ct_dot_add(const float *__restrict__ a, const float *__restrict__ b,
+                                                       float *out, int M)
+{
+    __shared__ float red[kBlock];
+    float t = 0.0f;
+    for (int m = threadIdx.x; m < M; m += kBlock) t = fmaf(a[m], b[m], t);
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += red[0];
+}
+
 }  // namespace tfk
 
 using namespace tfk;
@@ -962,6 +978,69 @@ int tfk_convnet_train_linear_wgrad(const float *g, const float *a, const float *
     hipLaunchKernelGGL(k_ct_linear_wgrad, dim3((M + 63) / 64), dim3(kWgradWaves * 64), lds, s, g, a, frame_bias, dW, db,
                        (long long)N, M, H_out, W_out, (H_out - 4) / 2, (W_out - 4) / 2);
     return check_launch(fn);
+}
+
+int64_t tfk_convnet_train_sums_floats(int32_t c, int32_t kh, int32_t kw, int32_t M)
+{
+    return (int64_t)(4 * c * kh * kw + 2 * c + 4) + (288 + 8) + (576 + 8) + (288 + 4) + 13 + 101 * (int64_t)M;
+}
+
+int tfk_convnet_train_forward(const tfk_convnet_train_plan *p, const float *x, float *theta, int64_t N, int32_t training,
+                              int32_t update_running, void *stream)
+{
+    const char *fn = "tfk_convnet_train_forward";
+    if (!p) return fail(TFK_EINVAL, "%s: null plan", fn);
+    if (N <= 0) return N == 0 ? TFK_OK : fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    static const int CI[3] = {4, 8, 8}, CO[3] = {8, 8, 4}, HH[3] = {32, 16, 8};
+    int rc = tfk_convnet_train_frame_fwd(x, nullptr, p->mod1_w, p->mod1_b, p->a0, N, p->c, 4, p->h, p->w, 32, 32, p->kh,
+                                         p->kw, stream);
+    for (int k = 0; k < 3 && rc == TFK_OK; ++k)
+        rc = tfk_convnet_train_block_fwd(k == 0 ? p->a0 : p->y[k - 1], k == 0 ? nullptr : p->stats[k - 1], p->conv_w[k],
+                                         p->conv_b[k], p->y[k], p->amax[k], p->bn_w[k], p->bn_b[k], p->bn_mean[k],
+                                         p->bn_var[k], p->bn_count[k], p->bn_eps[k], p->bn_momentum[k], training,
+                                         update_running, p->stats[k], p->workspace, N, CI[k], CO[k], HH[k], HH[k], stream);
+    if (rc != TFK_OK) return rc;
+    rc = tfk_convnet_train_frame_fwd(p->y[2], p->stats[2], p->mod2_w, p->mod2_b, p->a16, N, 4, 1, 4, 4, 4, 4, 1, 1, stream);
+    if (rc != TFK_OK) return rc;
+    float *W16 = p->lin_fold, *b_eff = W16 + 16 * (int64_t)p->M, *w_frame = b_eff + p->M;
+    rc = tfk_convnet_train_linear_prep(p->lin_w, p->lin_b, p->mod2_b, W16, b_eff, w_frame, p->M, 10, 10, stream);
+    if (rc != TFK_OK) return rc;
+    return tfk_convnet_train_linear_fwd(p->a16, W16, b_eff, theta, N, p->M, stream);
+}
+
+int tfk_convnet_train_backward(const tfk_convnet_train_plan *p, const float *x, const float *g_theta, float *g_x,
+                               float *scratch, float *bn_out, float *sums, int64_t N, int32_t training, void *stream)
+{
+    const char *fn = "tfk_convnet_train_backward";
+    if (!p || !scratch || !bn_out || !sums) return fail(TFK_EINVAL, "%s: null pointer", fn);
+    if (N <= 0) return N == 0 ? TFK_OK : fail(TFK_EINVAL, "%s: N = %lld < 0", fn, (long long)N);
+    const int M = p->M;
+    float *g16 = scratch, *gz3 = g16 + N * 16, *gz2 = gz3 + N * 64, *gz1 = gz2 + N * 512, *g_a0 = gz1 + N * 2048;
+    float *s_m1 = sums, *s_b1 = s_m1 + (4 * p->c * p->kh * p->kw + 2 * p->c + 4), *s_b2 = s_b1 + 296, *s_b3 = s_b2 + 584,
+          *s_m2 = s_b3 + 292, *dW_lin = s_m2 + 13, *db_lin = dW_lin + 100 * (int64_t)M;
+    float *bn1 = bn_out, *bn2 = bn_out + 40, *bn3 = bn_out + 80;          // coef 3 C | d weight C | d bias C
+    const float *W16 = p->lin_fold, *w_frame = W16 + 17 * (int64_t)M;
+    int rc = tfk_convnet_train_linear_bwd_input(g_theta, W16, g16, N, M, stream);
+    if (rc == TFK_OK) rc = tfk_convnet_train_linear_wgrad(g_theta, p->a16, p->mod2_b, dW_lin, db_lin, N, M, 10, 10, stream);
+    if (rc == TFK_OK)
+        rc = tfk_convnet_train_frame_bwd(g16, p->y[2], p->stats[2], p->mod2_w, gz3, s_m2, p->stats[2], bn3, bn3 + 12,
+                                         bn3 + 16, training, p->workspace, N, 4, 1, 4, 4, 4, 4, 1, 1, stream);
+    if (rc != TFK_OK) return rc;
+    hipLaunchKernelGGL(k_ct_dot_add, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), db_lin, w_frame, s_m2 + 12, M);
+    rc = check_launch(fn);
+    if (rc == TFK_OK)
+        rc = tfk_convnet_train_block_bwd(gz3, bn3, p->y[2], p->amax[2], p->y[1], p->stats[1], p->conv_w[2], gz2, s_b3,
+                                         p->stats[1], bn2, bn2 + 24, bn2 + 32, training, p->workspace, N, 8, 4, 8, stream);
+    if (rc == TFK_OK)
+        rc = tfk_convnet_train_block_bwd(gz2, bn2, p->y[1], p->amax[1], p->y[0], p->stats[0], p->conv_w[1], gz1, s_b2,
+                                         p->stats[0], bn1, bn1 + 24, bn1 + 32, training, p->workspace, N, 8, 8, 16, stream);
+    if (rc == TFK_OK)
+        rc = tfk_convnet_train_block_bwd(gz1, bn1, p->y[0], p->amax[0], p->a0, nullptr, p->conv_w[0], g_a0, s_b1, nullptr,
+                                         nullptr, nullptr, nullptr, training, p->workspace, N, 4, 8, 32, stream);
+    if (rc == TFK_OK)
+        rc = tfk_convnet_train_frame_bwd(g_a0, x, nullptr, p->mod1_w, g_x, s_m1, nullptr, nullptr, nullptr, nullptr, training,
+                                         p->workspace, N, p->c, 4, p->h, p->w, 32, 32, p->kh, p->kw, stream);
+    return rc;
 }
 
 }  // extern "C"

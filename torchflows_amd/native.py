@@ -52,7 +52,8 @@ SYMBOLS = (
     "tfk_convnet_train_workspace_bytes", "tfk_convnet_train_block_supported", "tfk_convnet_train_block_fwd",
     "tfk_convnet_train_block_bwd", "tfk_convnet_train_frame_fwd", "tfk_convnet_train_frame_bwd",
     "tfk_convnet_train_linear_wgrad", "tfk_convnet_train_linear_fwd", "tfk_convnet_train_linear_bwd_input",
-    "tfk_convnet_train_linear_prep",
+    "tfk_convnet_train_linear_prep", "tfk_convnet_train_forward", "tfk_convnet_train_backward",
+    "tfk_convnet_train_sums_floats",
 )
 
 ABI_VERSION = 29
@@ -76,6 +77,21 @@ class GlowLayer(C.Structure):
                 ("slots", _i32), ("block", _i32), ("cg1", _i32), ("cg2", _i32), ("grid", _i32),
                 ("src_idx", _vp), ("src_st", _vp), ("tgt_idx", _vp), ("tgt_st", _vp),
                 ("weights", _vp), ("bg1", _vp), ("bg2", _vp), ("w_eff", _vp), ("b_eff", _vp)]
+
+
+class ConvNetTrainPlan(C.Structure):
+    """``tfk_convnet_train_plan`` (include/tfk.h): the ConvNet conditioner's parameters and the activations its two passes
+    share, as device pointers."""
+    _fields_ = [("mod1_w", C.c_void_p), ("mod1_b", C.c_void_p),
+                ("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3),
+                ("bn_w", C.c_void_p * 3), ("bn_b", C.c_void_p * 3),
+                ("bn_mean", C.c_void_p * 3), ("bn_var", C.c_void_p * 3), ("bn_count", C.c_void_p * 3),
+                ("bn_eps", C.c_float * 3), ("bn_momentum", C.c_float * 3),
+                ("mod2_w", C.c_void_p), ("mod2_b", C.c_void_p), ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
+                ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("M", C.c_int32),
+                ("a0", C.c_void_p), ("y", C.c_void_p * 3), ("amax", C.c_void_p * 3), ("stats", C.c_void_p * 3),
+                ("a16", C.c_void_p), ("lin_fold", C.c_void_p), ("workspace", C.c_void_p)]
 
 
 class GlowLevelStep(C.Structure):
@@ -195,6 +211,11 @@ def _bind(L: C.CDLL) -> None:
                                               _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
     L.tfk_convnet_train_linear_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
     L.tfk_convnet_train_linear_prep.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    pp = C.POINTER(ConvNetTrainPlan)
+    L.tfk_convnet_train_forward.argtypes = [pp, _vp, _vp, _i64, _i32, _i32, _vp]
+    L.tfk_convnet_train_backward.argtypes = [pp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]
+    L.tfk_convnet_train_sums_floats.argtypes = [_i32, _i32, _i32, _i32]
+    L.tfk_convnet_train_sums_floats.restype = _i64
     L.tfk_convnet_train_linear_fwd.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _vp]
     L.tfk_convnet_train_linear_bwd_input.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp]
     L.tfk_last_error.restype = C.c_char_p
@@ -758,6 +779,78 @@ def convnet_train_workspace(t: torch.Tensor) -> torch.Tensor:
         ws = _convnet_ws[key] = torch.zeros(int(lib().tfk_convnet_train_workspace_bytes()) // 4, dtype=torch.float32,
                                             device=t.device)
     return ws
+
+
+# floats per sample the two passes of the whole-network calls keep / use
+CONVNET_ACT_FLOATS = 4 * 32 * 32 + 8 * 16 * 16 + 8 * 8 * 8 + 4 * 4 * 4 + 16       # a0, y1, y2, y3, a16
+CONVNET_AMAX_BYTES = 8 * 16 * 16 + 8 * 8 * 8 + 4 * 4 * 4
+CONVNET_SCRATCH_FLOATS = 16 + 64 + 512 + 2048 + 4096                             # g16, gz3, gz2, gz1, g_a0
+
+
+def convnet_train_forward(plan: "ConvNetTrainPlan", params, bns, x, training: bool, update_running: bool):
+    """The whole ConvNet conditioner in ONE call (tfk_convnet_train_forward): fills ``plan`` from ``params`` (the 18
+    tensors in convnet_train._params order), the three BatchNorm modules and fresh activation buffers; returns (theta,
+    acts, amax) -- the two buffers are what the backward call needs besides ``plan``."""
+    global calls
+    name = "tfk_convnet_train_forward"
+    N, c, h, w = x.shape
+    (w_m1, b_m1, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w_m2, b_m2, w_lin, b_lin) = params
+    M = w_lin.shape[0]
+    dev = x.device
+    acts = torch.empty(N * CONVNET_ACT_FLOATS + 80 + 18 * M, dtype=torch.float32, device=dev)
+    amax = torch.empty(N * CONVNET_AMAX_BYTES, dtype=torch.uint8, device=dev)
+    theta = torch.empty(N, M, dtype=torch.float32, device=dev)
+    p = plan
+    p.mod1_w, p.mod1_b, p.mod2_w, p.mod2_b = w_m1.data_ptr(), b_m1.data_ptr(), w_m2.data_ptr(), b_m2.data_ptr()
+    p.lin_w, p.lin_b = w_lin.data_ptr(), b_lin.data_ptr()
+    for k, (cw, cb, bw, bb, bn) in enumerate(((w1, b1, g1, be1, bns[0]), (w2, b2, g2, be2, bns[1]), (w3, b3, g3, be3, bns[2]))):
+        p.conv_w[k], p.conv_b[k], p.bn_w[k], p.bn_b[k] = cw.data_ptr(), cb.data_ptr(), bw.data_ptr(), bb.data_ptr()
+        p.bn_mean[k], p.bn_var[k] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        p.bn_count[k] = None if bn.num_batches_tracked is None else bn.num_batches_tracked.data_ptr()
+        p.bn_eps[k], p.bn_momentum[k] = float(bn.eps), float(bn.momentum)
+    p.c, p.h, p.w, p.kh, p.kw, p.M = c, h, w, w_m1.shape[2], w_m1.shape[3], M
+    base, fs = acts.data_ptr(), 4
+    off = 0
+    p.a0 = base
+    off += N * 4096
+    for k, n_el in enumerate((2048, 512, 64)):
+        p.y[k] = base + off * fs
+        off += N * n_el
+    p.a16 = base + off * fs
+    off += N * 16
+    for k, n_el in enumerate((32, 32, 16)):
+        p.stats[k] = base + off * fs
+        off += n_el
+    p.lin_fold = base + off * fs
+    ab = amax.data_ptr()
+    p.amax[0], p.amax[1], p.amax[2] = ab, ab + N * 2048, ab + N * (2048 + 512)
+    p.workspace = convnet_train_workspace(x).data_ptr()
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_forward(C.byref(p), _f32(x, name), theta.data_ptr(), N, 1 if training else 0,
+                                             1 if update_running else 0, _stream(x))
+    calls += 7
+    _check(rc, name)
+    return theta, acts, amax
+
+
+def convnet_train_backward(plan: "ConvNetTrainPlan", x, g_theta, training: bool):
+    """The reverse pass of the whole network in ONE call (tfk_convnet_train_backward; ``plan`` as the forward call left it,
+    its buffers alive): (g_x, bn_out (100 floats), sums) -- the layout of ``sums`` is in include/tfk.h."""
+    global calls
+    name = "tfk_convnet_train_backward"
+    N = x.shape[0]
+    p = plan
+    n_sums = int(lib().tfk_convnet_train_sums_floats(p.c, p.kh, p.kw, p.M))
+    g_x = torch.empty_like(x)
+    scratch = torch.empty(N * CONVNET_SCRATCH_FLOATS, dtype=torch.float32, device=x.device)
+    out = torch.empty(100 + n_sums, dtype=torch.float32, device=x.device)     # (its slices become the .grad tensors)
+    base = out.data_ptr()
+    with _device_guard(x):
+        rc = lib().tfk_convnet_train_backward(C.byref(p), _f32(x, name), _f32(g_theta, name), g_x.data_ptr(),
+                                              scratch.data_ptr(), base, base + 400, N, 1 if training else 0, _stream(x))
+    calls += 7
+    _check(rc, name)
+    return g_x, out[:100], out[100:]
 
 
 def convnet_train_block_fwd(x, in_affine, weight, bias, bn, training: bool, update_running: bool):
