@@ -270,3 +270,20 @@ def test_one_call_and_launch_by_launch_routes_agree_bitwise(native, monkeypatch)
             assert torch.equal(a, b), i
     for k in runs[0][2]:
         assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+
+
+@pytest.mark.parametrize("preset,shape", [("MultiscaleNICE", (1, 28, 28)), ("ShiftGlow", (3, 16, 16)), ("AffineGlow", (3, 16, 16))])
+def test_every_multiscale_preset_fits_on_the_captured_step(native, monkeypatch, preset, shape):
+    import torchflows_amd as tfa
+    from torchflows_amd.bijections.finite.multiscale import architectures
+    monkeypatch.setenv("TORCHFLOWS_AMD_GRAPH", "1")
+    torch.manual_seed(0)
+    flow = tfa.Flow(getattr(architectures, preset)(shape)).cuda()
+    assert flow._graph_safe()
+    x = torch.randn(96, *shape)
+    flow.fit(x, n_epochs=8, batch_size=96, lr=0.01)
+    stats = flow._fit_stats
+    assert stats["graph_captures"] == 1 and stats["graph_replays"] == 6, stats
+    assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
+    with torch.no_grad():
+        assert bool(torch.isfinite(flow.log_prob(x.cuda())).all())
