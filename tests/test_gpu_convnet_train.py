@@ -49,10 +49,15 @@ def _evaluate(net, x, g, training):
     return (out.detach().cpu().double().numpy(), [t.detach().cpu().double().numpy() for t in grads], state)
 
 
-@pytest.mark.parametrize("training", [True, False], ids=["batch-statistics", "running-statistics"])
-@pytest.mark.parametrize("shape,N", [((1, 14, 28), 37), ((3, 16, 32), 19), ((6, 16, 16), 64), ((12, 8, 8), 5),
-                                     ((2, 32, 32), 3), ((2, 7, 14), 21), ((4, 7, 7), 33), ((24, 3, 3), 9),
-                                     ((3, 16, 32), 640)])       # (several samples per workgroup, two-level sums)
+_SHAPES = [((1, 14, 28), 37), ((3, 16, 32), 19), ((6, 16, 16), 64), ((12, 8, 8), 5), ((2, 32, 32), 3), ((2, 7, 14), 21),
+           ((4, 7, 7), 33), ((24, 3, 3), 9),
+           ((3, 16, 32), 640)]      # (several samples per workgroup, two-level sums)
+# batch statistics (what Flow.fit runs) on every input frame; the running-statistics variant of the same launches on three
+_CASES = [(s, n, True) for s, n in _SHAPES] + [(s, n, False) for s, n in (_SHAPES[0], _SHAPES[5], _SHAPES[7])]
+
+
+@pytest.mark.parametrize("shape,N,training", _CASES,
+                         ids=[f"{'x'.join(map(str, s))}-N{n}-{'batch' if t else 'running'}" for s, n, t in _CASES])
 def test_convnet_forward_and_gradients(native, monkeypatch, shape, N, training):
     n_out = 2 * int(np.prod(shape))
     ref = _net(shape, n_out)
