@@ -6,8 +6,9 @@ Every coupling here is the ordinary ``CouplingBijection`` with an image mask and
 conditioner, so on a HIP device it runs the same libtfk kernels as the vector flows (masked
 index lists instead of the contiguous tail; the channel-wise split IS a contiguous tail);
 the 1x1 convolution is ``tfk_conv1x1_coupling``; ``Squeeze`` is a fixed permutation of the
-flattened event and runs as ``tfk_permute``.  The conditioner convolutions stay on
-PyTorch-ROCm (MIOpen).
+flattened event and runs as ``tfk_permute``.  The ConvNet conditioner runs on libtfk too: folded into
+one launch per coupling at inference (image_program.py), one launch per block with gradients or batch
+statistics (convnet_train.py); only conditioners of another shape stay on PyTorch-ROCm (MIOpen).
 
 Reference quirk kept: the recursive ``small_bijection`` does not inherit
 ``checkerboard_class`` / ``channel_wise_class`` / ``n_*_layers`` / ``use_resnet``, and the
