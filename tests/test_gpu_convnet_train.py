@@ -292,3 +292,27 @@ def test_every_multiscale_preset_fits_on_the_captured_step(native, monkeypatch, 
     assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
     with torch.no_grad():
         assert bool(torch.isfinite(flow.log_prob(x.cuda())).all())
+
+
+def test_image_flow_validation_pass_is_replayed_too(native, monkeypatch):
+    """Flow.fit with a validation set on an image flow: the validation pass is captured as well; its losses are the eager
+    pass's (same launches, same live parameters), so the two fits are the same fit."""
+    import torchflows_amd as tfa
+    from torchflows_amd.architectures import MultiscaleRealNVP
+    monkeypatch.setenv("TORCHFLOWS_AMD_GRAPH", "1")
+    torch.manual_seed(0)
+    x = torch.randn(200, 1, 28, 28)
+    xv = torch.randn(64, 1, 28, 28)
+    base = tfa.Flow(MultiscaleRealNVP((1, 28, 28)))
+    out = {}
+    for mode in ("1", "0"):
+        set_debug(monkeypatch, val_graph=None if mode == "1" else "0")
+        flow = copy.deepcopy(base).cuda()
+        torch.manual_seed(1)              # (the epoch's row order)
+        flow.fit(x, x_val=xv, n_epochs=10, batch_size=200, lr=0.01, early_stopping=True)
+        out[mode] = (dict(flow._fit_stats), [p.detach().clone() for p in flow.parameters()])
+    assert out["1"][0].get("val_graph_captures") == 1 and out["1"][0]["val_graph_replays"] >= 6, out["1"][0]
+    assert "val_graph_replays" not in out["0"][0]
+    assert out["1"][0]["val_loss"] == out["0"][0]["val_loss"]           # (every batch sum has a fixed order: same bits)
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert torch.equal(a, b)

@@ -120,7 +120,7 @@ def static_usable(net, device) -> bool:
     h, w = 32 - 2 * conv.padding[0] + kh - 1, 32 - 2 * conv.padding[1] + kw - 1
     if h < 1 or w < 1 or not _frame_ok(net, conv.weight.shape[1], h, w):
         return False
-    return all(p.device == device and p.dtype == torch.float32 for p in _params(net))
+    return all(p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in _params(net))
 
 
 def usable(net, x: torch.Tensor) -> bool:
@@ -134,8 +134,8 @@ def usable(net, x: torch.Tensor) -> bool:
     if not _frame_ok(net, c, h, w):
         return False
     params = _params(net)
-    if any(p.device != x.device or p.dtype != torch.float32 for p in params):
-        return False
+    if any(p.device != x.device or p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+        return False                    # (the one-call route hands raw pointers over)
     training = net.blocks[1].bn.training
     if any(blk.bn.training != training for blk in (net.blocks[2], net.blocks[3])):
         return False
