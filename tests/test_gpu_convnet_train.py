@@ -310,7 +310,8 @@ def test_image_flow_validation_pass_is_replayed_too(native, monkeypatch):
         flow = copy.deepcopy(base).cuda()
         torch.manual_seed(1)              # (the epoch's row order)
         flow.fit(x, x_val=xv, n_epochs=10, batch_size=200, lr=0.01, early_stopping=True)
-        out[mode] = (dict(flow._fit_stats), [p.detach().clone() for p in flow.parameters()])
+        out[mode] = (dict(flow._fit_stats), [p.detach().clone() for p in flow.parameters()]
+                     + [b.detach().clone() for b in flow.buffers()])           # (BatchNorm's running statistics too)
     assert out["1"][0].get("val_graph_captures") == 1 and out["1"][0]["val_graph_replays"] >= 6, out["1"][0]
     assert "val_graph_replays" not in out["0"][0]
     assert out["1"][0]["val_loss"] == out["0"][0]["val_loss"]           # (every batch sum has a fixed order: same bits)

@@ -763,3 +763,29 @@ def test_fit_notices_a_non_finite_loss_among_replayed_steps(native):
     assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
     with torch.no_grad():
         assert bool(torch.isfinite(flow.log_prob(x)).all())
+
+
+def test_vector_flow_validation_pass_is_replayed_on_live_parameters(monkeypatch):
+    """Flow.fit with a validation set: the validation pass is captured on the training route's launches (they read the live
+    parameters; a packed flow program would go stale under replays) -- its losses track an eager evaluation of the same
+    weights, and the fit ends where the eager-validation fit ends."""
+    import copy
+    import torchflows_amd as tfa
+    from conftest import set_debug
+    monkeypatch.setenv("TORCHFLOWS_AMD_GRAPH", "1")
+    torch.manual_seed(0)
+    x = torch.randn(1000, 50) * 2 + 1
+    xv = torch.randn(200, 50) * 2 + 1
+    base = tfa.Flow(tfa.RealNVP(50))
+    out = {}
+    for mode in ("1", "0"):
+        set_debug(monkeypatch, val_graph=None if mode == "1" else "0")
+        flow = copy.deepcopy(base).cuda()
+        torch.manual_seed(1)
+        flow.fit(x, x_val=xv, n_epochs=40, early_stopping=True)
+        with torch.no_grad():
+            out[mode] = (dict(flow._fit_stats), float(-flow.log_prob(xv.cuda()).mean()))
+    assert out["1"][0].get("val_graph_captures") == 1 and out["1"][0]["val_graph_replays"] >= 30, out["1"][0]
+    assert "val_graph_replays" not in out["0"][0]
+    assert abs(out["1"][0]["val_loss"] - out["0"][0]["val_loss"]) <= 1e-4 * abs(out["0"][0]["val_loss"])
+    assert abs(out["1"][1] - out["0"][1]) <= 1e-3 * abs(out["0"][1])

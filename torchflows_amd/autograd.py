@@ -19,7 +19,9 @@ anything else keeps the ATen composite graph.  ``TORCHFLOWS_AMD_TRAIN=0`` forces
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from typing import List, Optional, Tuple
 
 import torch
@@ -33,6 +35,27 @@ FORWARD, INVERSE = 0, 1
 
 def enabled() -> bool:
     return os.environ.get("TORCHFLOWS_AMD_TRAIN", "1") != "0"
+
+
+_live = threading.local()
+
+
+@contextlib.contextmanager
+def live_route():
+    """Inside: an evaluation WITHOUT gradients takes the training route too (the chain's per-layer launches, operands
+    gathered from the live parameter tensors) instead of the packed flow programs.  A packed program is a copy of the
+    weights, refreshed when a parameter's version counter moves -- which a replayed hipGraph never does; the launches of
+    this route read the parameters themselves, so they can sit in a captured validation pass (Flow.fit)."""
+    prev = getattr(_live, "on", False)
+    _live.on = True
+    try:
+        yield
+    finally:
+        _live.on = prev
+
+
+def live_forced() -> bool:
+    return getattr(_live, "on", False)
 
 
 def _flatten(layers, attr: str):
@@ -115,7 +138,7 @@ class Plan(list):
 
 def applicable(composition, x: torch.Tensor, context) -> bool:
     """Autograd is on, something needs a gradient, and everything is fp32 on one HIP device."""
-    if not enabled() or not torch.is_grad_enabled():
+    if not enabled() or not (torch.is_grad_enabled() or live_forced()):
         return False
     if x.device.type != "cuda" or x.dtype != torch.float32:
         return False
@@ -1006,7 +1029,7 @@ class ChainFunction(torch.autograd.Function):
                 rqs_blocks[step] = block
                 cur, cur_is_saved = out, False
             else:
-                if _keeps_graph(layer):
+                if _keeps_graph(layer) and any(ctx.needs_input_grad):
                     # a convolutional conditioner: evaluated ONCE, with its graph (the activations it saves are what a
                     # re-evaluation in the backward pass would produce again -- and a BatchNorm in training mode counts
                     # the batch once, as the reference's single forward does)

@@ -164,6 +164,11 @@ class RowState:
             self.started = True
 
 
+def _live_forced() -> bool:
+    from torchflows_amd import autograd as hip_autograd
+    return hip_autograd.live_forced()
+
+
 class BijectiveComposition(Bijection):
     """Layers applied in order, log-dets summed in layer order (reference :170-243)."""
 
@@ -259,7 +264,7 @@ class BijectiveComposition(Bijection):
     def forward(self, x: torch.Tensor, context: torch.Tensor = None, **kwargs):
         if x.numel() == 0:          # no rows: nothing to launch (the reference's reshapes reject this)
             return x.clone(), x.new_zeros(get_batch_shape(x, self.event_shape))
-        if not kwargs and torch.is_grad_enabled():
+        if not kwargs and (torch.is_grad_enabled() or _live_forced()):
             trained = self._run_trainable(x, context, FORWARD)
             if trained is not None:
                 return trained
@@ -281,7 +286,7 @@ class BijectiveComposition(Bijection):
         order = list(self.layers)[::-1]
         if z.numel() == 0:
             return z.clone(), z.new_zeros(get_batch_shape(z, self.event_shape))
-        if not kwargs and torch.is_grad_enabled():
+        if not kwargs and (torch.is_grad_enabled() or _live_forced()):
             trained = self._run_trainable(z, context, INVERSE)
             if trained is not None:
                 return trained

@@ -201,6 +201,9 @@ class Flow(BaseFlow):
             return None
         if context is not None and not native.eligible(context):
             return None
+        from torchflows_amd import autograd as hip_autograd
+        if hip_autograd.live_forced():
+            return None             # (a captured validation pass: launches that read the live parameters, autograd.live_route)
         d = method_direction(b.forward)
         chain = None if d is None else fused.get_compiled(b, d, x.device, context=context is not None)
         if chain is None:
@@ -579,16 +582,22 @@ class Flow(BaseFlow):
                     best_train, best_train_epoch = average, epoch
                 if val is not None:
                     acc = None
-                    if val_graph is not False and graphed is not None and image_flow and len(x_val) <= batch_size \
+                    if val_graph is not False and graphed is not None and len(x_val) <= batch_size \
                             and val[2] is None and graphed[5] == where() and stats.get("val_eager_passes", 0) >= 1:
-                        # an image flow's validation pass (one batch, resident tensors) is libtfk launches that read the
-                        # live parameters: captured once as well, replayed per epoch (2.2 -> 0.7 ms of a 7.9 ms epoch of
-                        # the notebook's multiscale fit).  Vector flows are NOT eligible: their no-grad route is a packed
-                        # flow program, i.e. a copy of the weights that a replay would never refresh.
+                        # the validation pass (one batch, resident tensors) on the training route's launches, which read
+                        # the LIVE parameters (autograd.live_route): captured once as well and replayed per epoch
+                        # (2.2 -> 0.7 ms of a 7.9 ms epoch of the notebook's multiscale fit).  The packed flow programs
+                        # that a no-grad evaluation normally takes are copies of the weights: a replay would never
+                        # refresh them.
                         if val_graph is None:
                             try:
+                                from torchflows_amd import autograd as hip_autograd, convnet_train
+                                # (lazy state of this route, set up outside the capture; BatchNorm's running statistics
+                                # are left alone: this epoch's validation batch is counted by the replay below)
+                                with torch.no_grad(), hip_autograd.live_route(), convnet_train.recomputing():
+                                    self._base_batch_loss((val[0], val[1]), reduction=torch.sum, use_regularization=False)
                                 vg = torch.cuda.CUDAGraph()
-                                with torch.no_grad(), torch.cuda.graph(vg):
+                                with torch.no_grad(), hip_autograd.live_route(), torch.cuda.graph(vg):
                                     static_val = self._base_batch_loss((val[0], val[1]), reduction=torch.sum,
                                                                        use_regularization=False)
                                 val_graph = (vg, static_val)
