@@ -308,7 +308,8 @@ def test_fit_on_device_follows_the_host_trajectory(native, arch, D, lr):
     # tfk_rows_outer instead of GEMM-library calls -- so 40 full-size steps are enough for TORCHFLOWS_AMD_GRAPH's default
     # "auto" to capture the step after two eager ones)
     want = {"eager_steps": 2, "graph_replays": 38, "graph_captures": 1}
-    assert dev._fit_stats == want
+    assert {k: dev._fit_stats[k] for k in want} == want
+    assert dev._fit_stats.get("val_graph_replays", 0) >= 3      # (the validation pass rides along, on live parameters)
     with torch.no_grad():
         after_h = float(host.log_prob(x).mean())
         after_d = float(dev.log_prob(x.cuda()).mean())
@@ -329,7 +330,8 @@ def test_fit_with_hipgraph_replay_in_a_subprocess(native):
     assert proc.returncode == 0, proc.stderr[-2000:]
     out = json.loads(proc.stdout.strip().splitlines()[-1])
     print(out)
-    assert out["graph_stats"] == {"eager_steps": 2, "graph_replays": 38, "graph_captures": 1}
+    assert {k: out["graph_stats"][k] for k in ("eager_steps", "graph_replays", "graph_captures")} == \
+        {"eager_steps": 2, "graph_replays": 38, "graph_captures": 1}
     assert out["eager_stats"]["graph_replays"] == 0 and out["eager_stats"]["eager_steps"] == 40
     assert out["after_graph"] > out["before"]
     assert abs(out["after_graph"] - out["after_eager"]) < 1e-3 * max(1.0, abs(out["after_eager"]))
@@ -614,7 +616,7 @@ def test_small_event_sizes_train_on_the_fused_launches(native, monkeypatch, arch
         with torch.no_grad():
             lp0 = float(dev.log_prob(data).mean())
         dev.fit(data, n_epochs=10, lr=0.01, batch_size=512, shuffle=False)
-        assert dev._fit_stats == {"eager_steps": 2, "graph_replays": 78, "graph_captures": 1}
+        assert dev._fit_stats == {"eager_steps": 2, "graph_replays": 78, "graph_captures": 1}      # (no validation set)
         with torch.no_grad():
             assert float(dev.log_prob(data).mean()) > lp0
 
