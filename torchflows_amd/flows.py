@@ -435,9 +435,7 @@ class Flow(BaseFlow):
             # corrections for ever -- a silently wrong trajectory.  Such a fit runs eager steps.
             use_graph = False
         graphed = None               # (batch size, graph, static x, static w, static loss, tensor addresses)
-        from torchflows_amd.bijections.finite.multiscale.base import MultiscaleBijection as _Multiscale
         from torchflows_amd.utils import debug_switch as _debug_switch
-        image_flow = isinstance(self.bijection, _Multiscale)
         val_graph = None if _debug_switch("val_graph", "1") != "0" else False     # None: not tried yet; False: not used
         stats = {"eager_steps": 0, "graph_replays": 0, "graph_captures": 0}
         self._fit_stats = stats
