@@ -340,10 +340,11 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int HW = H * W, HTWT = HT * WT, T = KH * KW;
     const int GH = H + KH - 1, GW = W + KW - 1, GHW = GH * GW;
+    const int HWP = HW | 1, GHWP = GHW | 1;         // odd plane pitches: lanes that differ in the channel meet no bank
     const int K1 = COUT * C * T + 2 * C, K = K1 + COUT;
     const int SL = (NO == 1) ? kBlock / K1 : 1;     // slices of the pixels per sum
     double *tot = ldsd;                             // K doubles
-    float *gI = reinterpret_cast<float *>(tot + K), *xr = gI + COUT * GHW, *gin = xr + C * HW, *wl = gin + C * HW;
+    float *gI = reinterpret_cast<float *>(tot + K), *xr = gI + COUT * GHWP, *gin = xr + C * HWP, *wl = gin + C * HWP;
     float *ia = wl + COUT * C * T, *vals = ia + 2 * C, *wred = vals + K;       // 2 C | K | 4 COUT floats
     __shared__ int flag;
     for (int i = threadIdx.x; i < COUT * C * T; i += kBlock) wl[i] = weight[i];
@@ -367,10 +368,10 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
                 const float g = src[pos];
                 dbl[co] += g;
                 const int r = pos / WT - r0, q = pos % WT - s0;
-                if (r >= 0 && r < GH && q >= 0 && q < GW) gI[co * GHW + r * GW + q] = g;
+                if (r >= 0 && r < GH && q >= 0 && q < GW) gI[co * GHWP + r * GW + q] = g;
             }
         }
-        for (int i = threadIdx.x; i < C * HW; i += kBlock) xr[i] = x[n * C * HW + i];
+        for (int i = threadIdx.x; i < C * HW; i += kBlock) xr[(i / HW) * HWP + i % HW] = x[n * C * HW + i];
         __syncthreads();
         for (int i = threadIdx.x; i < C * HW; i += kBlock) {
             const int c = i / HW, pix = i - c * HW, yy = pix / W, xx = pix - yy * W;
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
                 for (int dy = 0; dy < KH; ++dy)
                     for (int dx = 0; dx < KW; ++dx)
                         gi = fmaf(wl[(co * C + c) * T + dy * KW + dx],
-                                  gI[co * GHW + (yy + KH - 1 - dy) * GW + xx + KW - 1 - dx], gi);
-            gin[i] = gi;
+                                  gI[co * GHWP + (yy + KH - 1 - dy) * GW + xx + KW - 1 - dx], gi);
+            gin[c * HWP + pix] = gi;
             g_in[n * C * HW + i] = gi;
         }
         __syncthreads();
@@ -395,17 +396,17 @@ __global__ __launch_bounds__(kBlock) void k_ct_frame_bwd(
             } else if (o < COUT * C * T) {
                 const int tap = o % T, cc = o / T, co = cc / C, c = cc - co * C, dy = tap / KW, dx = tap - dy * KW;
                 const float sc = ia[c], sh = ia[C + c];
-                const float *gsrc = gI + co * GHW + (KH - 1 - dy) * GW + KW - 1 - dx;
+                const float *gsrc = gI + co * GHWP + (KH - 1 - dy) * GW + KW - 1 - dx;
                 for (int pix = sl; pix < HW; pix += SL) {
                     const int yy = pix / W, xx = pix - yy * W;
-                    a = fmaf(gsrc[yy * GW + xx], fmaf(xr[c * HW + pix], sc, sh), a);
+                    a = fmaf(gsrc[yy * GW + xx], fmaf(xr[c * HWP + pix], sc, sh), a);
                 }
             } else if (o < COUT * C * T + C) {
                 const int c = o - COUT * C * T;
-                for (int pix = sl; pix < HW; pix += SL) a += gin[c * HW + pix];
+                for (int pix = sl; pix < HW; pix += SL) a += gin[c * HWP + pix];
             } else if (o < K1) {
                 const int c = o - COUT * C * T - C;
-                for (int pix = sl; pix < HW; pix += SL) a = fmaf(gin[c * HW + pix], xr[c * HW + pix], a);
+                for (int pix = sl; pix < HW; pix += SL) a = fmaf(gin[c * HWP + pix], xr[c * HWP + pix], a);
             }
             acc[q] = a;
         }
@@ -450,8 +451,11 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *zin = lds;                               // CIN x P x P, zero halo
     float *dc = zin + CIN * PP;                     // COUT x P x P, zero halo: d(loss)/d(convolution output)
-    float *dv = dc + COUT * PP;                     // COUT x CELLS: the one non-zero of every 2x2 window
-    unsigned char *da = reinterpret_cast<unsigned char *>(dv + COUT * CELLS);       // its position
+    // (pitches CELLS + 1 floats / CELLS + 4 bytes: lanes that differ in c_out at the same cell would otherwise meet
+    // in one bank -- 38 % of this kernel's LDS cycles were bank conflicts before)
+    constexpr int CP = CELLS + 1, CPB = CELLS + 4;
+    float *dv = dc + COUT * PP;                     // COUT x CP: the one non-zero of every 2x2 window
+    unsigned char *da = reinterpret_cast<unsigned char *>(dv + COUT * CP);          // COUT x CPB: its position
     __shared__ float cf[3 * COUT], ia[2 * CIN], vals[K], wred[4 * 2 * CIN];
     __shared__ double tot[K];
     __shared__ int flag;
@@ -478,8 +482,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
             const float g = gz[gi], yv = y[gi];
             const int a = amax[gi];
             const float d = yv > 0.0f ? fmaf(cf[co], g, fmaf(cf[COUT + co], yv, cf[2 * COUT + co])) : 0.0f;
-            dv[it] = d;
-            da[it] = (unsigned char)a;
+            dv[co * CP + cell] = d;
+            da[co * CPB + cell] = (unsigned char)a;
             const int py = cell / HP, px = cell - py * HP;
             float *dst = dc + co * PP + (2 * py + 1) * P + 2 * px + 1;
             dst[0] = a == 0 ? d : 0.0f;
@@ -494,8 +498,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_block_bwd(
         __syncthreads();
         // (c) weight gradient: this thread's (c_out, c_in) pair, its share of the pooled cells, 9 taps
         for (int cell = grp; cell < CELLS; cell += GROUPS) {
-            const float d = dv[pco * CELLS + cell];
-            const int a = da[pco * CELLS + cell];
+            const float d = dv[pco * CP + cell];
+            const int a = da[pco * CPB + cell];
             const int py = cell / HP, px = cell - py * HP;
             const float *src = zin + pci * PP + (2 * py + (a >> 1)) * P + 2 * px + (a & 1);
 #pragma unroll
@@ -859,8 +863,8 @@ int tfk_convnet_train_frame_bwd(const float *g_out, const float *x, const float 
     const int T = kh * kw, K1 = c_out * c_in * T + 2 * c_in, K = K1 + c_out;
     if (K1 > 3 * kBlock || K > kCtMaxK)
         return fail(TFK_EINVAL, "%s: %d x %d channels x %d taps: too many sums for one workgroup", fn, c_out, c_in, T);
-    const int64_t lds_floats = (int64_t)c_out * (H + kh - 1) * (W + kw - 1) + 2 * (int64_t)c_in * H * W + c_out * c_in * T +
-                               2 * c_in + K + 4 * c_out + 2 * (int64_t)K + kBlock;
+    const int64_t lds_floats = (int64_t)c_out * (((H + kh - 1) * (W + kw - 1)) | 1) + 2 * (int64_t)c_in * ((H * W) | 1) +
+                               c_out * c_in * T + 2 * c_in + K + 4 * c_out + 2 * (int64_t)K + kBlock;
     if (lds_floats * 4 > 150 * 1024) return fail(TFK_EINVAL, "%s: %d x %d x %d input does not fit the LDS", fn, c_in, H, W);
     if (bn_stats && (!bn_coef || !bn_dweight || !bn_dbias)) return fail(TFK_EINVAL, "%s: BatchNorm outputs missing", fn);
     if (N == 0) return TFK_OK;
@@ -905,7 +909,7 @@ int tfk_convnet_train_block_bwd(const float *gz, const float *coef, const float 
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCtHeaderBytes);
     BnBwd bn{bn_stats, bn_coef, bn_dweight, bn_dbias, (double)N * H * H, bn_training ? 1 : 0};
     const int P = H + 2, cells = (H / 2) * (H / 2);
-    size_t lds = (size_t)(c_in + c_out) * P * P * 4 + (size_t)c_out * cells * 5 + 16;
+    size_t lds = (size_t)(c_in + c_out) * P * P * 4 + (size_t)c_out * (cells + 1) * 4 + (size_t)c_out * (cells + 4) + 16;
     if (lds < (size_t)kBlock * 10 * 4) lds = (size_t)kBlock * 10 * 4;       // (the cross-group reduction of dW)
     const int grid = bwd_grid(N, 2);        // (two workgroups per CU fit the LDS; measured 71 -> 49 us at 1 024 samples)
 #define TFK_CT(CI, CO, HH)                                                                                             \
