@@ -88,7 +88,7 @@ def structure_ok(net) -> bool:
                              and isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.track_running_stats
                              and bn.momentum is not None
                              and bool(native.lib().tfk_convnet_train_block_supported(ci, co, h)))
-    except (AttributeError, native.NativeError):
+    except AttributeError:          # (another module tree; a missing or mismatched libtfk raises NativeError: loud)
         ok = False
     net.__dict__["_tfk_ct_structure"] = ok
     return ok
