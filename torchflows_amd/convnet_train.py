@@ -8,17 +8,16 @@ BatchNorm into a per-channel scale / shift).  One ``torch.autograd.Function`` co
 
   forward   frame (ConvModifier) | block 1 | block 2 | block 3 | frame (+ BatchNorm 3 on load) | fold | linear    7 launches
   backward  linear input gradient | linear weight gradient | frame_bwd | block_bwd x 3 | frame_bwd              7 launches
-            (+ one dot product and one add for the second modifier's bias)
+            (+ one dot product for the second modifier's bias)
 
+against ~70 ATen / MIOpen launches, issued by ONE libtfk call per pass (``tfk_convnet_train_forward`` / ``_backward``).
 The Linear layer sees the second modifier's bias on 84 of its 100 inputs: it is evaluated as a 16-term product with an
-effective bias (``linear_prep``), as ``image_program`` does at inference.
-
-against ~70 ATen / MIOpen launches.  Each block launch writes the pooled activation BEFORE normalisation and the arg-max
+effective bias (``linear_prep``), as ``image_program`` does at inference.  Each block launch writes the pooled activation BEFORE normalisation and the arg-max
 byte of every pooling window; the normalisation is applied by whoever reads it next.  The batch sums (statistics in the
 forward; weight gradients and the two sums a BatchNorm backward needs in the reverse pass) are fixed-order sums of
 per-workgroup partials finished inside the same launch.
 
-Only the reference's own network shape is covered (``supported``); anything else keeps the ATen composite path.
+Only the reference's own network shape is covered (``structure_ok``); anything else keeps the ATen composite path.
 """
 from __future__ import annotations
 
