@@ -317,3 +317,17 @@ def test_image_flow_validation_pass_is_replayed_too(native, monkeypatch):
     assert out["1"][0]["val_loss"] == out["0"][0]["val_loss"]           # (every batch sum has a fixed order: same bits)
     for a, b in zip(out["1"][1], out["0"][1]):
         assert torch.equal(a, b)
+
+
+def test_image_flow_fit_with_a_ragged_last_batch(native, monkeypatch):
+    """Several steps per epoch, the last batch smaller: full batches replay the captured step, the ragged one runs eagerly."""
+    import torchflows_amd as tfa
+    from torchflows_amd.architectures import MultiscaleRealNVP
+    monkeypatch.setenv("TORCHFLOWS_AMD_GRAPH", "1")
+    torch.manual_seed(0)
+    flow = tfa.Flow(MultiscaleRealNVP((1, 28, 28))).cuda()
+    x = torch.randn(250, 1, 28, 28)
+    flow.fit(x, n_epochs=4, batch_size=100, lr=0.01)
+    stats = flow._fit_stats
+    assert stats["graph_captures"] == 1 and stats["graph_replays"] == 6 and stats["eager_steps"] == 2 + 4, stats
+    assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())

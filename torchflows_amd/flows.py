@@ -458,7 +458,9 @@ class Flow(BaseFlow):
                 static_loss.backward()
                 self._optimizer.step()
             stats["graph_captures"] += 1
-            return len(xb), graph, xs, ws, static_loss, where()
+            # (only the VALUE is read back: a tensor that kept the captured step's autograd graph -- and with it the
+            # AccumulateGrad nodes made on the capture stream -- alive made later eager steps warn about a stream mismatch)
+            return len(xb), graph, xs, ws, static_loss.detach(), where()
 
         def snapshot(into=None):
             """The state dict's values, copied -- into the previous snapshot's tensors when there is one (only the latest
