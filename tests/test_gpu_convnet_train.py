@@ -331,3 +331,15 @@ def test_image_flow_fit_with_a_ragged_last_batch(native, monkeypatch):
     stats = flow._fit_stats
     assert stats["graph_captures"] == 1 and stats["graph_replays"] == 6 and stats["eager_steps"] == 2 + 4, stats
     assert all(bool(torch.isfinite(p).all()) for p in flow.parameters())
+
+
+def test_linear_input_gradient_both_launch_shapes(native):
+    """g16 = g W16 of the folded Linear layer: the scalar launch (few rows) and the 16-byte-load launch (>= 16 rows per CU,
+    M % 4 == 0) against float64."""
+    torch.manual_seed(0)
+    for N, M in ((300, 392), (5000, 392), (5000, 394), (4100, 3072)):
+        g = torch.randn(N, M, device="cuda")
+        W16 = torch.randn(M, 16, device="cuda")
+        got = native.convnet_train_linear_bwd_input(g, W16)
+        want = (g.double() @ W16.double())
+        assert float((got.double() - want).abs().max()) < 2e-5 * float(want.abs().max()), (N, M)

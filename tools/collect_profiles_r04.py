@@ -37,7 +37,7 @@ def main():
             with open(os.path.join(d, "pmc_summary.csv"), "w") as f:
                 f.writelines(keep)
     shutil.copy(os.path.join(SRC, "prof_r04_train", "probe.txt"), os.path.join(DST, "train", "probe.txt"))
-    for f in ("probe.txt", "convtrain_bench.txt", "pmc_8192.txt"):        # (pmc_1024.txt: tools/convtrain_pmc.sh r04 1024, copied by hand)
+    for f in ("probe.txt", "convtrain_bench.txt", "pmc_8192.txt", "pmc_1024.txt"):
         with open(os.path.join(SRC, "prof_r04_train_glow", f)) as fh:
             keep = [ln for ln in fh if "amdgpu.ids" not in ln]
         with open(os.path.join(DST, "train_glow", f), "w") as fh:

@@ -17,6 +17,8 @@ mkdir -p gpurun_out/prof_r04_train_glow
 TORCHFLOWS_AMD_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r04_train_glow/trace -o trace -- python tools/image_graph_probe.py 60 glow > gpurun_out/prof_r04_train_glow/probe.txt 2> gpurun_out/prof_r04_train_glow/err.txt
 python tools/summarize_profile.py gpurun_out/prof_r04_train_glow > /dev/null; rm -rf gpurun_out/prof_r04_train_glow/trace
 python tools/convtrain_bench.py 1024 > gpurun_out/prof_r04_train_glow/convtrain_bench.txt 2>/dev/null
+bash tools/convtrain_pmc.sh r04 8192 > gpurun_out/prof_r04_train_glow/pmc_8192.txt 2>&1
+bash tools/convtrain_pmc.sh r04b 1024 > gpurun_out/prof_r04_train_glow/pmc_1024.txt 2>&1
 # one coupling launch of config 5 (the first checkerboard layer) under the SQ / TCC counters
 bash tools/glow_pmc.sh r04_step0 0 131072 > gpurun_out/prof_r04_glow32/step0_pmc.txt 2>&1
 bash tools/glow_pmc.sh r04_step3 3 131072 > gpurun_out/prof_r04_glow32/step3_pmc.txt 2>&1
